@@ -1,0 +1,374 @@
+/*
+ * gpnerf_oracle.c -- CPU restatement of GP-NeRF's per-ray render path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under gp-nerf_amd/ (the product) may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker / CPU baseline.
+ *
+ * Parity status: PINNED against outputs of the reference itself, generated in
+ * the build container by tests/golden/make_golden.py (which runs the reference's
+ * Renderer.render / NeRFHead.forward / SparseConvNet.forward / get_rays /
+ * get_near_far) and committed as tests/golden/*.npz.  The sparse-convolution
+ * volume builder (external spconv v1.2.1, absent from the tree) is NOT restated:
+ * the 4 dense feature levels are inputs here, as they are in the golden vectors.
+ *
+ * Every function cites the reference lines it follows (paths relative to the
+ * reference root).  Arithmetic is fp32 throughout, as the reference's is.
+ * Input layouts are the REFERENCE's (NCHW / NCDHW), deliberately not the
+ * product's channels-last layouts, so that the product's re-layout is under test.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NV 3    /* source views: rgb_fc's 96 = 3*32 hard-wires it (trainhead.py:96,143) */
+#define NC 32   /* encoder.out_ch */
+#define NL 4    /* volume levels */
+#define XF (NC + 3)
+
+typedef struct {
+    /* per-frame tensors, reference layouts */
+    const float *imgs;      /* [V,3,H,W] de-normalised to [0,1] (BaseRender.py:231) */
+    const float *featmaps;  /* [V,32,fh,fw] */
+    const float *vol[NL];   /* [32,Dk,Hk,Wk] */
+    int32_t vol_dhw[NL][3];
+    int32_t img_h, img_w, feat_h, feat_w;
+    float K4P4[NV][16];     /* train_intrinsics.bmm(train_poses), row-major 4x4 (BaseRender.py:314) */
+    float Rh[9];            /* row-major */
+    float Th[3];
+    float bounds_min[3];    /* SMPL-frame xyz */
+    float voxel[3];         /* cfg.dataset.voxel_size, used in dhw order */
+    int32_t out_sh[3];      /* d,h,w */
+    /* per-ray MLP, PyTorch layout W[out][in], b[out] */
+    const float *geo_w, *geo_b;            /* 64x128  sigmahead.out_geometry_fc.0 */
+    const float *b1_w, *b1_b, *b2_w, *b2_b;/* 64x105, 32x64  rgbhead.base_fc */
+    const float *v1_w, *v1_b, *v2_w, *v2_b;/* 32x32 x2       rgbhead.vis_fc */
+    const float *r1_w, *r1_b, *r2_w, *r2_b, *r3_w, *r3_b; /* 32x96,16x32,3x16 rgbhead.rgb_fc */
+    const float *d1_w, *d1_b, *d2_w, *d2_b, *d3_w, *d3_b, *d4_w, *d4_b; /* 64x134,32x64,16x32,1x16 */
+} OracleFrame;
+
+typedef struct {
+    float *rgb;      /* [N,3] */
+    float *depth;    /* [N] */
+    float *acc;      /* [N] */
+    float *disp;     /* [N] */
+    float *weights;  /* [N,S] or NULL */
+    float *z_vals;   /* [N,S] or NULL */
+    float *rgb_in;   /* [N,9] or NULL */
+    uint8_t *ray_mask; /* [N] or NULL */
+    /* stage dumps, any may be NULL */
+    float *st_grid;     /* [N,S,3] */
+    float *st_vol_feat; /* [N,S,128] */
+    float *st_rgb_feat; /* [N,S,V,35] */
+    float *st_mask;     /* [N,S,V] */
+    float *st_raw;      /* [N,S,4] */
+} OracleOut;
+
+static inline float elu(float x) { return x > 0.f ? x : expm1f(x); } /* nn.ELU(alpha=1) */
+
+/* y = W x + b, W row-major [n_out][n_in] (nn.Linear) */
+static void linear(const float *W, const float *b, const float *x, float *y, int n_out, int n_in) {
+    for (int o = 0; o < n_out; ++o) {
+        float s = 0.f;
+        const float *w = W + (size_t)o * n_in;
+        for (int i = 0; i < n_in; ++i) s += w[i] * x[i];
+        y[o] = s + b[o];
+    }
+}
+
+/* F.grid_sample 2-D, bilinear, zeros padding, align_corners=True, on one NCHW
+ * plane set (BaseRender.py:352,356).  gx,gy are normalised coords. */
+static void grid_sample2d(const float *src, int C, int H, int W, float gx, float gy, float *out) {
+    float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    float fx = floorf(ix), fy = floorf(iy);
+    float tx = ix - fx, ty = iy - fy;
+    float wnw = (1.f - tx) * (1.f - ty), wne = tx * (1.f - ty), wsw = (1.f - tx) * ty, wse = tx * ty;
+    /* bounds tests in float first: coordinates may be +-1e6-scale or non-finite */
+    int vx0 = (fx >= 0.f && fx <= (float)(W - 1)), vx1 = (fx + 1.f >= 0.f && fx + 1.f <= (float)(W - 1));
+    int vy0 = (fy >= 0.f && fy <= (float)(H - 1)), vy1 = (fy + 1.f >= 0.f && fy + 1.f <= (float)(H - 1));
+    int x0 = vx0 ? (int)fx : 0, x1 = vx1 ? (int)(fx + 1.f) : 0;
+    int y0 = vy0 ? (int)fy : 0, y1 = vy1 ? (int)(fy + 1.f) : 0;
+    for (int c = 0; c < C; ++c) {
+        const float *p = src + (size_t)c * H * W;
+        float v = 0.f;
+        if (vx0 && vy0) v += p[(size_t)y0 * W + x0] * wnw;
+        if (vx1 && vy0) v += p[(size_t)y0 * W + x1] * wne;
+        if (vx0 && vy1) v += p[(size_t)y1 * W + x0] * wsw;
+        if (vx1 && vy1) v += p[(size_t)y1 * W + x1] * wse;
+        out[c] = v;
+    }
+}
+
+/* F.grid_sample 3-D, trilinear, zeros padding, align_corners=True
+ * (SparseConvNet.py:113-116).  grid last dim is (x,y,z) -> (W,H,D). */
+static void grid_sample3d(const float *src, int C, int D, int H, int W, float gx, float gy, float gz, float *out) {
+    float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    float iz = ((gz + 1.f) / 2.f) * (float)(D - 1);
+    float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+    float wx[2] = {1.f - tx, tx}, wy[2] = {1.f - ty, ty}, wz[2] = {1.f - tz, tz};
+    int vx[2], vy[2], vz[2], xi[2], yi[2], zi[2];
+    for (int k = 0; k < 2; ++k) {
+        float cx = fx + (float)k, cy = fy + (float)k, cz = fz + (float)k;
+        vx[k] = (cx >= 0.f && cx <= (float)(W - 1)); xi[k] = vx[k] ? (int)cx : 0;
+        vy[k] = (cy >= 0.f && cy <= (float)(H - 1)); yi[k] = vy[k] ? (int)cy : 0;
+        vz[k] = (cz >= 0.f && cz <= (float)(D - 1)); zi[k] = vz[k] ? (int)cz : 0;
+    }
+    for (int c = 0; c < C; ++c) {
+        const float *p = src + (size_t)c * D * H * W;
+        float v = 0.f;
+        for (int a = 0; a < 2; ++a)       /* z: top, bottom */
+            for (int b = 0; b < 2; ++b)   /* y: north, south */
+                for (int e = 0; e < 2; ++e) /* x: west, east */
+                    if (vz[a] && vy[b] && vx[e])
+                        v += p[((size_t)zi[a] * H + yi[b]) * W + xi[e]] * (wx[e] * wy[b] * wz[a]);
+        out[c] = v;
+    }
+}
+
+/* One sample through NeRFHead.forward (trainhead.py:43-59,118-145,159-163):
+ * raw[4] = (rgb, sigma), rgb_in[V][3]. */
+static void head_forward(const OracleFrame *f, const float *vol_feat /*128*/, const float *x /*[V][35]*/,
+                         const float *mask /*[V]*/, float *raw, float *rgb_in) {
+    float s[64];
+    linear(f->geo_w, f->geo_b, vol_feat, s, 64, 128);            /* trainhead.py:39-40,58 */
+    for (int i = 0; i < 64; ++i) s[i] = elu(s[i]);
+    float mean[XF], var[XF];                                     /* fused_mean_variance :20-24 */
+    for (int c = 0; c < XF; ++c) {
+        float m = (x[c] + x[XF + c] + x[2 * XF + c]) / (float)NV;
+        float a = x[c] - m, b = x[XF + c] - m, d = x[2 * XF + c] - m;
+        mean[c] = m;
+        var[c] = (a * a + b * b + d * d) / (float)NV;
+    }
+    /* density branch :127-137 */
+    float sx[134], h1[64], h2[32], h3[16], sg;
+    memcpy(sx, s, 64 * sizeof(float));
+    memcpy(sx + 64, mean, XF * sizeof(float));
+    memcpy(sx + 64 + XF, var, XF * sizeof(float));
+    linear(f->d1_w, f->d1_b, sx, h1, 64, 134); for (int i = 0; i < 64; ++i) h1[i] = elu(h1[i]);
+    linear(f->d2_w, f->d2_b, h1, h2, 32, 64);  for (int i = 0; i < 32; ++i) h2[i] = elu(h2[i]);
+    linear(f->d3_w, f->d3_b, h2, h3, 16, 32);  for (int i = 0; i < 16; ++i) h3[i] = elu(h3[i]);
+    linear(f->d4_w, f->d4_b, h3, &sg, 1, 16);
+    sg = sg > 0.f ? sg : 0.f;                                    /* nn.ReLU :110 */
+    float nvalid = mask[0] + mask[1] + mask[2];
+    if (nvalid < 1.f) sg = 0.f;                                  /* masked_fill :136-137 */
+    /* colour branch :131,139-143 */
+    float y[NV * 32];
+    for (int v = 0; v < NV; ++v) {
+        float in[105], a1[64], a2[32], t1[32], t2[32], xs[32];
+        memcpy(in, mean, XF * sizeof(float));
+        memcpy(in + XF, var, XF * sizeof(float));
+        memcpy(in + 2 * XF, x + v * XF, XF * sizeof(float));
+        linear(f->b1_w, f->b1_b, in, a1, 64, 105); for (int i = 0; i < 64; ++i) a1[i] = elu(a1[i]);
+        linear(f->b2_w, f->b2_b, a1, a2, 32, 64);  for (int i = 0; i < 32; ++i) a2[i] = elu(a2[i]);
+        for (int i = 0; i < 32; ++i) xs[i] = a2[i] * 1.0f / (float)NV;   /* x * 1.0 / num_views :140 */
+        linear(f->v1_w, f->v1_b, xs, t1, 32, 32);  for (int i = 0; i < 32; ++i) t1[i] = elu(t1[i]);
+        linear(f->v2_w, f->v2_b, t1, t2, 32, 32);  for (int i = 0; i < 32; ++i) t2[i] = elu(t2[i]);
+        for (int i = 0; i < 32; ++i) y[v * 32 + i] = a2[i] + t2[i];
+        rgb_in[v * 3 + 0] = x[v * XF + 0]; rgb_in[v * 3 + 1] = x[v * XF + 1]; rgb_in[v * 3 + 2] = x[v * XF + 2];
+    }
+    float c1[32], c2[16], c3[3];
+    linear(f->r1_w, f->r1_b, y, c1, 32, 96);  for (int i = 0; i < 32; ++i) c1[i] = elu(c1[i]);
+    linear(f->r2_w, f->r2_b, c1, c2, 16, 32); for (int i = 0; i < 16; ++i) c2[i] = elu(c2[i]);
+    linear(f->r3_w, f->r3_b, c2, c3, 3, 16);
+    for (int i = 0; i < 3; ++i) raw[i] = 1.f / (1.f + expf(-c3[i]));    /* .sigmoid() :143 */
+    raw[3] = sg;
+}
+
+/* Renderer.render_rays for one ray (BaseRender.py:110-157) with is_train=False. */
+static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near far*/, int S, int neg_ray,
+                           int64_t r, OracleOut *o, float *scratch /* S*(4+9+1) */) {
+    float *raw = scratch;            /* [S][4] */
+    float *rin = scratch + 4 * S;    /* [S][9] */
+    float *zv = scratch + 13 * S;    /* [S] */
+    int n_two = 0;
+    const float near = ray[6], far = ray[7];
+    for (int k = 0; k < S; ++k) {
+        /* get_sampling_points :37-38,48.  torch.linspace(0,1,S) on CPU evaluates, per element,
+         * start + step*i for i < S/2 and end - step*(S-1-i) otherwise, each with ONE rounding (the
+         * compiler contracts it to an fma); verified bit-exact for S = 2..1000 against torch 2.10. */
+        const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
+        float t = (k < S / 2) ? fmaf(step, (float)k, 0.f) : fmaf(-step, (float)(S - 1 - k), 1.f);
+        if (S == 1) t = 0.f;
+        float z = near * (1.f - t) + far * t;
+        zv[k] = z;
+        float p[3] = {ray[0] + ray[3] * z, ray[1] + ray[4] * z, ray[2] + ray[5] * z};
+        /* pts_to_can_pts :52-60 : (p - Th) @ Rh */
+        float q0[3] = {p[0] - f->Th[0], p[1] - f->Th[1], p[2] - f->Th[2]}, q[3];
+        for (int j = 0; j < 3; ++j) q[j] = q0[0] * f->Rh[0 * 3 + j] + q0[1] * f->Rh[1 * 3 + j] + q0[2] * f->Rh[2 * 3 + j];
+        /* get_grid_coords :62-73 (dhw arithmetic, returned as xyz) */
+        float g[3];
+        for (int a = 0; a < 3; ++a) {       /* a indexes dhw; xyz component is 2-a */
+            float v = q[2 - a] - f->bounds_min[2 - a];
+            v = v / f->voxel[a];
+            v = v / (float)f->out_sh[a] * 2.f - 1.f;
+            g[2 - a] = v;
+        }
+        if (o->st_grid) memcpy(o->st_grid + ((size_t)r * S + k) * 3, g, 3 * sizeof(float));
+        /* SparseConvNet.forward :113-122 */
+        float vf[NL * NC];
+        for (int l = 0; l < NL; ++l)
+            grid_sample3d(f->vol[l], NC, f->vol_dhw[l][0], f->vol_dhw[l][1], f->vol_dhw[l][2], g[0], g[1], g[2], vf + l * NC);
+        if (o->st_vol_feat) memcpy(o->st_vol_feat + ((size_t)r * S + k) * 128, vf, 128 * sizeof(float));
+        /* Projector.compute :326-363 */
+        float x[NV * XF], mask[NV];
+        for (int v = 0; v < NV; ++v) {
+            const float *M = f->K4P4[v];
+            float h[3];
+            for (int a = 0; a < 3; ++a) h[a] = M[a * 4 + 0] * p[0] + M[a * 4 + 1] * p[1] + M[a * 4 + 2] * p[2] + M[a * 4 + 3];
+            float u = h[0] / h[2], w = h[1] / h[2];
+            u = fminf(fmaxf(u, -1e6f), 1e6f);       /* torch.clamp :316 (NaN propagates in torch; fmin/fmax drop it: */
+            w = fminf(fmaxf(w, -1e6f), 1e6f);       /*  only reachable at h_z == 0 exactly, sample then out of bounds) */
+            if (h[0] / h[2] != h[0] / h[2]) u = NAN;
+            if (h[1] / h[2] != h[1] / h[2]) w = NAN;
+            int front = neg_ray ? (h[2] < 0.f) : (h[2] > 0.f);
+            int inb = (u <= (float)f->img_w - 1.f) && (u >= 0.f) && (w <= (float)f->img_h - 1.f) && (w >= 0.f); /* :283-294 */
+            mask[v] = (front && inb) ? 1.f : 0.f;
+            float nx = 2.f * u / ((float)f->img_w - 1.f) - 1.f;     /* normalize :296-299 */
+            float ny = 2.f * w / ((float)f->img_h - 1.f) - 1.f;
+            grid_sample2d(f->imgs + (size_t)v * 3 * f->img_h * f->img_w, 3, f->img_h, f->img_w, nx, ny, x + v * XF);
+            grid_sample2d(f->featmaps + (size_t)v * NC * f->feat_h * f->feat_w, NC, f->feat_h, f->feat_w, nx, ny, x + v * XF + 3);
+        }
+        if (o->st_rgb_feat) memcpy(o->st_rgb_feat + ((size_t)r * S + k) * NV * XF, x, sizeof(x));
+        if (o->st_mask) memcpy(o->st_mask + ((size_t)r * S + k) * NV, mask, sizeof(mask));
+        if (mask[0] + mask[1] + mask[2] > 1.f) ++n_two;             /* pixel_mask :139 */
+        head_forward(f, vf, x, mask, raw + 4 * k, rin + 9 * k);
+        if (o->st_raw) memcpy(o->st_raw + ((size_t)r * S + k) * 4, raw + 4 * k, 4 * sizeof(float));
+    }
+    /* raw2outputs :75-107 */
+    float T = 1.f, rgb[3] = {0, 0, 0}, depth = 0.f, acc = 0.f, rgbin[9] = {0};
+    for (int k = 0; k < S; ++k) {
+        int src = neg_ray ? (S - 1 - k) : k;           /* torch.flip of rgb and sigma only :86-88 */
+        float alpha = 1.f - expf(-raw[4 * src + 3]);
+        float w = alpha * T;
+        T = T * (1.f - alpha + 1e-10f);
+        for (int c = 0; c < 3; ++c) rgb[c] += w * raw[4 * src + c];
+        depth += w * zv[k];
+        acc += w;
+        /* rgb_in_map :147 uses the un-flipped rgb_in with the (flipped-order) weights */
+        for (int c = 0; c < 9; ++c) rgbin[c] += w * rin[9 * k + c];
+        if (o->weights) o->weights[(size_t)r * S + k] = w;
+        if (o->z_vals) o->z_vals[(size_t)r * S + k] = zv[k];
+    }
+    memcpy(o->rgb + 3 * r, rgb, sizeof(rgb));
+    o->depth[r] = depth;
+    o->acc[r] = acc;
+    {   /* 1 / max(1e-10, depth / acc); torch.max propagates NaN (0/0) */
+        float q = depth / acc;
+        o->disp[r] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+    }
+    if (o->rgb_in) memcpy(o->rgb_in + 9 * r, rgbin, sizeof(rgbin));
+    if (o->ray_mask) o->ray_mask[r] = (uint8_t)(n_two > 8);
+}
+
+/* rays: [N][8] = o(3) d(3) near far  (BaseRender.py:250).  Returns 0. */
+int oracle_render(const OracleFrame *f, const float *rays, int64_t N, int S, int neg_ray, OracleOut *out, int n_threads) {
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel
+    {
+        float *scratch = (float *)malloc(sizeof(float) * 14 * (size_t)S);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t r = 0; r < N; ++r) render_one_ray(f, rays + 8 * r, S, neg_ray, r, out, scratch);
+        free(scratch);
+    }
+    return 0;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* raw2outputs alone (BaseRender.py:75-107): raw [N,S,4], z [N,S], nvalid [N,S] (sum of view masks). */
+int oracle_composite(const float *raw, const float *z, const float *nvalid, int64_t N, int S, int neg,
+                     float *rgb, float *depth, float *acc, float *disp, float *weights, uint8_t *ray_mask) {
+    for (int64_t r = 0; r < N; ++r) {
+        float T = 1.f, c3[3] = {0, 0, 0}, d = 0.f, a = 0.f;
+        int n_two = 0;
+        for (int k = 0; k < S; ++k) {
+            int src = neg ? (S - 1 - k) : k;
+            const float *rw = raw + ((size_t)r * S + src) * 4;
+            float alpha = 1.f - expf(-rw[3]);
+            float w = alpha * T;
+            T = T * (1.f - alpha + 1e-10f);
+            for (int c = 0; c < 3; ++c) c3[c] += w * rw[c];
+            d += w * z[(size_t)r * S + k];
+            a += w;
+            if (weights) weights[(size_t)r * S + k] = w;
+            if (nvalid && nvalid[(size_t)r * S + k] > 1.f) ++n_two;
+        }
+        memcpy(rgb + 3 * r, c3, sizeof(c3));
+        depth[r] = d; acc[r] = a;
+        float q = d / a;
+        disp[r] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+        if (ray_mask) ray_mask[r] = (uint8_t)(n_two > 8);
+    }
+    return 0;
+}
+
+/* get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130).
+ * K,R row-major 3x3 fp32, T[3], bounds[2][3] world AABB (un-padded).
+ * Outputs sized H*W; returns the number of rays kept (raster order); mask[H*W]. */
+int64_t oracle_make_rays(int H, int W, const float *K, const float *R, const float *T, const float *bounds,
+                         float *ray_o, float *ray_d, float *near, float *far, uint8_t *mask) {
+    /* inverses in double, then the reference's float32 pipeline */
+    double Kd[9], Ki[9], Rd[9], Ri[9];
+    for (int i = 0; i < 9; ++i) { Kd[i] = K[i]; Rd[i] = R[i]; }
+#define INV3(A, B) do { \
+    double det = A[0]*(A[4]*A[8]-A[5]*A[7]) - A[1]*(A[3]*A[8]-A[5]*A[6]) + A[2]*(A[3]*A[7]-A[4]*A[6]); \
+    B[0]=(A[4]*A[8]-A[5]*A[7])/det; B[1]=(A[2]*A[7]-A[1]*A[8])/det; B[2]=(A[1]*A[5]-A[2]*A[4])/det; \
+    B[3]=(A[5]*A[6]-A[3]*A[8])/det; B[4]=(A[0]*A[8]-A[2]*A[6])/det; B[5]=(A[2]*A[3]-A[0]*A[5])/det; \
+    B[6]=(A[3]*A[7]-A[4]*A[6])/det; B[7]=(A[1]*A[6]-A[0]*A[7])/det; B[8]=(A[0]*A[4]-A[1]*A[3])/det; } while (0)
+    INV3(Kd, Ki);
+    INV3(Rd, Ri);
+    float Kif[9], Rif[9], o[3];
+    for (int i = 0; i < 9; ++i) { Kif[i] = (float)Ki[i]; Rif[i] = (float)Ri[i]; }
+    for (int i = 0; i < 3; ++i) o[i] = -(Rif[i * 3 + 0] * T[0] + Rif[i * 3 + 1] * T[1] + Rif[i * 3 + 2] * T[2]); /* :50-51 */
+    float bmin[3], bmax[3];
+    for (int i = 0; i < 3; ++i) { bmin[i] = (float)((double)bounds[i] - 0.01); bmax[i] = (float)((double)bounds[3 + i] + 0.01); } /* :98 */
+    const float eps = 1e-6f;
+    int64_t n = 0;
+    for (int j = 0; j < H; ++j)
+        for (int i = 0; i < W; ++i) {
+            float xy1[3] = {(float)i, (float)j, 1.f}, pc[3], pw[3], d[3];
+            for (int a = 0; a < 3; ++a) pc[a] = xy1[0] * Kif[a * 3 + 0] + xy1[1] * Kif[a * 3 + 1] + xy1[2] * Kif[a * 3 + 2]; /* xy1 @ K^-T :56-57 */
+            for (int a = 0; a < 3; ++a) pw[a] = pc[0] * Rif[a * 3 + 0] + pc[1] * Rif[a * 3 + 1] + pc[2] * Rif[a * 3 + 2] + o[a]; /* :58 */
+            for (int a = 0; a < 3; ++a) { d[a] = pw[a] - o[a]; if (fabsf(d[a]) < 1e-5f) d[a] = 1e-5f; }  /* :60, :101 */
+            float hit[6][3]; int ok[6], cnt = 0;
+            for (int s = 0; s < 2; ++s)
+                for (int a = 0; a < 3; ++a) {
+                    float bd = s ? bmax[a] : bmin[a];
+                    float tt = (bd - o[a]) / d[a];                                   /* :102 */
+                    int m = s * 3 + a;
+                    for (int c = 0; c < 3; ++c) hit[m][c] = tt * d[c] + o[c];        /* :104 */
+                    ok[m] = hit[m][0] >= bmin[0] - eps && hit[m][0] <= bmax[0] + eps && hit[m][1] >= bmin[1] - eps &&
+                            hit[m][1] <= bmax[1] + eps && hit[m][2] >= bmin[2] - eps && hit[m][2] <= bmax[2] + eps;
+                    cnt += ok[m];
+                }
+            int keep = (cnt == 2);                                                   /* :116 */
+            mask[(size_t)j * W + i] = (uint8_t)keep;
+            if (!keep) continue;
+            float *p0 = NULL, *p1 = NULL;
+            for (int m = 0; m < 6; ++m) if (ok[m]) { if (!p0) p0 = hit[m]; else p1 = hit[m]; }
+            float nd = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            float v0[3] = {p0[0] - o[0], p0[1] - o[1], p0[2] - o[2]}, v1[3] = {p1[0] - o[0], p1[1] - o[1], p1[2] - o[2]};
+            float sg = (v0[0] * d[0] + v0[1] * d[1] + v0[2] * d[2]) < 0.f ? -1.f : 1.f;   /* both use p0 :123,126 */
+            float d0 = sqrtf(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]) / nd * sg;
+            float d1 = sqrtf(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) / nd * sg;
+            for (int a = 0; a < 3; ++a) { ray_o[3 * n + a] = o[a]; ray_d[3 * n + a] = d[a]; }
+            near[n] = fminf(d0, d1); far[n] = fmaxf(d0, d1);
+            ++n;
+        }
+    return n;
+}

@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference.
+
+Runs only in the build container (needs /root/reference); the .npz files it
+writes are committed, this script is committed, nothing of the reference is.
+
+What executes here is the reference's own code:
+  * libs/renders/BaseRender.py  Renderer.render / batchify_rays / render_rays /
+    get_sampling_points / pts_to_can_pts / get_grid_coords / raw2outputs, Projector.*
+  * libs/nerfheads/trainhead.py NeRFHead.forward / NeRFSigmaHead.forward /
+    NeRFRGBHead.forward / fused_mean_variance
+  * libs/nerfheads/networks/SparseConvNet.py SparseConvNet.forward (the
+    F.grid_sample + cat + view lines :105-124)
+  * libs/datasets/data_utils.py get_rays / get_near_far
+
+What is NOT the reference: `spconv` (v1.2.1, not in the tree, not installed) is
+replaced by inert stand-ins so the modules import and construct; the sparse
+convolution stages are replaced by objects whose .dense() returns the synthetic
+dense volumes, i.e. the 4 feature levels are INPUTS of every vector here.  The
+encoder is likewise replaced by a module returning the synthetic featmaps.
+cv2/mcubes/trimesh are empty stubs (import-time only); np.int is aliased for
+numpy>=1.24.  Parity of the volume *builder* stays unpinned.
+
+Inputs are never stored: they are regenerated from (seed, config) by
+gp-nerf_amd/synthetic.py; each .npz carries a SHA-256 over the input bytes.
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def _install_stubs():
+    for name in ("mcubes", "trimesh", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sp = types.ModuleType("spconv")
+
+    class SparseSequential(nn.Sequential):
+        pass
+
+    class _InertConv(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    class SparseConvTensor:
+        def __init__(self, features, indices, spatial_shape, batch_size):
+            self.features, self.indices = features, indices
+            self.spatial_shape, self.batch_size = spatial_shape, batch_size
+
+    sp.SparseSequential = SparseSequential
+    sp.SubMConv3d = _InertConv
+    sp.SparseConv3d = _InertConv
+    sp.SparseConvTensor = SparseConvTensor
+    sys.modules["spconv"] = sp
+    if not hasattr(np, "int"):
+        np.int = int  # data_utils.py:123,126 predate numpy 1.24
+
+
+def _paths():
+    for sub in ("", "libs/datasets", "libs/encoders", "libs/nerfheads", "libs/renders"):
+        p = os.path.join(REF, sub)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+
+
+class _Dense:
+    def __init__(self, vol):
+        self.vol = vol
+
+    def dense(self):
+        return self.vol
+
+
+class _Level(nn.Module):
+    """Stands where a double_conv stage stood; hands back the synthetic level."""
+
+    def __init__(self, vol):
+        super().__init__()
+        self.vol = vol
+
+    def forward(self, x):
+        return _Dense(self.vol)
+
+
+class _Pass(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class _FixedEncoder(nn.Module):
+    def __init__(self, featmaps):
+        super().__init__()
+        self.featmaps = featmaps
+
+    def forward(self, x):
+        return self.featmaps
+
+
+def sha_inputs(scene):
+    h = hashlib.sha256()
+    for k in ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "feature", "bounds",
+              "out_sh", "Rh", "Th", "featmaps"):
+        h.update(np.ascontiguousarray(scene[k]).tobytes())
+    for v in scene["volumes"]:
+        h.update(np.ascontiguousarray(v).tobytes())
+    for k, v in scene["head"].items():
+        h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+def build_reference_renderer(scene, n_samples, neg_ray):
+    BaseRender = importlib.import_module("BaseRender")
+    trainhead = importlib.import_module("trainhead")
+    head = trainhead.NeRFHead(in_feat_ch=32, n_smpl=6890, code_dim=32, attn_n_heads=4,
+                              spconv_n_layers=4, spconv_out_dim=[32, 32, 32, 32], use_rgbhead=True)
+    sd = head.state_dict()
+    for k, v in scene["head"].items():
+        assert k in sd and tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v.copy())
+    head.load_state_dict(sd, strict=True)
+    vols = [torch.from_numpy(v) for v in scene["volumes"]]
+    net = [_Pass()]
+    for v in vols:
+        net += [_Pass(), _Level(v)]
+    head.sigmahead.xyzc_net.net = nn.ModuleList(net)
+    enc = _FixedEncoder(torch.from_numpy(scene["featmaps"]))
+    r = BaseRender.Renderer(enc, head, is_train=False, neg_ray_train=neg_ray, neg_ray_val=neg_ray,
+                            n_rays=1024, n_samples=n_samples,
+                            voxel_size=[float(x) for x in scene["voxel_size"]], chunk=400)
+    r.eval()
+    return r, BaseRender, trainhead
+
+
+def to_batch(scene):
+    keys = ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "target_K", "target_pose",
+            "feature", "coord", "out_sh", "bounds", "Rh", "R", "Th", "body_msk")
+    return {k: torch.from_numpy(np.ascontiguousarray(scene[k])) for k in keys}
+
+
+def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays=4, outputs_only=False):
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    scene = syn.make_scene(**scene_kw)
+    if stretch is not None:
+        # push samples outside the volume / the source images: zero-padding paths
+        mid = 0.5 * (scene["near"] + scene["far"])
+        half = 0.5 * (scene["far"] - scene["near"])
+        scene["near"] = (mid - stretch * half).astype(np.float32)
+        scene["far"] = (mid + stretch * half).astype(np.float32)
+    r, BaseRender, trainhead = build_reference_renderer(scene, n_samples, neg_ray)
+    batch = to_batch(scene)
+    with torch.no_grad():
+        ret = r.render(batch)
+    out = {
+        "rgb_map": ret["rgb_map"][0].numpy(),
+        "depth_map": ret["depth_map"][0, :, 0].numpy(),
+        "acc_map": ret["acc_map"][0, :, 0].numpy(),
+        "disp_map": ret["disp_map"][0, :, 0].numpy(),
+        "rgb_in_map": ret["rgb_in_map"][0].numpy(),
+    }
+    if not outputs_only:
+        out["weights"] = ret["alpha"][0].numpy()
+        out["z_vals"] = ret["z_vals"][0].numpy()
+        # stage-level vectors for the first few rays, through the reference's own functions
+        with torch.no_grad():
+            k = stages_rays
+            rays_o, rays_d = batch["ray_o"][:, :k], batch["ray_d"][:, :k]
+            pts, z = r.get_sampling_points(rays_o, rays_d, batch["near"][:, :k], batch["far"][:, :k])
+            pts_smpl = r.pts_to_can_pts(pts.float(), batch)
+            sp_input = r.prepare_sp_input(batch)
+            grid = r.get_grid_coords(pts_smpl, sp_input, batch).view(1, -1, 3)
+            src_imgs = batch["src_imgs"] * 0.5 + 0.5
+            V = 3
+            H, W = src_imgs.shape[-2:]
+            cams = torch.ones((1, V, 34))
+            cams[:, :, 0], cams[:, :, 1] = H, W
+            Kh = torch.eye(4)[None, None].repeat(1, V, 1, 1)
+            Kh[:, :, :3, :3] = batch["src_Ks"]
+            Ph = torch.eye(4)[None, None].repeat(1, V, 1, 1)
+            Ph[:, :, :3, :4] = batch["src_poses"]
+            cams[:, :, 2:18] = Kh.reshape(1, V, -1)
+            cams[:, :, -16:] = Ph.reshape(1, V, -1)
+            xyz = batch["feature"][..., :3]
+            smpl_xyz = torch.bmm(xyz, batch["Rh"].transpose(1, 2)) + batch["Th"]
+            proj = BaseRender.Projector("cpu", neg_ray=neg_ray)
+            rgb_feat, smpl_feat, mask = proj.compute(pts.squeeze(0), smpl_xyz, src_imgs, cams,
+                                                     featmaps=torch.from_numpy(scene["featmaps"]))
+            raw, rgb_in = r.nerfhead(sp_input, grid, smpl_feat, rgb_feat, mask)
+            pixel_mask = mask[..., 0].sum(dim=2) > 1
+            _, _, _, _, _, ray_mask, alpha = r.raw2outputs(raw, z.squeeze(0), pixel_mask, neg=neg_ray)
+            vol_feat = r.nerfhead.sigmahead.xyzc_net(None, grid[:, None, None].float())  # [1,128,P]
+        out.update({
+            "st_pts": pts[0].numpy(), "st_z": z[0].numpy(), "st_pts_smpl": pts_smpl[0].numpy(),
+            "st_grid": grid[0].numpy(), "st_rgb_feat": rgb_feat.numpy(), "st_mask": mask[..., 0].numpy(),
+            "st_raw": raw.numpy(), "st_rgb_in": rgb_in.numpy(), "st_vol_feat": vol_feat[0].t().contiguous().numpy(),
+            "st_ray_mask": ray_mask.numpy(), "st_alpha": alpha.numpy(),
+        })
+    meta = {"scene_kw": scene_kw, "n_samples": n_samples, "neg_ray": bool(neg_ray), "stretch": stretch,
+            "n_rays": int(scene["ray_o"].shape[1]), "sha256_inputs": sha_inputs(scene),
+            "torch": torch.__version__, "numpy": np.__version__}
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: N={meta['n_rays']} S={n_samples} rgb mean={out['rgb_map'].mean():.4f} "
+          f"acc mean={out['acc_map'].mean():.4f} depth mean={out['depth_map'].mean():.4f} -> {os.path.getsize(path)} B")
+
+
+def run_rays_case(name, H, W, seed):
+    """get_rays + get_near_far (data_utils.py:47-63,96-130) on a synthetic camera/box."""
+    du = importlib.import_module("data_utils")
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    sc = syn.make_scene(H=H, W=W, seed=seed, fill="survey", pose="random", make_volumes=False)
+    K = sc["target_K"][0]
+    R = sc["target_pose"][0][:, :3]
+    T = sc["target_pose"][0][:, 3]  # (3,) as ZjumocapDataset.py:410 passes it
+    ray_o, ray_d = du.get_rays(H, W, K, R, T)
+    ray_o = ray_o.reshape(-1, 3).astype(np.float32)
+    ray_d = ray_d.reshape(-1, 3).astype(np.float32)
+    near, far, mask_at_box = du.get_near_far(sc["can_bounds"][0], ray_o, ray_d)
+    out = {"K": K, "R": R, "T": T, "bounds": sc["can_bounds"][0], "H": np.int32(H), "W": np.int32(W),
+           "ray_o": ray_o[mask_at_box], "ray_d": ray_d[mask_at_box],
+           "near": near.astype(np.float32), "far": far.astype(np.float32), "mask_at_box": mask_at_box}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {int(mask_at_box.sum())}/{H*W} rays hit -> {os.path.getsize(path)} B")
+
+
+SMALL = dict(aabb_half=(0.12, 0.16, 0.05), voxel=0.005, bias_std=0.1, sigma_bias=0.0)
+
+CASES = [
+    # name, scene kwargs, S, extras
+    ("base_s32", dict(H=16, W=16, seed=1, fill="full", pose="random", **SMALL), 32, {}),
+    ("base_s64", dict(H=16, W=16, seed=2, fill="full", pose="random", **SMALL), 64, {}),
+    ("base_s8", dict(H=16, W=16, seed=3, fill="full", pose="identity", **SMALL), 8, {}),
+    ("neg_s32", dict(H=16, W=16, seed=4, fill="full", pose="random", neg_cams=True, **SMALL), 32,
+     dict(neg_ray=True)),
+    ("allmasked_s32", dict(H=8, W=8, seed=8, fill="full", pose="random", **SMALL), 32, dict(neg_ray=True)),
+    ("partial_s32", dict(H=32, W=32, seed=5, focal_mul=8.0, pose="random", **SMALL), 32, {}),
+    ("stretch_s32", dict(H=16, W=16, seed=6, fill="full", pose="random", **SMALL), 32, dict(stretch=2.5)),
+    ("wide_s16", dict(H=24, W=24, seed=7, focal_mul=0.6, pose="random", **SMALL), 16, {}),
+    ("config1_64x64_s32", dict(H=64, W=64, seed=0, fill="full", pose="identity",
+                               aabb_half=(0.25, 0.45, 0.125), voxel=0.005), 32, dict(outputs_only=True)),
+]
+
+
+def main():
+    _install_stubs()
+    _paths()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    only = set(sys.argv[1:])
+    for name, kw, S, extra in CASES:
+        if only and name not in only:
+            continue
+        run_case(name, kw, S, **extra)
+    if not only or "rays_48" in only:
+        run_rays_case("rays_48", 48, 48, 11)
+
+
+if __name__ == "__main__":
+    main()

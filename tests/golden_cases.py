@@ -1,0 +1,62 @@
+"""Rebuild the inputs of a golden vector from its (seed, config) metadata."""
+import glob
+import hashlib
+import importlib
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                  if not os.path.basename(p).startswith("rays_"))
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode()) if "meta_json" in z else {}
+    return z, meta
+
+
+def sha_inputs(scene):
+    h = hashlib.sha256()
+    for k in ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "feature", "bounds",
+              "out_sh", "Rh", "Th", "featmaps"):
+        h.update(np.ascontiguousarray(scene[k]).tobytes())
+    for v in scene["volumes"]:
+        h.update(np.ascontiguousarray(v).tobytes())
+    for k, v in scene["head"].items():
+        h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+def scene_of(meta):
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    kw = dict(meta["scene_kw"])
+    for k in ("aabb_half",):
+        if k in kw:
+            kw[k] = tuple(kw[k])
+    scene = syn.make_scene(**kw)
+    if meta.get("stretch") is not None:
+        s = meta["stretch"]
+        mid = 0.5 * (scene["near"] + scene["far"])
+        half = 0.5 * (scene["far"] - scene["near"])
+        scene["near"] = (mid - s * half).astype(np.float32)
+        scene["far"] = (mid + s * half).astype(np.float32)
+    return scene
+
+
+def assert_close(a, b, atol, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), f"{what}: NaN pattern differs ({na.sum()} vs {nb.sum()})"
+    ia, ib = np.isinf(a), np.isinf(b)
+    assert np.array_equal(ia, ib), f"{what}: inf pattern differs"
+    ok = ~(na | ia)
+    err = np.abs(a[ok].astype(np.float64) - b[ok].astype(np.float64)).max() if ok.any() else 0.0
+    assert err <= atol, f"{what}: max-abs {err:.3e} > {atol:.1e}"
+    return err

@@ -1,0 +1,56 @@
+"""CPU: the oracle (oracle/gpnerf_oracle.c) against every golden vector captured from the reference."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_cases import GOLDEN_DIR, assert_close, case_names, load, scene_of, sha_inputs
+
+# fp32 re-association only: the reference's own fp32-vs-fp64 spread is 6.5e-7
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_oracle_matches_reference_outputs(name, oracle):
+    z, meta = load(name)
+    scene = scene_of(meta)
+    assert sha_inputs(scene) == meta["sha256_inputs"], "synthetic inputs are not byte-identical to the golden run"
+    S = meta["n_samples"]
+    stages = "st_raw" in z
+    res = oracle.render(scene, S, neg_ray=meta["neg_ray"], stages=stages)
+    assert_close(res["rgb_map"], z["rgb_map"], TOL, "rgb_map")
+    assert_close(res["depth_map"], z["depth_map"], TOL, "depth_map")
+    assert_close(res["acc_map"], z["acc_map"], TOL, "acc_map")
+    assert_close(res["rgb_in_map"], z["rgb_in_map"], TOL, "rgb_in_map")
+    # disp = 1/max(1e-10, depth/acc); NaN pattern (acc == 0) must agree
+    assert_close(res["disp_map"], z["disp_map"], 1e-4, "disp_map")
+    if "weights" in z:
+        assert_close(res["weights"], z["weights"], TOL, "weights")
+        assert_close(res["z_vals"], z["z_vals"], 1e-6, "z_vals")
+    if stages:
+        k = z["st_raw"].shape[0]
+        assert_close(res["st_grid"][:k].reshape(-1, 3), z["st_grid"], 2e-5, "grid_coords")
+        assert_close(res["st_vol_feat"][:k].reshape(-1, 128), z["st_vol_feat"], 2e-4, "volume features")
+        assert_close(res["st_rgb_feat"][:k], z["st_rgb_feat"], 2e-4, "rgb_feat")
+        assert np.array_equal(res["st_mask"][:k], z["st_mask"]), "view masks"
+        assert_close(res["st_raw"][:k], z["st_raw"], TOL, "raw")
+        assert np.array_equal(res["ray_mask"][:k].astype(bool), z["st_ray_mask"]), "ray mask"
+
+
+def test_oracle_rays_match_reference(oracle):
+    z = np.load(os.path.join(GOLDEN_DIR, "rays_48.npz"))
+    ro, rd, near, far, mask = oracle.make_rays(int(z["H"]), int(z["W"]), z["K"], z["R"], z["T"], z["bounds"])
+    assert np.array_equal(mask, z["mask_at_box"])
+    assert_close(ro, z["ray_o"], 1e-6, "ray_o")
+    assert_close(rd, z["ray_d"], 1e-6, "ray_d")
+    assert_close(near, z["near"], 1e-5, "near")
+    assert_close(far, z["far"], 1e-5, "far")
+
+
+def test_synthetic_rays_agree_with_oracle(oracle, syn):
+    sc = syn.make_scene(H=40, W=40, seed=3, focal_mul=6.0, pose="random", aabb_half=(0.12, 0.16, 0.05), make_volumes=False)
+    K, P = sc["target_K"][0], sc["target_pose"][0]
+    ro, rd, near, far, mask = oracle.make_rays(40, 40, K, P[:, :3], P[:, 3], sc["can_bounds"][0])
+    assert np.array_equal(mask, sc["mask_at_box"][0])
+    assert_close(near, sc["near"][0], 1e-5, "near")
+    assert_close(far, sc["far"][0], 1e-5, "far")
