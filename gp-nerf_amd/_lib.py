@@ -1,0 +1,104 @@
+"""ctypes binding of include/gpnerf_hip.h.
+
+The shared library is built in-tree (gp-nerf_amd/csrc/libgpnerf_hip.so) by
+``__graft_entry__.build()`` / ``make -C gp-nerf_amd/csrc``.  There is NO fallback: if the
+library is missing or fails to load, every entry point raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libgpnerf_hip.so")
+
+VIEWS, CH, LEVELS = 3, 32, 4
+FP = C.POINTER(C.c_float)
+U8P = C.POINTER(C.c_uint8)
+
+
+class GpnerfFrame(C.Structure):
+    _fields_ = [
+        ("vol", C.c_void_p * LEVELS),
+        ("vol_dhw", (C.c_int32 * 3) * LEVELS),
+        ("featmaps", C.c_void_p),
+        ("feat_h", C.c_int32), ("feat_w", C.c_int32),
+        ("imgs", C.c_void_p),
+        ("img_h", C.c_int32), ("img_w", C.c_int32),
+        ("proj", (C.c_float * 12) * VIEWS),
+        ("Rh", C.c_float * 9), ("Th", C.c_float * 3),
+        ("bounds_min", C.c_float * 3), ("voxel", C.c_float * 3),
+        ("out_sh", C.c_int32 * 3),
+        ("head_blob", C.c_void_p),
+    ]
+
+
+HEAD_FIELDS = [
+    ("geo", "sigmahead.out_geometry_fc.0"), ("b1", "rgbhead.base_fc.0"), ("b2", "rgbhead.base_fc.2"),
+    ("v1", "rgbhead.vis_fc.0"), ("v2", "rgbhead.vis_fc.2"), ("r1", "rgbhead.rgb_fc.0"),
+    ("r2", "rgbhead.rgb_fc.2"), ("r3", "rgbhead.rgb_fc.4"), ("d1", "rgbhead.out_geometry_fc.0"),
+    ("d2", "rgbhead.out_geometry_fc.2"), ("d3", "rgbhead.out_geometry_fc.4"), ("d4", "rgbhead.out_geometry_fc.6"),
+]
+HEAD_SHAPES = {
+    "geo": (64, 128), "b1": (64, 105), "b2": (32, 64), "v1": (32, 32), "v2": (32, 32), "r1": (32, 96),
+    "r2": (16, 32), "r3": (3, 16), "d1": (64, 134), "d2": (32, 64), "d3": (16, 32), "d4": (1, 16),
+}
+
+
+class GpnerfHeadParams(C.Structure):
+    _fields_ = [f for s, _ in HEAD_FIELDS for f in ((s + "_w", FP), (s + "_b", FP))]
+
+
+class GpnerfOutputs(C.Structure):
+    _fields_ = [
+        ("rgb", C.c_void_p), ("depth", C.c_void_p), ("acc", C.c_void_p), ("disp", C.c_void_p),
+        ("weights", C.c_void_p), ("z_vals", C.c_void_p), ("rgb_in", C.c_void_p), ("ray_mask", C.c_void_p),
+        ("raw", C.c_void_p),
+    ]
+
+
+FLAG_NEG_RAY = 1
+FLAG_EARLY_TERM = 2
+
+# every symbol include/gpnerf_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "gpnerf_head_blob_floats": (C.c_int64, []),
+    "gpnerf_pack_head": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
+    "gpnerf_render_fused": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float,
+                                      C.POINTER(GpnerfOutputs), C.c_void_p]),
+    "gpnerf_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gpnerf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                   C.POINTER(GpnerfOutputs), C.c_void_p]),
+    "gpnerf_make_rays": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_relayout_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gpnerf_relayout_featmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gpnerf_relayout_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gpnerf_strerror": (C.c_char_p, [C.c_int]),
+    "gpnerf_rays_per_tile": (C.c_int32, []),
+    "gpnerf_build_info": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class GpnerfError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library; fails loudly when it is absent (no CPU / PyTorch fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpnerfError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gp-nerf_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the ABI and the header drift apart
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise GpnerfError(f"{what} failed: {lib().gpnerf_strerror(code).decode()} ({code})")

@@ -1,0 +1,829 @@
+// gpnerf_kernels.hip -- gfx950 (MI355X) kernels and C ABI of GP-NeRF's per-ray render path.
+//
+// One wavefront renders a tile of 32 rays: ray = lane & 31, the two lane-halves split the K
+// dimension of every dense layer (v_mfma_f32_32x32x2_f32 takes k = lane >> 5).  The wave walks the
+// samples of its rays front to back; per step it gathers the features of 32 samples (one per ray),
+// runs the whole density/colour MLP on the matrix cores with activations kept in registers
+// (see head_layout.h), and folds the result into per-lane compositing state -- so the
+// transmittance "scan" of the reference's cumprod is a plain per-lane running product and
+// early ray termination is one __all() per step.
+//
+// Reference semantics (paths relative to the reference root) are cited at each step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/gpnerf_hip.h"
+#include "head_layout.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define DEV __device__ __forceinline__
+
+namespace {
+
+constexpr int NV = GPNERF_VIEWS;
+constexpr int RAYS_PER_WAVE = 32;
+constexpr float LOG2E = 1.44269504088896340736f;
+
+DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }       // v_exp_f32
+DEV float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }             // nn.ELU(alpha=1)
+
+// ---------------------------------------------------------------------------------------------
+// dense layers on v_mfma_f32_32x32x2_f32
+// ---------------------------------------------------------------------------------------------
+// One 32-row output tile: acc += W_tile * B.  `w` points at the tile's LDS image
+// [NT/4][64 lanes][4 k-steps] (+ [64][2] tail when NT % 4 == 2); b[t] is this lane's B value of k-step t.
+template <int NT>
+DEV void mfma_tile(const float* __restrict__ w, int lane, const float (&b)[NT], f32x16& acc) {
+    constexpr int NG = NT / 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + (g * 64 + lane) * 4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * g + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[4 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[4 * g + 3], acc, 0, 0, 0);
+    }
+    if constexpr (NT % 4 == 2) {
+        const f32x2 a = *reinterpret_cast<const f32x2*>(w + NG * 256 + lane * 2);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * NG + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * NG + 1], acc, 0, 0, 0);
+    }
+}
+
+// accumulator initialised with the bias of tile m of layer L (image: [half][16 regs])
+template <int L>
+DEV f32x16 bias_tile(const float* __restrict__ lds, int m, int half) {
+    const float* p = lds + gpl::b_off(L) + m * 32 + half * 16;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+        acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+    }
+    return acc;
+}
+
+template <int L>
+DEV const float* wtile(const float* lds, int m) { return lds + gpl::w_off(L) + m * gpl::NT[L] * 64; }
+
+// sigma feature: Linear(128,64)+ELU on the volume features (trainhead.py:39-40,58), 32 samples.
+//   fv[64] : this half's 16 channels of each of the 4 volume levels (k-step t: level t>>4, channel 16h+(t&15))
+//   sf[32] : the 64 output features as two accumulator tiles (B-operand order of the density layer)
+DEV void geo_eval(const float* __restrict__ lds, int lane, const float (&fv)[64], float (&sf)[32]) {
+    // The weights are loop-invariant across samples; without this the compiler hoists every LDS weight
+    // read out of the sample loop and spills ~140 KB of them to scratch.  Launder the lane id so the
+    // reads depend on a value the optimiser cannot see through.
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    f32x16 g0 = bias_tile<gpl::GEO>(lds, 0, half), g1 = bias_tile<gpl::GEO>(lds, 1, half);
+    mfma_tile<64>(wtile<gpl::GEO>(lds, 0), lane, fv, g0);
+    mfma_tile<64>(wtile<gpl::GEO>(lds, 1), lane, fv, g1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sf[r] = elu1(g0[r]); sf[16 + r] = elu1(g1[r]); }
+}
+
+// The rest of NeRFHead.forward (libs/nerfheads/trainhead.py:118-145,159-163) for 32 samples.
+//   x[v][18]: this half's slots of [rgb(3), feat(32)] of view v (gpl::idx35)
+//   nvalid : number of valid views of this lane's sample
+// returns sigma and rgb (identical in both halves of a ray).
+DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
+                  float nvalid, float& sigma, float (&rgb)[3]) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    float d1in[68];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) d1in[r] = sf[r];
+
+    // ---- cross-view mean / variance (fused_mean_variance, trainhead.py:20-24): all 3 views, unmasked ----
+    float mv[36];
+#pragma unroll
+    for (int t = 0; t < 18; ++t) {
+        const float m = ((x[0][t] + x[1][t]) + x[2][t]) * (1.f / 3.f);
+        const float a = x[0][t] - m, b = x[1][t] - m, c = x[2][t] - m;
+        mv[t] = m;
+        mv[18 + t] = ((a * a + b * b) + c * c) * (1.f / 3.f);
+    }
+#pragma unroll
+    for (int t = 0; t < 36; ++t) d1in[32 + t] = mv[t];
+
+    // ---- density branch 134 -> 64 -> 32 -> 16 -> 1 (trainhead.py:102-110,133-137) ----
+    {
+        f32x16 a0 = bias_tile<gpl::D1>(lds, 0, half), a1 = bias_tile<gpl::D1>(lds, 1, half);
+        mfma_tile<68>(wtile<gpl::D1>(lds, 0), lane, d1in, a0);
+        mfma_tile<68>(wtile<gpl::D1>(lds, 1), lane, d1in, a1);
+        float h1[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { h1[r] = elu1(a0[r]); h1[16 + r] = elu1(a1[r]); }
+        f32x16 a2 = bias_tile<gpl::D2>(lds, 0, half);
+        mfma_tile<32>(wtile<gpl::D2>(lds, 0), lane, h1, a2);
+        float h2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[r] = elu1(a2[r]);
+        f32x16 a3 = bias_tile<gpl::D3>(lds, 0, half);
+        mfma_tile<16>(wtile<gpl::D3>(lds, 0), lane, h2, a3);
+        // 16 -> 1 on the VALU: this half holds features ft(r,h), r < 8
+        const float* w4 = lds + gpl::D4_W + half * 8;
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part = fmaf(w4[r], elu1(a3[r]), part);
+        float s = part + __shfl_xor(part, 32) + lds[gpl::D4_B];
+        s = fmaxf(s, 0.f);                              // nn.ReLU
+        sigma = (nvalid < 1.f) ? 0.f : s;               // masked_fill(num_valid_obs < 1, 0)
+    }
+
+    // ---- colour branch (trainhead.py:85-100,131,139-143) ----
+    // base_fc layer 1 on [mean, var, x_v]: the [mean, var] part is view-independent, computed once
+    f32x16 s0 = bias_tile<gpl::BS>(lds, 0, half), s1 = bias_tile<gpl::BS>(lds, 1, half);
+    mfma_tile<36>(wtile<gpl::BS>(lds, 0), lane, mv, s0);
+    mfma_tile<36>(wtile<gpl::BS>(lds, 1), lane, mv, s1);
+    float y[48];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        f32x16 a0 = s0, a1 = s1;
+        mfma_tile<18>(wtile<gpl::BV>(lds, 0), lane, x[v], a0);
+        mfma_tile<18>(wtile<gpl::BV>(lds, 1), lane, x[v], a1);
+        float h1[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { h1[r] = elu1(a0[r]); h1[16 + r] = elu1(a1[r]); }
+        f32x16 a2 = bias_tile<gpl::B2>(lds, 0, half);
+        mfma_tile<32>(wtile<gpl::B2>(lds, 0), lane, h1, a2);
+        float xb[16], xs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xb[r] = elu1(a2[r]); xs[r] = xb[r] * (1.f / 3.f); }   // x * 1.0 / num_views
+        f32x16 t1 = bias_tile<gpl::V1>(lds, 0, half);
+        mfma_tile<16>(wtile<gpl::V1>(lds, 0), lane, xs, t1);
+        float u1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u1[r] = elu1(t1[r]);
+        f32x16 t2 = bias_tile<gpl::V2>(lds, 0, half);
+        mfma_tile<16>(wtile<gpl::V2>(lds, 0), lane, u1, t2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * v + r] = xb[r] + elu1(t2[r]);                  // x = x + x_vis
+    }
+    {
+        f32x16 c1 = bias_tile<gpl::R1>(lds, 0, half);
+        mfma_tile<48>(wtile<gpl::R1>(lds, 0), lane, y, c1);
+        float h1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[r] = elu1(c1[r]);
+        f32x16 c2 = bias_tile<gpl::R2>(lds, 0, half);
+        mfma_tile<16>(wtile<gpl::R2>(lds, 0), lane, h1, c2);
+        float e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) e[r] = elu1(c2[r]);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float* w3 = lds + gpl::R3_W + o * 16 + half * 8;
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) part = fmaf(w3[r], e[r], part);
+            const float s = part + __shfl_xor(part, 32) + lds[gpl::R3_B + o];
+            rgb[o] = 1.f / (1.f + fast_exp(-s));        // .sigmoid()
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// feature gathers (channels-last sources)
+// ---------------------------------------------------------------------------------------------
+struct Axis {
+    int i0, i1;     // clamped tap indices
+    float w0, w1;   // weights, zeroed for out-of-range taps (padding_mode='zeros')
+};
+
+// F.grid_sample coordinate handling, align_corners=True: index = ((g + 1) / 2) * (size - 1)
+DEV Axis axis_taps(float g, int size) {
+    const float sm1 = (float)(size - 1);
+    const float ix = ((g + 1.f) * 0.5f) * sm1;
+    const float f0 = floorf(ix), f1 = f0 + 1.f;
+    const float t = ix - f0;
+    const bool v0 = (f0 >= 0.f) && (f0 <= sm1);          // false for NaN / +-huge
+    const bool v1 = (f1 >= 0.f) && (f1 <= sm1);
+    Axis a;
+    a.i0 = v0 ? (int)f0 : 0;
+    a.i1 = v1 ? (int)f1 : 0;
+    a.w0 = v0 ? 1.f - t : 0.f;
+    a.w1 = v1 ? t : 0.f;
+    return a;
+}
+
+DEV void fma16(const float* __restrict__ p, float w, float* f) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(p);
+    const f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    f[0] = fmaf(a[0], w, f[0]);   f[1] = fmaf(a[1], w, f[1]);   f[2] = fmaf(a[2], w, f[2]);   f[3] = fmaf(a[3], w, f[3]);
+    f[4] = fmaf(b[0], w, f[4]);   f[5] = fmaf(b[1], w, f[5]);   f[6] = fmaf(b[2], w, f[6]);   f[7] = fmaf(b[3], w, f[7]);
+    f[8] = fmaf(c[0], w, f[8]);   f[9] = fmaf(c[1], w, f[9]);   f[10] = fmaf(c[2], w, f[10]); f[11] = fmaf(c[3], w, f[11]);
+    f[12] = fmaf(d[0], w, f[12]); f[13] = fmaf(d[1], w, f[13]); f[14] = fmaf(d[2], w, f[14]); f[15] = fmaf(d[3], w, f[15]);
+}
+
+// trilinear sample of one level [D][H][W][32] at normalised (gx,gy,gz) -> this half's 16 channels
+// (libs/nerfheads/networks/SparseConvNet.py:113-116)
+DEV void gather_volume(const float* __restrict__ vol, int D, int H, int W, float gx, float gy, float gz, int half,
+                       float* f) {
+    const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) f[c] = 0.f;
+    const int ch = half * 16;
+    const int zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1}, xi[2] = {ax.i0, ax.i1};
+    const float zw[2] = {az.w0, az.w1}, yw[2] = {ay.w0, ay.w1}, xw[2] = {ax.w0, ax.w1};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float w = (xw[e] * yw[b]) * zw[a];
+                const int off = ((zi[a] * H + yi[b]) * W + xi[e]) * 32 + ch;
+                fma16(vol + off, w, f);
+            }
+}
+
+struct ViewSample {
+    float rgb[3];
+    float valid;
+};
+
+// Projector.compute for one view (libs/renders/BaseRender.py:301-324,296-299,283-294,352-362):
+// project p, bilinear RGB from imgs[v] (NHWC4) and 16 feature channels from featmaps[v] (NHWC32).
+DEV ViewSample gather_view(const float* __restrict__ M, const float* __restrict__ img, int ih, int iw,
+                           const float* __restrict__ fm, int fh, int fw, float px, float py, float pz, bool neg,
+                           int half, float* f) {
+    const float hx = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3];
+    const float hy = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7];
+    const float hz = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11];
+    float u = hx / hz, w = hy / hz;
+    u = fminf(fmaxf(u, -1e6f), 1e6f);        // torch.clamp; a NaN lands out of bounds here as it does there
+    w = fminf(fmaxf(w, -1e6f), 1e6f);
+    const bool front = neg ? (hz < 0.f) : (hz > 0.f);
+    const float wm1 = (float)iw - 1.f, hm1 = (float)ih - 1.f;
+    const bool inb = (u <= wm1) && (u >= 0.f) && (w <= hm1) && (w >= 0.f);
+    const float nx = 2.f * u / wm1 - 1.f, ny = 2.f * w / hm1 - 1.f;
+    ViewSample s;
+    s.valid = (front && inb) ? 1.f : 0.f;
+    {   // RGB from the full-resolution image
+        const Axis ax = axis_taps(nx, iw), ay = axis_taps(ny, ih);
+        const f32x4 nw = *reinterpret_cast<const f32x4*>(img + (ay.i0 * iw + ax.i0) * 4);
+        const f32x4 ne = *reinterpret_cast<const f32x4*>(img + (ay.i0 * iw + ax.i1) * 4);
+        const f32x4 sw = *reinterpret_cast<const f32x4*>(img + (ay.i1 * iw + ax.i0) * 4);
+        const f32x4 se = *reinterpret_cast<const f32x4*>(img + (ay.i1 * iw + ax.i1) * 4);
+        const float wnw = ax.w0 * ay.w0, wne = ax.w1 * ay.w0, wsw = ax.w0 * ay.w1, wse = ax.w1 * ay.w1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.rgb[c] = fmaf(se[c], wse, fmaf(sw[c], wsw, fmaf(ne[c], wne, nw[c] * wnw)));
+    }
+    {   // features from the quarter-resolution map, same normalised coordinates
+        const Axis ax = axis_taps(nx, fw), ay = axis_taps(ny, fh);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) f[c] = 0.f;
+        const int ch = half * 16;
+        fma16(fm + (ay.i0 * fw + ax.i0) * 32 + ch, ax.w0 * ay.w0, f);
+        fma16(fm + (ay.i0 * fw + ax.i1) * 32 + ch, ax.w1 * ay.w0, f);
+        fma16(fm + (ay.i1 * fw + ax.i0) * 32 + ch, ax.w0 * ay.w1, f);
+        fma16(fm + (ay.i1 * fw + ax.i1) * 32 + ch, ax.w1 * ay.w1, f);
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the fused kernel
+// ---------------------------------------------------------------------------------------------
+struct FrameK {           // GpnerfFrame by value (kernel argument; lands in SGPRs / scalar loads)
+    const float* vol[GPNERF_LEVELS];
+    int vol_dhw[GPNERF_LEVELS][3];
+    const float* featmaps;
+    int feat_h, feat_w;
+    const float* imgs;
+    int img_h, img_w;
+    float proj[NV][12];
+    float Rh[9], Th[3], bounds_min[3], voxel[3];
+    float out_sh[3];      // as float
+    const float* head_blob;
+};
+
+struct OutK {
+    float *rgb, *depth, *acc, *disp, *weights, *z_vals, *rgb_in, *raw;
+    uint8_t* ray_mask;
+};
+
+// bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
+// contiguous run of tiles so neighbouring ray tiles hit the same L2 (speed only, never correctness)
+DEV int xcd_remap(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// torch.linspace(0,1,S)[k] as the CPU kernel evaluates it (one rounding per element; see oracle)
+DEV float linspace01(int k, int S, float step) {
+    return (k < (S >> 1)) ? step * (float)k : fmaf(-step, (float)(S - 1 - k), 1.f);
+}
+
+template <int NWAVES>
+__global__ void __launch_bounds__(NWAVES * 64, NWAVES / 4)
+render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
+                    const unsigned flags, const float term_eps, const OutK out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(fr.head_blob);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < gpl::BLOB_FLOATS / 4; i += NWAVES * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, half = lane >> 5;
+    const long tile = (long)xcd_remap(blockIdx.x, gridDim.x) * NWAVES + wave;
+    const long ray0 = tile * RAYS_PER_WAVE;
+    if (ray0 >= n_rays) return;
+    const bool active = (ray0 + n) < n_rays;
+    const long ray = active ? ray0 + n : n_rays - 1;
+    const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;
+    const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
+
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rays + ray * 8);
+    const f32x4 r1 = *reinterpret_cast<const f32x4*>(rays + ray * 8 + 4);
+    const float ox = r0[0], oy = r0[1], oz = r0[2], dx = r0[3], dy = r1[0], dz = r1[1], near = r1[2], far = r1[3];
+
+    float T = 1.f, c_r = 0.f, c_g = 0.f, c_b = 0.f, depth = 0.f, acc = 0.f;
+    float rin[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rin[i] = 0.f;
+    int n_two = 0;
+    const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
+    const bool writer = active && (half == 0);
+
+    int k = 0;
+    for (; k < S; ++k) {
+        // raw2outputs(neg=True) flips rgb and sigma along the ray but not z (BaseRender.py:86-88,101):
+        // composite step k consumes the network output of sample S-1-k.
+        const int ks = neg ? (S - 1 - k) : k;
+        // get_sampling_points (BaseRender.py:37-38,48), jitter off
+        const float t = (S > 1) ? linspace01(ks, S, step) : 0.f;
+        const float z = near * (1.f - t) + far * t;
+        const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
+
+        // pts_to_can_pts (:52-60): (p - Th) @ Rh ; get_grid_coords (:62-73), dhw arithmetic, xyz result
+        const float qx0 = px - fr.Th[0], qy0 = py - fr.Th[1], qz0 = pz - fr.Th[2];
+        const float qx = (qx0 * fr.Rh[0] + qy0 * fr.Rh[3]) + qz0 * fr.Rh[6];
+        const float qy = (qx0 * fr.Rh[1] + qy0 * fr.Rh[4]) + qz0 * fr.Rh[7];
+        const float qz = (qx0 * fr.Rh[2] + qy0 * fr.Rh[5]) + qz0 * fr.Rh[8];
+        const float gx = ((qx - fr.bounds_min[0]) / fr.voxel[2]) / fr.out_sh[2] * 2.f - 1.f;
+        const float gy = ((qy - fr.bounds_min[1]) / fr.voxel[1]) / fr.out_sh[1] * 2.f - 1.f;
+        const float gz = ((qz - fr.bounds_min[2]) / fr.voxel[0]) / fr.out_sh[0] * 2.f - 1.f;
+
+        // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
+        float fv[64];
+#pragma unroll
+        for (int l = 0; l < GPNERF_LEVELS; ++l)
+            gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
+        float sf[32];
+        geo_eval(lds, lane, fv, sf);
+
+        // Projector.compute (:326-363)
+        float x[NV][18];
+        float nvalid = 0.f;
+        float vrgb[NV][3];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const ViewSample s = gather_view(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
+                                             fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
+                                             px, py, pz, neg, half, x[v]);
+            x[v][16] = half ? s.rgb[1] : s.rgb[0];
+            x[v][17] = half ? 0.f : s.rgb[2];
+            vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
+            nvalid += s.valid;
+        }
+        if (nvalid > 1.f) ++n_two;                      // pixel_mask (:139)
+
+        float sigma, rgb[3];
+        mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb);
+
+        if (out.raw && writer) {
+            f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
+            *reinterpret_cast<f32x4*>(out.raw + ((size_t)ray * S + ks) * 4) = rw;
+        }
+
+        // rgb_in_map (:147) pairs weight k with the UN-flipped rgb_in of sample k
+        float irgb[NV][3];
+        float zk = z;
+        if (neg) {
+            const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
+            zk = near * (1.f - tk) + far * tk;
+            const float ax_ = ox + dx * zk, ay_ = oy + dy * zk, az_ = oz + dz * zk;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float dump[16];
+                const ViewSample s2 = gather_view(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
+                                                  fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
+                                                  ax_, ay_, az_, neg, half, dump);
+                irgb[v][0] = s2.rgb[0]; irgb[v][1] = s2.rgb[1]; irgb[v][2] = s2.rgb[2];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { irgb[v][0] = vrgb[v][0]; irgb[v][1] = vrgb[v][1]; irgb[v][2] = vrgb[v][2]; }
+        }
+
+        // raw2outputs (:90-104): alpha = 1 - exp(-sigma); T = cumprod(1 - alpha + 1e-10) exclusive
+        const float alpha = 1.f - fast_exp(-sigma);
+        const float wgt = alpha * T;
+        T = T * ((1.f - alpha) + 1e-10f);
+        c_r = fmaf(wgt, rgb[0], c_r); c_g = fmaf(wgt, rgb[1], c_g); c_b = fmaf(wgt, rgb[2], c_b);
+        depth = fmaf(wgt, zk, depth);
+        acc += wgt;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            rin[3 * v + 0] = fmaf(wgt, irgb[v][0], rin[3 * v + 0]);
+            rin[3 * v + 1] = fmaf(wgt, irgb[v][1], rin[3 * v + 1]);
+            rin[3 * v + 2] = fmaf(wgt, irgb[v][2], rin[3 * v + 2]);
+        }
+        if (writer) {
+            if (out.weights) out.weights[(size_t)ray * S + k] = wgt;
+            if (out.z_vals) out.z_vals[(size_t)ray * S + k] = zk;
+        }
+        // wavefront-level early termination (not in the reference): every ray of the tile is opaque
+        if (early && __all(T < term_eps)) { ++k; break; }
+    }
+    if (writer) {
+        // samples skipped by early termination carry weight 0
+        for (; k < S; ++k) {
+            if (out.weights) out.weights[(size_t)ray * S + k] = 0.f;
+            if (out.z_vals) {
+                const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
+                out.z_vals[(size_t)ray * S + k] = near * (1.f - tk) + far * tk;
+            }
+        }
+        out.rgb[ray * 3 + 0] = c_r; out.rgb[ray * 3 + 1] = c_g; out.rgb[ray * 3 + 2] = c_b;
+        out.depth[ray] = depth;
+        out.acc[ray] = acc;
+        const float q = depth / acc;                    // 1 / max(1e-10, depth / acc); torch.max keeps NaN
+        out.disp[ray] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+        if (out.rgb_in) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) out.rgb_in[ray * 9 + i] = rin[i];
+        }
+        if (out.ray_mask) out.ray_mask[ray] = (uint8_t)(n_two > 8);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NeRFHead.forward on pre-gathered features
+// ---------------------------------------------------------------------------------------------
+template <int NWAVES>
+__global__ void __launch_bounds__(NWAVES * 64, NWAVES / 4)
+head_forward_kernel(const float* __restrict__ blob, const float* __restrict__ vol_feat, const float* __restrict__ rgb_feat,
+                    const float* __restrict__ mask, const long P, float* __restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(blob);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < gpl::BLOB_FLOATS / 4; i += NWAVES * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
+    const long ntile = (P + 31) / 32;
+    for (long tile = (long)blockIdx.x * NWAVES + wave; tile < ntile; tile += (long)gridDim.x * NWAVES) {
+        const bool active = tile * 32 + n < P;
+        const long p = active ? tile * 32 + n : P - 1;
+        float fv[64];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) fv[16 * l + c] = vol_feat[p * 128 + 32 * l + 16 * half + c];
+        float x[NV][18];
+        float nvalid = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float* xv = rgb_feat + (p * NV + v) * 35;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[v][c] = xv[3 + 16 * half + c];
+            x[v][16] = half ? xv[1] : xv[0];
+            x[v][17] = half ? 0.f : xv[2];
+            nvalid += mask[p * NV + v];
+        }
+        float sf[32];
+        geo_eval(lds, lane, fv, sf);
+        float sigma, rgb[3];
+        mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb);
+        if (active && half == 0) {
+            f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
+            *reinterpret_cast<f32x4*>(raw + p * 4) = rw;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// raw2outputs alone (BaseRender.py:75-107): one lane per ray, sequential product over samples
+// ---------------------------------------------------------------------------------------------
+__global__ void composite_kernel(const float* __restrict__ raw, const float* __restrict__ zv, const float* __restrict__ nvalid,
+                                 const long N, const int S, const int neg, const OutK out) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, d = 0.f, a = 0.f;
+    int n_two = 0;
+    for (int k = 0; k < S; ++k) {
+        const int ks = neg ? (S - 1 - k) : k;
+        const f32x4 rw = *reinterpret_cast<const f32x4*>(raw + ((size_t)r * S + ks) * 4);
+        const float alpha = 1.f - fast_exp(-rw[3]);
+        const float w = alpha * T;
+        T = T * ((1.f - alpha) + 1e-10f);
+        cr = fmaf(w, rw[0], cr); cg = fmaf(w, rw[1], cg); cb = fmaf(w, rw[2], cb);
+        d = fmaf(w, zv[(size_t)r * S + k], d);
+        a += w;
+        if (out.weights) out.weights[(size_t)r * S + k] = w;
+        if (nvalid && nvalid[(size_t)r * S + k] > 1.f) ++n_two;
+    }
+    out.rgb[r * 3 + 0] = cr; out.rgb[r * 3 + 1] = cg; out.rgb[r * 3 + 2] = cb;
+    out.depth[r] = d; out.acc[r] = a;
+    const float q = d / a;
+    out.disp[r] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+    if (out.ray_mask) out.ray_mask[r] = (uint8_t)(n_two > 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130), one lane per pixel
+// ---------------------------------------------------------------------------------------------
+struct RayCam { float Kinv[9], Rinv[9], o[3], bmin[3], bmax[3]; };
+
+__global__ void make_rays_kernel(const int H, const int W, const RayCam cam, float* __restrict__ rays, uint8_t* __restrict__ hit) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const float i = (float)(idx % W), j = (float)(idx / W);
+    float pc[3], d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pc[a] = (i * cam.Kinv[a * 3 + 0] + j * cam.Kinv[a * 3 + 1]) + cam.Kinv[a * 3 + 2];   // xy1 @ K^-T
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float pw = ((pc[0] * cam.Rinv[a * 3 + 0] + pc[1] * cam.Rinv[a * 3 + 1]) + pc[2] * cam.Rinv[a * 3 + 2]) + cam.o[a];
+        float da = pw - cam.o[a];
+        if (fabsf(da) < 1e-5f) da = 1e-5f;            // ray_d[np.abs(ray_d) < 1e-5] = 1e-5 (:101)
+        d[a] = da;
+    }
+    const float eps = 1e-6f;
+    float p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {                     // order: min_x,min_y,min_z,max_x,max_y,max_z (:99-103)
+        const int a = m % 3;
+        const float bd = (m < 3) ? cam.bmin[a] : cam.bmax[a];
+        const float tt = (bd - cam.o[a]) / d[a];
+        const float hx = tt * d[0] + cam.o[0], hy = tt * d[1] + cam.o[1], hz = tt * d[2] + cam.o[2];
+        const bool ok = hx >= cam.bmin[0] - eps && hx <= cam.bmax[0] + eps && hy >= cam.bmin[1] - eps &&
+                        hy <= cam.bmax[1] + eps && hz >= cam.bmin[2] - eps && hz <= cam.bmax[2] + eps;
+        if (ok) {
+            if (cnt == 0) { p0[0] = hx; p0[1] = hy; p0[2] = hz; }
+            else if (cnt == 1) { p1[0] = hx; p1[1] = hy; p1[2] = hz; }
+            ++cnt;
+        }
+    }
+    const bool keep = (cnt == 2);
+    hit[idx] = (uint8_t)keep;
+    float near = 0.f, far = 0.f;
+    if (keep) {
+        const float nd = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        const float v0x = p0[0] - cam.o[0], v0y = p0[1] - cam.o[1], v0z = p0[2] - cam.o[2];
+        const float v1x = p1[0] - cam.o[0], v1y = p1[1] - cam.o[1], v1z = p1[2] - cam.o[2];
+        const float sg = ((v0x * d[0] + v0y * d[1]) + v0z * d[2]) < 0.f ? -1.f : 1.f;     // both from p0 (:123,126)
+        const float d0 = sqrtf((v0x * v0x + v0y * v0y) + v0z * v0z) / nd * sg;
+        const float d1 = sqrtf((v1x * v1x + v1y * v1y) + v1z * v1z) / nd * sg;
+        near = fminf(d0, d1); far = fmaxf(d0, d1);
+    }
+    f32x4 a, b;
+    a[0] = cam.o[0]; a[1] = cam.o[1]; a[2] = cam.o[2]; a[3] = d[0];
+    b[0] = d[1]; b[1] = d[2]; b[2] = near; b[3] = far;
+    *reinterpret_cast<f32x4*>(rays + (size_t)idx * 8) = a;
+    *reinterpret_cast<f32x4*>(rays + (size_t)idx * 8 + 4) = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// channels-last re-layouts: [C=32][P] -> [P][32] through a padded LDS tile (coalesced both ways)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cfirst_to_clast32_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                const long P, const long src_img_stride,
+                                                                const long dst_img_stride) {
+    __shared__ float tile[32][65];
+    const float* s = src + (size_t)blockIdx.y * src_img_stride;
+    float* d = dst + (size_t)blockIdx.y * dst_img_stride;
+    const long p0 = (long)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+#pragma unroll
+    for (int c = ty; c < 32; c += 4) {
+        const long p = p0 + tx;
+        tile[c][tx] = (p < P) ? s[(size_t)c * P + p] : 0.f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;       // 32 x 8
+#pragma unroll
+    for (int pp = q; pp < 64; pp += 8) {
+        const long p = p0 + pp;
+        if (p < P) d[(size_t)p * 32 + c] = tile[c][pp];
+    }
+}
+
+__global__ void images_to_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, const long HW, const int V) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW * V) return;
+    const long v = i / HW, p = i % HW;
+    const float* s = src + (size_t)v * 3 * HW + p;
+    f32x4 o;
+    o[0] = s[0] * 0.5f + 0.5f; o[1] = s[HW] * 0.5f + 0.5f; o[2] = s[2 * HW] * 0.5f + 0.5f; o[3] = 0.f;   // BaseRender.py:231
+    *reinterpret_cast<f32x4*>(dst + (size_t)i * 4) = o;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+namespace {
+constexpr int FUSED_WAVES = 8;
+
+int col_ok(int c, int n_in) { return c >= 0 && c < n_in; }
+
+void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, float* blob) {
+    for (int m = 0; m < gpl::MT[L]; ++m) {
+        float* wt = blob + gpl::w_off(L) + m * gpl::NT[L] * 64;
+        const int NT = gpl::NT[L], NG = NT / 4;
+        for (int t = 0; t < NT; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = 32 * m + (lane & 31), h = lane >> 5;
+                const int c = gpl::col_of(L, t, h);
+                const float v = (row < n_out && col_ok(c, n_in)) ? W[(size_t)row * n_in + c] : 0.f;
+                const int g = t / 4;
+                if (g < NG) wt[(g * 64 + lane) * 4 + (t & 3)] = v;
+                else wt[NG * 256 + lane * 2 + (t - 4 * NG)] = v;
+            }
+        float* bt = blob + gpl::b_off(L) + m * 32;
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + gpl::ft(r, h);
+                bt[h * 16 + r] = (b && row < n_out) ? b[row] : 0.f;
+            }
+    }
+}
+
+hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int launch_status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
+
+OutK to_outk(const GpnerfOutputs* o) {
+    OutK k;
+    k.rgb = o->rgb; k.depth = o->depth; k.acc = o->acc; k.disp = o->disp; k.weights = o->weights;
+    k.z_vals = o->z_vals; k.rgb_in = o->rgb_in; k.raw = o->raw; k.ray_mask = o->ray_mask;
+    return k;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t gpnerf_head_blob_floats(void) { return gpl::BLOB_FLOATS; }
+int32_t gpnerf_rays_per_tile(void) { return RAYS_PER_WAVE; }
+const char* gpnerf_build_info(void) { return "gpnerf-hip gfx950 fp32-mfma32x32x2 waves=8"; }
+
+const char* gpnerf_strerror(int code) {
+    switch (code) {
+        case GPNERF_OK: return "ok";
+        case GPNERF_E_ARG: return "invalid argument";
+        case GPNERF_E_LAUNCH: return "kernel launch failed";
+        case GPNERF_E_DEVICE: return "no usable gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+int gpnerf_pack_head(const GpnerfHeadParams* p, float* blob) {
+    if (!p || !blob) return GPNERF_E_ARG;
+    const float* const* all = reinterpret_cast<const float* const*>(p);
+    for (size_t i = 0; i < sizeof(GpnerfHeadParams) / sizeof(float*); ++i)
+        if (!all[i]) return GPNERF_E_ARG;
+    memset(blob, 0, sizeof(float) * gpl::BLOB_FLOATS);
+    pack_layer(gpl::GEO, p->geo_w, p->geo_b, 64, 128, blob);
+    pack_layer(gpl::D1, p->d1_w, p->d1_b, 64, 134, blob);
+    pack_layer(gpl::D2, p->d2_w, p->d2_b, 32, 64, blob);
+    pack_layer(gpl::D3, p->d3_w, p->d3_b, 16, 32, blob);
+    pack_layer(gpl::BS, p->b1_w, p->b1_b, 64, 105, blob);     // [mean,var] columns + the layer's bias
+    pack_layer(gpl::BV, p->b1_w, nullptr, 64, 105, blob);     // per-view columns, accumulates onto BS
+    pack_layer(gpl::B2, p->b2_w, p->b2_b, 32, 64, blob);
+    pack_layer(gpl::V1, p->v1_w, p->v1_b, 32, 32, blob);
+    pack_layer(gpl::V2, p->v2_w, p->v2_b, 32, 32, blob);
+    pack_layer(gpl::R1, p->r1_w, p->r1_b, 32, 96, blob);
+    pack_layer(gpl::R2, p->r2_w, p->r2_b, 16, 32, blob);
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 8; ++r) {
+            blob[gpl::D4_W + h * 8 + r] = p->d4_w[gpl::ft(r, h)];
+            for (int o = 0; o < 3; ++o) blob[gpl::R3_W + o * 16 + h * 8 + r] = p->r3_w[o * 16 + gpl::ft(r, h)];
+        }
+    blob[gpl::D4_B] = p->d4_b[0];
+    for (int o = 0; o < 3; ++o) blob[gpl::R3_B + o] = p->r3_b[o];
+    return GPNERF_OK;
+}
+
+int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, uint32_t flags,
+                        float term_eps, const GpnerfOutputs* out, void* stream) {
+    if (n_rays == 0) return GPNERF_OK;          // empty ray list: nothing to do (pointers may be null)
+    if (!f || !rays || !out || n_rays < 0 || n_samples < 1) return GPNERF_E_ARG;
+    if (!out->rgb || !out->depth || !out->acc || !out->disp || !f->head_blob || !f->featmaps || !f->imgs)
+        return GPNERF_E_ARG;
+    for (int l = 0; l < GPNERF_LEVELS; ++l)
+        if (!f->vol[l] || f->vol_dhw[l][0] < 1 || f->vol_dhw[l][1] < 1 || f->vol_dhw[l][2] < 1) return GPNERF_E_ARG;
+    if (n_rays == 0) return GPNERF_OK;
+    FrameK k;
+    for (int l = 0; l < GPNERF_LEVELS; ++l) {
+        k.vol[l] = f->vol[l];
+        for (int a = 0; a < 3; ++a) k.vol_dhw[l][a] = f->vol_dhw[l][a];
+    }
+    k.featmaps = f->featmaps; k.feat_h = f->feat_h; k.feat_w = f->feat_w;
+    k.imgs = f->imgs; k.img_h = f->img_h; k.img_w = f->img_w;
+    memcpy(k.proj, f->proj, sizeof(k.proj));
+    memcpy(k.Rh, f->Rh, sizeof(k.Rh));
+    memcpy(k.Th, f->Th, sizeof(k.Th));
+    memcpy(k.bounds_min, f->bounds_min, sizeof(k.bounds_min));
+    memcpy(k.voxel, f->voxel, sizeof(k.voxel));
+    for (int a = 0; a < 3; ++a) k.out_sh[a] = (float)f->out_sh[a];
+    k.head_blob = f->head_blob;
+    const int64_t tiles = (n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+    const int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
+    const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<FUSED_WAVES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return GPNERF_E_DEVICE;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(render_fused_kernel<FUSED_WAVES>, dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
+                       k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out));
+    return launch_status();
+}
+
+int gpnerf_head_forward(const float* head_blob, const float* vol_feat, const float* rgb_feat, const float* mask,
+                        int64_t n_points, float* raw, void* stream) {
+    if (n_points == 0) return GPNERF_OK;
+    if (!head_blob || !vol_feat || !rgb_feat || !mask || !raw || n_points < 0) return GPNERF_E_ARG;
+    const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return GPNERF_E_DEVICE;
+        attr_set = true;
+    }
+    const int64_t tiles = (n_points + 31) / 32;
+    int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(head_forward_kernel<FUSED_WAVES>, dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
+                       head_blob, vol_feat, rgb_feat, mask, (long)n_points, raw);
+    return launch_status();
+}
+
+int gpnerf_composite(const float* raw, const float* z_vals, const float* nvalid, int64_t n_rays, int32_t n_samples,
+                     int32_t neg, const GpnerfOutputs* out, void* stream) {
+    if (n_rays == 0) return GPNERF_OK;
+    if (!raw || !z_vals || !out || !out->rgb || !out->depth || !out->acc || !out->disp || n_rays < 0 || n_samples < 1)
+        return GPNERF_E_ARG;
+    const int bs = 64;
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n_rays + bs - 1) / bs)), dim3(bs), 0, S_(stream), raw, z_vals, nvalid,
+                       (long)n_rays, (int)n_samples, (int)neg, to_outk(out));
+    return launch_status();
+}
+
+int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o, const float* bounds,
+                     float* rays, uint8_t* hit, void* stream) {
+    if (!Kinv || !Rinv || !cam_o || !bounds || !rays || !hit || H < 1 || W < 1) return GPNERF_E_ARG;
+    RayCam c;
+    memcpy(c.Kinv, Kinv, sizeof(c.Kinv));
+    memcpy(c.Rinv, Rinv, sizeof(c.Rinv));
+    memcpy(c.o, cam_o, sizeof(c.o));
+    for (int a = 0; a < 3; ++a) {   // bounds + [-0.01, 0.01] (data_utils.py:98)
+        c.bmin[a] = (float)((double)bounds[a] - 0.01);
+        c.bmax[a] = (float)((double)bounds[3 + a] + 0.01);
+    }
+    const int n = H * W, bs = 256;
+    hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, rays, hit);
+    return launch_status();
+}
+
+int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t H, int32_t W, void* stream) {
+    if (!ncdhw || !ndhwc || D < 1 || H < 1 || W < 1) return GPNERF_E_ARG;
+    const long P = (long)D * H * W;
+    hipLaunchKernelGGL(cfirst_to_clast32_kernel, dim3((unsigned)((P + 63) / 64), 1), dim3(256), 0, S_(stream), ncdhw, ndhwc, P,
+                       0L, 0L);
+    return launch_status();
+}
+
+int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t H, int32_t W, void* stream) {
+    if (!nchw || !nhwc || V < 1 || H < 1 || W < 1) return GPNERF_E_ARG;
+    const long P = (long)H * W;
+    hipLaunchKernelGGL(cfirst_to_clast32_kernel, dim3((unsigned)((P + 63) / 64), (unsigned)V), dim3(256), 0, S_(stream), nchw,
+                       nhwc, P, 32 * P, 32 * P);
+    return launch_status();
+}
+
+int gpnerf_relayout_images(const float* nchw, float* nhwc4, int32_t V, int32_t H, int32_t W, void* stream) {
+    if (!nchw || !nhwc4 || V < 1 || H < 1 || W < 1) return GPNERF_E_ARG;
+    const long HW = (long)H * W, n = HW * V;
+    hipLaunchKernelGGL(images_to_nhwc4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), nchw, nhwc4, HW, (int)V);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// head_layout.h -- the LDS image of the per-ray MLP ("head blob"), shared by the host
+// packer (gpnerf_pack_head) and the device kernels.
+//
+// The MLP runs transposed on v_mfma_f32_32x32x2_f32:  H_out[feat][ray] = W[feat][in] * H_in[in][ray].
+//   A operand = weights   (lane l supplies W[row = l&31][k = k_of(step, l>>5)])
+//   B operand = activations, one VGPR per k-step (lane l supplies H_in[k_of(step, l>>5)][ray = l&31])
+//   C/D       = 32 features x 32 rays, feature f held by (reg r, half h) with f = (r&3) + 8*(r>>2) + 4*h
+// Because the accumulator already has "ray on the lane, features in registers", the output tile of
+// one layer IS the B operand of the next: k-step t of a tile-sourced input consumes register t of both
+// halves, i.e. features ft(t,0) and ft(t,1).  The weight columns are permuted at pack time to match,
+// so activations never leave the register file.
+#pragma once
+
+namespace gpl {
+
+constexpr int GEO = 0, D1 = 1, D2 = 2, D3 = 3, BS = 4, BV = 5, B2 = 6, V1 = 7, V2 = 8, R1 = 9, R2 = 10, NLAYER = 11;
+// k-steps (K/2, K padded to even) and 32-row output tiles of each MFMA layer
+//                              GEO  D1  D2  D3  BS  BV  B2  V1  V2  R1  R2
+constexpr int NT[NLAYER] = {64, 68, 32, 16, 36, 18, 32, 16, 16, 48, 16};
+constexpr int MT[NLAYER] = {2, 2, 1, 1, 2, 2, 1, 1, 1, 1, 1};
+
+constexpr int w_off(int l) {
+    int o = 0;
+    for (int j = 0; j < l; ++j) o += NT[j] * MT[j] * 64;
+    return o;
+}
+constexpr int W_TOTAL = w_off(NLAYER);
+constexpr int b_off(int l) {
+    int o = W_TOTAL;
+    for (int j = 0; j < l; ++j) o += MT[j] * 32;
+    return o;
+}
+constexpr int B_END = b_off(NLAYER);
+// VALU tails: density 16->1 and colour 16->3, weights as [out][half][8], then biases
+constexpr int D4_W = B_END;         // 16 floats
+constexpr int D4_B = D4_W + 16;     // 1 (+3 pad)
+constexpr int R3_W = D4_B + 4;      // 48 floats
+constexpr int R3_B = R3_W + 48;     // 3 (+1 pad)
+constexpr int BLOB_FLOATS = R3_B + 4;
+static_assert(BLOB_FLOATS % 4 == 0, "blob is copied as float4");
+static_assert(BLOB_FLOATS * 4 <= 160 * 1024, "head image must fit the 160 KiB LDS of one CU");
+
+// feature index held by accumulator register r of lane-half h (32x32 C/D layout)
+constexpr int ft(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// index into the reference's 35-vector [r,g,b, feat0..31] of slot t (0..17) of half h; -1 = zero pad
+constexpr int idx35(int t, int h) {
+    return t < 16 ? 3 + 16 * h + t : (t == 16 ? (h == 0 ? 0 : 1) : (h == 0 ? 2 : -1));
+}
+
+// PyTorch weight column consumed by k-step t, lane-half h of layer l (-1: zero)
+constexpr int col_of(int l, int t, int h) {
+    switch (l) {
+        case GEO: return 32 * (t >> 4) + 16 * h + (t & 15);                       // [level][channel]
+        case D1:  return t < 32 ? 32 * (t >> 4) + ft(t & 15, h)
+                       : (t < 50 ? (idx35(t - 32, h) < 0 ? -1 : 64 + idx35(t - 32, h))
+                                 : (idx35(t - 50, h) < 0 ? -1 : 99 + idx35(t - 50, h)));
+        case BS:  return t < 18 ? (idx35(t, h) < 0 ? -1 : idx35(t, h))
+                                : (idx35(t - 18, h) < 0 ? -1 : 35 + idx35(t - 18, h));
+        case BV:  return idx35(t, h) < 0 ? -1 : 70 + idx35(t, h);
+        case D2: case B2: case R1: return 32 * (t >> 4) + ft(t & 15, h);
+        default:  return ft(t, h);                                                  // D3 V1 V2 R2
+    }
+}
+
+}  // namespace gpl

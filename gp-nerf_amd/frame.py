@@ -1,0 +1,220 @@
+"""Per-frame constants and the Python face of the fused render entry point.
+
+torch is used for device memory and streams only; all arithmetic of the path runs in
+the HIP library (include/gpnerf_hip.h).  Nothing here falls back to PyTorch ops.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise L.GpnerfError(f"{what} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+
+
+def pack_head(state, device):
+    """Pack the per-ray MLP parameters into the kernel's LDS image (gpnerf_pack_head).
+
+    ``state`` maps reference parameter names (relative to ``nerfhead.``, e.g.
+    ``rgbhead.base_fc.0.weight``) to tensors / arrays.  Returns a float32 device tensor.
+    """
+    lib = L.lib()
+    params = L.GpnerfHeadParams()
+    keep = []
+    for short, name in L.HEAD_FIELDS:
+        for suffix, field in (("weight", "_w"), ("bias", "_b")):
+            v = state[f"{name}.{suffix}"]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            want = L.HEAD_SHAPES[short] if suffix == "weight" else (L.HEAD_SHAPES[short][0],)
+            if tuple(a.shape) != want:
+                raise L.GpnerfError(f"{name}.{suffix}: shape {a.shape}, expected {want}")
+            keep.append(a)
+            setattr(params, short + field, a.ctypes.data_as(L.FP))
+    n = int(lib.gpnerf_head_blob_floats())
+    blob = np.zeros(n, np.float32)
+    L.check(lib.gpnerf_pack_head(C.byref(params), blob.ctypes.data_as(L.FP)), "gpnerf_pack_head")
+    return torch.from_numpy(blob).to(device)
+
+
+class Frame:
+    """Everything render_rays reads that does not depend on the ray (BaseRender.py:110-157),
+    re-laid out channels-last on the device.  Built once per target view."""
+
+    def __init__(self, src_imgs, featmaps, volumes, src_Ks, src_poses, Rh, Th, bounds_min, voxel_size, out_sh,
+                 head_blob):
+        """
+        src_imgs   [V,3,H,W] in [-1,1] (batch['src_imgs'][0]); de-normalised here (BaseRender.py:231)
+        featmaps   [V,32,h,w]           encoder output (BaseRender.py:222)
+        volumes    4 x [1,32,D,H,W] or [32,D,H,W]   dense levels (SparseConvNet.py:111)
+        src_Ks [V,3,3], src_poses [V,3,4], Rh [3,3], Th [1,3] or [3], bounds_min [3] (xyz), voxel_size [3], out_sh [3] (dhw)
+        head_blob  device tensor from pack_head()
+        """
+        lib = L.lib()
+        dev = src_imgs.device
+        for t, w in ((src_imgs, "src_imgs"), (featmaps, "featmaps"), (head_blob, "head_blob")):
+            _require_gpu(t, w)
+        if src_imgs.shape[0] != L.VIEWS or featmaps.shape[0] != L.VIEWS or featmaps.shape[1] != L.CH:
+            raise L.GpnerfError(f"the kernels are built for V={L.VIEWS} views x {L.CH} channels "
+                                f"(rgb_fc's 96 inputs hard-wire it: trainhead.py:96,143); got {tuple(src_imgs.shape)}, {tuple(featmaps.shape)}")
+        if len(volumes) != L.LEVELS:
+            raise L.GpnerfError(f"expected {L.LEVELS} volume levels, got {len(volumes)}")
+        st = _stream_ptr(dev)
+        self.device = dev
+        f = L.GpnerfFrame()
+        V, _, H, W = src_imgs.shape
+        src = src_imgs.contiguous().float()
+        self.imgs = torch.empty((V, H, W, 4), device=dev, dtype=torch.float32)
+        L.check(lib.gpnerf_relayout_images(src.data_ptr(), self.imgs.data_ptr(), V, H, W, st), "gpnerf_relayout_images")
+        fm = featmaps.contiguous().float()
+        fh, fw = fm.shape[-2:]
+        self.featmaps = torch.empty((V, fh, fw, L.CH), device=dev, dtype=torch.float32)
+        L.check(lib.gpnerf_relayout_featmaps(fm.data_ptr(), self.featmaps.data_ptr(), V, fh, fw, st), "gpnerf_relayout_featmaps")
+        self.vols = []
+        keep = [src, fm]
+        for l, v in enumerate(volumes):
+            _require_gpu(v, f"volumes[{l}]")
+            v = v.reshape(v.shape[-4:]).contiguous().float()
+            if v.shape[0] != L.CH:
+                raise L.GpnerfError(f"volume level {l}: {v.shape[0]} channels, expected {L.CH}")
+            D, Hh, Ww = v.shape[1:]
+            o = torch.empty((D, Hh, Ww, L.CH), device=dev, dtype=torch.float32)
+            L.check(lib.gpnerf_relayout_volume(v.data_ptr(), o.data_ptr(), D, Hh, Ww, st), "gpnerf_relayout_volume")
+            self.vols.append(o)
+            keep.append(v)
+            f.vol[l] = o.data_ptr()
+            f.vol_dhw[l][0], f.vol_dhw[l][1], f.vol_dhw[l][2] = D, Hh, Ww
+        self._keep = keep  # sources stay alive until the re-layout kernels have run (stream order)
+        f.featmaps, f.feat_h, f.feat_w = self.featmaps.data_ptr(), fh, fw
+        f.imgs, f.img_h, f.img_w = self.imgs.data_ptr(), H, W
+        # K4 @ P4 in fp32, as train_intrinsics.bmm(train_poses) does (BaseRender.py:233-247,314)
+        K4 = torch.eye(4, dtype=torch.float32).repeat(V, 1, 1)
+        K4[:, :3, :3] = src_Ks.detach().float().cpu()
+        P4 = torch.eye(4, dtype=torch.float32).repeat(V, 1, 1)
+        P4[:, :3, :4] = src_poses.detach().float().cpu()
+        M = torch.bmm(K4, P4).numpy()
+        for v in range(V):
+            for i in range(12):
+                f.proj[v][i] = float(M[v].ravel()[i])
+
+        def flat(x, n):
+            a = x.detach().float().cpu().numpy().ravel() if isinstance(x, torch.Tensor) else np.asarray(x, np.float32).ravel()
+            assert a.size == n, (a.shape, n)
+            return a
+
+        for i, v in enumerate(flat(Rh, 9)):
+            f.Rh[i] = float(v)
+        for i, v in enumerate(flat(Th, 3)):
+            f.Th[i] = float(v)
+        for i, v in enumerate(flat(bounds_min, 3)):
+            f.bounds_min[i] = float(v)
+        for i, v in enumerate(flat(voxel_size, 3)):
+            f.voxel[i] = float(np.float32(v))
+        osh = out_sh.detach().cpu().numpy().ravel() if isinstance(out_sh, torch.Tensor) else np.asarray(out_sh).ravel()
+        for i in range(3):
+            f.out_sh[i] = int(osh[i])
+        self.head_blob = head_blob
+        f.head_blob = head_blob.data_ptr()
+        self.c = f
+
+    @classmethod
+    def from_batch(cls, batch, featmaps, volumes, voxel_size, head_blob):
+        """batch: the reference's batch dict (leading dim 1) with device tensors."""
+        return cls(batch["src_imgs"][0], featmaps, volumes, batch["src_Ks"][0], batch["src_poses"][0], batch["Rh"][0],
+                   batch["Th"][0], batch["bounds"][0, 0], voxel_size, batch["out_sh"][0], head_blob)
+
+
+def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
+                 want=("weights", "z_vals", "rgb_in", "ray_mask")):
+    """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...]."""
+    lib = L.lib()
+    _require_gpu(rays, "rays")
+    rays = rays.contiguous().float()
+    N, S = rays.shape[0], int(n_samples)
+    dev = rays.device
+    res = {
+        "rgb_map": torch.empty((N, 3), device=dev), "depth_map": torch.empty((N,), device=dev),
+        "acc_map": torch.empty((N,), device=dev), "disp_map": torch.empty((N,), device=dev),
+    }
+    o = L.GpnerfOutputs()
+    o.rgb, o.depth, o.acc, o.disp = (res[k].data_ptr() for k in ("rgb_map", "depth_map", "acc_map", "disp_map"))
+    if "weights" in want:
+        res["weights"] = torch.empty((N, S), device=dev)
+        o.weights = res["weights"].data_ptr()
+    if "z_vals" in want:
+        res["z_vals"] = torch.empty((N, S), device=dev)
+        o.z_vals = res["z_vals"].data_ptr()
+    if "rgb_in" in want:
+        res["rgb_in_map"] = torch.empty((N, 9), device=dev)
+        o.rgb_in = res["rgb_in_map"].data_ptr()
+    if "ray_mask" in want:
+        res["ray_mask"] = torch.empty((N,), device=dev, dtype=torch.uint8)
+        o.ray_mask = res["ray_mask"].data_ptr()
+    if "raw" in want:
+        res["raw"] = torch.empty((N, S, 4), device=dev)
+        o.raw = res["raw"].data_ptr()
+    flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
+    L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), N, S, flags, float(term_eps), C.byref(o),
+                                    _stream_ptr(dev)), "gpnerf_render_fused")
+    return res
+
+
+def head_forward(head_blob, vol_feat, rgb_feat, mask):
+    """gpnerf_head_forward: vol_feat [P,128], rgb_feat [P,V,35], mask [P,V] -> raw [P,4]."""
+    lib = L.lib()
+    for t, w in ((vol_feat, "vol_feat"), (rgb_feat, "rgb_feat"), (mask, "mask")):
+        _require_gpu(t, w)
+    vol_feat, rgb_feat, mask = vol_feat.contiguous().float(), rgb_feat.contiguous().float(), mask.contiguous().float()
+    P = vol_feat.shape[0]
+    raw = torch.empty((P, 4), device=vol_feat.device)
+    L.check(lib.gpnerf_head_forward(head_blob.data_ptr(), vol_feat.data_ptr(), rgb_feat.data_ptr(), mask.data_ptr(), P,
+                                    raw.data_ptr(), _stream_ptr(vol_feat.device)), "gpnerf_head_forward")
+    return raw
+
+
+def composite(raw, z_vals, nvalid=None, neg=False):
+    """gpnerf_composite: Renderer.raw2outputs (BaseRender.py:75-107)."""
+    lib = L.lib()
+    _require_gpu(raw, "raw")
+    raw, z_vals = raw.contiguous().float(), z_vals.contiguous().float()
+    N, S = z_vals.shape
+    dev = raw.device
+    res = {"rgb_map": torch.empty((N, 3), device=dev), "depth_map": torch.empty((N,), device=dev),
+           "acc_map": torch.empty((N,), device=dev), "disp_map": torch.empty((N,), device=dev),
+           "weights": torch.empty((N, S), device=dev), "ray_mask": torch.zeros((N,), device=dev, dtype=torch.uint8)}
+    o = L.GpnerfOutputs()
+    o.rgb, o.depth, o.acc, o.disp = (res[k].data_ptr() for k in ("rgb_map", "depth_map", "acc_map", "disp_map"))
+    o.weights, o.ray_mask = res["weights"].data_ptr(), res["ray_mask"].data_ptr()
+    nv = nvalid.contiguous().float() if nvalid is not None else None
+    L.check(lib.gpnerf_composite(raw.data_ptr(), z_vals.data_ptr(), nv.data_ptr() if nv is not None else None, N, S,
+                                 int(bool(neg)), C.byref(o), _stream_ptr(dev)), "gpnerf_composite")
+    return res
+
+
+def make_rays(H, W, K, R, T, bounds, device):
+    """gpnerf_make_rays: get_rays + get_near_far (data_utils.py:47-63,96-130) on the device.
+
+    Returns (rays [n,8] packed in raster order of the hit pixels, mask_at_box [H*W] bool)."""
+    lib = L.lib()
+    K = np.asarray(K, np.float32)
+    R = np.asarray(R, np.float32)
+    T = np.asarray(T, np.float32).ravel()
+    Kinv = np.ascontiguousarray(np.linalg.inv(K).astype(np.float32))
+    Rinv = np.ascontiguousarray(np.linalg.inv(R).astype(np.float32))
+    o = np.ascontiguousarray((-(Rinv @ T)).astype(np.float32))
+    b = np.ascontiguousarray(np.asarray(bounds, np.float32))
+    rays = torch.empty((H * W, 8), device=device)
+    hit = torch.empty((H * W,), device=device, dtype=torch.uint8)
+    L.check(lib.gpnerf_make_rays(H, W, Kinv.ctypes.data_as(L.FP), Rinv.ctypes.data_as(L.FP), o.ctypes.data_as(L.FP),
+                                 b.ctypes.data_as(L.FP), rays.data_ptr(), hit.data_ptr(), _stream_ptr(rays.device)),
+            "gpnerf_make_rays")
+    mask = hit.bool()
+    return rays[mask], mask

@@ -1,0 +1,148 @@
+/*
+ * gpnerf_hip.h -- C ABI of the MI355X (gfx950) per-ray render path of GP-NeRF.
+ *
+ * This is the drop-in boundary for the reference's per-ray hot path
+ * (libs/renders + libs/nerfheads).  The reference is pure Python: there is no
+ * existing FFI; each entry point below names the reference function(s) it
+ * replaces (paths relative to the reference root).  The library is loaded with
+ * ctypes.CDLL by gp-nerf_amd/_lib.py; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer marked "device" is HBM memory owned by the caller and only
+ *     borrowed for the call; "host" pointers are ordinary CPU memory;
+ *   - entry points never allocate, never synchronise and never throw; kernels are
+ *     enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *   - return value: 0 on success, a negative GPNERF_E_* code otherwise;
+ *     gpnerf_strerror() gives the text;
+ *   - all arithmetic is fp32 (the reference's dtype); V = 3 source views and
+ *     C = 32 feature channels are compiled in (rgb_fc's 96 = 3*32 inputs hard-wire
+ *     them in the reference too: libs/nerfheads/trainhead.py:96,143).
+ */
+#ifndef GPNERF_HIP_H
+#define GPNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPNERF_VIEWS 3
+#define GPNERF_CH 32
+#define GPNERF_LEVELS 4
+
+#define GPNERF_OK 0
+#define GPNERF_E_ARG (-1)      /* null pointer / bad size */
+#define GPNERF_E_LAUNCH (-2)   /* hipLaunchKernel failed; see hipGetLastError */
+#define GPNERF_E_DEVICE (-3)   /* not a gfx950 device / no device */
+
+/* flags of gpnerf_render_fused */
+#define GPNERF_FLAG_NEG_RAY 1u     /* Projector(neg_ray=True) + raw2outputs(neg=True): BaseRender.py:86-88,317-320 */
+#define GPNERF_FLAG_EARLY_TERM 2u  /* stop a 32-ray wave tile once every ray has T < term_eps (not in the reference) */
+
+/* Per-frame constants (everything render_rays reads that does not depend on the ray).
+ * Layouts are channels-last so that one bilinear / trilinear tap is one contiguous
+ * 128-byte line; gpnerf_relayout_* produce them from the reference's NCHW tensors. */
+typedef struct GpnerfFrame {
+    const float* vol[GPNERF_LEVELS];        /* device; level k: [D_k][H_k][W_k][32]; SparseConvNet.py:111 `.dense()` */
+    int32_t vol_dhw[GPNERF_LEVELS][3];
+    const float* featmaps;                  /* device; [V][fh][fw][32]; encoder output, BaseRender.py:222 */
+    int32_t feat_h, feat_w;
+    const float* imgs;                      /* device; [V][H][W][4] = r,g,b,0 in [0,1]; BaseRender.py:231 */
+    int32_t img_h, img_w;
+    float proj[GPNERF_VIEWS][12];           /* rows 0..2 of K4 @ P4, row-major 3x4; BaseRender.py:233-247,314 */
+    float Rh[9];                            /* batch['Rh'][0], row-major; BaseRender.py:52-60 */
+    float Th[3];
+    float bounds_min[3];                    /* batch['bounds'][0,0], SMPL-frame xyz; BaseRender.py:65 */
+    float voxel[3];                         /* cfg.dataset.voxel_size (applied in d,h,w order); BaseRender.py:67 */
+    int32_t out_sh[3];                      /* batch['out_sh'] d,h,w; BaseRender.py:69-70 */
+    const float* head_blob;                 /* device; gpnerf_pack_head() image, gpnerf_head_blob_floats() floats */
+} GpnerfFrame;
+
+/* The per-ray MLP parameters in PyTorch layout (weight [out][in] row-major, bias [out]),
+ * host memory.  Names follow the reference state_dict. */
+typedef struct GpnerfHeadParams {
+    const float *geo_w, *geo_b;   /* sigmahead.out_geometry_fc.0  64x128 */
+    const float *b1_w, *b1_b;     /* rgbhead.base_fc.0            64x105 */
+    const float *b2_w, *b2_b;     /* rgbhead.base_fc.2            32x64  */
+    const float *v1_w, *v1_b;     /* rgbhead.vis_fc.0             32x32  */
+    const float *v2_w, *v2_b;     /* rgbhead.vis_fc.2             32x32  */
+    const float *r1_w, *r1_b;     /* rgbhead.rgb_fc.0             32x96  */
+    const float *r2_w, *r2_b;     /* rgbhead.rgb_fc.2             16x32  */
+    const float *r3_w, *r3_b;     /* rgbhead.rgb_fc.4              3x16  */
+    const float *d1_w, *d1_b;     /* rgbhead.out_geometry_fc.0    64x134 */
+    const float *d2_w, *d2_b;     /* rgbhead.out_geometry_fc.2    32x64  */
+    const float *d3_w, *d3_b;     /* rgbhead.out_geometry_fc.4    16x32  */
+    const float *d4_w, *d4_b;     /* rgbhead.out_geometry_fc.6     1x16  */
+} GpnerfHeadParams;
+
+/* Outputs of Renderer.render_rays (BaseRender.py:148-156), all device, [N,...] row-major.
+ * rgb/depth/acc/disp are required, the rest may be NULL. */
+typedef struct GpnerfOutputs {
+    float* rgb;        /* [N,3]  rgb_map   */
+    float* depth;      /* [N]    depth_map */
+    float* acc;        /* [N]    acc_map   */
+    float* disp;       /* [N]    disp_map  */
+    float* weights;    /* [N,S]  ret['alpha'] (= weights) */
+    float* z_vals;     /* [N,S]  */
+    float* rgb_in;     /* [N,9]  rgb_in_map (view-major, then rgb) */
+    uint8_t* ray_mask; /* [N]    raw2outputs' mask: #samples with >1 valid view > 8 */
+    float* raw;        /* [N,S,4] NeRFHead.forward output (rgb, sigma), un-flipped sample order */
+} GpnerfOutputs;
+
+/* Number of floats of the packed head image. */
+int64_t gpnerf_head_blob_floats(void);
+
+/* Re-arrange the PyTorch-layout parameters into the LDS image the kernels stage
+ * (MFMA A-operand order).  Host-side, model-load time.
+ * Replaces nothing in the reference; it is what load_state_dict is to nn.Linear. */
+int gpnerf_pack_head(const GpnerfHeadParams* params_host, float* blob_host);
+
+/* Fused sample -> gather -> MLP -> composite over N rays.
+ * Replaces Renderer.batchify_rays + render_rays with is_train=False
+ * (libs/renders/BaseRender.py:110-184): get_sampling_points :35-50, pts_to_can_pts :52-60,
+ * get_grid_coords :62-73, Projector.compute :326-363 (sample part), SparseConvNet.forward's
+ * trilinear sampling (libs/nerfheads/networks/SparseConvNet.py:113-122),
+ * NeRFSigmaHead.out_geometry_fc + NeRFRGBHead.forward (libs/nerfheads/trainhead.py:39-40,58,118-145)
+ * and raw2outputs :75-107, rgb_in_map :147.
+ *   rays: device [N][8] = origin(3), direction(3, un-normalised), near, far (BaseRender.py:250)
+ *   term_eps: transmittance threshold, read only with GPNERF_FLAG_EARLY_TERM */
+int gpnerf_render_fused(const GpnerfFrame* frame, const float* rays, int64_t n_rays, int32_t n_samples,
+                        uint32_t flags, float term_eps, const GpnerfOutputs* out, void* stream);
+
+/* NeRFHead.forward on already-gathered features (libs/nerfheads/trainhead.py:159-163, with the
+ * sparse volume replaced by its sampled features): P points.
+ *   vol_feat [P][128] (level-major), rgb_feat [P][V][35], mask [P][V] (0/1 floats), all device
+ *   raw [P][4] = rgb, sigma.   head_blob as in GpnerfFrame. */
+int gpnerf_head_forward(const float* head_blob, const float* vol_feat, const float* rgb_feat, const float* mask,
+                        int64_t n_points, float* raw, void* stream);
+
+/* Renderer.raw2outputs (BaseRender.py:75-107) alone.  raw [N][S][4], z [N][S],
+ * nvalid [N][S] = per-sample number of valid views (may be NULL), all device. */
+int gpnerf_composite(const float* raw, const float* z_vals, const float* nvalid, int64_t n_rays, int32_t n_samples,
+                     int32_t neg, const GpnerfOutputs* out, void* stream);
+
+/* get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130) for one target camera.
+ *   Kinv, Rinv: host 3x3 row-major fp32 inverses; cam_o: host [3] camera centre (-R^-1 T);
+ *   bounds: host [2][3] world AABB (un-padded).
+ *   rays: device [H*W][8]; hit: device [H*W] uint8 (mask_at_box).  Rays are written at their
+ *   pixel index; gpnerf_compact_rays packs the hit ones in raster order. */
+int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o,
+                     const float* bounds, float* rays, uint8_t* hit, void* stream);
+
+/* Channels-last re-layouts of the per-frame tensors (device -> device). */
+int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t H, int32_t W, void* stream);
+int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t H, int32_t W, void* stream);
+/* src_imgs [V][3][H][W] in [-1,1] -> [V][H][W][4] = x*0.5+0.5 (BaseRender.py:231), 4th lane 0 */
+int gpnerf_relayout_images(const float* nchw, float* nhwc4, int32_t V, int32_t H, int32_t W, void* stream);
+
+const char* gpnerf_strerror(int code);
+/* compile-time facts for callers / tests */
+int32_t gpnerf_rays_per_tile(void);   /* rays one wavefront renders together (32) */
+const char* gpnerf_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPNERF_HIP_H */

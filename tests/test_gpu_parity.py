@@ -1,0 +1,131 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors and the CPU oracle."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import assert_close, case_names, load, scene_of
+
+pytestmark = pytest.mark.gpu
+
+# north_star: within 1e-4 max-abs of the reference on RGB / depth
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def fm():
+    return importlib.import_module("gp-nerf_amd.frame")
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def build_frame(fm, sc):
+    blob = fm.pack_head(sc["head"], torch.device("cuda:0"))
+    return fm.Frame(to_dev(sc["src_imgs"][0]), to_dev(sc["featmaps"]), [to_dev(v) for v in sc["volumes"]],
+                    to_dev(sc["src_Ks"][0]), to_dev(sc["src_poses"][0]), sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0],
+                    sc["voxel_size"], sc["out_sh"][0], blob)
+
+
+def rays_of(sc):
+    return to_dev(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1))
+
+
+def cpu(d):
+    return {k: v.cpu().numpy() for k, v in d.items()}
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_fused_matches_reference_golden(name, fm):
+    z, meta = load(name)
+    sc = scene_of(meta)
+    S = meta["n_samples"]
+    fr = build_frame(fm, sc)
+    got = cpu(fm.render_fused(fr, rays_of(sc), S, neg_ray=meta["neg_ray"], want=("weights", "z_vals", "rgb_in", "ray_mask", "raw")))
+    assert_close(got["rgb_map"], z["rgb_map"], TOL, "rgb_map")
+    assert_close(got["depth_map"], z["depth_map"], TOL, "depth_map")
+    assert_close(got["acc_map"], z["acc_map"], TOL, "acc_map")
+    assert_close(got["rgb_in_map"], z["rgb_in_map"], TOL, "rgb_in_map")
+    assert_close(got["disp_map"], z["disp_map"], 5e-4, "disp_map")
+    if "weights" in z:
+        assert_close(got["weights"], z["weights"], TOL, "weights")
+        assert_close(got["z_vals"], z["z_vals"], 1e-6, "z_vals")
+    if "st_raw" in z:
+        k = z["st_raw"].shape[0]
+        assert_close(got["raw"][:k], z["st_raw"], TOL, "raw")
+        assert np.array_equal(got["ray_mask"][:k].astype(bool), z["st_ray_mask"])
+
+
+@pytest.mark.parametrize("S,n_rays", [(1, 5), (2, 33), (7, 31), (64, 100), (128, 64)])
+def test_fused_matches_oracle_ragged(S, n_rays, fm, oracle, syn):
+    sc = syn.make_scene(H=16, W=16, seed=100 + S, fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1,
+                        max_rays=n_rays)
+    fr = build_frame(fm, sc)
+    got = cpu(fm.render_fused(fr, rays_of(sc), S, want=("weights", "z_vals", "rgb_in", "ray_mask", "raw")))
+    ref = oracle.render(sc, S, stages=True)
+    for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map", "weights"):
+        assert_close(got[k], ref[k], TOL, k)
+    assert_close(got["z_vals"], ref["z_vals"], 1e-6, "z_vals")
+    assert_close(got["raw"], ref["st_raw"], TOL, "raw")
+    assert np.array_equal(got["ray_mask"], ref["ray_mask"])
+
+
+def test_empty_ray_list(fm, syn):
+    sc = syn.make_scene(H=8, W=8, seed=1, aabb_half=(0.12, 0.16, 0.05))
+    fr = build_frame(fm, sc)
+    got = fm.render_fused(fr, torch.empty((0, 8), device="cuda:0"), 8)
+    assert got["rgb_map"].shape == (0, 3)
+
+
+def test_head_forward_matches_oracle(fm, oracle, syn):
+    sc = syn.make_scene(H=16, W=16, seed=9, fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1, max_rays=70)
+    S = 8
+    ref = oracle.render(sc, S, stages=True)
+    blob = fm.pack_head(sc["head"], torch.device("cuda:0"))
+    raw = fm.head_forward(blob, to_dev(ref["st_vol_feat"].reshape(-1, 128)), to_dev(ref["st_rgb_feat"].reshape(-1, 3, 35)),
+                          to_dev(ref["st_mask"].reshape(-1, 3))).cpu().numpy()
+    assert_close(raw, ref["st_raw"].reshape(-1, 4), TOL, "raw")
+
+
+def test_composite_matches_oracle(fm, oracle):
+    g = np.random.Generator(np.random.PCG64(5))
+    N, S = 77, 40
+    raw = g.random((N, S, 4), dtype=np.float32)
+    raw[..., 3] = np.maximum(g.standard_normal((N, S), dtype=np.float32), 0) * 2
+    raw[:3, :, 3] = 0  # acc == 0 -> disp NaN
+    z = np.sort(g.random((N, S), dtype=np.float32) * 2 + 2, axis=1)
+    nvalid = g.integers(0, 4, (N, S)).astype(np.float32)
+    for neg in (False, True):
+        got = cpu(fm.composite(to_dev(raw), to_dev(z), to_dev(nvalid), neg=neg))
+        ref = oracle.composite(raw, z, nvalid, neg=neg)
+        for k in ("rgb_map", "depth_map", "acc_map", "weights"):
+            assert_close(got[k], ref[k], 1e-5, k)
+        assert_close(got["disp_map"], ref["disp_map"], 1e-4, "disp")
+        assert np.array_equal(got["ray_mask"].astype(bool), ref["ray_mask"])
+
+
+def test_make_rays_matches_oracle_and_golden(fm, oracle, syn):
+    import os
+    from golden_cases import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "rays_48.npz"))
+    rays, mask = fm.make_rays(int(z["H"]), int(z["W"]), z["K"], z["R"], z["T"], z["bounds"], torch.device("cuda:0"))
+    rays, mask = rays.cpu().numpy(), mask.cpu().numpy()
+    assert np.array_equal(mask, z["mask_at_box"])
+    assert_close(rays[:, 0:3], z["ray_o"], 1e-6, "ray_o")
+    assert_close(rays[:, 3:6], z["ray_d"], 1e-6, "ray_d")
+    assert_close(rays[:, 6], z["near"], 1e-5, "near")
+    assert_close(rays[:, 7], z["far"], 1e-5, "far")
+
+
+def test_early_termination_stays_within_bound(fm, oracle, syn):
+    sc = syn.make_scene(H=16, W=16, seed=21, fill="full", pose="identity", aabb_half=(0.12, 0.16, 0.05), sigma_bias=1.0)
+    S = 64
+    fr = build_frame(fm, sc)
+    full = cpu(fm.render_fused(fr, rays_of(sc), S))
+    cut = cpu(fm.render_fused(fr, rays_of(sc), S, early_term=True, term_eps=1e-5))
+    # stopping at T < eps leaves rgb/acc within eps and depth within eps * far
+    assert_close(cut["rgb_map"], full["rgb_map"], 2e-5, "rgb (early term)")
+    assert_close(cut["depth_map"], full["depth_map"], 1e-4, "depth (early term)")
+    assert (cut["weights"] == 0).sum() > (full["weights"] == 0).sum(), "no sample was skipped: the test scene is not opaque enough"
