@@ -64,6 +64,11 @@ SYMBOLS = {
     "gpnerf_pack_head": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
     "gpnerf_render_fused": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float,
                                       C.POINTER(GpnerfOutputs), C.c_void_p]),
+    "gpnerf_sample_points": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "gpnerf_sample_volume": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gpnerf_project_gather": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "gpnerf_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gpnerf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.POINTER(GpnerfOutputs), C.c_void_p]),
@@ -71,6 +76,7 @@ SYMBOLS = {
     "gpnerf_relayout_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_featmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gpnerf_head_layout": (C.c_int, [C.POINTER(C.c_int32)]),
     "gpnerf_strerror": (C.c_char_p, [C.c_int]),
     "gpnerf_rays_per_tile": (C.c_int32, []),
     "gpnerf_build_info": (C.c_char_p, []),

@@ -320,6 +320,18 @@ DEV float linspace01(int k, int S, float step) {
     return (k < (S >> 1)) ? step * (float)k : fmaf(-step, (float)(S - 1 - k), 1.f);
 }
 
+// pts_to_can_pts (BaseRender.py:52-60): (p - Th) @ Rh, then get_grid_coords (:62-73): voxel-normalised
+// coordinate in [-1,1], dhw arithmetic, returned in xyz order.
+DEV void grid_coords(const FrameK& fr, float px, float py, float pz, float& gx, float& gy, float& gz) {
+    const float qx0 = px - fr.Th[0], qy0 = py - fr.Th[1], qz0 = pz - fr.Th[2];
+    const float qx = (qx0 * fr.Rh[0] + qy0 * fr.Rh[3]) + qz0 * fr.Rh[6];
+    const float qy = (qx0 * fr.Rh[1] + qy0 * fr.Rh[4]) + qz0 * fr.Rh[7];
+    const float qz = (qx0 * fr.Rh[2] + qy0 * fr.Rh[5]) + qz0 * fr.Rh[8];
+    gx = ((qx - fr.bounds_min[0]) / fr.voxel[2]) / fr.out_sh[2] * 2.f - 1.f;
+    gy = ((qy - fr.bounds_min[1]) / fr.voxel[1]) / fr.out_sh[1] * 2.f - 1.f;
+    gz = ((qz - fr.bounds_min[2]) / fr.voxel[0]) / fr.out_sh[0] * 2.f - 1.f;
+}
+
 template <int NWAVES>
 __global__ void __launch_bounds__(NWAVES * 64, NWAVES / 4)
 render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
@@ -364,14 +376,8 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         const float z = near * (1.f - t) + far * t;
         const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
 
-        // pts_to_can_pts (:52-60): (p - Th) @ Rh ; get_grid_coords (:62-73), dhw arithmetic, xyz result
-        const float qx0 = px - fr.Th[0], qy0 = py - fr.Th[1], qz0 = pz - fr.Th[2];
-        const float qx = (qx0 * fr.Rh[0] + qy0 * fr.Rh[3]) + qz0 * fr.Rh[6];
-        const float qy = (qx0 * fr.Rh[1] + qy0 * fr.Rh[4]) + qz0 * fr.Rh[7];
-        const float qz = (qx0 * fr.Rh[2] + qy0 * fr.Rh[5]) + qz0 * fr.Rh[8];
-        const float gx = ((qx - fr.bounds_min[0]) / fr.voxel[2]) / fr.out_sh[2] * 2.f - 1.f;
-        const float gy = ((qy - fr.bounds_min[1]) / fr.voxel[1]) / fr.out_sh[1] * 2.f - 1.f;
-        const float gz = ((qz - fr.bounds_min[2]) / fr.voxel[0]) / fr.out_sh[0] * 2.f - 1.f;
+        float gx, gy, gz;
+        grid_coords(fr, px, py, pz, gx, gy, gz);
 
         // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
         float fv[64];
@@ -509,6 +515,69 @@ head_forward_kernel(const float* __restrict__ blob, const float* __restrict__ vo
         if (active && half == 0) {
             f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
             *reinterpret_cast<f32x4*>(raw + p * 4) = rw;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage entry points: the same device functions as the fused kernel, one stage per launch
+// ---------------------------------------------------------------------------------------------
+// get_sampling_points + pts_to_can_pts + get_grid_coords (BaseRender.py:35-73): one lane per sample
+__global__ void stage_points_kernel(const FrameK fr, const float* __restrict__ rays, const long N, const int S,
+                                    float* __restrict__ pts, float* __restrict__ zv, float* __restrict__ grid) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * S) return;
+    const long r = i / S;
+    const int k = (int)(i % S);
+    const float* ry = rays + r * 8;
+    const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
+    const float t = (S > 1) ? linspace01(k, S, step) : 0.f;
+    const float z = ry[6] * (1.f - t) + ry[7] * t;
+    const float px = ry[0] + ry[3] * z, py = ry[1] + ry[4] * z, pz = ry[2] + ry[5] * z;
+    float gx, gy, gz;
+    grid_coords(fr, px, py, pz, gx, gy, gz);
+    if (pts) { pts[i * 3 + 0] = px; pts[i * 3 + 1] = py; pts[i * 3 + 2] = pz; }
+    if (zv) zv[i] = z;
+    if (grid) { grid[i * 3 + 0] = gx; grid[i * 3 + 1] = gy; grid[i * 3 + 2] = gz; }
+}
+
+// SparseConvNet.forward's sampling (SparseConvNet.py:113-122): two lanes per point (16 channels each)
+__global__ void stage_volume_kernel(const FrameK fr, const float* __restrict__ grid, const long P, float* __restrict__ vol_feat) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long p = i >> 1;
+    const int half = (int)(i & 1);
+    if (p >= P) return;
+    const float gx = grid[p * 3 + 0], gy = grid[p * 3 + 1], gz = grid[p * 3 + 2];
+#pragma unroll
+    for (int l = 0; l < GPNERF_LEVELS; ++l) {
+        float f[16];
+        gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, f);
+        f32x4* o = reinterpret_cast<f32x4*>(vol_feat + p * 128 + 32 * l + 16 * half);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { f32x4 v; v[0] = f[4 * q]; v[1] = f[4 * q + 1]; v[2] = f[4 * q + 2]; v[3] = f[4 * q + 3]; o[q] = v; }
+    }
+}
+
+// Projector.compute (BaseRender.py:326-363) for arbitrary points: two lanes per point
+__global__ void stage_project_kernel(const FrameK fr, const float* __restrict__ pts, const long P, const int neg,
+                                     float* __restrict__ rgb_feat, float* __restrict__ mask) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long p = i >> 1;
+    const int half = (int)(i & 1);
+    if (p >= P) return;
+    const float px = pts[p * 3 + 0], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        float f[16];
+        const ViewSample s = gather_view(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
+                                         fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w, px, py, pz,
+                                         neg != 0, half, f);
+        float* o = rgb_feat + (p * NV + v) * 35;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) o[3 + 16 * half + c] = f[c];
+        if (half == 0) {
+            o[0] = s.rgb[0]; o[1] = s.rgb[1]; o[2] = s.rgb[2];
+            mask[p * NV + v] = s.valid;
         }
     }
 }
@@ -667,6 +736,29 @@ hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 int launch_status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
 
+// GpnerfFrame -> kernel argument; need_vol / need_img say which tensors the launch will touch
+bool to_framek(const GpnerfFrame* f, FrameK& k, bool need_vol, bool need_img) {
+    memset(&k, 0, sizeof(k));
+    if (need_vol)
+        for (int l = 0; l < GPNERF_LEVELS; ++l)
+            if (!f->vol[l] || f->vol_dhw[l][0] < 1 || f->vol_dhw[l][1] < 1 || f->vol_dhw[l][2] < 1) return false;
+    if (need_img && (!f->featmaps || !f->imgs || f->feat_h < 1 || f->feat_w < 1 || f->img_h < 1 || f->img_w < 1)) return false;
+    for (int l = 0; l < GPNERF_LEVELS; ++l) {
+        k.vol[l] = f->vol[l];
+        for (int a = 0; a < 3; ++a) k.vol_dhw[l][a] = f->vol_dhw[l][a];
+    }
+    k.featmaps = f->featmaps; k.feat_h = f->feat_h; k.feat_w = f->feat_w;
+    k.imgs = f->imgs; k.img_h = f->img_h; k.img_w = f->img_w;
+    memcpy(k.proj, f->proj, sizeof(k.proj));
+    memcpy(k.Rh, f->Rh, sizeof(k.Rh));
+    memcpy(k.Th, f->Th, sizeof(k.Th));
+    memcpy(k.bounds_min, f->bounds_min, sizeof(k.bounds_min));
+    memcpy(k.voxel, f->voxel, sizeof(k.voxel));
+    for (int a = 0; a < 3; ++a) k.out_sh[a] = (float)f->out_sh[a];
+    k.head_blob = f->head_blob;
+    return true;
+}
+
 OutK to_outk(const GpnerfOutputs* o) {
     OutK k;
     k.rgb = o->rgb; k.depth = o->depth; k.acc = o->acc; k.disp = o->disp; k.weights = o->weights;
@@ -680,6 +772,27 @@ extern "C" {
 int64_t gpnerf_head_blob_floats(void) { return gpl::BLOB_FLOATS; }
 int32_t gpnerf_rays_per_tile(void) { return RAYS_PER_WAVE; }
 const char* gpnerf_build_info(void) { return "gpnerf-hip gfx950 fp32-mfma32x32x2 waves=8"; }
+
+int gpnerf_head_layout(int32_t* table) {
+    if (!table) return GPNERF_E_ARG;
+    for (int l = 0; l < gpl::NLAYER; ++l) {
+        table[4 * l + 0] = gpl::NT[l]; table[4 * l + 1] = gpl::MT[l];
+    }
+    table[4 * gpl::GEO + 2] = gpl::w_off(gpl::GEO); table[4 * gpl::GEO + 3] = gpl::b_off(gpl::GEO);
+    table[4 * gpl::D1 + 2] = gpl::w_off(gpl::D1);   table[4 * gpl::D1 + 3] = gpl::b_off(gpl::D1);
+    table[4 * gpl::D2 + 2] = gpl::w_off(gpl::D2);   table[4 * gpl::D2 + 3] = gpl::b_off(gpl::D2);
+    table[4 * gpl::D3 + 2] = gpl::w_off(gpl::D3);   table[4 * gpl::D3 + 3] = gpl::b_off(gpl::D3);
+    table[4 * gpl::BS + 2] = gpl::w_off(gpl::BS);   table[4 * gpl::BS + 3] = gpl::b_off(gpl::BS);
+    table[4 * gpl::BV + 2] = gpl::w_off(gpl::BV);   table[4 * gpl::BV + 3] = gpl::b_off(gpl::BV);
+    table[4 * gpl::B2 + 2] = gpl::w_off(gpl::B2);   table[4 * gpl::B2 + 3] = gpl::b_off(gpl::B2);
+    table[4 * gpl::V1 + 2] = gpl::w_off(gpl::V1);   table[4 * gpl::V1 + 3] = gpl::b_off(gpl::V1);
+    table[4 * gpl::V2 + 2] = gpl::w_off(gpl::V2);   table[4 * gpl::V2 + 3] = gpl::b_off(gpl::V2);
+    table[4 * gpl::R1 + 2] = gpl::w_off(gpl::R1);   table[4 * gpl::R1 + 3] = gpl::b_off(gpl::R1);
+    table[4 * gpl::R2 + 2] = gpl::w_off(gpl::R2);   table[4 * gpl::R2 + 3] = gpl::b_off(gpl::R2);
+    table[4 * gpl::NLAYER + 0] = gpl::D4_W; table[4 * gpl::NLAYER + 1] = gpl::D4_B;
+    table[4 * gpl::NLAYER + 2] = gpl::R3_W; table[4 * gpl::NLAYER + 3] = gpl::R3_B;
+    return GPNERF_OK;
+}
 
 const char* gpnerf_strerror(int code) {
     switch (code) {
@@ -722,25 +835,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
                         float term_eps, const GpnerfOutputs* out, void* stream) {
     if (n_rays == 0) return GPNERF_OK;          // empty ray list: nothing to do (pointers may be null)
     if (!f || !rays || !out || n_rays < 0 || n_samples < 1) return GPNERF_E_ARG;
-    if (!out->rgb || !out->depth || !out->acc || !out->disp || !f->head_blob || !f->featmaps || !f->imgs)
-        return GPNERF_E_ARG;
-    for (int l = 0; l < GPNERF_LEVELS; ++l)
-        if (!f->vol[l] || f->vol_dhw[l][0] < 1 || f->vol_dhw[l][1] < 1 || f->vol_dhw[l][2] < 1) return GPNERF_E_ARG;
-    if (n_rays == 0) return GPNERF_OK;
+    if (!out->rgb || !out->depth || !out->acc || !out->disp || !f->head_blob) return GPNERF_E_ARG;
     FrameK k;
-    for (int l = 0; l < GPNERF_LEVELS; ++l) {
-        k.vol[l] = f->vol[l];
-        for (int a = 0; a < 3; ++a) k.vol_dhw[l][a] = f->vol_dhw[l][a];
-    }
-    k.featmaps = f->featmaps; k.feat_h = f->feat_h; k.feat_w = f->feat_w;
-    k.imgs = f->imgs; k.img_h = f->img_h; k.img_w = f->img_w;
-    memcpy(k.proj, f->proj, sizeof(k.proj));
-    memcpy(k.Rh, f->Rh, sizeof(k.Rh));
-    memcpy(k.Th, f->Th, sizeof(k.Th));
-    memcpy(k.bounds_min, f->bounds_min, sizeof(k.bounds_min));
-    memcpy(k.voxel, f->voxel, sizeof(k.voxel));
-    for (int a = 0; a < 3; ++a) k.out_sh[a] = (float)f->out_sh[a];
-    k.head_blob = f->head_blob;
+    if (!to_framek(f, k, true, true)) return GPNERF_E_ARG;
     const int64_t tiles = (n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     const int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
@@ -753,6 +850,41 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     }
     hipLaunchKernelGGL(render_fused_kernel<FUSED_WAVES>, dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
                        k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out));
+    return launch_status();
+}
+
+int gpnerf_sample_points(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, float* pts,
+                         float* z_vals, float* grid, void* stream) {
+    if (n_rays == 0) return GPNERF_OK;
+    if (!f || !rays || n_rays < 0 || n_samples < 1) return GPNERF_E_ARG;
+    FrameK k;
+    if (!to_framek(f, k, false, false)) return GPNERF_E_ARG;
+    const long n = (long)n_rays * n_samples;
+    hipLaunchKernelGGL(stage_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), k, rays, (long)n_rays,
+                       (int)n_samples, pts, z_vals, grid);
+    return launch_status();
+}
+
+int gpnerf_sample_volume(const GpnerfFrame* f, const float* grid, int64_t n_points, float* vol_feat, void* stream) {
+    if (n_points == 0) return GPNERF_OK;
+    if (!f || !grid || !vol_feat || n_points < 0) return GPNERF_E_ARG;
+    FrameK k;
+    if (!to_framek(f, k, true, false)) return GPNERF_E_ARG;
+    const long n = (long)n_points * 2;
+    hipLaunchKernelGGL(stage_volume_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), k, grid, (long)n_points,
+                       vol_feat);
+    return launch_status();
+}
+
+int gpnerf_project_gather(const GpnerfFrame* f, const float* pts, int64_t n_points, int32_t neg_ray, float* rgb_feat,
+                          float* mask, void* stream) {
+    if (n_points == 0) return GPNERF_OK;
+    if (!f || !pts || !rgb_feat || !mask || n_points < 0) return GPNERF_E_ARG;
+    FrameK k;
+    if (!to_framek(f, k, false, true)) return GPNERF_E_ARG;
+    const long n = (long)n_points * 2;
+    hipLaunchKernelGGL(stage_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), k, pts, (long)n_points,
+                       (int)neg_ray, rgb_feat, mask);
     return launch_status();
 }
 

@@ -78,20 +78,8 @@ class Frame:
         fh, fw = fm.shape[-2:]
         self.featmaps = torch.empty((V, fh, fw, L.CH), device=dev, dtype=torch.float32)
         L.check(lib.gpnerf_relayout_featmaps(fm.data_ptr(), self.featmaps.data_ptr(), V, fh, fw, st), "gpnerf_relayout_featmaps")
-        self.vols = []
         keep = [src, fm]
-        for l, v in enumerate(volumes):
-            _require_gpu(v, f"volumes[{l}]")
-            v = v.reshape(v.shape[-4:]).contiguous().float()
-            if v.shape[0] != L.CH:
-                raise L.GpnerfError(f"volume level {l}: {v.shape[0]} channels, expected {L.CH}")
-            D, Hh, Ww = v.shape[1:]
-            o = torch.empty((D, Hh, Ww, L.CH), device=dev, dtype=torch.float32)
-            L.check(lib.gpnerf_relayout_volume(v.data_ptr(), o.data_ptr(), D, Hh, Ww, st), "gpnerf_relayout_volume")
-            self.vols.append(o)
-            keep.append(v)
-            f.vol[l] = o.data_ptr()
-            f.vol_dhw[l][0], f.vol_dhw[l][1], f.vol_dhw[l][2] = D, Hh, Ww
+        self._set_volumes(f, volumes, keep)
         self._keep = keep  # sources stay alive until the re-layout kernels have run (stream order)
         f.featmaps, f.feat_h, f.feat_w = self.featmaps.data_ptr(), fh, fw
         f.imgs, f.img_h, f.img_w = self.imgs.data_ptr(), H, W
@@ -124,6 +112,38 @@ class Frame:
         self.head_blob = head_blob
         f.head_blob = head_blob.data_ptr()
         self.c = f
+
+    def _set_volumes(self, f, volumes, keep):
+        lib = L.lib()
+        self.vols = []
+        for l, v in enumerate(volumes):
+            _require_gpu(v, f"volumes[{l}]")
+            v = v.reshape(v.shape[-4:]).contiguous().float()
+            if v.shape[0] != L.CH:
+                raise L.GpnerfError(f"volume level {l}: {v.shape[0]} channels, expected {L.CH}")
+            D, Hh, Ww = v.shape[1:]
+            o = torch.empty((D, Hh, Ww, L.CH), device=v.device, dtype=torch.float32)
+            L.check(lib.gpnerf_relayout_volume(v.data_ptr(), o.data_ptr(), D, Hh, Ww, _stream_ptr(v.device)),
+                    "gpnerf_relayout_volume")
+            self.vols.append(o)
+            keep.append(v)
+            f.vol[l] = o.data_ptr()
+            f.vol_dhw[l][0], f.vol_dhw[l][1], f.vol_dhw[l][2] = D, Hh, Ww
+
+    @classmethod
+    def for_volumes(cls, volumes, head_blob):
+        """A frame that carries only the 4 dense levels (enough for gpnerf_sample_volume)."""
+        if len(volumes) != L.LEVELS:
+            raise L.GpnerfError(f"expected {L.LEVELS} volume levels, got {len(volumes)}")
+        self = cls.__new__(cls)
+        f = L.GpnerfFrame()
+        self._keep = []
+        self._set_volumes(f, volumes, self._keep)
+        self.device = self.vols[0].device
+        self.head_blob = head_blob
+        f.head_blob = head_blob.data_ptr() if head_blob is not None else None
+        self.c = f
+        return self
 
     @classmethod
     def from_batch(cls, batch, featmaps, volumes, voxel_size, head_blob):
@@ -218,3 +238,40 @@ def make_rays(H, W, K, R, T, bounds, device):
             "gpnerf_make_rays")
     mask = hit.bool()
     return rays[mask], mask
+
+
+def sample_points(frame, rays, n_samples):
+    """gpnerf_sample_points: (pts [N,S,3], z_vals [N,S], grid_coords [N,S,3]) as BaseRender.py:35-73 computes them."""
+    lib = L.lib()
+    _require_gpu(rays, "rays")
+    rays = rays.contiguous().float()
+    N, S, dev = rays.shape[0], int(n_samples), rays.device
+    pts, z, grid = torch.empty((N, S, 3), device=dev), torch.empty((N, S), device=dev), torch.empty((N, S, 3), device=dev)
+    L.check(lib.gpnerf_sample_points(C.byref(frame.c), rays.data_ptr(), N, S, pts.data_ptr(), z.data_ptr(), grid.data_ptr(),
+                                     _stream_ptr(dev)), "gpnerf_sample_points")
+    return pts, z, grid
+
+
+def sample_volume(frame, grid):
+    """gpnerf_sample_volume: grid [P,3] (normalised xyz) -> [P,128] features of the 4 dense levels."""
+    lib = L.lib()
+    _require_gpu(grid, "grid")
+    grid = grid.reshape(-1, 3).contiguous().float()
+    P = grid.shape[0]
+    out = torch.empty((P, 128), device=grid.device)
+    L.check(lib.gpnerf_sample_volume(C.byref(frame.c), grid.data_ptr(), P, out.data_ptr(), _stream_ptr(grid.device)),
+            "gpnerf_sample_volume")
+    return out
+
+
+def project_gather(frame, pts, neg_ray=False):
+    """gpnerf_project_gather: pts [P,3] -> (rgb_feat [P,V,35], mask [P,V]) as Projector.compute does (BaseRender.py:326-363)."""
+    lib = L.lib()
+    _require_gpu(pts, "pts")
+    pts = pts.reshape(-1, 3).contiguous().float()
+    P = pts.shape[0]
+    feat = torch.empty((P, L.VIEWS, 35), device=pts.device)
+    mask = torch.empty((P, L.VIEWS), device=pts.device)
+    L.check(lib.gpnerf_project_gather(C.byref(frame.c), pts.data_ptr(), P, int(bool(neg_ray)), feat.data_ptr(), mask.data_ptr(),
+                                      _stream_ptr(pts.device)), "gpnerf_project_gather")
+    return feat, mask

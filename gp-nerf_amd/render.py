@@ -1,0 +1,143 @@
+"""`build_render(cfg)` / `Renderer` with the reference's interface (libs/renders/BaseRender.py:11-403),
+rendering through the fused HIP kernel.
+
+Drop-in contract:
+  * `build_render(cfg) -> nn.Module` whose `.render(batch)` returns the reference's dict
+    (`rgb_map, disp_map, acc_map, depth_map, alpha, z_vals, rgb_in_map`, leading dims [1,N,.];
+    BaseRender.py:148-156,254) plus `rtime` / `etime`, which tools/inference.py's caller needs
+    (libs/trainers/BaseTrainer.py:276) and only the reference's demo renderer returned.
+  * sub-modules are named `encoder` and `nerfhead` and own the reference's parameters, so
+    `load_state_dict(ckpt['state_dict'], strict=True)` works (tools/inference.py:67-74).
+  * sampling is deterministic (is_train=False, as libs/renders/demo_render.py:661 forces for inference;
+    SURVEY.md §0-6 explains why the dense renderer's `is_train` latch is not reproduced).
+
+The per-ray work never touches torch ops; per-frame producers (encoder, volume builder) are ordinary
+PyTorch-ROCm modules and can be bypassed by putting their products into the batch
+(`batch['featmaps']`, `batch['volumes']`).
+"""
+import time
+from importlib import import_module as impm
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import frame as F_
+from . import parallel as P_
+
+
+class Renderer(nn.Module):
+    def __init__(self, encoder, nerfhead, is_train=False, neg_ray_train=False, neg_ray_val=False, n_rays=1024,
+                 n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=False, term_eps=1e-5):
+        super().__init__()
+        self.encoder = encoder
+        self.nerfhead = nerfhead
+        if is_train:
+            raise L.GpnerfError("the HIP render path is inference-only: stratified jitter / autograd (is_train=True) "
+                                "stay on the reference's PyTorch renderer")
+        self.is_train = False
+        self.neg_ray_train, self.neg_ray_val = neg_ray_train, neg_ray_val
+        self.n_rays, self.n_samples = n_rays, n_samples
+        self.voxel_size = np.array(voxel_size)
+        self.chunk = chunk          # kept for interface parity; the fused kernel tiles rays itself
+        self.mesh_th = mesh_th
+        self.early_term, self.term_eps = early_term, term_eps
+
+    # ---- helpers the reference exposes as methods (stage entry points) ----------------------------
+    def _neg_ray(self, batch):
+        # BaseRender.py:165-168
+        return self.neg_ray_val if batch["body_msk"].shape[-1] > self.n_rays else self.neg_ray_train
+
+    def prepare_sp_input(self, batch):
+        """BaseRender.py:187-209 (the fields the volume builder reads)."""
+        sh = batch["coord"].shape
+        idx = torch.cat([torch.full([sh[1]], i) for i in range(sh[0])]).to(batch["coord"])
+        coord = torch.cat([idx[:, None], batch["coord"].view(-1, sh[-1])], dim=1)
+        out_sh, _ = torch.max(batch["out_sh"], dim=0)
+        sp = {"feature": batch["feature"].view(-1, batch["feature"].shape[-1]), "coord": coord,
+              "out_sh": out_sh.tolist(), "batch_size": sh[0], "Rh": batch["Rh"], "R": batch.get("R", batch["Rh"]),
+              "src_imgs": batch["src_imgs"]}
+        if "volumes" in batch:
+            sp["volumes"] = batch["volumes"]
+        return sp
+
+    def build_frame(self, batch):
+        """Per-frame work: encoder, volume pyramid, channels-last re-layout, weight image."""
+        src_imgs = batch["src_imgs"]
+        dev = src_imgs.device
+        if src_imgs.shape[0] != 1:
+            raise L.GpnerfError("only batch_size=1 is supported (as BaseRender.py:336 asserts)")
+        featmaps = batch["featmaps"] if "featmaps" in batch else self.encoder(src_imgs.squeeze(0))  # BaseRender.py:222
+        if featmaps.dim() == 5:
+            featmaps = featmaps[0]
+        blob = self.nerfhead.head_blob(dev)
+        if "volumes" in batch:
+            return F_.Frame.from_batch(batch, featmaps, batch["volumes"], self.voxel_size, blob)
+        # No pre-built pyramid: gather the SMPL vertices' per-view features with the image half of the frame
+        # (BaseRender.py:128-131,344-347), run the per-frame volume builder (trainhead.py:48-56), then attach it.
+        placeholder = [torch.zeros((1, L.CH, 1, 1, 1), device=dev) for _ in range(L.LEVELS)]
+        frame = F_.Frame.from_batch(batch, featmaps, placeholder, self.voxel_size, blob)
+        xyz = batch["feature"][..., :3].float()
+        smpl_xyz = torch.bmm(xyz, batch["Rh"].float().transpose(1, 2)) + batch["Th"].float()
+        feat, _ = F_.project_gather(frame, smpl_xyz[0], neg_ray=False)
+        smpl_feat = feat[:, :, 3:].unsqueeze(0)                     # [1,6890,V,32]
+        volumes = self.nerfhead.sigmahead.build_volumes(self.prepare_sp_input(batch), smpl_feat)
+        frame._set_volumes(frame.c, volumes, frame._keep)
+        return frame
+
+    def get_sampling_points(self, ray_o, ray_d, near, far, frame):
+        rays = torch.cat([ray_o, ray_d, near[..., None], far[..., None]], -1)[0]
+        pts, z, _ = F_.sample_points(frame, rays, self.n_samples)
+        return pts[None], z[None]
+
+    @staticmethod
+    def raw2outputs(raw, z_vals, mask, neg):
+        """BaseRender.py:75-107 on gpnerf_composite; mask [R,S] = pixel_mask (>1 valid view)."""
+        nvalid = mask.float() * 2.0   # the kernel tests nvalid > 1
+        o = F_.composite(raw, z_vals, nvalid, neg=bool(neg))
+        alpha = 1.0 - torch.exp(-(torch.flip(raw[..., 3], [1]) if neg else raw[..., 3]))
+        return o["rgb_map"], o["disp_map"], o["acc_map"], o["weights"], o["depth_map"], o["ray_mask"].bool(), alpha
+
+    # ---- the hot path ---------------------------------------------------------------------------------
+    def render(self, batch):
+        if not self.nerfhead.use_rgbhead:
+            raise L.GpnerfError("mesh extraction (use_rgbhead=False, BaseRender.py:255-272) is outside the per-ray render path")
+        dev = batch["ray_o"].device
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        frame = self.build_frame(batch)
+        torch.cuda.synchronize(dev)
+        t1 = time.time()
+        rays = torch.cat([batch["ray_o"], batch["ray_d"], batch["near"].unsqueeze(-1), batch["far"].unsqueeze(-1)], dim=-1)[0]
+        neg = self._neg_ray(batch)
+
+        def fn(r):
+            return F_.render_fused(frame, r, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps)
+
+        keys = ("rgb_map", "depth_map", "acc_map", "disp_map", "weights", "z_vals", "rgb_in_map")
+        o = P_.render_sharded(fn, rays, keys=keys)
+        torch.cuda.synchronize(dev)
+        t2 = time.time()
+        n = rays.shape[0]
+        return {
+            "rgb_map": o["rgb_map"].view(1, n, 3), "disp_map": o["disp_map"].view(1, n, 1),
+            "acc_map": o["acc_map"].view(1, n, 1), "depth_map": o["depth_map"].view(1, n, 1),
+            "alpha": o["weights"].view(1, n, -1), "z_vals": o["z_vals"].view(1, n, -1),
+            "rgb_in_map": o["rgb_in_map"].view(1, n, 9),
+            "etime": t1 - t0, "rtime": t2 - t0,
+        }
+
+
+def build_render(cfg):
+    """Same cfg keys as BaseRender.py:367-403; encoder / head come from the plugins cfg names."""
+    encoder = getattr(impm(cfg.encoder.file), "build_encoder")(cfg)
+    nerfhead = getattr(impm(cfg.head.file), "build_head")(cfg)
+    if not hasattr(nerfhead, "head_blob"):
+        raise L.GpnerfError(f"head.file='{cfg.head.file}' does not provide the HIP head; use head.file 'hip_head'")
+    neg_ray_train = "thuman" in cfg.dataset.train.name
+    neg_ray_val = "thuman" in cfg.dataset.test.name
+    mesh_th = -1 if cfg.head.rgb.use_rgbhead else 1.0 / cfg.test.mesh_th
+    return Renderer(encoder=encoder, nerfhead=nerfhead, is_train=False, neg_ray_train=neg_ray_train,
+                    neg_ray_val=neg_ray_val, n_rays=cfg.train.n_rays, n_samples=cfg.train.n_samples,
+                    voxel_size=cfg.dataset.voxel_size, chunk=cfg.dataset.test.chunk, mesh_th=mesh_th)

@@ -1,0 +1,181 @@
+"""Per-frame producers of the dense feature pyramid -- NOT on the per-ray path.
+
+The reference builds the 4 dense levels with the external spconv v1.2.1 CUDA library
+(libs/nerfheads/networks/SparseConvNet.py:22-124), which is neither in the reference tree nor
+installable here, so its arithmetic cannot be pinned ("parity unpinned" at this boundary,
+SURVEY.md §8c).  This module restates the published algorithm of submanifold / strided sparse
+convolution with a coordinate rulebook, on stock PyTorch-ROCm tensor ops (6 890 active voxels per
+frame: a few matmuls), under the reference's parameter names so reference checkpoints load with
+strict=True.  It is validated against a dense conv3d-with-mask formulation in tests/.
+
+`MultiHeadAttention` mirrors libs/nerfheads/networks/MultiHeadAttention.py:42-98 (parameter names
+w_qs, w_ks, w_vs, fc, layer_norm).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class MultiHeadAttention(nn.Module):
+    """Query = SMPL vertex code (length 1), keys/values = that vertex's features in the V source views."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1, kv_dim=None, sum=True):
+        super().__init__()
+        self.n_head, self.d_k, self.d_v, self.sum_flag = n_head, d_k, d_v, sum
+        kv_dim = d_model if kv_dim is None else kv_dim
+        self.w_qs = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_ks = nn.Linear(kv_dim, n_head * d_k, bias=False)
+        self.w_vs = nn.Linear(kv_dim, n_head * d_v, bias=False)
+        self.fc = nn.Linear(n_head * d_v, d_model, bias=False)
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)  # owned for checkpoint parity; used only when sum=True
+
+    def forward(self, q, k, v, mask=None):
+        b, lq, lk = q.size(0), q.size(1), k.size(1)
+        residual = q
+        qh = self.w_qs(q).view(b, lq, self.n_head, self.d_k).transpose(1, 2)
+        kh = self.w_ks(k).view(k.size(0), lk, self.n_head, self.d_k).transpose(1, 2)
+        vh = self.w_vs(v).view(v.size(0), v.size(1), self.n_head, self.d_v).transpose(1, 2)
+        attn = torch.matmul(qh / (self.d_k ** 0.5), kh.transpose(2, 3))
+        if mask is not None:
+            attn = attn.masked_fill(mask.unsqueeze(1) == 0, -1e9)
+        attn = F.softmax(attn, dim=-1)
+        out = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(b, lq, -1)
+        out = self.fc(out)
+        if self.sum_flag:
+            out = self.layer_norm(out + residual)
+        return out, attn
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse 3-D convolution by rulebook
+# ------------------------------------------------------------------------------------------------
+class SparseTensor:
+    """features [M,C]; coords [M,3] (d,h,w) int64; spatial shape (D,H,W).  Batch size 1."""
+
+    def __init__(self, features, coords, shape):
+        self.features, self.coords, self.shape = features, coords, tuple(int(s) for s in shape)
+
+    def keys(self):
+        D, H, W = self.shape
+        return (self.coords[:, 0] * H + self.coords[:, 1]) * W + self.coords[:, 2]
+
+    def dense(self):
+        """[1,C,D,H,W], zeros where inactive (spconv's .dense(), SparseConvNet.py:111)."""
+        D, H, W = self.shape
+        C = self.features.shape[1]
+        out = torch.zeros((D * H * W, C), dtype=self.features.dtype, device=self.features.device)
+        out[self.keys()] = self.features
+        return out.view(D, H, W, C).permute(3, 0, 1, 2).unsqueeze(0).contiguous()
+
+
+def _lookup(sorted_keys, order, query):
+    """index into the original rows of the entry whose key equals `query`, or -1."""
+    pos = torch.searchsorted(sorted_keys, query).clamp_(max=sorted_keys.numel() - 1)
+    hit = sorted_keys[pos] == query
+    return torch.where(hit, order[pos], torch.full_like(pos, -1))
+
+
+class _SparseConv3d(nn.Module):
+    """Weight [k,k,k,Cin,Cout] as spconv v1.x stores it; out[o] = sum_k W[k] in[o*stride - pad + k]."""
+
+    def __init__(self, cin, cout, ksize, stride=1, padding=0, subm=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.padding, self.subm = cin, cout, ksize, stride, padding, subm
+        self.weight = nn.Parameter(torch.empty(ksize, ksize, ksize, cin, cout))
+        nn.init.kaiming_uniform_(self.weight.view(-1, cout), a=5 ** 0.5)
+
+    def forward(self, x):
+        k, s = self.k, self.stride
+        pad = (k // 2) if self.subm else self.padding
+        D, H, W = x.shape
+        dev = x.coords.device
+        offs = torch.stack(torch.meshgrid(torch.arange(k), torch.arange(k), torch.arange(k), indexing="ij"), -1).view(-1, 3).to(dev)
+        Wk = self.weight.view(k * k * k, self.cin, self.cout)
+        if self.subm:
+            keys = x.keys()
+            sk, order = torch.sort(keys, stable=True)
+            out = torch.zeros((x.coords.shape[0], self.cout), dtype=x.features.dtype, device=dev)
+            for i in range(k * k * k):
+                nb = x.coords - pad + offs[i]                       # input position feeding output site through tap i
+                ok = ((nb >= 0) & (nb < torch.tensor([D, H, W], device=dev))).all(1)
+                q = (nb[:, 0] * H + nb[:, 1]) * W + nb[:, 2]
+                j = _lookup(sk, order, torch.where(ok, q, torch.full_like(q, -1)))
+                sel = (j >= 0) & ok
+                if sel.any():
+                    out[sel] += x.features[j[sel]] @ Wk[i]
+            return SparseTensor(out, x.coords, x.shape)
+        oD, oH, oW = [(n + 2 * pad - k) // s + 1 for n in (D, H, W)]
+        pairs_o, pairs_i, pairs_k = [], [], []
+        lim = torch.tensor([oD, oH, oW], device=dev)
+        for i in range(k * k * k):
+            num = x.coords + pad - offs[i]                           # o*stride = p + pad - k
+            o = torch.div(num, s, rounding_mode="floor")
+            ok = ((num % s) == 0).all(1) & ((o >= 0) & (o < lim)).all(1)
+            idx = torch.nonzero(ok).squeeze(1)
+            pairs_o.append((o[idx, 0] * oH + o[idx, 1]) * oW + o[idx, 2])
+            pairs_i.append(idx)
+            pairs_k.append(torch.full_like(idx, i))
+        okeys, iidx, kidx = torch.cat(pairs_o), torch.cat(pairs_i), torch.cat(pairs_k)
+        ukeys, inv = torch.unique(okeys, sorted=True, return_inverse=True)
+        out = torch.zeros((ukeys.numel(), self.cout), dtype=x.features.dtype, device=dev)
+        for i in range(k * k * k):
+            m = kidx == i
+            if m.any():
+                out.index_add_(0, inv[m], x.features[iidx[m]] @ Wk[i])
+        oc = torch.stack([ukeys // (oH * oW), (ukeys // oW) % oH, ukeys % oW], 1)
+        return SparseTensor(out, oc, (oD, oH, oW))
+
+
+class _SparseSequential(nn.Sequential):
+    """conv -> BatchNorm1d -> ReLU chains on the active features (spconv.SparseSequential)."""
+
+    def forward(self, x):
+        for m in self:
+            if isinstance(m, _SparseConv3d):
+                x = m(x)
+            else:
+                x = SparseTensor(m(x.features), x.coords, x.shape)
+        return x
+
+
+def _bn(c):
+    return nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+
+
+def double_conv(cin, cout):      # SparseConvNet.py:33-49: SubM 3^3 x2
+    return _SparseSequential(_SparseConv3d(cin, cout, 3, subm=True), _bn(cout), nn.ReLU(),
+                             _SparseConv3d(cout, cout, 3, subm=True), _bn(cout), nn.ReLU())
+
+
+def stride_conv(cin, cout):      # SparseConvNet.py:78-87: k3 s2 p1
+    return _SparseSequential(_SparseConv3d(cin, cout, 3, stride=2, padding=1), _bn(cout), nn.ReLU())
+
+
+class SparseConvNet(nn.Module):
+    """Same module tree / state_dict keys as SparseConvNet.py:90-103 (`net.{0..8}`)."""
+
+    def __init__(self, n_layers=4, in_dim=16, out_dim=(32, 32, 32, 32)):
+        super().__init__()
+        self.n_layers = n_layers
+        assert len(out_dim) == n_layers
+        net = []
+        for i in range(n_layers):
+            cin = in_dim if i == 0 else out_dim[i - 1]
+            net.append(double_conv(cin, cin))
+            net.append(stride_conv(cin, out_dim[i]))
+        net.append(double_conv(out_dim[-1], out_dim[-1]))
+        self.net = nn.ModuleList(net)
+
+    def dense_levels(self, code, coord, out_sh, batch_size=1):
+        """code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) ->
+        list of 4 dense levels [1,C_k,D/2^k,H/2^k,W/2^k] (SparseConvNet.py:105-111)."""
+        if int(batch_size) != 1:
+            raise ValueError("the per-ray path renders one frame at a time (BaseRender.py:336 asserts batch 1)")
+        x = SparseTensor(code, coord[:, 1:].long(), out_sh)
+        x = self.net[0](x)
+        levels = []
+        for i in range(self.n_layers):
+            x = self.net[2 * i + 1](x)
+            x = self.net[2 * i + 2](x)
+            levels.append(x.dense())
+        return levels

@@ -111,6 +111,20 @@ int gpnerf_pack_head(const GpnerfHeadParams* params_host, float* blob_host);
 int gpnerf_render_fused(const GpnerfFrame* frame, const float* rays, int64_t n_rays, int32_t n_samples,
                         uint32_t flags, float term_eps, const GpnerfOutputs* out, void* stream);
 
+/* Stage entry points (the same device code as the fused kernel, one reference function per launch).
+ *
+ * get_sampling_points + pts_to_can_pts + get_grid_coords (libs/renders/BaseRender.py:35-73), jitter off:
+ *   pts [N][S][3] world points, z_vals [N][S], grid [N][S][3] normalised volume coords (xyz); any may be NULL. */
+int gpnerf_sample_points(const GpnerfFrame* frame, const float* rays, int64_t n_rays, int32_t n_samples, float* pts,
+                         float* z_vals, float* grid, void* stream);
+/* SparseConvNet.forward's F.grid_sample over the 4 dense levels
+ * (libs/nerfheads/networks/SparseConvNet.py:113-122): grid [P][3] -> vol_feat [P][128] (level-major). */
+int gpnerf_sample_volume(const GpnerfFrame* frame, const float* grid, int64_t n_points, float* vol_feat, void* stream);
+/* Projector.compute for sample points (libs/renders/BaseRender.py:326-363, without the SMPL-vertex branch):
+ *   pts [P][3] world -> rgb_feat [P][V][35] = (rgb, 32 features), mask [P][V] (0/1). */
+int gpnerf_project_gather(const GpnerfFrame* frame, const float* pts, int64_t n_points, int32_t neg_ray, float* rgb_feat,
+                          float* mask, void* stream);
+
 /* NeRFHead.forward on already-gathered features (libs/nerfheads/trainhead.py:159-163, with the
  * sparse volume replaced by its sampled features): P points.
  *   vol_feat [P][128] (level-major), rgb_feat [P][V][35], mask [P][V] (0/1 floats), all device
@@ -127,7 +141,7 @@ int gpnerf_composite(const float* raw, const float* z_vals, const float* nvalid,
  *   Kinv, Rinv: host 3x3 row-major fp32 inverses; cam_o: host [3] camera centre (-R^-1 T);
  *   bounds: host [2][3] world AABB (un-padded).
  *   rays: device [H*W][8]; hit: device [H*W] uint8 (mask_at_box).  Rays are written at their
- *   pixel index; gpnerf_compact_rays packs the hit ones in raster order. */
+ *   pixel index; the caller keeps the hit ones in raster order. */
 int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o,
                      const float* bounds, float* rays, uint8_t* hit, void* stream);
 
@@ -136,6 +150,12 @@ int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t 
 int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t H, int32_t W, void* stream);
 /* src_imgs [V][3][H][W] in [-1,1] -> [V][H][W][4] = x*0.5+0.5 (BaseRender.py:231), 4th lane 0 */
 int gpnerf_relayout_images(const float* nchw, float* nhwc4, int32_t V, int32_t H, int32_t W, void* stream);
+
+/* Layout of the head image, for tools and tests: table[4*l + {0,1,2,3}] = k-steps, 32-row output tiles,
+ * weight offset, bias offset (in floats) of MFMA layer l = GEO,D1,D2,D3,BS,BV,B2,V1,V2,R1,R2 (11 layers),
+ * then table[44..47] = offsets of the 16->1 / 16->3 VALU tails (D4 weights, D4 bias, R3 weights, R3 bias).
+ * table: host, 48 int32. */
+int gpnerf_head_layout(int32_t* table);
 
 const char* gpnerf_strerror(int code);
 /* compile-time facts for callers / tests */

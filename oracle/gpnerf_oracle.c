@@ -372,3 +372,15 @@ int64_t oracle_make_rays(int H, int W, const float *K, const float *R, const flo
         }
     return n;
 }
+
+/* NeRFHead.forward on pre-gathered features for P points (trainhead.py:159-163):
+ * vol_feat [P][128], rgb_feat [P][V][35], mask [P][V] -> raw [P][4]. */
+int oracle_head_forward(const OracleFrame *f, const float *vol_feat, const float *rgb_feat, const float *mask,
+                        int64_t P, float *raw) {
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < P; ++p) {
+        float rin[9];
+        head_forward(f, vol_feat + p * 128, rgb_feat + p * NV * XF, mask + p * NV, raw + p * 4, rin);
+    }
+    return 0;
+}

@@ -66,6 +66,8 @@ def lib():
         _lib.oracle_composite.restype = C.c_int
         _lib.oracle_composite.argtypes = [FP, FP, FP, C.c_int64, C.c_int, C.c_int, FP, FP, FP, FP, FP, C.POINTER(C.c_uint8)]
         _lib.oracle_max_threads.restype = C.c_int
+        _lib.oracle_head_forward.restype = C.c_int
+        _lib.oracle_head_forward.argtypes = [C.POINTER(OracleFrame), FP, FP, FP, C.c_int64, FP]
     return _lib
 
 
@@ -88,6 +90,31 @@ def k4p4(src_Ks, src_poses):
         P4[:3, :4] = src_poses[v].astype(np.float32)
         out[v] = (K4 @ P4).astype(np.float32)
     return out
+
+
+def head_only_frame(head):
+    """OracleFrame carrying only the MLP parameters (for head_forward)."""
+    fr = Frame.__new__(Frame)
+    fr.keep = []
+    f = OracleFrame()
+    for short, name in _W.items():
+        w = _f32(head[name + ".weight"])
+        b = _f32(head[name + ".bias"])
+        fr.keep += [w, b]
+        setattr(f, short + "_w", _p(w))
+        setattr(f, short + "_b", _p(b))
+    fr.c = f
+    return fr
+
+
+def head_forward(head, vol_feat, rgb_feat, mask):
+    """NeRFHead.forward on gathered features: [P,128], [P,V,35], [P,V] -> raw [P,4]."""
+    fr = head_only_frame(head)
+    vol_feat, rgb_feat, mask = _f32(vol_feat), _f32(rgb_feat), _f32(mask)
+    P = vol_feat.shape[0]
+    raw = np.zeros((P, 4), np.float32)
+    assert lib().oracle_head_forward(C.byref(fr.c), _p(vol_feat), _p(rgb_feat), _p(mask), P, _p(raw)) == 0
+    return raw
 
 
 class Frame:

@@ -129,3 +129,30 @@ def test_early_termination_stays_within_bound(fm, oracle, syn):
     assert_close(cut["rgb_map"], full["rgb_map"], 2e-5, "rgb (early term)")
     assert_close(cut["depth_map"], full["depth_map"], 1e-4, "depth (early term)")
     assert (cut["weights"] == 0).sum() > (full["weights"] == 0).sum(), "no sample was skipped: the test scene is not opaque enough"
+
+
+@pytest.mark.parametrize("name", ["base_s32", "neg_s32", "stretch_s32", "partial_s32"])
+def test_stage_entry_points_match_reference_golden(name, fm):
+    """One reference function per launch: sampling, volume gather, projection gather, head, composite."""
+    z, meta = load(name)
+    sc = scene_of(meta)
+    S, neg = meta["n_samples"], meta["neg_ray"]
+    k = z["st_raw"].shape[0]
+    fr = build_frame(fm, sc)
+    rays = rays_of(sc)[:k]
+    pts, zv, grid = fm.sample_points(fr, rays, S)
+    assert_close(pts.cpu().numpy(), z["st_pts"], 1e-6, "pts")
+    assert_close(zv.cpu().numpy(), z["st_z"], 1e-6, "z_vals")
+    assert_close(grid.cpu().numpy().reshape(-1, 3), z["st_grid"], 2e-5, "grid_coords")
+    vf = fm.sample_volume(fr, grid)
+    assert_close(vf.cpu().numpy(), z["st_vol_feat"], 2e-4, "volume features")
+    feat, mask = fm.project_gather(fr, pts, neg_ray=neg)
+    assert_close(feat.cpu().numpy().reshape(k, S, 3, 35), z["st_rgb_feat"], 2e-4, "rgb_feat")
+    assert np.array_equal(mask.cpu().numpy().reshape(k, S, 3), z["st_mask"])
+    raw = fm.head_forward(fr.head_blob, vf, feat, mask)
+    assert_close(raw.cpu().numpy().reshape(k, S, 4), z["st_raw"], TOL, "raw")
+    comp = cpu(fm.composite(raw.reshape(k, S, 4), zv, mask.sum(-1).reshape(k, S), neg=neg))
+    assert_close(comp["rgb_map"], z["rgb_map"][:k], TOL, "rgb_map")
+    assert_close(comp["depth_map"], z["depth_map"][:k], TOL, "depth_map")
+    assert_close(comp["weights"], z["weights"][:k], TOL, "weights")
+    assert np.array_equal(comp["ray_mask"].astype(bool), z["st_ray_mask"])

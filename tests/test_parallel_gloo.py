@@ -1,0 +1,67 @@
+"""CPU: ray sharding + pixel all-gather over torch.distributed (gloo, world_size 2)."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_shard_bounds_are_tile_aligned_and_cover():
+    par = importlib.import_module("gp-nerf_amd.parallel")
+    for n in (0, 1, 31, 32, 33, 667, 4096, 262144, 262145):
+        for world in (1, 2, 3, 4, 8):
+            b = par.shard_bounds(n, world)
+            assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+            for (s, e), (s2, e2) in zip(b, b[1:]):
+                assert e == s2
+                assert s2 % 32 == 0 or s2 == e2      # non-empty shards start on a 32-ray tile
+            sizes = [e - s for s, e in b]
+            assert max(sizes) - min(sizes) <= 32 + 31
+
+
+def _fake_render(rays):
+    # any per-ray function stands in for the kernel: shard-invariance is what is under test
+    s = rays.sum(1)
+    return {"rgb_map": torch.stack([s, s * 2, s * 3], 1), "depth_map": s + 1, "acc_map": s * 0 + 1, "disp_map": 1 / (s + 1)}
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module("gp-nerf_amd.parallel")
+    g = torch.Generator().manual_seed(7)
+    rays = torch.rand((n, 8), generator=g)
+    full = par.render_sharded(_fake_render, rays)
+    ref = _fake_render(rays)
+    ok = all(torch.equal(full[k], ref[k]) for k in ref)
+    # equal-sized shards, the bench's collective
+    s, e = par.shard_bounds(n - n % (32 * world), world)[rank]
+    local = _fake_render(rays[s:e])
+    gathered = torch.empty((world, e - s, 4))
+    par.all_gather_pixels(local, gathered)
+    exp = par.pack_pixels(_fake_render(rays[: (e - s) * world]))
+    ok = ok and torch.equal(gathered.view(-1, 4), exp)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [667, 4096])
+def test_render_sharded_equals_unsharded_world2(n):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
