@@ -143,6 +143,8 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
     float y[48];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
+        // the three views share these weights; keep the compiler from holding ~100 VGPRs of them across views
+        asm volatile("" : "+v"(lane));
         f32x16 a0 = s0, a1 = s1;
         mfma_tile<18>(wtile<gpl::BV>(lds, 0), lane, x[v], a0);
         mfma_tile<18>(wtile<gpl::BV>(lds, 1), lane, x[v], a1);
@@ -383,7 +385,10 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         float fv[64];
 #pragma unroll
         for (int l = 0; l < GPNERF_LEVELS; ++l)
+        {
             gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
+            __builtin_amdgcn_sched_barrier(0);      // one level's 32 loads in flight at a time (register pressure)
+        }
         float sf[32];
         geo_eval(lds, lane, fv, sf);
 
