@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the fused kernel (build: make -C gp-nerf_amd/csrc libgpnerf_hip_stamps.so).
+Loads the stamped library IN PLACE of the product library for this process only.  Shares, not run times."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+L = importlib.import_module("gp-nerf_amd._lib")
+L.LIB_PATH = os.path.join(ROOT, "gp-nerf_amd", "csrc", os.environ.get("GPNERF_DIAG_LIB", "libgpnerf_hip_stamps.so"))
+fm = importlib.import_module("gp-nerf_amd.frame")
+syn = importlib.import_module("gp-nerf_amd.synthetic")
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+S = 64
+dev = torch.device("cuda:0")
+sc = syn.make_scene(H=size, W=size, seed=0, fill="full", pose="identity")
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+fr = fm.Frame(t(sc["src_imgs"][0]), t(sc["featmaps"]), [t(v) for v in sc["volumes"]], t(sc["src_Ks"][0]), t(sc["src_poses"][0]),
+              sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0], fm.pack_head(sc["head"], dev))
+rays = t(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1))
+lib = L.lib()
+lib.gpnerf_debug_read_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
+buf = (C.c_ulonglong * 16)()
+fm.render_fused(fr, rays, S, want=())
+torch.cuda.synchronize()
+lib.gpnerf_debug_read_stamps(buf)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+fm.render_fused(fr, rays, S, want=())
+e1.record()
+torch.cuda.synchronize()
+lib.gpnerf_debug_read_stamps(buf)
+names = ["0 sample+volume gather", "1 geo MFMA+ELU", "2 view gather", "3 density branch", "4 colour base/vis x3", "5 rgb_fc tail", "6 composite+stores"]
+tot = sum(buf[i] for i in range(7))
+waves = (rays.shape[0] + 31) // 32
+print(f"stamped kernel {e0.elapsed_time(e1):.2f} ms; per wave per sample cycles (s_memtime ticks):")
+for i, n in enumerate(names):
+    print(f"  {n:28s} {buf[i] / waves / S:9.0f}  {100.0 * buf[i] / tot:5.1f}%")
+print(f"  total {tot / waves / S:.0f}")
