@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ray-order", default="patch", choices=["patch", "raster"],
+                    help="patch: 32x8-pixel workgroup tiles (gpnerf_render_fused's ray_order); raster: the list as given")
     return ap.parse_args()
 
 
@@ -75,6 +77,9 @@ def main():
     rays_h = np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32)
     rays = t(rays_h)                       # this rank's band: weak scaling, same ray count on every rank
     n_local = rays.shape[0]
+    order = None
+    if args.ray_order == "patch":
+        order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], H, W)).to(dev)
     n_total = n_local * world
     torch.cuda.synchronize()
 
@@ -86,7 +91,7 @@ def main():
     def step(i=None):
         if i is not None:
             k_start[i].record()
-        out = fm.render_fused(frame, rays, S, early_term=args.early_term, term_eps=args.term_eps, want=want)
+        out = fm.render_fused(frame, rays, S, early_term=args.early_term, term_eps=args.term_eps, want=want, ray_order=order)
         if i is not None:
             k_stop[i].record()
         if world > 1:
@@ -124,7 +129,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{H}x{W} frame, {S} samples/ray, fused HIP render kernel, synthetic SMPL bound + random "
                                    f"feature volume (BASELINE.json configs[{2 if args.early_term else 1}])",
-                       "rays_per_gpu": int(n_local), "rays_total": int(n_total), "samples_per_ray": S, "fill": args.fill,
+                       "rays_per_gpu": int(n_local), "rays_total": int(n_total), "samples_per_ray": S, "fill": args.fill, "ray_order": args.ray_order,
                        "early_term": bool(args.early_term), "out_sh_dhw": [int(x) for x in sc["out_sh"][0]],
                        "parallelism": f"ray bands over {world} GPU(s), all-gather of rgb+depth" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -59,7 +59,11 @@ struct Stamps { DEV void start() {} DEV void flush(int) {} };
 #endif
 
 DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }       // v_exp_f32
+#ifdef GPNERF_ABLATE_ELU
+DEV float elu1(float x) { return x; }
+#else
 DEV float elu1(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }             // nn.ELU(alpha=1)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // dense layers on v_mfma_f32_32x32x2_f32
@@ -346,6 +350,7 @@ struct FrameK {           // GpnerfFrame by value (kernel argument; lands in SGP
 struct OutK {
     float *rgb, *depth, *acc, *disp, *weights, *z_vals, *rgb_in, *raw;
     uint8_t* ray_mask;
+    const int32_t* order;     // optional: slot i of the launch renders ray order[i] (locality-friendly tiling)
 };
 
 // bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
@@ -375,7 +380,7 @@ DEV void grid_coords(const FrameK& fr, float px, float py, float pz, float& gx, 
 template <int NWAVES>
 __global__ void __launch_bounds__(NWAVES * 64, 2)
 render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
-                    const unsigned flags, const float term_eps, const OutK out) {
+                    const unsigned flags, const float term_eps, const OutK out, const int stagger) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(fr.head_blob);
@@ -390,7 +395,8 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
     const long ray0 = tile * RAYS_PER_WAVE;
     if (ray0 >= n_rays) return;
     const bool active = (ray0 + n) < n_rays;
-    const long ray = active ? ray0 + n : n_rays - 1;
+    const long slot = active ? ray0 + n : n_rays - 1;
+    const long ray = out.order ? (long)out.order[slot] : slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;
     const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
 
@@ -406,6 +412,11 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0);
 
+    // The two waves a SIMD hosts run the same program; started together they gather together and queue for the
+    // matrix pipe together.  Delay the second-dispatched half of the workgroup by a fraction of a sample so that
+    // one wave's gather phase faces the other's MFMA phase (units of s_sleep 64 = 4096 cycles).
+    if (__builtin_amdgcn_readfirstlane(wave) >= NWAVES / 2)
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);
     Stamps st;
     st.start();
     int k = 0;
@@ -605,7 +616,8 @@ render_pipe_kernel(const FrameK fr, const float* __restrict__ rays, const long n
     const long ray0 = tile * RAYS_PER_WAVE;
     if (ray0 >= n_rays) return;
     const bool active = (ray0 + n) < n_rays;
-    const long ray = active ? ray0 + n : n_rays - 1;
+    const long slot = active ? ray0 + n : n_rays - 1;
+    const long ray = out.order ? (long)out.order[slot] : slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;
     const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
 
@@ -1274,8 +1286,9 @@ bool to_framek(const GpnerfFrame* f, FrameK& k, bool need_vol, bool need_img) {
     return true;
 }
 
-OutK to_outk(const GpnerfOutputs* o) {
+OutK to_outk(const GpnerfOutputs* o, const int32_t* order = nullptr) {
     OutK k;
+    k.order = order;
     k.rgb = o->rgb; k.depth = o->depth; k.acc = o->acc; k.disp = o->disp; k.weights = o->weights;
     k.z_vals = o->z_vals; k.rgb_in = o->rgb_in; k.raw = o->raw; k.ray_mask = o->ray_mask;
     return k;
@@ -1357,7 +1370,7 @@ int gpnerf_pack_head(const GpnerfHeadParams* p, float* blob) {
 }
 
 int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, uint32_t flags,
-                        float term_eps, const GpnerfOutputs* out, void* stream) {
+                        float term_eps, const int32_t* ray_order, const GpnerfOutputs* out, void* stream) {
     if (n_rays == 0) return GPNERF_OK;          // empty ray list: nothing to do (pointers may be null)
     if (!f || !rays || !out || n_rays < 0 || n_samples < 1) return GPNERF_E_ARG;
     if (!out->rgb || !out->depth || !out->acc || !out->disp || !f->head_blob) return GPNERF_E_ARG;
@@ -1379,12 +1392,14 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     }
     if (variant == 1) {
         const int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
+        static int stagger = -1;
+        if (stagger < 0) { const char* e = getenv("GPNERF_STAGGER"); stagger = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(render_fused_kernel<FUSED_WAVES>, dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
-                           k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out));
+                           k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out, ray_order), stagger);
     } else {
         const int64_t blocks = (tiles + PIPE_WAVES - 1) / PIPE_WAVES;
         hipLaunchKernelGGL(render_pipe_kernel<PIPE_WAVES>, dim3((unsigned)blocks), dim3(PIPE_WAVES * 64), lds_bytes, S_(stream),
-                           k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out));
+                           k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out, ray_order));
     }
     return launch_status();
 }

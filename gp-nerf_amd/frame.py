@@ -152,9 +152,24 @@ class Frame:
                    batch["Th"][0], batch["bounds"][0, 0], voxel_size, batch["out_sh"][0], head_blob)
 
 
+def patch_order(mask_at_box, H, W, patch_w=32, patch_h=8):
+    """Permutation of the hit-ray list (raster order of `mask_at_box`) into image patches: each run of
+    patch_w*patch_h consecutive slots covers one patch, one patch row (patch_w pixels) per wavefront.
+    Returns an int32 numpy array for render_fused(ray_order=...)."""
+    m = np.asarray(mask_at_box).reshape(H, W).astype(bool)
+    idx = np.full((H, W), -1, np.int64)
+    idx[m] = np.arange(int(m.sum()))
+    Hp, Wp = -(-H // patch_h) * patch_h, -(-W // patch_w) * patch_w
+    pad = np.full((Hp, Wp), -1, np.int64)
+    pad[:H, :W] = idx
+    t = pad.reshape(Hp // patch_h, patch_h, Wp // patch_w, patch_w).transpose(0, 2, 1, 3).reshape(-1)
+    return t[t >= 0].astype(np.int32)
+
+
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
-                 want=("weights", "z_vals", "rgb_in", "ray_mask")):
-    """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...]."""
+                 want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None):
+    """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
+    ray_order: optional int32 device tensor [N], a permutation that groups rays into cache-friendly tiles."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()
@@ -182,7 +197,12 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         res["raw"] = torch.empty((N, S, 4), device=dev)
         o.raw = res["raw"].data_ptr()
     flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
-    L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), N, S, flags, float(term_eps), C.byref(o),
+    if ray_order is not None:
+        _require_gpu(ray_order, "ray_order")
+        if ray_order.dtype != torch.int32 or ray_order.numel() != N or not ray_order.is_contiguous():
+            raise L.GpnerfError("ray_order must be a contiguous int32 tensor with one entry per ray")
+    L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), N, S, flags, float(term_eps),
+                                    ray_order.data_ptr() if ray_order is not None else None, C.byref(o),
                                     _stream_ptr(dev)), "gpnerf_render_fused")
     return res
 

@@ -107,9 +107,13 @@ int gpnerf_pack_head(const GpnerfHeadParams* params_host, float* blob_host);
  * NeRFSigmaHead.out_geometry_fc + NeRFRGBHead.forward (libs/nerfheads/trainhead.py:39-40,58,118-145)
  * and raw2outputs :75-107, rgb_in_map :147.
  *   rays: device [N][8] = origin(3), direction(3, un-normalised), near, far (BaseRender.py:250)
- *   term_eps: transmittance threshold, read only with GPNERF_FLAG_EARLY_TERM */
+ *   term_eps: transmittance threshold, read only with GPNERF_FLAG_EARLY_TERM
+ *   ray_order: optional device [N] permutation of 0..N-1 (NULL = identity).  Launch slot i renders ray
+ *     ray_order[i]; inputs are read and outputs written at the ray's own index, so results do not depend on it.
+ *     It only decides which 32 rays share a wavefront and which 256 share a workgroup: pass image patches
+ *     (e.g. 32x8 pixels per workgroup) so neighbouring rays hit the same cache lines. */
 int gpnerf_render_fused(const GpnerfFrame* frame, const float* rays, int64_t n_rays, int32_t n_samples,
-                        uint32_t flags, float term_eps, const GpnerfOutputs* out, void* stream);
+                        uint32_t flags, float term_eps, const int32_t* ray_order, const GpnerfOutputs* out, void* stream);
 
 /* Stage entry points (the same device code as the fused kernel, one reference function per launch).
  *

@@ -156,3 +156,17 @@ def test_stage_entry_points_match_reference_golden(name, fm):
     assert_close(comp["depth_map"], z["depth_map"][:k], TOL, "depth_map")
     assert_close(comp["weights"], z["weights"][:k], TOL, "weights")
     assert np.array_equal(comp["ray_mask"].astype(bool), z["st_ray_mask"])
+
+
+def test_ray_order_changes_tiling_not_results(fm, syn):
+    sc = syn.make_scene(H=40, W=48, seed=31, focal_mul=5.0, pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1)
+    fr = build_frame(fm, sc)
+    rays = rays_of(sc)
+    n = rays.shape[0]
+    base = fm.render_fused(fr, rays, 16)
+    order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], 40, 48)).to("cuda:0")
+    assert sorted(order.cpu().tolist()) == list(range(n))
+    for o in (order, torch.randperm(n, device="cuda:0").int()):
+        got = fm.render_fused(fr, rays, 16, ray_order=o)
+        for k in base:
+            assert torch.equal(torch.nan_to_num(got[k].float()), torch.nan_to_num(base[k].float())), k
