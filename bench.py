@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--occ-cull", action="store_true",
+                    help="progressive sample culling (demo_render.py semantics) on a sparse synthetic pyramid")
+    ap.add_argument("--occupancy", type=float, default=None, help="fraction of coarse volume blocks that are occupied")
     ap.add_argument("--ray-order", default="patch", choices=["patch", "raster"],
                     help="patch: 32x8-pixel workgroup tiles (gpnerf_render_fused's ray_order); raster: the list as given")
     return ap.parse_args()
@@ -69,7 +72,7 @@ def main():
 
     H = W = args.size
     S = args.samples
-    sc = syn.make_scene(H=H, W=W, seed=args.seed, fill=args.fill, pose="identity")
+    sc = syn.make_scene(H=H, W=W, seed=args.seed, fill=args.fill, pose="identity", vol_occupancy=args.occupancy)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     blob = fm.pack_head(sc["head"], dev)
     frame = fm.Frame(t(sc["src_imgs"][0]), t(sc["featmaps"]), [t(v) for v in sc["volumes"]], t(sc["src_Ks"][0]),
@@ -91,7 +94,7 @@ def main():
     def step(i=None):
         if i is not None:
             k_start[i].record()
-        out = fm.render_fused(frame, rays, S, early_term=args.early_term, term_eps=args.term_eps, want=want, ray_order=order)
+        out = fm.render_fused(frame, rays, S, early_term=args.early_term, term_eps=args.term_eps, want=want, ray_order=order, occ_cull=args.occ_cull)
         if i is not None:
             k_stop[i].record()
         if world > 1:
@@ -130,7 +133,7 @@ def main():
             "config": {"workload": f"{H}x{W} frame, {S} samples/ray, fused HIP render kernel, synthetic SMPL bound + random "
                                    f"feature volume (BASELINE.json configs[{2 if args.early_term else 1}])",
                        "rays_per_gpu": int(n_local), "rays_total": int(n_total), "samples_per_ray": S, "fill": args.fill, "ray_order": args.ray_order,
-                       "early_term": bool(args.early_term), "out_sh_dhw": [int(x) for x in sc["out_sh"][0]],
+                       "early_term": bool(args.early_term), "occ_cull": bool(args.occ_cull), "vol_occupancy": args.occupancy, "out_sh_dhw": [int(x) for x in sc["out_sh"][0]],
                        "parallelism": f"ray bands over {world} GPU(s), all-gather of rgb+depth" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(args),
@@ -152,7 +155,8 @@ def measured_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot run the
     profiler itself); only reported for the configuration the counters were collected on."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if args.size == 512 and args.samples == 64 and args.fill == "full" and not args.early_term and os.path.exists(p):
+    if (args.size == 512 and args.samples == 64 and args.fill == "full" and not args.early_term and not args.occ_cull
+            and args.occupancy is None and os.path.exists(p)):
         return json.load(open(p))["hbm_bytes_per_launch"]
     return None
 

@@ -28,6 +28,7 @@ class GpnerfFrame(C.Structure):
         ("bounds_min", C.c_float * 3), ("voxel", C.c_float * 3),
         ("out_sh", C.c_int32 * 3),
         ("head_blob", C.c_void_p),
+        ("occ", C.c_void_p),
     ]
 
 
@@ -57,6 +58,7 @@ class GpnerfOutputs(C.Structure):
 
 FLAG_NEG_RAY = 1
 FLAG_EARLY_TERM = 2
+FLAG_OCC_CULL = 4
 
 # every symbol include/gpnerf_hip.h declares: (restype, argtypes)
 SYMBOLS = {
@@ -73,6 +75,7 @@ SYMBOLS = {
     "gpnerf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.POINTER(GpnerfOutputs), C.c_void_p]),
     "gpnerf_make_rays": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_build_occupancy": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_void_p]),
     "gpnerf_relayout_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_featmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

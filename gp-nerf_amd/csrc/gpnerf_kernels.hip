@@ -286,6 +286,21 @@ DEV void gather_volume(const float* __restrict__ vol, int D, int H, int W, float
             }
 }
 
+// F.grid_sample of the single-channel occupancy volume (demo_render.py:274-279), same coordinates as the features
+DEV float sample_occupancy(const float* __restrict__ occ, int D, int H, int W, float gx, float gy, float gz) {
+    const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
+    const int zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1}, xi[2] = {ax.i0, ax.i1};
+    const float zw[2] = {az.w0, az.w1}, yw[2] = {ay.w0, ay.w1}, xw[2] = {ax.w0, ax.w1};
+    float v = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) v = fmaf(occ[(zi[a] * H + yi[b]) * W + xi[e]], (xw[e] * yw[b]) * zw[a], v);
+    return v;
+}
+
 struct ViewSample {
     float rgb[3];
     float valid;
@@ -345,6 +360,7 @@ struct FrameK {           // GpnerfFrame by value (kernel argument; lands in SGP
     float Rh[9], Th[3], bounds_min[3], voxel[3];
     float out_sh[3];      // as float
     const float* head_blob;
+    const float* occ;     // level-1-sized occupancy volume or nullptr
 };
 
 struct OutK {
@@ -399,6 +415,7 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
     const long ray = out.order ? (long)out.order[slot] : slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;
     const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
+    const bool cull = (flags & GPNERF_FLAG_OCC_CULL) != 0 && fr.occ != nullptr;
 
     const f32x4 r0 = *reinterpret_cast<const f32x4*>(rays + ray * 8);
     const f32x4 r1 = *reinterpret_cast<const f32x4*>(rays + ray * 8 + 4);
@@ -432,6 +449,23 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         float gx, gy, gz;
         grid_coords(fr, px, py, pz, gx, gy, gz);
 
+        // progressive culling (demo_render.py:270-283): evaluate only samples whose occupancy interpolates to > 0;
+        // a tile whose 32 samples are all culled skips its gathers and the MLP (alpha = 0 for all of them)
+        bool keep = true;
+        if (cull) {
+            keep = sample_occupancy(fr.occ, fr.vol_dhw[0][0], fr.vol_dhw[0][1], fr.vol_dhw[0][2], gx, gy, gz) > 0.f;
+            if (!__any(keep)) {
+                if (writer) {
+                    const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
+                    if (out.weights) out.weights[(size_t)ray * S + k] = 0.f;
+                    if (out.z_vals) out.z_vals[(size_t)ray * S + k] = near * (1.f - tk) + far * tk;
+                    if (out.raw) *reinterpret_cast<f32x4*>(out.raw + ((size_t)ray * S + ks) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                T = T * (1.f + 1e-10f);                 // cumprod(1 - alpha + 1e-10) with alpha = 0
+                continue;
+            }
+        }
+
         // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
         float fv[64];
 #pragma unroll
@@ -464,6 +498,10 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         STAMP(st, 2);
         float sigma, rgb[3];
         mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
+        if (cull) {
+            if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
+            if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
+        }
 
         if (out.raw && writer) {
             f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
@@ -1213,6 +1251,29 @@ __global__ void __launch_bounds__(256) cfirst_to_clast32_kernel(const float* __r
     }
 }
 
+// SparseConvNet.encode's masks3d (SparseConvNet.py:135-139): one lane per level-1 voxel
+__global__ void occupancy_kernel(const FrameK fr, float* __restrict__ occ) {
+    const int D = fr.vol_dhw[0][0], H = fr.vol_dhw[0][1], W = fr.vol_dhw[0][2];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)D * H * W) return;
+    const int w = (int)(i % W), h = (int)((i / W) % H), d = (int)(i / ((long)W * H));
+    float total = 0.f;
+#pragma unroll
+    for (int l = 0; l < GPNERF_LEVELS; ++l) {
+        const int Dl = fr.vol_dhw[l][0], Hl = fr.vol_dhw[l][1], Wl = fr.vol_dhw[l][2];
+        // F.interpolate(mode='nearest'): src = floor(dst * in / out)
+        const int dl = min((int)floorf((float)d * ((float)Dl / (float)D)), Dl - 1);
+        const int hl = min((int)floorf((float)h * ((float)Hl / (float)H)), Hl - 1);
+        const int wl = min((int)floorf((float)w * ((float)Wl / (float)W)), Wl - 1);
+        const f32x4* p = reinterpret_cast<const f32x4*>(fr.vol[l] + (((size_t)dl * Hl + hl) * Wl + wl) * 32);
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const f32x4 v = p[q]; sum += (v[0] + v[1]) + (v[2] + v[3]); }
+        total += sum;
+    }
+    occ[i] = total;
+}
+
 __global__ void images_to_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, const long HW, const int V) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= HW * V) return;
@@ -1283,6 +1344,7 @@ bool to_framek(const GpnerfFrame* f, FrameK& k, bool need_vol, bool need_img) {
     memcpy(k.voxel, f->voxel, sizeof(k.voxel));
     for (int a = 0; a < 3; ++a) k.out_sh[a] = (float)f->out_sh[a];
     k.head_blob = f->head_blob;
+    k.occ = f->occ;
     return true;
 }
 
@@ -1483,6 +1545,15 @@ int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv,
     }
     const int n = H * W, bs = 256;
     hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, rays, hit);
+    return launch_status();
+}
+
+int gpnerf_build_occupancy(const GpnerfFrame* f, float* occ, void* stream) {
+    if (!f || !occ) return GPNERF_E_ARG;
+    FrameK k;
+    if (!to_framek(f, k, true, false)) return GPNERF_E_ARG;
+    const long n = (long)k.vol_dhw[0][0] * k.vol_dhw[0][1] * k.vol_dhw[0][2];
+    hipLaunchKernelGGL(occupancy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), k, occ);
     return launch_status();
 }
 

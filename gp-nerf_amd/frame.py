@@ -130,6 +130,15 @@ class Frame:
             f.vol[l] = o.data_ptr()
             f.vol_dhw[l][0], f.vol_dhw[l][1], f.vol_dhw[l][2] = D, Hh, Ww
 
+    def build_occupancy(self):
+        """SparseConvNet.encode's `masks3d` (SparseConvNet.py:135-139) from the 4 levels; enables occ_cull renders."""
+        D, H, W = self.vols[0].shape[:3]
+        self.occ = torch.empty((D, H, W), device=self.vols[0].device, dtype=torch.float32)
+        L.check(L.lib().gpnerf_build_occupancy(C.byref(self.c), self.occ.data_ptr(), _stream_ptr(self.occ.device)),
+                "gpnerf_build_occupancy")
+        self.c.occ = self.occ.data_ptr()
+        return self.occ
+
     @classmethod
     def for_volumes(cls, volumes, head_blob):
         """A frame that carries only the 4 dense levels (enough for gpnerf_sample_volume)."""
@@ -167,7 +176,7 @@ def patch_order(mask_at_box, H, W, patch_w=32, patch_h=8):
 
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
-                 want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None):
+                 want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     ray_order: optional int32 device tensor [N], a permutation that groups rays into cache-friendly tiles."""
     lib = L.lib()
@@ -197,6 +206,10 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         res["raw"] = torch.empty((N, S, 4), device=dev)
         o.raw = res["raw"].data_ptr()
     flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
+    if occ_cull:
+        if not frame.c.occ:
+            frame.build_occupancy()
+        flags |= L.FLAG_OCC_CULL
     if ray_order is not None:
         _require_gpu(ray_order, "ray_order")
         if ray_order.dtype != torch.int32 or ray_order.numel() != N or not ray_order.is_contiguous():

@@ -160,6 +160,7 @@ def make_scene(
     max_rays=None,
     make_volumes=True,
     neg_cams=False,
+    vol_occupancy=None,
 ):
     """Build one synthetic frame.
 
@@ -235,10 +236,21 @@ def make_scene(
 
     volumes = []
     if make_volumes:
+        occ_coarse = None
+        if vol_occupancy is not None:
+            # sparse, non-negative pyramid like the sparse conv net's ReLU outputs: a random block mask at the
+            # coarsest level, nearest-upsampled to the finer ones, times |N(0,1)|
+            d4, h4, w4 = [int(s) >> N_LEVELS for s in out_sh]
+            occ_coarse = _rng(seed, 300).random((d4, h4, w4)) < float(vol_occupancy)
         for k in range(1, N_LEVELS + 1):
             d, h, w = [int(s) >> k for s in out_sh]
             gv = _rng(seed, 200 + k)
-            volumes.append(gv.standard_normal((1, FEAT_CH, d, h, w), dtype=np.float32) * np.float32(vol_scale))
+            v = gv.standard_normal((1, FEAT_CH, d, h, w), dtype=np.float32) * np.float32(vol_scale)
+            if occ_coarse is not None:
+                r = 1 << (N_LEVELS - k)
+                m = np.repeat(np.repeat(np.repeat(occ_coarse, r, 0), r, 1), r, 2)
+                v = np.abs(v) * m[None, None].astype(np.float32)
+            volumes.append(v)
 
     # voxel index of every vertex, dhw order (ZjumocapDataset.py:243-247); only the
     # (out-of-scope) sparse volume builder reads it, kept for schema completeness

@@ -40,6 +40,9 @@ extern "C" {
 /* flags of gpnerf_render_fused */
 #define GPNERF_FLAG_NEG_RAY 1u     /* Projector(neg_ray=True) + raw2outputs(neg=True): BaseRender.py:86-88,317-320 */
 #define GPNERF_FLAG_EARLY_TERM 2u  /* stop a 32-ray wave tile once every ray has T < term_eps (not in the reference) */
+#define GPNERF_FLAG_OCC_CULL 4u    /* progressive sample culling of libs/renders/demo_render.py:270-283,317-347: a sample is
+                                      evaluated only where the occupancy volume (frame->occ) interpolates to > 0; culled
+                                      samples carry alpha = 0, and colour is kept only where alpha > 1e-14 */
 
 /* Per-frame constants (everything render_rays reads that does not depend on the ray).
  * Layouts are channels-last so that one bilinear / trilinear tap is one contiguous
@@ -58,6 +61,8 @@ typedef struct GpnerfFrame {
     float voxel[3];                         /* cfg.dataset.voxel_size (applied in d,h,w order); BaseRender.py:67 */
     int32_t out_sh[3];                      /* batch['out_sh'] d,h,w; BaseRender.py:69-70 */
     const float* head_blob;                 /* device; gpnerf_pack_head() image, gpnerf_head_blob_floats() floats */
+    const float* occ;                       /* device or NULL; [D_1][H_1][W_1] occupancy `masks3d` at level-1 size
+                                               (SparseConvNet.py:135-139), read only with GPNERF_FLAG_OCC_CULL */
 } GpnerfFrame;
 
 /* The per-ray MLP parameters in PyTorch layout (weight [out][in] row-major, bias [out]),
@@ -148,6 +153,11 @@ int gpnerf_composite(const float* raw, const float* z_vals, const float* nvalid,
  *   pixel index; the caller keeps the hit ones in raster order. */
 int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o,
                      const float* bounds, float* rays, uint8_t* hit, void* stream);
+
+/* SparseConvNet.encode's occupancy volume (libs/nerfheads/networks/SparseConvNet.py:135-139):
+ * occ[d][h][w] = sum over the 4 levels of (channel sum of level k, nearest-upsampled to level-1 size).
+ * Reads frame->vol / vol_dhw (channels-last); occ: device [D_1][H_1][W_1]. */
+int gpnerf_build_occupancy(const GpnerfFrame* frame, float* occ, void* stream);
 
 /* Channels-last re-layouts of the per-frame tensors (device -> device). */
 int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t H, int32_t W, void* stream);

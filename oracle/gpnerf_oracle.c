@@ -49,6 +49,7 @@ typedef struct {
     const float *v1_w, *v1_b, *v2_w, *v2_b;/* 32x32 x2       rgbhead.vis_fc */
     const float *r1_w, *r1_b, *r2_w, *r2_b, *r3_w, *r3_b; /* 32x96,16x32,3x16 rgbhead.rgb_fc */
     const float *d1_w, *d1_b, *d2_w, *d2_b, *d3_w, *d3_b, *d4_w, *d4_b; /* 64x134,32x64,16x32,1x16 */
+    const float *occ;       /* [D1,H1,W1] masks3d (SparseConvNet.py:135-139) or NULL; progressive mode only */
 } OracleFrame;
 
 typedef struct {
@@ -182,8 +183,13 @@ static void head_forward(const OracleFrame *f, const float *vol_feat /*128*/, co
 }
 
 /* Renderer.render_rays for one ray (BaseRender.py:110-157) with is_train=False. */
-static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near far*/, int S, int neg_ray,
+/* flags: bit 0 = neg_ray; bit 2 (value 4) = progressive sample culling, restating
+ * libs/renders/demo_render.py:270-283 (keep a sample iff grid_sample(masks3d) > 0), :317 (colour only where
+ * alpha > 1e-14) and :336-344 (culled samples carry alpha = 0, rgb = 0).  demo_render.py hard-codes CUDA and
+ * cannot be run in the build container: this branch is a restatement WITHOUT a golden vector (parity unpinned). */
+static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near far*/, int S, int flags,
                            int64_t r, OracleOut *o, float *scratch /* S*(4+9+1) */) {
+    const int neg_ray = flags & 1, cull = (flags & 4) && f->occ;
     float *raw = scratch;            /* [S][4] */
     float *rin = scratch + 4 * S;    /* [S][9] */
     float *zv = scratch + 13 * S;    /* [S] */
@@ -239,6 +245,12 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
         if (o->st_mask) memcpy(o->st_mask + ((size_t)r * S + k) * NV, mask, sizeof(mask));
         if (mask[0] + mask[1] + mask[2] > 1.f) ++n_two;             /* pixel_mask :139 */
         head_forward(f, vf, x, mask, raw + 4 * k, rin + 9 * k);
+        if (cull) {
+            float occv;
+            grid_sample3d(f->occ, 1, f->vol_dhw[0][0], f->vol_dhw[0][1], f->vol_dhw[0][2], g[0], g[1], g[2], &occv);
+            if (!(occv > 0.f)) raw[4 * k + 3] = 0.f;
+            if (!(1.f - expf(-raw[4 * k + 3]) > 1e-14f)) raw[4 * k] = raw[4 * k + 1] = raw[4 * k + 2] = 0.f;
+        }
         if (o->st_raw) memcpy(o->st_raw + ((size_t)r * S + k) * 4, raw + 4 * k, 4 * sizeof(float));
     }
     /* raw2outputs :75-107 */
@@ -268,7 +280,7 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
 }
 
 /* rays: [N][8] = o(3) d(3) near far  (BaseRender.py:250).  Returns 0. */
-int oracle_render(const OracleFrame *f, const float *rays, int64_t N, int S, int neg_ray, OracleOut *out, int n_threads) {
+int oracle_render(const OracleFrame *f, const float *rays, int64_t N, int S, int flags, OracleOut *out, int n_threads) {
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
@@ -276,7 +288,7 @@ int oracle_render(const OracleFrame *f, const float *rays, int64_t N, int S, int
     {
         float *scratch = (float *)malloc(sizeof(float) * 14 * (size_t)S);
 #pragma omp for schedule(dynamic, 16)
-        for (int64_t r = 0; r < N; ++r) render_one_ray(f, rays + 8 * r, S, neg_ray, r, out, scratch);
+        for (int64_t r = 0; r < N; ++r) render_one_ray(f, rays + 8 * r, S, flags, r, out, scratch);
         free(scratch);
     }
     return 0;
@@ -382,5 +394,29 @@ int oracle_head_forward(const OracleFrame *f, const float *vol_feat, const float
         float rin[9];
         head_forward(f, vol_feat + p * 128, rgb_feat + p * NV * XF, mask + p * NV, raw + p * 4, rin);
     }
+    return 0;
+}
+
+/* SparseConvNet.encode's masks3d (libs/nerfheads/networks/SparseConvNet.py:135-139): per level, sum over channels,
+ * F.interpolate(nearest) to the level-1 size, summed over levels.  vol[l] are NCDHW; occ is [D1,H1,W1]. */
+int oracle_build_occupancy(const OracleFrame *f, float *occ) {
+    const int D = f->vol_dhw[0][0], H = f->vol_dhw[0][1], W = f->vol_dhw[0][2];
+    for (int d = 0; d < D; ++d)
+        for (int h = 0; h < H; ++h)
+            for (int w = 0; w < W; ++w) {
+                float total = 0.f;
+                for (int l = 0; l < NL; ++l) {
+                    const int Dl = f->vol_dhw[l][0], Hl = f->vol_dhw[l][1], Wl = f->vol_dhw[l][2];
+                    int dl = (int)floorf((float)d * ((float)Dl / (float)D)), hl = (int)floorf((float)h * ((float)Hl / (float)H)),
+                        wl = (int)floorf((float)w * ((float)Wl / (float)W));
+                    if (dl > Dl - 1) dl = Dl - 1;
+                    if (hl > Hl - 1) hl = Hl - 1;
+                    if (wl > Wl - 1) wl = Wl - 1;
+                    float sum = 0.f;
+                    for (int c = 0; c < NC; ++c) sum += f->vol[l][(((size_t)c * Dl + dl) * Hl + hl) * Wl + wl];
+                    total += sum;
+                }
+                occ[((size_t)d * H + h) * W + w] = total;
+            }
     return 0;
 }

@@ -25,6 +25,7 @@ class OracleFrame(C.Structure):
         ("v1_w", FP), ("v1_b", FP), ("v2_w", FP), ("v2_b", FP),
         ("r1_w", FP), ("r1_b", FP), ("r2_w", FP), ("r2_b", FP), ("r3_w", FP), ("r3_b", FP),
         ("d1_w", FP), ("d1_b", FP), ("d2_w", FP), ("d2_b", FP), ("d3_w", FP), ("d3_b", FP), ("d4_w", FP), ("d4_b", FP),
+        ("occ", FP),
     ]
 
 
@@ -66,6 +67,8 @@ def lib():
         _lib.oracle_composite.restype = C.c_int
         _lib.oracle_composite.argtypes = [FP, FP, FP, C.c_int64, C.c_int, C.c_int, FP, FP, FP, FP, FP, C.POINTER(C.c_uint8)]
         _lib.oracle_max_threads.restype = C.c_int
+        _lib.oracle_build_occupancy.restype = C.c_int
+        _lib.oracle_build_occupancy.argtypes = [C.POINTER(OracleFrame), FP]
         _lib.oracle_head_forward.restype = C.c_int
         _lib.oracle_head_forward.argtypes = [C.POINTER(OracleFrame), FP, FP, FP, C.c_int64, FP]
     return _lib
@@ -162,9 +165,23 @@ def rays_of(scene):
     return _f32(np.concatenate([scene["ray_o"][0], scene["ray_d"][0], scene["near"][0][:, None], scene["far"][0][:, None]], 1))
 
 
-def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None, want_weights=True):
-    """Run the oracle over all rays of a synthetic scene; returns a dict of numpy arrays."""
+def build_occupancy(scene):
+    """masks3d of SparseConvNet.encode (SparseConvNet.py:135-139) from the scene's dense levels."""
     fr = Frame(scene)
+    D, H, W = scene["volumes"][0].shape[-3:]
+    occ = np.zeros((D, H, W), np.float32)
+    assert lib().oracle_build_occupancy(C.byref(fr.c), _p(occ)) == 0
+    return occ
+
+
+def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None, want_weights=True, occ=None):
+    """Run the oracle over all rays of a synthetic scene; returns a dict of numpy arrays.
+    occ: masks3d -> progressive sample culling (demo_render.py semantics, parity unpinned)."""
+    fr = Frame(scene)
+    if occ is not None:
+        occ = _f32(occ)
+        fr.keep.append(occ)
+        fr.c.occ = _p(occ)
     rays = rays_of(scene) if rays is None else _f32(rays)
     N, S = rays.shape[0], int(n_samples)
     res = {
@@ -190,7 +207,7 @@ def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None
     if stages:
         for k in ("st_grid", "st_vol_feat", "st_rgb_feat", "st_mask", "st_raw"):
             setattr(o, k, _p(res[k]))
-    rc = lib().oracle_render(C.byref(fr.c), _p(rays), N, S, int(bool(neg_ray)), C.byref(o), int(n_threads))
+    rc = lib().oracle_render(C.byref(fr.c), _p(rays), N, S, int(bool(neg_ray)) | (4 if occ is not None else 0), C.byref(o), int(n_threads))
     assert rc == 0
     return res
 

@@ -36,6 +36,7 @@ def test_struct_layouts_match_the_header(pkg):
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(GpnerfFrame), offsetof(GpnerfFrame, vol_dhw), offsetof(GpnerfFrame, featmaps),
          offsetof(GpnerfFrame, proj), offsetof(GpnerfFrame, out_sh), offsetof(GpnerfFrame, head_blob), offsetof(GpnerfFrame, imgs));
+  printf("%zu\n", offsetof(GpnerfFrame, occ));
   printf("%zu %zu\n", sizeof(GpnerfHeadParams), sizeof(GpnerfOutputs));
   return 0;
 }'''
@@ -44,11 +45,12 @@ int main(void) {
         open(c, "w").write(src)
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        a, b = subprocess.check_output([exe]).decode().strip().split("\n")
+        a, occ_off, b = subprocess.check_output([exe]).decode().strip().split("\n")
     L = pkg._lib
     F = L.GpnerfFrame
     assert [int(x) for x in a.split()] == [C.sizeof(F), F.vol_dhw.offset, F.featmaps.offset, F.proj.offset, F.out_sh.offset,
                                            F.head_blob.offset, F.imgs.offset]
+    assert int(occ_off) == F.occ.offset
     assert [int(x) for x in b.split()] == [C.sizeof(L.GpnerfHeadParams), C.sizeof(L.GpnerfOutputs)]
 
 

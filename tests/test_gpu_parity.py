@@ -170,3 +170,23 @@ def test_ray_order_changes_tiling_not_results(fm, syn):
         got = fm.render_fused(fr, rays, 16, ray_order=o)
         for k in base:
             assert torch.equal(torch.nan_to_num(got[k].float()), torch.nan_to_num(base[k].float())), k
+
+
+def test_progressive_sample_culling_matches_restatement(fm, oracle, syn):
+    """demo_render.py's occupancy / alpha culling (parity unpinned: restated, the CUDA-only reference path cannot run)."""
+    sc = syn.make_scene(H=24, W=24, seed=77, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1,
+                        vol_occupancy=0.35)
+    S = 48
+    fr = build_frame(fm, sc)
+    occ = fr.build_occupancy().cpu().numpy()
+    occ_ref = oracle.build_occupancy(sc)
+    assert_close(occ, occ_ref, 1e-4, "masks3d")
+    assert 0.2 < (occ_ref > 0).mean() < 0.8
+    got = cpu(fm.render_fused(fr, rays_of(sc), S, occ_cull=True, want=("weights", "raw", "z_vals")))
+    ref = oracle.render(sc, S, stages=True, occ=occ_ref)
+    for k in ("rgb_map", "acc_map", "depth_map", "weights"):
+        assert_close(got[k], ref[k], TOL, k)
+    assert_close(got["raw"], ref["st_raw"], TOL, "raw")
+    culled = (ref["st_raw"][..., 3] == 0).mean()
+    dense = cpu(fm.render_fused(fr, rays_of(sc), S))
+    assert culled > 0.3 and np.abs(dense["acc_map"] - got["acc_map"]).max() > 1e-3, "the scene does not exercise culling"
