@@ -75,6 +75,10 @@ SYMBOLS = {
     "gpnerf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.POINTER(GpnerfOutputs), C.c_void_p]),
     "gpnerf_make_rays": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_select_pixels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, FP, FP, FP, FP, FP, FP, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "gpnerf_build_occupancy": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_void_p]),
     "gpnerf_relayout_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_featmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

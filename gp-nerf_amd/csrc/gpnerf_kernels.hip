@@ -1176,9 +1176,13 @@ __global__ void composite_kernel(const float* __restrict__ raw, const float* __r
 // ---------------------------------------------------------------------------------------------
 struct RayCam { float Kinv[9], Rinv[9], o[3], bmin[3], bmax[3]; };
 
-__global__ void make_rays_kernel(const int H, const int W, const RayCam cam, float* __restrict__ rays, uint8_t* __restrict__ hit) {
+// demo != 0: the inference renderer's variant (libs/renders/demo_render.py:201-239): box used as given, no small-|d|
+// clamp, d1 negated under neg_ray instead of the sign test; sel (optional) restricts the pixels considered (:179-200)
+__global__ void make_rays_kernel(const int H, const int W, const RayCam cam, const int demo, const int neg,
+                                 const uint8_t* __restrict__ sel, float* __restrict__ rays, uint8_t* __restrict__ hit) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= H * W) return;
+    if (sel && !sel[idx]) { hit[idx] = 0; return; }
     const float i = (float)(idx % W), j = (float)(idx / W);
     float pc[3], d[3];
 #pragma unroll
@@ -1187,7 +1191,7 @@ __global__ void make_rays_kernel(const int H, const int W, const RayCam cam, flo
     for (int a = 0; a < 3; ++a) {
         const float pw = ((pc[0] * cam.Rinv[a * 3 + 0] + pc[1] * cam.Rinv[a * 3 + 1]) + pc[2] * cam.Rinv[a * 3 + 2]) + cam.o[a];
         float da = pw - cam.o[a];
-        if (fabsf(da) < 1e-5f) da = 1e-5f;            // ray_d[np.abs(ray_d) < 1e-5] = 1e-5 (:101)
+        if (!demo && fabsf(da) < 1e-5f) da = 1e-5f;   // ray_d[np.abs(ray_d) < 1e-5] = 1e-5 (:101)
         d[a] = da;
     }
     const float eps = 1e-6f;
@@ -1214,9 +1218,9 @@ __global__ void make_rays_kernel(const int H, const int W, const RayCam cam, flo
         const float nd = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
         const float v0x = p0[0] - cam.o[0], v0y = p0[1] - cam.o[1], v0z = p0[2] - cam.o[2];
         const float v1x = p1[0] - cam.o[0], v1y = p1[1] - cam.o[1], v1z = p1[2] - cam.o[2];
-        const float sg = ((v0x * d[0] + v0y * d[1]) + v0z * d[2]) < 0.f ? -1.f : 1.f;     // both from p0 (:123,126)
+        const float sg = (!demo && ((v0x * d[0] + v0y * d[1]) + v0z * d[2]) < 0.f) ? -1.f : 1.f;     // both from p0 (:123,126)
         const float d0 = sqrtf((v0x * v0x + v0y * v0y) + v0z * v0z) / nd * sg;
-        const float d1 = sqrtf((v1x * v1x + v1y * v1y) + v1z * v1z) / nd * sg;
+        const float d1 = sqrtf((v1x * v1x + v1y * v1y) + v1z * v1z) / nd * ((demo && neg) ? -1.f : sg);
         near = fminf(d0, d1); far = fmaxf(d0, d1);
     }
     f32x4 a, b;
@@ -1224,6 +1228,42 @@ __global__ void make_rays_kernel(const int H, const int W, const RayCam cam, flo
     b[0] = d[1]; b[1] = d[2]; b[2] = near; b[3] = far;
     *reinterpret_cast<f32x4*>(rays + (size_t)idx * 8) = a;
     *reinterpret_cast<f32x4*>(rays + (size_t)idx * 8 + 4) = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// progressive ray selection (libs/renders/demo_render.py:166-200): every occupied level-1 voxel (masks3d > threshold)
+// becomes a world point; its 4 neighbouring pixels in the target view are marked, and the points' world AABB is reduced
+// ---------------------------------------------------------------------------------------------
+struct SelGeom { float voxel[3], bmin[3], Rh[9], Th[3], pose[12], K[9]; };
+
+DEV int ordered_int(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+
+__global__ void select_pixels_kernel(const float* __restrict__ occ, const int D, const int H, const int W, const float thr,
+                                     const SelGeom g, const int ih, const int iw, uint8_t* __restrict__ sel, int* __restrict__ mm) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)D * H * W) return;
+    if (!(occ[i] > thr)) return;
+    const int w = (int)(i % W), h = (int)((i / W) % H), d = (int)(i / ((long)W * H));
+    // mask_xyz = (w,h,d) * 2 (SparseConvNet.py:140-141); pts = mask_xyz * voxel_size + bounds_min; world = pts @ R^T + Th
+    const float sx = (float)w * 2.f * g.voxel[0] + g.bmin[0], sy = (float)h * 2.f * g.voxel[1] + g.bmin[1],
+                sz = (float)d * 2.f * g.voxel[2] + g.bmin[2];
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = ((sx * g.Rh[a * 3 + 0] + sy * g.Rh[a * 3 + 1]) + sz * g.Rh[a * 3 + 2]) + g.Th[a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { atomicMin(mm + a, ordered_int(p[a])); atomicMax(mm + 3 + a, ordered_int(p[a])); }
+    float c[3], q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = ((p[0] * g.pose[a * 4 + 0] + p[1] * g.pose[a * 4 + 1]) + p[2] * g.pose[a * 4 + 2]) + g.pose[a * 4 + 3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q[a] = (c[0] * g.K[a * 3 + 0] + c[1] * g.K[a * 3 + 1]) + c[2] * g.K[a * 3 + 2];
+    const float fx = q[0] / q[2], fy = q[1] / q[2];
+    if (!(fabsf(fx) < 1e9f) || !(fabsf(fy) < 1e9f)) return;            // .long() of inf/nan is undefined in the reference
+    int x0 = (int)fx, y0 = (int)fy;                                     // .long(): truncation toward zero
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = min(max(x0, 0), iw - 1); x1 = min(max(x1, 0), iw - 1);        // the reference clamps to its literal W = 512
+    y0 = min(max(y0, 0), ih - 1); y1 = min(max(y1, 0), ih - 1);
+    sel[y0 * iw + x0] = 1; sel[y1 * iw + x0] = 1; sel[y0 * iw + x1] = 1; sel[y1 * iw + x1] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1544,7 +1584,44 @@ int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv,
         c.bmax[a] = (float)((double)bounds[3 + a] + 0.01);
     }
     const int n = H * W, bs = 256;
-    hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, rays, hit);
+    hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, 0, 0,
+                       (const uint8_t*)nullptr, rays, hit);
+    return launch_status();
+}
+
+int gpnerf_select_pixels(const float* occ, int32_t D, int32_t H, int32_t W, float threshold, const float* voxel_xyz,
+                         const float* bounds_min, const float* Rh, const float* Th, const float* pose, const float* K,
+                         int32_t img_h, int32_t img_w, uint8_t* pixel_sel, int32_t* world_minmax, void* stream) {
+    if (!occ || !voxel_xyz || !bounds_min || !Rh || !Th || !pose || !K || !pixel_sel || !world_minmax || D < 1 || H < 1 ||
+        W < 1 || img_h < 1 || img_w < 1)
+        return GPNERF_E_ARG;
+    SelGeom g;
+    memcpy(g.voxel, voxel_xyz, sizeof(g.voxel));
+    memcpy(g.bmin, bounds_min, sizeof(g.bmin));
+    memcpy(g.Rh, Rh, sizeof(g.Rh));
+    memcpy(g.Th, Th, sizeof(g.Th));
+    memcpy(g.pose, pose, sizeof(g.pose));
+    memcpy(g.K, K, sizeof(g.K));
+    if (hipMemsetAsync(pixel_sel, 0, (size_t)img_h * img_w, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+    const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    if (hipMemcpyAsync(world_minmax, init, sizeof(init), hipMemcpyHostToDevice, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+    const long n = (long)D * H * W;
+    hipLaunchKernelGGL(select_pixels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), occ, (int)D, (int)H,
+                       (int)W, threshold, g, (int)img_h, (int)img_w, pixel_sel, (int*)world_minmax);
+    return launch_status();
+}
+
+int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o, const float* bounds,
+                          int32_t neg_ray, const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream) {
+    if (!Kinv || !Rinv || !cam_o || !bounds || !rays || !hit || H < 1 || W < 1) return GPNERF_E_ARG;
+    RayCam c;
+    memcpy(c.Kinv, Kinv, sizeof(c.Kinv));
+    memcpy(c.Rinv, Rinv, sizeof(c.Rinv));
+    memcpy(c.o, cam_o, sizeof(c.o));
+    for (int a = 0; a < 3; ++a) { c.bmin[a] = bounds[a]; c.bmax[a] = bounds[3 + a]; }   // used as given (demo_render.py:215)
+    const int n = H * W, bs = 256;
+    hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, 1, (int)neg_ray,
+                       pixel_sel, rays, hit);
     return launch_status();
 }
 

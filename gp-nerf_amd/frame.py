@@ -308,3 +308,40 @@ def project_gather(frame, pts, neg_ray=False):
     L.check(lib.gpnerf_project_gather(C.byref(frame.c), pts.data_ptr(), P, int(bool(neg_ray)), feat.data_ptr(), mask.data_ptr(),
                                       _stream_ptr(pts.device)), "gpnerf_project_gather")
     return feat, mask
+
+
+def select_rays(frame, target_K, target_pose, H, W, voxel_size, bounds_min, Rh, Th, neg_ray=False, threshold=0.1):
+    """Progressive ray selection of the inference renderer (demo_render.py:166-247) on the device:
+    occupied voxels -> marked pixels (gpnerf_select_pixels) -> rays with near/far (gpnerf_make_rays_demo).
+    Returns (rays [n,8] in raster order of the kept pixels, mask_at_box [H*W] bool)."""
+    lib = L.lib()
+    if not frame.c.occ:
+        frame.build_occupancy()
+    occ = frame.occ
+    dev = occ.device
+    f32 = lambda a, n: np.ascontiguousarray((a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)).astype(np.float32).ravel()[:n])
+    K, pose = f32(target_K, 9), f32(target_pose, 12)
+    vox, bmin, rh, th = f32(voxel_size, 3), f32(bounds_min, 3), f32(Rh, 9), f32(Th, 3)
+    sel = torch.empty((H * W,), device=dev, dtype=torch.uint8)
+    mm = torch.empty((6,), device=dev, dtype=torch.int32)
+    D1, H1, W1 = occ.shape
+    st = _stream_ptr(dev)
+    p = lambda a: a.ctypes.data_as(L.FP)
+    L.check(lib.gpnerf_select_pixels(occ.data_ptr(), D1, H1, W1, float(threshold), p(vox), p(bmin), p(rh), p(th), p(pose), p(K),
+                                     H, W, sel.data_ptr(), mm.data_ptr(), st), "gpnerf_select_pixels")
+    bits = mm.cpu().numpy().astype(np.int32)                      # per-frame sync: the box is a host-side constant
+    bits = np.where(bits >= 0, bits, bits ^ 0x7FFFFFFF).astype(np.int32)
+    box = bits.view(np.float32).copy()
+    box[2] -= np.float32(0.05)
+    box[5] += np.float32(0.05)
+    R, T = pose.reshape(3, 4)[:, :3], pose.reshape(3, 4)[:, 3]
+    Kinv = np.ascontiguousarray(np.linalg.inv(K.reshape(3, 3).astype(np.float64)).astype(np.float32))
+    Rinv = np.ascontiguousarray(R.T.astype(np.float32))           # the reference multiplies by R, i.e. uses R^T as the inverse
+    o = np.ascontiguousarray((-(R.T @ T)).astype(np.float32))
+    # pixel_world = (pixel_camera - T) @ R = R^T pixel_camera + o
+    rays = torch.empty((H * W, 8), device=dev)
+    hit = torch.empty((H * W,), device=dev, dtype=torch.uint8)
+    L.check(lib.gpnerf_make_rays_demo(H, W, p(Kinv), p(Rinv), p(o), p(np.ascontiguousarray(box)), int(bool(neg_ray)),
+                                      sel.data_ptr(), rays.data_ptr(), hit.data_ptr(), st), "gpnerf_make_rays_demo")
+    mask = hit.bool()
+    return rays[mask], mask

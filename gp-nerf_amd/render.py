@@ -29,7 +29,8 @@ from . import parallel as P_
 
 class Renderer(nn.Module):
     def __init__(self, encoder, nerfhead, is_train=False, neg_ray_train=False, neg_ray_val=False, n_rays=1024,
-                 n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=False, term_eps=1e-5):
+                 n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=False, term_eps=1e-5,
+                 progressive=False):
         super().__init__()
         self.encoder = encoder
         self.nerfhead = nerfhead
@@ -43,6 +44,9 @@ class Renderer(nn.Module):
         self.chunk = chunk          # kept for interface parity; the fused kernel tiles rays itself
         self.mesh_th = mesh_th
         self.early_term, self.term_eps = early_term, term_eps
+        # progressive=True: the inference renderer's path (libs/renders/demo_render.py): rays are selected from the
+        # occupied voxels of the frame's volume, samples are occupancy-culled, and the result is returned as `pred_img`
+        self.progressive = progressive
 
     # ---- helpers the reference exposes as methods (stage entry points) ----------------------------
     def _neg_ray(self, batch):
@@ -99,8 +103,39 @@ class Renderer(nn.Module):
         alpha = 1.0 - torch.exp(-(torch.flip(raw[..., 3], [1]) if neg else raw[..., 3]))
         return o["rgb_map"], o["disp_map"], o["acc_map"], o["weights"], o["depth_map"], o["ray_mask"].bool(), alpha
 
+    def render_progressive(self, batch):
+        """libs/renders/demo_render.py:429-498 + :96-376: returns `pred_img` [H,W,3] (float64 numpy, background 0),
+        `mask_at_box`, `rgb_map`, `time_slots`, `rtime`, `etime` (libs/evaluators/if_nerf.py:50-56 reads pred_img[mask])."""
+        dev = batch["src_imgs"].device
+        H, W = batch["src_imgs"].shape[-2:]
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        frame = self.build_frame(batch)
+        frame.build_occupancy()
+        torch.cuda.synchronize(dev)
+        t1 = time.time()
+        neg = self.neg_ray_val
+        rays, mask = F_.select_rays(frame, batch["target_K"][0], batch["target_pose"][0], H, W, self.voxel_size,
+                                    batch["bounds"][0, 0], batch["Rh"][0], batch["Th"][0], neg_ray=neg)
+        torch.cuda.synchronize(dev)
+        t2 = time.time()
+        o = F_.render_fused(frame, rays, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
+                            occ_cull=True, want=())
+        rgb = o["rgb_map"]
+        torch.cuda.synchronize(dev)
+        t3 = time.time()
+        mask_np = mask.cpu().numpy()
+        pred_img = np.zeros((H, W, 3))
+        pred_img[mask_np.reshape(H, W)] = rgb.cpu().numpy()
+        t4 = time.time()
+        return {"rgb_map": rgb.cpu().numpy(), "pred_img": pred_img, "mask_at_box": mask_np.reshape(-1),
+                "time_slots": {"frame": t1 - t0, "ray_select": t2 - t1, "render": t3 - t2, "bc_render": t4 - t3},
+                "etime": t1 - t0, "rtime": t4 - t0}
+
     # ---- the hot path ---------------------------------------------------------------------------------
     def render(self, batch):
+        if self.progressive:
+            return self.render_progressive(batch)
         if not self.nerfhead.use_rgbhead:
             raise L.GpnerfError("mesh extraction (use_rgbhead=False, BaseRender.py:255-272) is outside the per-ray render path")
         dev = batch["ray_o"].device
@@ -129,7 +164,7 @@ class Renderer(nn.Module):
         }
 
 
-def build_render(cfg):
+def build_render(cfg, progressive=False):
     """Same cfg keys as BaseRender.py:367-403; encoder / head come from the plugins cfg names."""
     encoder = getattr(impm(cfg.encoder.file), "build_encoder")(cfg)
     nerfhead = getattr(impm(cfg.head.file), "build_head")(cfg)
@@ -140,4 +175,4 @@ def build_render(cfg):
     mesh_th = -1 if cfg.head.rgb.use_rgbhead else 1.0 / cfg.test.mesh_th
     return Renderer(encoder=encoder, nerfhead=nerfhead, is_train=False, neg_ray_train=neg_ray_train,
                     neg_ray_val=neg_ray_val, n_rays=cfg.train.n_rays, n_samples=cfg.train.n_samples,
-                    voxel_size=cfg.dataset.voxel_size, chunk=cfg.dataset.test.chunk, mesh_th=mesh_th)
+                    voxel_size=cfg.dataset.voxel_size, chunk=cfg.dataset.test.chunk, mesh_th=mesh_th, progressive=progressive)

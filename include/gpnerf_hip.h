@@ -159,6 +159,21 @@ int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv,
  * Reads frame->vol / vol_dhw (channels-last); occ: device [D_1][H_1][W_1]. */
 int gpnerf_build_occupancy(const GpnerfFrame* frame, float* occ, void* stream);
 
+/* Progressive ray selection of the inference renderer (libs/renders/demo_render.py:166-200): every level-1 voxel with
+ * occ > threshold (SparseConvNet.py:140: 0.1) is mapped to a world point (voxel index * 2 * voxel + bounds_min, then
+ * @ Rh^T + Th), projected with the target camera (pose 3x4 row-major [R|T], K 3x3), and its 4 neighbouring pixels
+ * (truncation toward zero, clamped) are marked in pixel_sel (device [img_h*img_w], cleared here).  world_minmax: device
+ * int32[6] = order-preserving integer images of min xyz / max xyz of the world points (decode: i >= 0 ? bits : bits ^ 0x7FFFFFFF).
+ * voxel_xyz, bounds_min, Rh, Th, pose, K: host. */
+int gpnerf_select_pixels(const float* occ, int32_t D, int32_t H, int32_t W, float threshold, const float* voxel_xyz,
+                         const float* bounds_min, const float* Rh, const float* Th, const float* pose, const float* K,
+                         int32_t img_h, int32_t img_w, uint8_t* pixel_sel, int32_t* world_minmax, void* stream);
+/* The inference renderer's on-device get_rays / near-far (libs/renders/demo_render.py:201-239): like gpnerf_make_rays
+ * but the box is used as given (no +-0.01), directions are not clamped, and under neg_ray the second distance is negated.
+ * pixel_sel: optional device [H*W] mask of the pixels to consider (others get hit = 0). */
+int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o, const float* bounds,
+                          int32_t neg_ray, const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream);
+
 /* Channels-last re-layouts of the per-frame tensors (device -> device). */
 int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t H, int32_t W, void* stream);
 int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t H, int32_t W, void* stream);

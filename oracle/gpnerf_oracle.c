@@ -420,3 +420,70 @@ int oracle_build_occupancy(const OracleFrame *f, float *occ) {
             }
     return 0;
 }
+
+/* Progressive ray selection + on-device rays of the inference renderer, restating
+ * libs/renders/demo_render.py:166-247 (parity unpinned: the file hard-codes CUDA and cannot run in the build container).
+ * occ [D,H,W] = masks3d; voxel (xyz), bmin = bounds[0,0], Rh row-major, Th; pose 3x4 row-major [R|T]; K, Kinv 3x3.
+ * Outputs sized ih*iw; returns the number of rays kept (raster order); mask[ih*iw] = final mask_at_box. */
+int64_t oracle_select_rays(const float *occ, int D, int H, int W, float thr, const float *voxel, const float *bmin,
+                           const float *Rh, const float *Th, const float *pose, const float *K, const float *Kinv,
+                           int ih, int iw, int neg_ray, float *ray_o, float *ray_d, float *near, float *far, uint8_t *mask) {
+    uint8_t *sel = (uint8_t *)calloc((size_t)ih * iw, 1);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int d = 0; d < D; ++d)
+        for (int h = 0; h < H; ++h)
+            for (int w = 0; w < W; ++w) {
+                if (!(occ[((size_t)d * H + h) * W + w] > thr)) continue;              /* SparseConvNet.py:140 */
+                float s[3] = {(float)w * 2.f * voxel[0] + bmin[0], (float)h * 2.f * voxel[1] + bmin[1],
+                              (float)d * 2.f * voxel[2] + bmin[2]};                    /* :166 */
+                float p[3], c[3], q[3];
+                for (int a = 0; a < 3; ++a) p[a] = s[0] * Rh[a * 3] + s[1] * Rh[a * 3 + 1] + s[2] * Rh[a * 3 + 2] + Th[a];   /* :167 */
+                for (int a = 0; a < 3; ++a) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+                for (int a = 0; a < 3; ++a) c[a] = p[0] * pose[a * 4] + p[1] * pose[a * 4 + 1] + p[2] * pose[a * 4 + 2] + pose[a * 4 + 3]; /* :179 */
+                for (int a = 0; a < 3; ++a) q[a] = c[0] * K[a * 3] + c[1] * K[a * 3 + 1] + c[2] * K[a * 3 + 2];           /* :180 */
+                float fx = q[0] / q[2], fy = q[1] / q[2];
+                if (!(fabsf(fx) < 1e9f) || !(fabsf(fy) < 1e9f)) continue;
+                int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;               /* .long() :182-183 */
+#define CL(v, hi) ((v) < 0 ? 0 : ((v) > (hi) ? (hi) : (v)))
+                x0 = CL(x0, iw - 1); x1 = CL(x1, iw - 1); y0 = CL(y0, ih - 1); y1 = CL(y1, ih - 1);   /* :185-188 */
+                sel[y0 * iw + x0] = sel[y1 * iw + x0] = sel[y0 * iw + x1] = sel[y1 * iw + x1] = 1;   /* :189-200 */
+            }
+    mn[2] -= 0.05f; mx[2] += 0.05f;                                                     /* :172-174 */
+    float o[3];
+    for (int a = 0; a < 3; ++a) o[a] = -(pose[0 * 4 + a] * pose[3] + pose[1 * 4 + a] * pose[7] + pose[2 * 4 + a] * pose[11]);  /* -R^T T :203 */
+    const float eps = 1e-6f;
+    int64_t n = 0;
+    for (int j = 0; j < ih; ++j)
+        for (int i = 0; i < iw; ++i) {
+            mask[(size_t)j * iw + i] = 0;
+            if (!sel[(size_t)j * iw + i]) continue;
+            float pc[3], pw[3], dd[3];
+            for (int a = 0; a < 3; ++a) pc[a] = (float)i * Kinv[a * 3] + (float)j * Kinv[a * 3 + 1] + Kinv[a * 3 + 2];   /* :205 */
+            for (int a = 0; a < 3; ++a) {                                                                             /* :206-208 */
+                float t0 = pc[0] - pose[3], t1 = pc[1] - pose[7], t2 = pc[2] - pose[11];
+                pw[a] = t0 * pose[0 * 4 + a] + t1 * pose[1 * 4 + a] + t2 * pose[2 * 4 + a];
+                dd[a] = pw[a] - o[a];
+            }
+            float hit[2][3]; int cnt = 0;
+            for (int m = 0; m < 6; ++m) {
+                int a = m % 3;
+                float bd = m < 3 ? mn[a] : mx[a];
+                float tt = (bd - o[a]) / dd[a];
+                float hx = tt * dd[0] + o[0], hy = tt * dd[1] + o[1], hz = tt * dd[2] + o[2];
+                int ok = hx >= mn[0] - eps && hx <= mx[0] + eps && hy >= mn[1] - eps && hy <= mx[1] + eps && hz >= mn[2] - eps && hz <= mx[2] + eps;
+                if (ok) { if (cnt < 2) { hit[cnt][0] = hx; hit[cnt][1] = hy; hit[cnt][2] = hz; } ++cnt; }
+            }
+            if (cnt != 2) continue;                                                     /* :227 */
+            mask[(size_t)j * iw + i] = 1;
+            float nd = sqrtf(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+            float v0[3] = {hit[0][0] - o[0], hit[0][1] - o[1], hit[0][2] - o[2]}, v1[3] = {hit[1][0] - o[0], hit[1][1] - o[1], hit[1][2] - o[2]};
+            float d0 = sqrtf(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]) / nd;
+            float d1 = sqrtf(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) / nd;
+            if (neg_ray) d1 = -d1;                                                      /* :236-237 */
+            for (int a = 0; a < 3; ++a) { ray_o[3 * n + a] = o[a]; ray_d[3 * n + a] = dd[a]; }
+            near[n] = fminf(d0, d1); far[n] = fmaxf(d0, d1);
+            ++n;
+        }
+    free(sel);
+    return n;
+}

@@ -67,6 +67,9 @@ def lib():
         _lib.oracle_composite.restype = C.c_int
         _lib.oracle_composite.argtypes = [FP, FP, FP, C.c_int64, C.c_int, C.c_int, FP, FP, FP, FP, FP, C.POINTER(C.c_uint8)]
         _lib.oracle_max_threads.restype = C.c_int
+        _lib.oracle_select_rays.restype = C.c_int64
+        _lib.oracle_select_rays.argtypes = [FP, C.c_int, C.c_int, C.c_int, C.c_float, FP, FP, FP, FP, FP, FP, FP, C.c_int, C.c_int,
+                                            C.c_int, FP, FP, FP, FP, C.POINTER(C.c_uint8)]
         _lib.oracle_build_occupancy.restype = C.c_int
         _lib.oracle_build_occupancy.argtypes = [C.POINTER(OracleFrame), FP]
         _lib.oracle_head_forward.restype = C.c_int
@@ -237,3 +240,17 @@ def composite(raw, z, nvalid, neg=False):
 
 def max_threads():
     return int(lib().oracle_max_threads())
+
+
+def select_rays(occ, voxel, bmin, Rh, Th, pose, K, ih, iw, neg_ray=False, thr=0.1):
+    """demo_render.py:166-247: occupied voxels -> pixel set -> rays / near / far (parity unpinned restatement)."""
+    occ, voxel, bmin, Rh, Th, pose, K = (_f32(a) for a in (occ, voxel, bmin, Rh, Th, pose, K))
+    Kinv = _f32(np.linalg.inv(K.astype(np.float64)))
+    n = ih * iw
+    ro, rd, near, far = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    mask = np.zeros(n, np.uint8)
+    D, H, W = occ.shape
+    k = lib().oracle_select_rays(_p(occ), D, H, W, float(thr), _p(voxel.ravel()), _p(bmin.ravel()), _p(Rh.ravel()), _p(Th.ravel()),
+                                 _p(pose.ravel()), _p(K.ravel()), _p(Kinv.ravel()), ih, iw, int(bool(neg_ray)), _p(ro), _p(rd),
+                                 _p(near), _p(far), mask.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return ro[:k], rd[:k], near[:k], far[:k], mask.astype(bool)

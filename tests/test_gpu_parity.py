@@ -190,3 +190,21 @@ def test_progressive_sample_culling_matches_restatement(fm, oracle, syn):
     culled = (ref["st_raw"][..., 3] == 0).mean()
     dense = cpu(fm.render_fused(fr, rays_of(sc), S))
     assert culled > 0.3 and np.abs(dense["acc_map"] - got["acc_map"]).max() > 1e-3, "the scene does not exercise culling"
+
+
+def test_progressive_ray_selection_matches_restatement(fm, oracle, syn):
+    """demo_render.py:166-247 (unpinned restatement): occupied voxels -> pixel set -> rays."""
+    H = W = 48
+    sc = syn.make_scene(H=H, W=W, seed=78, focal_mul=6.0, pose="random", aabb_half=(0.2, 0.3, 0.12), vol_occupancy=0.3)
+    fr = build_frame(fm, sc)
+    occ_ref = oracle.build_occupancy(sc)
+    K, P = sc["target_K"][0], sc["target_pose"][0]
+    rays, mask = fm.select_rays(fr, K, P, H, W, sc["voxel_size"], sc["bounds"][0, 0], sc["Rh"][0], sc["Th"][0])
+    ro, rd, near, far, mref = oracle.select_rays(occ_ref, sc["voxel_size"], sc["bounds"][0, 0], sc["Rh"][0], sc["Th"][0], P, K, H, W)
+    rays, mask = rays.cpu().numpy(), mask.cpu().numpy()
+    assert 50 < mref.sum() < H * W
+    assert np.array_equal(mask, mref)
+    assert_close(rays[:, 0:3], ro, 1e-5, "ray_o")
+    assert_close(rays[:, 3:6], rd, 1e-5, "ray_d")
+    assert_close(rays[:, 6], near, 2e-5, "near")
+    assert_close(rays[:, 7], far, 2e-5, "far")

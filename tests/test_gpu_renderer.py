@@ -164,3 +164,26 @@ def test_full_size_parity_on_a_ray_sample_and_invariants(full_scene, oracle):
     cut = fm.render_fused(fr, rays, S, early_term=True, term_eps=1e-5)
     assert float((cut["rgb_map"] - out["rgb_map"]).abs().max()) < 2e-5
     assert float((cut["depth_map"] - out["depth_map"]).abs().max()) < 1e-4
+
+
+def test_progressive_renderer_returns_pred_img(plugins, syn, oracle):
+    """`render.file hip_demo_render`: ray selection + culled render, checked against the (unpinned) restatement."""
+    hip_demo = importlib.import_module("hip_demo_render")
+    H = W = 48
+    sc = syn.make_scene(H=H, W=W, seed=90, focal_mul=6.0, pose="random", aabb_half=(0.2, 0.3, 0.12), vol_occupancy=0.3, bias_std=0.1)
+    r = hip_demo.build_render(cfg(n_samples=32)).to("cuda:0").eval()
+    load_head(r, sc)
+    b = batch_of(sc)
+    b["target_K"] = torch.from_numpy(sc["target_K"]).to("cuda:0")
+    b["target_pose"] = torch.from_numpy(sc["target_pose"]).to("cuda:0")
+    with torch.no_grad():
+        ret = r.render(b)
+    assert ret["pred_img"].shape == (H, W, 3) and ret["pred_img"].dtype == np.float64 and ret["mask_at_box"].shape == (H * W,)
+    assert ret["rtime"] > 0 and "time_slots" in ret
+    occ = oracle.build_occupancy(sc)
+    ro, rd, near, far, mref = oracle.select_rays(occ, sc["voxel_size"], sc["bounds"][0, 0], sc["Rh"][0], sc["Th"][0],
+                                                 sc["target_pose"][0], sc["target_K"][0], H, W)
+    assert np.array_equal(ret["mask_at_box"], mref)
+    ref = oracle.render(sc, 32, rays=np.concatenate([ro, rd, near[:, None], far[:, None]], 1), occ=occ)
+    assert_close(ret["rgb_map"], ref["rgb_map"], TOL, "progressive rgb_map")
+    assert np.abs(ret["pred_img"][~mref.reshape(H, W)]).max() == 0
