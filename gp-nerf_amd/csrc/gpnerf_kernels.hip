@@ -396,7 +396,7 @@ DEV void grid_coords(const FrameK& fr, float px, float py, float pz, float& gx, 
 template <int NWAVES>
 __global__ void __launch_bounds__(NWAVES * 64, 2)
 render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
-                    const unsigned flags, const float term_eps, const OutK out, const int stagger) {
+                    const unsigned flags, const float term_eps, const OutK out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(fr.head_blob);
@@ -429,11 +429,6 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0);
 
-    // The two waves a SIMD hosts run the same program; started together they gather together and queue for the
-    // matrix pipe together.  Delay the second-dispatched half of the workgroup by a fraction of a sample so that
-    // one wave's gather phase faces the other's MFMA phase (units of s_sleep 64 = 4096 cycles).
-    if (__builtin_amdgcn_readfirstlane(wave) >= NWAVES / 2)
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);
     Stamps st;
     st.start();
     int k = 0;
@@ -563,466 +558,6 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         out.depth[ray] = depth;
         out.acc[ray] = acc;
         const float q = depth / acc;                    // 1 / max(1e-10, depth / acc); torch.max keeps NaN
-        out.disp[ray] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
-        if (out.rgb_in) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) out.rgb_in[ray * 9 + i] = rin[i];
-        }
-        if (out.ray_mask) out.ray_mask[ray] = (uint8_t)(n_two > 8);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// the fused kernel, statically scheduled form: ONE wave per SIMD (4-wave workgroups, 512 registers).
-//
-// An in-order wave can only overlap its own VALU / memory work with its own MFMAs when they alternate in
-// program order, so the sample loop is written as a fixed sequence of regions  { one MFMA chain segment  ||
-// independent VALU / gather work }  separated by sched_barrier(0):
-//   * the gathers of sample k+1 (volume levels, then the three views) ride under the MFMA chains of sample k;
-//   * the sigma-feature layer of sample k+1 is accumulated level by level as its volume features arrive
-//     (W_geo . f = sum over levels), so only its 32 accumulators cross the iteration, not 128 features;
-//   * the three per-view colour chains, the density chain and those partial products are interleaved so that
-//     every ELU epilogue has an independent MFMA segment in front of it.
-// Arithmetic per sample is the same as in render_fused_kernel (same layers, same k order inside each layer).
-// ---------------------------------------------------------------------------------------------
-#define LAUNDER(l) asm("" : "+v"(l))   // opaque copy: keeps LDS weight reads in the loop / un-shared between views
-#define REGION() __builtin_amdgcn_sched_barrier(0)
-// hipcc's list scheduler emits a region's MFMA chain back to back and everything else after it, which an in-order
-// wave cannot overlap; spell the interleave out: per 4 MFMAs one weight read, per MFMA up to NV VALU and NG loads
-template <int NM, int NV, int NG>
-DEV void interleave() {
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // MFMA
-        if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);         // VALU
-        if (NG > 0) __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);         // VMEM read
-    }
-}
-// materialise an accumulator here: MFMAs are pure, so without this instruction selection lets a whole chain
-// drift to its first use, out of the region it was written in
-#define PIN(acc) asm volatile("" : "+v"(acc))
-
-// groups [G0, G0+NG) of a layer tile whose image has NT k-steps; b[] holds the NG*4 B values of those groups
-template <int G0, int NG>
-DEV void mfma_groups(const float* __restrict__ w, int lane, const float* b, f32x16& acc) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(w + ((G0 + g) * 64 + lane) * 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * g + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * g + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[4 * g + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[4 * g + 3], acc, 0, 0, 0);
-    }
-}
-
-DEV void elu16(const f32x16& a, float* o) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = elu1(a[r]);
-}
-
-struct ViewOut { float rgb[3]; float valid; };
-
-DEV ViewOut view_slots(const FrameK& fr, int v, float px, float py, float pz, bool neg, int half, float* x18) {
-    const ViewSample s = gather_view(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
-                                     fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w, px, py, pz,
-                                     neg, half, x18);
-    x18[16] = half ? s.rgb[1] : s.rgb[0];
-    x18[17] = half ? 0.f : s.rgb[2];
-    ViewOut o;
-    o.rgb[0] = s.rgb[0]; o.rgb[1] = s.rgb[1]; o.rgb[2] = s.rgb[2]; o.valid = s.valid;
-    return o;
-}
-
-template <int NWAVES>
-__global__ void __launch_bounds__(NWAVES * 64, 1)
-render_pipe_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
-                   const unsigned flags, const float term_eps, const OutK out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(fr.head_blob);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < gpl::BLOB_FLOATS / 4; i += NWAVES * 64) dst[i] = src[i];
-    }
-    __syncthreads();
-
-    int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int n = lane & 31, half = lane >> 5;
-    const long tile = (long)xcd_remap(blockIdx.x, gridDim.x) * NWAVES + wave;
-    const long ray0 = tile * RAYS_PER_WAVE;
-    if (ray0 >= n_rays) return;
-    const bool active = (ray0 + n) < n_rays;
-    const long slot = active ? ray0 + n : n_rays - 1;
-    const long ray = out.order ? (long)out.order[slot] : slot;
-    const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;
-    const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
-
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rays + ray * 8);
-    const f32x4 r1 = *reinterpret_cast<const f32x4*>(rays + ray * 8 + 4);
-    const float ox = r0[0], oy = r0[1], oz = r0[2], dx = r0[3], dy = r1[0], dz = r1[1], near = r1[2], far = r1[3];
-
-    float T = 1.f, c_r = 0.f, c_g = 0.f, c_b = 0.f, depth = 0.f, acc = 0.f;
-    float rin[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rin[i] = 0.f;
-    int n_two = 0;
-    const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
-    const bool writer = active && (half == 0);
-
-    // network-sample position of composite step kk (S-1-kk under neg: BaseRender.py:86-88)
-    auto z_of = [&](int kk) {
-        const int ks = neg ? (S - 1 - kk) : kk;
-        const float t = (S > 1) ? linspace01(ks, S, step) : 0.f;
-        return near * (1.f - t) + far * t;
-    };
-
-    // ---- loop-carried state of the CURRENT sample ----
-    float sf[32];            // ELU(sigma feature), two accumulator tiles
-    float x[NV][18];         // per-view [rgb, feat] slots of this lane half
-    float vrgb[NV][3];
-    float nvalid, zc;
-    {   // prologue: everything of sample 0, unpipelined
-        zc = z_of(0);
-        const float px = ox + dx * zc, py = oy + dy * zc, pz = oz + dz * zc;
-        float gx, gy, gz;
-        grid_coords(fr, px, py, pz, gx, gy, gz);
-        float fv[64];
-#pragma unroll
-        for (int l = 0; l < GPNERF_LEVELS; ++l)
-            gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
-        f32x16 g0 = bias_tile<gpl::GEO>(lds, 0, half), g1 = bias_tile<gpl::GEO>(lds, 1, half);
-        mfma_tile<64>(wtile<gpl::GEO>(lds, 0), lane, fv, g0);
-        mfma_tile<64>(wtile<gpl::GEO>(lds, 1), lane, fv, g1);
-        elu16(g0, sf); elu16(g1, sf + 16);
-        nvalid = 0.f;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const ViewOut o = view_slots(fr, v, px, py, pz, neg, half, x[v]);
-            vrgb[v][0] = o.rgb[0]; vrgb[v][1] = o.rgb[1]; vrgb[v][2] = o.rgb[2];
-            nvalid += o.valid;
-        }
-    }
-
-    int k = 0;
-    for (; k < S; ++k) {
-        LAUNDER(lane);
-        // coordinates of the NEXT sample (the last iteration re-gathers its own sample; the result is unused)
-        const float zn = z_of(k + 1 < S ? k + 1 : k);
-        const float npx = ox + dx * zn, npy = oy + dy * zn, npz = oz + dz * zn;
-        float ngx, ngy, ngz;
-        grid_coords(fr, npx, npy, npz, ngx, ngy, ngz);
-        float xN[NV][18], vrgbN[NV][3], nvalidN = 0.f;
-        float fA[16], fB[16];
-
-        // cross-view mean / variance of the current sample (trainhead.py:20-24)
-        float d1in[68];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) d1in[r] = sf[r];
-#pragma unroll
-        for (int t = 0; t < 18; ++t) {
-            const float m = ((x[0][t] + x[1][t]) + x[2][t]) * (1.f / 3.f);
-            const float a = x[0][t] - m, b = x[1][t] - m, c = x[2][t] - m;
-            d1in[32 + t] = m;
-            d1in[50 + t] = ((a * a + b * b) + c * c) * (1.f / 3.f);
-        }
-        REGION();
-        // R1: density layer 1, tile 0  ||  next volume level 0
-        f32x16 a0 = bias_tile<gpl::D1>(lds, 0, half);
-        mfma_tile<68>(wtile<gpl::D1>(lds, 0), lane, d1in, a0);
-        gather_volume(fr.vol[0], fr.vol_dhw[0][0], fr.vol_dhw[0][1], fr.vol_dhw[0][2], ngx, ngy, ngz, half, fA);
-        interleave<68, 8, 1>();
-        PIN(a0);
-        REGION();
-        // R2: density layer 1, tile 1  ||  next volume level 1
-        f32x16 a1 = bias_tile<gpl::D1>(lds, 1, half);
-        mfma_tile<68>(wtile<gpl::D1>(lds, 1), lane, d1in, a1);
-        gather_volume(fr.vol[1], fr.vol_dhw[1][0], fr.vol_dhw[1][1], fr.vol_dhw[1][2], ngx, ngy, ngz, half, fB);
-        interleave<68, 5, 1>();
-        PIN(a1);
-        REGION();
-        // R3: next sigma-feature, level 0 part  ||  ELU(density 1)
-        f32x16 gN0 = bias_tile<gpl::GEO>(lds, 0, half), gN1 = bias_tile<gpl::GEO>(lds, 1, half);
-        mfma_groups<0, 4>(wtile<gpl::GEO>(lds, 0), lane, fA, gN0);
-        mfma_groups<0, 4>(wtile<gpl::GEO>(lds, 1), lane, fA, gN1);
-        float h1[32];
-        elu16(a0, h1); elu16(a1, h1 + 16);
-        interleave<32, 8, 0>();
-        PIN(gN0); PIN(gN1);
-        REGION();
-        // R4: density layer 2  ||  next volume level 2
-        f32x16 a2 = bias_tile<gpl::D2>(lds, 0, half);
-        mfma_tile<32>(wtile<gpl::D2>(lds, 0), lane, h1, a2);
-        gather_volume(fr.vol[2], fr.vol_dhw[2][0], fr.vol_dhw[2][1], fr.vol_dhw[2][2], ngx, ngy, ngz, half, fA);
-        interleave<32, 8, 1>();
-        PIN(a2);
-        REGION();
-        // R5: next sigma-feature, level 1 part  ||  ELU(density 2)
-        mfma_groups<4, 4>(wtile<gpl::GEO>(lds, 0), lane, fB, gN0);
-        mfma_groups<4, 4>(wtile<gpl::GEO>(lds, 1), lane, fB, gN1);
-        float h2[16];
-        elu16(a2, h2);
-        interleave<32, 6, 0>();
-        PIN(gN0); PIN(gN1);
-        REGION();
-        // R6: density layer 3
-        f32x16 a3 = bias_tile<gpl::D3>(lds, 0, half);
-        mfma_tile<16>(wtile<gpl::D3>(lds, 0), lane, h2, a3);
-        interleave<16, 3, 0>();
-        PIN(a3);
-        REGION();
-        // R7: next sigma-feature, level 2 part  ||  density tail 16 -> 1, ReLU, mask (trainhead.py:108-110,136-137)
-        mfma_groups<8, 4>(wtile<gpl::GEO>(lds, 0), lane, fA, gN0);
-        mfma_groups<8, 4>(wtile<gpl::GEO>(lds, 1), lane, fA, gN1);
-        float sigma;
-        {
-            const float* w4 = lds + gpl::D4_W + half * 8;
-            float part = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) part = fmaf(w4[r], elu1(a3[r]), part);
-            float sg = part + __shfl_xor(part, 32) + lds[gpl::D4_B];
-            sg = fmaxf(sg, 0.f);
-            sigma = (nvalid < 1.f) ? 0.f : sg;
-        }
-        interleave<32, 6, 0>();
-        PIN(gN0); PIN(gN1);
-        REGION();
-        // R8: base_fc layer 1, view-independent [mean,var] part  ||  next volume level 3
-        f32x16 s0 = bias_tile<gpl::BS>(lds, 0, half), s1 = bias_tile<gpl::BS>(lds, 1, half);
-        mfma_groups<0, 9>(wtile<gpl::BS>(lds, 0), lane, d1in + 32, s0);
-        mfma_groups<0, 9>(wtile<gpl::BS>(lds, 1), lane, d1in + 32, s1);
-        gather_volume(fr.vol[3], fr.vol_dhw[3][0], fr.vol_dhw[3][1], fr.vol_dhw[3][2], ngx, ngy, ngz, half, fB);
-        interleave<72, 5, 1>();
-        PIN(s0); PIN(s1);
-        REGION();
-        // R9: next sigma-feature, level 3 part  ||  next view 0
-        mfma_groups<12, 4>(wtile<gpl::GEO>(lds, 0), lane, fB, gN0);
-        mfma_groups<12, 4>(wtile<gpl::GEO>(lds, 1), lane, fB, gN1);
-        {
-            const ViewOut o = view_slots(fr, 0, npx, npy, npz, neg, half, xN[0]);
-            vrgbN[0][0] = o.rgb[0]; vrgbN[0][1] = o.rgb[1]; vrgbN[0][2] = o.rgb[2];
-            nvalidN += o.valid;
-        }
-        interleave<32, 8, 1>();
-        PIN(gN0); PIN(gN1);
-        REGION();
-        // R10: view 0 base layer 1  ||  (gN still in flight)
-        LAUNDER(lane);
-        f32x16 p00 = s0, p01 = s1;
-        mfma_tile<18>(wtile<gpl::BV>(lds, 0), lane, x[0], p00);
-        mfma_tile<18>(wtile<gpl::BV>(lds, 1), lane, x[0], p01);
-        interleave<36, 4, 0>();
-        PIN(p00); PIN(p01);
-        REGION();
-        // R11: view 1 base layer 1  ||  ELU(next sigma-feature), ELU(view 0 layer 1)
-        LAUNDER(lane);
-        f32x16 p10 = s0, p11 = s1;
-        mfma_tile<18>(wtile<gpl::BV>(lds, 0), lane, x[1], p10);
-        mfma_tile<18>(wtile<gpl::BV>(lds, 1), lane, x[1], p11);
-        float sfN[32];
-        elu16(gN0, sfN); elu16(gN1, sfN + 16);
-        float q0[32];
-        elu16(p00, q0); elu16(p01, q0 + 16);
-        interleave<36, 7, 0>();
-        PIN(p10); PIN(p11);
-        REGION();
-        // R12: view 0 base layer 2  ||  ELU(view 1 layer 1), next view 1
-        f32x16 b0 = bias_tile<gpl::B2>(lds, 0, half);
-        mfma_tile<32>(wtile<gpl::B2>(lds, 0), lane, q0, b0);
-        float q1[32];
-        elu16(p10, q1); elu16(p11, q1 + 16);
-        {
-            const ViewOut o = view_slots(fr, 1, npx, npy, npz, neg, half, xN[1]);
-            vrgbN[1][0] = o.rgb[0]; vrgbN[1][1] = o.rgb[1]; vrgbN[1][2] = o.rgb[2];
-            nvalidN += o.valid;
-        }
-        interleave<32, 11, 1>();
-        PIN(b0);
-        REGION();
-        // R13: view 2 base layer 1  ||  ELU(view 0 layer 2) and its 1/V scaling
-        LAUNDER(lane);
-        f32x16 p20 = s0, p21 = s1;
-        mfma_tile<18>(wtile<gpl::BV>(lds, 0), lane, x[2], p20);
-        mfma_tile<18>(wtile<gpl::BV>(lds, 1), lane, x[2], p21);
-        float xb0[16], xs0[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { xb0[r] = elu1(b0[r]); xs0[r] = xb0[r] * (1.f / 3.f); }
-        interleave<36, 7, 0>();
-        PIN(p20); PIN(p21);
-        REGION();
-        // R14: view 1 base layer 2  ||  ELU(view 2 layer 1), next view 2
-        LAUNDER(lane);
-        f32x16 b1 = bias_tile<gpl::B2>(lds, 0, half);
-        mfma_tile<32>(wtile<gpl::B2>(lds, 0), lane, q1, b1);
-        float q2[32];
-        elu16(p20, q2); elu16(p21, q2 + 16);
-        {
-            const ViewOut o = view_slots(fr, 2, npx, npy, npz, neg, half, xN[2]);
-            vrgbN[2][0] = o.rgb[0]; vrgbN[2][1] = o.rgb[1]; vrgbN[2][2] = o.rgb[2];
-            nvalidN += o.valid;
-        }
-        interleave<32, 12, 1>();
-        PIN(b1);
-        REGION();
-        // R15: view 0 vis layer 1  ||  ELU(view 1 layer 2)
-        f32x16 t10 = bias_tile<gpl::V1>(lds, 0, half);
-        mfma_tile<16>(wtile<gpl::V1>(lds, 0), lane, xs0, t10);
-        float xb1[16], xs1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { xb1[r] = elu1(b1[r]); xs1[r] = xb1[r] * (1.f / 3.f); }
-        interleave<16, 12, 0>();
-        PIN(t10);
-        REGION();
-        // R16: view 2 base layer 2  ||  ELU(view 0 vis 1)
-        LAUNDER(lane);
-        f32x16 b2 = bias_tile<gpl::B2>(lds, 0, half);
-        mfma_tile<32>(wtile<gpl::B2>(lds, 0), lane, q2, b2);
-        float u0[16];
-        elu16(t10, u0);
-        interleave<32, 4, 0>();
-        PIN(b2);
-        REGION();
-        // R17: view 0 vis layer 2, view 1 vis layer 1  ||  ELU(view 2 layer 2)
-        f32x16 t20 = bias_tile<gpl::V2>(lds, 0, half);
-        mfma_tile<16>(wtile<gpl::V2>(lds, 0), lane, u0, t20);
-        LAUNDER(lane);
-        f32x16 t11 = bias_tile<gpl::V1>(lds, 0, half);
-        mfma_tile<16>(wtile<gpl::V1>(lds, 0), lane, xs1, t11);
-        float xb2[16], xs2[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { xb2[r] = elu1(b2[r]); xs2[r] = xb2[r] * (1.f / 3.f); }
-        interleave<32, 7, 0>();
-        PIN(t20); PIN(t11);
-        REGION();
-        // R18: view 2 vis layer 1  ||  y0 = x + x_vis (view 0), ELU(view 1 vis 1)
-        LAUNDER(lane);
-        f32x16 t12 = bias_tile<gpl::V1>(lds, 0, half);
-        mfma_tile<16>(wtile<gpl::V1>(lds, 0), lane, xs2, t12);
-        float y[48];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = xb0[r] + elu1(t20[r]);
-        float u1[16];
-        elu16(t11, u1);
-        interleave<16, 14, 0>();
-        PIN(t12);
-        REGION();
-        // R19: view 1 vis layer 2, rgb layer 1 (view 0 part)  ||  ELU(view 2 vis 1)
-        f32x16 t21 = bias_tile<gpl::V2>(lds, 0, half);
-        mfma_tile<16>(wtile<gpl::V2>(lds, 0), lane, u1, t21);
-        f32x16 c1 = bias_tile<gpl::R1>(lds, 0, half);
-        mfma_groups<0, 4>(wtile<gpl::R1>(lds, 0), lane, y, c1);
-        float u2[16];
-        elu16(t12, u2);
-        interleave<32, 4, 0>();
-        PIN(t21); PIN(c1);
-        REGION();
-        // R20: view 2 vis layer 2  ||  y1
-        LAUNDER(lane);
-        f32x16 t22 = bias_tile<gpl::V2>(lds, 0, half);
-        mfma_tile<16>(wtile<gpl::V2>(lds, 0), lane, u2, t22);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[16 + r] = xb1[r] + elu1(t21[r]);
-        interleave<16, 11, 0>();
-        PIN(t22);
-        REGION();
-        // R21: rgb layer 1 (view 1 part)  ||  y2
-        mfma_groups<4, 4>(wtile<gpl::R1>(lds, 0), lane, y + 16, c1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[32 + r] = xb2[r] + elu1(t22[r]);
-        interleave<16, 9, 0>();
-        PIN(c1);
-        REGION();
-        // R22: rgb layer 1 (view 2 part), then the exposed tail: ELU, rgb layer 2, 16 -> 3, sigmoid
-        mfma_groups<8, 4>(wtile<gpl::R1>(lds, 0), lane, y + 32, c1);
-        float rgb[3];
-        {
-            float hh[16];
-            elu16(c1, hh);
-            f32x16 c2 = bias_tile<gpl::R2>(lds, 0, half);
-            mfma_tile<16>(wtile<gpl::R2>(lds, 0), lane, hh, c2);
-            float e[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) e[r] = elu1(c2[r]);
-#pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const float* w3 = lds + gpl::R3_W + o * 16 + half * 8;
-                float part = 0.f;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) part = fmaf(w3[r], e[r], part);
-                const float sx = part + __shfl_xor(part, 32) + lds[gpl::R3_B + o];
-                rgb[o] = 1.f / (1.f + fast_exp(-sx));
-            }
-        }
-        REGION();
-
-        if (nvalid > 1.f) ++n_two;                      // pixel_mask (BaseRender.py:139)
-        const int ks = neg ? (S - 1 - k) : k;
-        if (out.raw && writer) {
-            f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
-            *reinterpret_cast<f32x4*>(out.raw + ((size_t)ray * S + ks) * 4) = rw;
-        }
-        // rgb_in_map (:147) pairs weight k with the UN-flipped rgb_in of sample k; depth with the un-flipped z
-        float irgb[NV][3];
-        float zk = zc;
-        if (neg) {
-            const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
-            zk = near * (1.f - tk) + far * tk;
-            const float ax_ = ox + dx * zk, ay_ = oy + dy * zk, az_ = oz + dz * zk;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                float dump[16];
-                const ViewSample s2 = gather_view(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
-                                                  fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
-                                                  ax_, ay_, az_, neg, half, dump);
-                irgb[v][0] = s2.rgb[0]; irgb[v][1] = s2.rgb[1]; irgb[v][2] = s2.rgb[2];
-            }
-        } else {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) { irgb[v][0] = vrgb[v][0]; irgb[v][1] = vrgb[v][1]; irgb[v][2] = vrgb[v][2]; }
-        }
-        // raw2outputs (:90-104)
-        const float alpha = 1.f - fast_exp(-sigma);
-        const float wgt = alpha * T;
-        T = T * ((1.f - alpha) + 1e-10f);
-        c_r = fmaf(wgt, rgb[0], c_r); c_g = fmaf(wgt, rgb[1], c_g); c_b = fmaf(wgt, rgb[2], c_b);
-        depth = fmaf(wgt, zk, depth);
-        acc += wgt;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            rin[3 * v + 0] = fmaf(wgt, irgb[v][0], rin[3 * v + 0]);
-            rin[3 * v + 1] = fmaf(wgt, irgb[v][1], rin[3 * v + 1]);
-            rin[3 * v + 2] = fmaf(wgt, irgb[v][2], rin[3 * v + 2]);
-        }
-        if (writer) {
-            if (out.weights) out.weights[(size_t)ray * S + k] = wgt;
-            if (out.z_vals) out.z_vals[(size_t)ray * S + k] = zk;
-        }
-        // hand the prefetched sample over
-#pragma unroll
-        for (int r = 0; r < 32; ++r) sf[r] = sfN[r];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-#pragma unroll
-            for (int t = 0; t < 18; ++t) x[v][t] = xN[v][t];
-            vrgb[v][0] = vrgbN[v][0]; vrgb[v][1] = vrgbN[v][1]; vrgb[v][2] = vrgbN[v][2];
-        }
-        nvalid = nvalidN;
-        zc = zn;
-        if (early && __all(T < term_eps)) { ++k; break; }
-    }
-    if (writer) {
-        for (; k < S; ++k) {
-            if (out.weights) out.weights[(size_t)ray * S + k] = 0.f;
-            if (out.z_vals) {
-                const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
-                out.z_vals[(size_t)ray * S + k] = near * (1.f - tk) + far * tk;
-            }
-        }
-        out.rgb[ray * 3 + 0] = c_r; out.rgb[ray * 3 + 1] = c_g; out.rgb[ray * 3 + 2] = c_b;
-        out.depth[ray] = depth;
-        out.acc[ray] = acc;
-        const float q = depth / acc;
         out.disp[ray] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
         if (out.rgb_in) {
 #pragma unroll
@@ -1334,7 +869,6 @@ namespace {
 #define GPNERF_FUSED_WAVES 8
 #endif
 constexpr int FUSED_WAVES = GPNERF_FUSED_WAVES;
-constexpr int PIPE_WAVES = 4;
 
 int col_ok(int c, int n_in) { return c >= 0 && c < n_in; }
 
@@ -1480,29 +1014,16 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (!to_framek(f, k, true, true)) return GPNERF_E_ARG;
     const int64_t tiles = (n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
-    static int variant = -1;       // GPNERF_KERNEL=v2 selects the 1-wave-per-SIMD region-scheduled form (A/B comparisons)
-    if (variant < 0) {
-        const char* e = getenv("GPNERF_KERNEL");
-        variant = (e && e[0] == 'v' && e[1] == '2') ? 2 : 1;
+    static bool attr_set = false;
+    if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<FUSED_WAVES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&render_pipe_kernel<PIPE_WAVES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
-            variant = -1;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return GPNERF_E_DEVICE;
-        }
+        attr_set = true;
     }
-    if (variant == 1) {
-        const int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
-        static int stagger = -1;
-        if (stagger < 0) { const char* e = getenv("GPNERF_STAGGER"); stagger = e ? atoi(e) : 0; }
-        hipLaunchKernelGGL(render_fused_kernel<FUSED_WAVES>, dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
-                           k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out, ray_order), stagger);
-    } else {
-        const int64_t blocks = (tiles + PIPE_WAVES - 1) / PIPE_WAVES;
-        hipLaunchKernelGGL(render_pipe_kernel<PIPE_WAVES>, dim3((unsigned)blocks), dim3(PIPE_WAVES * 64), lds_bytes, S_(stream),
-                           k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out, ray_order));
-    }
+    const int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
+    hipLaunchKernelGGL(render_fused_kernel<FUSED_WAVES>, dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
+                       k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out, ray_order));
     return launch_status();
 }
 
