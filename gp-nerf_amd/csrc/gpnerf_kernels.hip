@@ -901,6 +901,10 @@ int launch_status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNER
 // GpnerfFrame -> kernel argument; need_vol / need_img say which tensors the launch will touch
 bool to_framek(const GpnerfFrame* f, FrameK& k, bool need_vol, bool need_img) {
     memset(&k, 0, sizeof(k));
+    // tap offsets are 32-bit float indices inside the kernels
+    for (int l = 0; l < GPNERF_LEVELS; ++l)
+        if (f->vol[l] && (int64_t)f->vol_dhw[l][0] * f->vol_dhw[l][1] * f->vol_dhw[l][2] * GPNERF_CH >= (int64_t)1 << 31) return false;
+    if ((int64_t)f->img_h * f->img_w * 4 >= (int64_t)1 << 31 || (int64_t)f->feat_h * f->feat_w * GPNERF_CH >= (int64_t)1 << 31) return false;
     if (need_vol)
         for (int l = 0; l < GPNERF_LEVELS; ++l)
             if (!f->vol[l] || f->vol_dhw[l][0] < 1 || f->vol_dhw[l][1] < 1 || f->vol_dhw[l][2] < 1) return false;
