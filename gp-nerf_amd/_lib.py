@@ -65,7 +65,8 @@ SYMBOLS = {
     "gpnerf_head_blob_floats": (C.c_int64, []),
     "gpnerf_pack_head": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
     "gpnerf_render_fused": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float,
-                                      C.c_void_p, C.POINTER(GpnerfOutputs), C.c_void_p]),
+                                      C.c_void_p, C.POINTER(GpnerfOutputs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpnerf_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "gpnerf_sample_points": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "gpnerf_sample_volume": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

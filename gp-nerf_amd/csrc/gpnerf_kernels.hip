@@ -393,21 +393,26 @@ DEV void grid_coords(const FrameK& fr, float px, float py, float pz, float& gx, 
     gz = ((qz - fr.bounds_min[2]) / fr.voxel[0]) / fr.out_sh[0] * 2.f - 1.f;
 }
 
-template <int NWAVES>
-__global__ void __launch_bounds__(NWAVES * 64, 2)
+// Launched with 1..8 waves per workgroup (blockDim.x = 64 * waves): one workgroup per CU either way (LDS), so the
+// host picks the width that balances the grid over the 256 CUs (choose_waves()).
+__global__ void __launch_bounds__(512, 2)
 render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
-                    const unsigned flags, const float term_eps, const OutK out) {
+                    const unsigned flags, const float term_eps, const OutK out, const int split, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(fr.head_blob);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < gpl::BLOB_FLOATS / 4; i += NWAVES * 64) dst[i] = src[i];
+        for (int i = threadIdx.x; i < gpl::BLOB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, half = lane >> 5;
-    const long tile = (long)xcd_remap(blockIdx.x, gridDim.x) * NWAVES + wave;
+    // work unit = (32-ray tile, sample segment): with split > 1 the samples of a tile are divided between `split`
+    // waves, whose partial composites are merged by combine_segments_kernel (finer load balance for small frames)
+    const long unit = (long)xcd_remap(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
+    const long tile = unit / split;
+    const int seg = (int)(unit % split);
     const long ray0 = tile * RAYS_PER_WAVE;
     if (ray0 >= n_rays) return;
     const bool active = (ray0 + n) < n_rays;
@@ -431,8 +436,9 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
 
     Stamps st;
     st.start();
-    int k = 0;
-    for (; k < S; ++k) {
+    const int k_end = (int)(((long)S * (seg + 1)) / split);
+    int k = (int)(((long)S * seg) / split);
+    for (; k < k_end; ++k) {
         // raw2outputs(neg=True) flips rgb and sigma along the ray but not z (BaseRender.py:86-88,101):
         // composite step k consumes the network output of sample S-1-k.
         const int ks = neg ? (S - 1 - k) : k;
@@ -545,6 +551,18 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         if (early && __all(T < term_eps)) { ++k; break; }
     }
     st.flush(lane);
+    if (writer && split > 1) {
+        // partial composite of this segment: rgb, depth, acc, segment transmittance, rgb_in, #samples with >1 valid view
+        float* p = part + ((size_t)ray * split + seg) * 16;
+        f32x4 a, b, c, d;
+        a[0] = c_r; a[1] = c_g; a[2] = c_b; a[3] = depth;
+        b[0] = acc; b[1] = T; b[2] = (float)n_two; b[3] = rin[0];
+        c[0] = rin[1]; c[1] = rin[2]; c[2] = rin[3]; c[3] = rin[4];
+        d[0] = rin[5]; d[1] = rin[6]; d[2] = rin[7]; d[3] = rin[8];
+        reinterpret_cast<f32x4*>(p)[0] = a; reinterpret_cast<f32x4*>(p)[1] = b;
+        reinterpret_cast<f32x4*>(p)[2] = c; reinterpret_cast<f32x4*>(p)[3] = d;
+        return;
+    }
     if (writer) {
         // samples skipped by early termination carry weight 0
         for (; k < S; ++k) {
@@ -567,6 +585,43 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
     }
 }
 
+
+// merge the per-segment partial composites of a ray front to back: out = sum_s (prod_{j<s} T_j) * partial_s
+__global__ void combine_segments_kernel(const float* __restrict__ part, const long n_rays, const int S, const int split,
+                                        const OutK out) {
+    const long ray = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= n_rays) return;
+    float Tp = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, depth = 0.f, acc = 0.f, n_two = 0.f;
+    float rin[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rin[i] = 0.f;
+    for (int s = 0; s < split; ++s) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)ray * split + s) * 16);
+        const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+        cr = fmaf(Tp, a[0], cr); cg = fmaf(Tp, a[1], cg); cb = fmaf(Tp, a[2], cb);
+        depth = fmaf(Tp, a[3], depth);
+        acc = fmaf(Tp, b[0], acc);
+        n_two += b[2];
+        rin[0] = fmaf(Tp, b[3], rin[0]);
+        rin[1] = fmaf(Tp, c[0], rin[1]); rin[2] = fmaf(Tp, c[1], rin[2]); rin[3] = fmaf(Tp, c[2], rin[3]); rin[4] = fmaf(Tp, c[3], rin[4]);
+        rin[5] = fmaf(Tp, d[0], rin[5]); rin[6] = fmaf(Tp, d[1], rin[6]); rin[7] = fmaf(Tp, d[2], rin[7]); rin[8] = fmaf(Tp, d[3], rin[8]);
+        if (out.weights && s > 0) {
+            const int k0 = (int)(((long)S * s) / split), k1 = (int)(((long)S * (s + 1)) / split);
+            for (int k = k0; k < k1; ++k) out.weights[(size_t)ray * S + k] *= Tp;
+        }
+        Tp *= b[1];
+    }
+    out.rgb[ray * 3 + 0] = cr; out.rgb[ray * 3 + 1] = cg; out.rgb[ray * 3 + 2] = cb;
+    out.depth[ray] = depth;
+    out.acc[ray] = acc;
+    const float q = depth / acc;
+    out.disp[ray] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+    if (out.rgb_in) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out.rgb_in[ray * 9 + i] = rin[i];
+    }
+    if (out.ray_mask) out.ray_mask[ray] = (uint8_t)(n_two > 8.f);
+}
 
 // ---------------------------------------------------------------------------------------------
 // NeRFHead.forward on pre-gathered features
@@ -894,6 +949,37 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
     }
 }
 
+// Launch geometry of the fused kernel.  One workgroup is resident per CU (LDS), a wave's step time depends on how many
+// waves share its SIMD (measured: ~86k cycles per 32-sample step with one wave per SIMD, ~134k with two), and a work unit
+// (32 rays x S samples) is long, so a grid that is not many times 256 workgroups quantises badly.  Choose the waves per
+// workgroup and, when the caller lends a workspace, how many waves share the samples of one tile (split), minimising
+// rounds x step time x samples per unit.  GPNERF_WAVES / GPNERF_SPLIT override (diagnostics).
+struct Geometry { int waves, split; };
+
+Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, int64_t n_rays) {
+    static int f_waves = -1, f_split = -1;
+    if (f_waves < 0) {
+        const char* e = getenv("GPNERF_WAVES"); f_waves = e ? atoi(e) : 0;
+        const char* g = getenv("GPNERF_SPLIT"); f_split = g ? atoi(g) : 0;
+    }
+    const int64_t cus = 256;
+    Geometry best{8, 1};
+    double best_t = 1e300;
+    for (int split = 1; split <= 4; split *= 2) {
+        if (split > 1 && (!may_split || S / split < 8 || ws_bytes < (size_t)n_rays * split * 16 * sizeof(float))) continue;
+        if (f_split > 0 && split != f_split && !(split == 1 && f_split > 1 && !may_split)) continue;
+        for (int w = 8; w >= 1; --w) {
+            if (f_waves > 0 && w != f_waves) continue;
+            const int64_t blocks = (tiles * split + w - 1) / w;
+            const int64_t rounds = (blocks + cus - 1) / cus;
+            const double step = w <= 4 ? 85.7 : 134.0;                    // kilo-cycles per 32-sample step
+            const double t = (double)rounds * step * ((double)S / split) + (split > 1 ? 60.0 : 0.0);
+            if (t < best_t * 0.97) { best_t = t; best = Geometry{w, split}; }   // ties: wider workgroup, no split
+        }
+    }
+    return best;
+}
+
 hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 int launch_status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
@@ -939,7 +1025,7 @@ extern "C" {
 
 int64_t gpnerf_head_blob_floats(void) { return gpl::BLOB_FLOATS; }
 int32_t gpnerf_rays_per_tile(void) { return RAYS_PER_WAVE; }
-const char* gpnerf_build_info(void) { return "gpnerf-hip gfx950 fp32-mfma32x32x2 waves=8"; }
+const char* gpnerf_build_info(void) { return "gpnerf-hip gfx950 fp32-mfma32x32x2 waves<=8"; }
 
 #ifdef GPNERF_STAMPS
 // diagnostic library only: read and clear the per-phase cycle sums
@@ -1010,7 +1096,8 @@ int gpnerf_pack_head(const GpnerfHeadParams* p, float* blob) {
 }
 
 int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, uint32_t flags,
-                        float term_eps, const int32_t* ray_order, const GpnerfOutputs* out, void* stream) {
+                        float term_eps, const int32_t* ray_order, const GpnerfOutputs* out, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     if (n_rays == 0) return GPNERF_OK;          // empty ray list: nothing to do (pointers may be null)
     if (!f || !rays || !out || n_rays < 0 || n_samples < 1) return GPNERF_E_ARG;
     if (!out->rgb || !out->depth || !out->acc || !out->disp || !f->head_blob) return GPNERF_E_ARG;
@@ -1020,15 +1107,29 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<FUSED_WAVES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return GPNERF_E_DEVICE;
         attr_set = true;
     }
-    const int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
-    hipLaunchKernelGGL(render_fused_kernel<FUSED_WAVES>, dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
-                       k, rays, (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, to_outk(out, ray_order));
+    const bool may_split = workspace && !(flags & GPNERF_FLAG_EARLY_TERM);
+    const Geometry g = choose_geometry(tiles, n_samples, may_split, workspace ? workspace_bytes : 0, n_rays);
+    const int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
+    const OutK ok = to_outk(out, ray_order);
+    hipLaunchKernelGGL(render_fused_kernel, dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), k, rays,
+                       (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, ok, g.split, (float*)workspace);
+    if (g.split > 1) {
+        if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
+        hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),
+                           (const float*)workspace, (long)n_rays, (int)n_samples, g.split, ok);
+    }
     return launch_status();
+}
+
+size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples) {
+    (void)n_samples;
+    // room for 4 sample segments per ray, 16 floats each; only frames small enough to profit from splitting
+    return n_rays > 0 && n_rays <= 131072 ? (size_t)n_rays * 4 * 16 * sizeof(float) : 0;
 }
 
 int gpnerf_sample_points(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, float* pts,

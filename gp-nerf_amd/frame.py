@@ -176,9 +176,10 @@ def patch_order(mask_at_box, H, W, patch_w=32, patch_h=8):
 
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
-                 want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False):
+                 want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
-    ray_order: optional int32 device tensor [N], a permutation that groups rays into cache-friendly tiles."""
+    ray_order: optional int32 device tensor [N], a permutation that groups rays into cache-friendly tiles.
+    load_balance: lend the kernel a workspace so small frames can split a tile's samples over several wavefronts."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()
@@ -214,9 +215,11 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         _require_gpu(ray_order, "ray_order")
         if ray_order.dtype != torch.int32 or ray_order.numel() != N or not ray_order.is_contiguous():
             raise L.GpnerfError("ray_order must be a contiguous int32 tensor with one entry per ray")
+    ws_bytes = int(lib.gpnerf_render_workspace_bytes(N, S)) if (load_balance and not early_term) else 0
+    ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8) if ws_bytes else None
     L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), N, S, flags, float(term_eps),
                                     ray_order.data_ptr() if ray_order is not None else None, C.byref(o),
-                                    _stream_ptr(dev)), "gpnerf_render_fused")
+                                    ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(dev)), "gpnerf_render_fused")
     return res
 
 

@@ -116,9 +116,16 @@ int gpnerf_pack_head(const GpnerfHeadParams* params_host, float* blob_host);
  *   ray_order: optional device [N] permutation of 0..N-1 (NULL = identity).  Launch slot i renders ray
  *     ray_order[i]; inputs are read and outputs written at the ray's own index, so results do not depend on it.
  *     It only decides which 32 rays share a wavefront and which 256 share a workgroup: pass image patches
- *     (e.g. 32x8 pixels per workgroup) so neighbouring rays hit the same cache lines. */
+ *     (e.g. 32x8 pixels per workgroup) so neighbouring rays hit the same cache lines.
+ *   workspace: optional device scratch of gpnerf_render_workspace_bytes() bytes (NULL = none).  With it, frames too
+ *     small to fill the chip are load-balanced by letting 2 or 4 wavefronts share the samples of one 32-ray tile and
+ *     merging their partial composites (second small launch); the transmittance product is then associated per
+ *     segment, a ~1e-7 relative difference.  Never used with GPNERF_FLAG_EARLY_TERM. */
 int gpnerf_render_fused(const GpnerfFrame* frame, const float* rays, int64_t n_rays, int32_t n_samples,
-                        uint32_t flags, float term_eps, const int32_t* ray_order, const GpnerfOutputs* out, void* stream);
+                        uint32_t flags, float term_eps, const int32_t* ray_order, const GpnerfOutputs* out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* Bytes of workspace gpnerf_render_fused can use for this launch (0: it would not split). */
+size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples);
 
 /* Stage entry points (the same device code as the fused kernel, one reference function per launch).
  *
