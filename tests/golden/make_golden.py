@@ -251,6 +251,7 @@ CASES = [
     ("allmasked_s32", dict(H=8, W=8, seed=8, fill="full", pose="random", **SMALL), 32, dict(neg_ray=True)),
     ("partial_s32", dict(H=32, W=32, seed=5, focal_mul=8.0, pose="random", **SMALL), 32, {}),
     ("stretch_s32", dict(H=16, W=16, seed=6, fill="full", pose="random", **SMALL), 32, dict(stretch=2.5)),
+    ("nonsquare_s16", dict(H=24, W=40, seed=9, focal_mul=7.0, pose="random", **SMALL), 16, {}),
     ("wide_s16", dict(H=24, W=24, seed=7, focal_mul=0.6, pose="random", **SMALL), 16, {}),
     ("config1_64x64_s32", dict(H=64, W=64, seed=0, fill="full", pose="identity",
                                aabb_half=(0.25, 0.45, 0.125), voxel=0.005), 32, dict(outputs_only=True)),
