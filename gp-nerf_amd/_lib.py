@@ -81,6 +81,15 @@ SYMBOLS = {
     "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     "gpnerf_build_occupancy": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_void_p]),
+    "gpnerf_sparse_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
+    "gpnerf_sparse_conv3": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_sparse_merge_duplicates": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                                                 C.c_void_p]),
+    "gpnerf_sparse_down_sites": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_void_p]),
+    "gpnerf_sparse_to_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "gpnerf_relayout_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_featmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -395,7 +395,10 @@ DEV void grid_coords(const FrameK& fr, float px, float py, float pz, float& gx, 
 
 // Launched with 1..8 waves per workgroup (blockDim.x = 64 * waves): one workgroup per CU either way (LDS), so the
 // host picks the width that balances the grid over the 256 CUs (choose_waves()).
-__global__ void __launch_bounds__(512, 2)
+#ifndef GPNERF_MAX_WAVES
+#define GPNERF_MAX_WAVES 8
+#endif
+__global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
                     const unsigned flags, const float term_eps, const OutK out, const int split, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -968,11 +971,11 @@ Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, 
     for (int split = 1; split <= 4; split *= 2) {
         if (split > 1 && (!may_split || S / split < 8 || ws_bytes < (size_t)n_rays * split * 16 * sizeof(float))) continue;
         if (f_split > 0 && split != f_split && !(split == 1 && f_split > 1 && !may_split)) continue;
-        for (int w = 8; w >= 1; --w) {
+        for (int w = GPNERF_MAX_WAVES; w >= 1; --w) {
             if (f_waves > 0 && w != f_waves) continue;
             const int64_t blocks = (tiles * split + w - 1) / w;
             const int64_t rounds = (blocks + cus - 1) / cus;
-            const double step = w <= 4 ? 85.7 : 134.0;                    // kilo-cycles per 32-sample step
+            const double step = w <= 4 ? 85.7 : (w <= 8 ? 134.0 : 190.0);  // kilo-cycles per 32-sample step
             const double t = (double)rounds * step * ((double)S / split) + (split > 1 ? 60.0 : 0.0);
             if (t < best_t * 0.97) { best_t = t; best = Geometry{w, split}; }   // ties: wider workgroup, no split
         }

@@ -118,6 +118,13 @@ class Frame:
         self.vols = []
         for l, v in enumerate(volumes):
             _require_gpu(v, f"volumes[{l}]")
+            if getattr(v, "_gpnerf_ndhwc", False):            # already channels-last (gpnerf_sparse_to_dense): no copy
+                if v.shape[-1] != L.CH or v.dtype != torch.float32 or not v.is_contiguous():
+                    raise L.GpnerfError(f"volume level {l}: expected contiguous fp32 [D,H,W,{L.CH}]")
+                self.vols.append(v)
+                f.vol[l] = v.data_ptr()
+                f.vol_dhw[l][0], f.vol_dhw[l][1], f.vol_dhw[l][2] = v.shape[0], v.shape[1], v.shape[2]
+                continue
             v = v.reshape(v.shape[-4:]).contiguous().float()
             if v.shape[0] != L.CH:
                 raise L.GpnerfError(f"volume level {l}: {v.shape[0]} channels, expected {L.CH}")

@@ -46,6 +46,8 @@ class NeRFSigmaHead(nn.Module):
         code = self.c(torch.arange(0, self.n_smpl, device=smpl_feat_sampled.device))
         feat = smpl_feat_sampled.flatten(0, 1)
         fused = self.xyzc_attn(code.unsqueeze(1), feat, feat)[0].squeeze(1)
+        if fused.is_cuda and not self.training:
+            return self.xyzc_net.dense_levels_hip(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
         return self.xyzc_net.dense_levels(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
 
 

@@ -11,9 +11,13 @@ strict=True.  It is validated against a dense conv3d-with-mask formulation in te
 `MultiHeadAttention` mirrors libs/nerfheads/networks/MultiHeadAttention.py:42-98 (parameter names
 w_qs, w_ks, w_vs, fc, layer_norm).
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib as L
 
 
 class MultiHeadAttention(nn.Module):
@@ -69,8 +73,8 @@ class SparseTensor:
 
 
 def _lookup(sorted_keys, order, query):
-    """index into the original rows of the entry whose key equals `query`, or -1."""
-    pos = torch.searchsorted(sorted_keys, query).clamp_(max=sorted_keys.numel() - 1)
+    """index into the original rows of the entry whose key equals `query` (the highest row among duplicates), or -1."""
+    pos = (torch.searchsorted(sorted_keys, query, right=True) - 1).clamp_(min=0)
     hit = sorted_keys[pos] == query
     return torch.where(hit, order[pos], torch.full_like(pos, -1))
 
@@ -165,6 +169,71 @@ class SparseConvNet(nn.Module):
             net.append(stride_conv(cin, out_dim[i]))
         net.append(double_conv(out_dim[-1], out_dim[-1]))
         self.net = nn.ModuleList(net)
+
+    # ---- the MI355X-native path: gpnerf_volume.hip ---------------------------------------------------------
+    @staticmethod
+    def _folded_bn(bn):
+        """inference-mode BatchNorm1d as y = x * scale + shift"""
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        return scale.float().contiguous(), (bn.bias - bn.running_mean * scale).float().contiguous()
+
+    def dense_levels_hip(self, code, coord, out_sh, batch_size=1):
+        """Same result as dense_levels(), computed by the HIP sparse-convolution kernels and returned directly in the
+        render kernel's channels-last layout: a list of 4 tensors [D_k,H_k,W_k,C] (tagged `_gpnerf_ndhwc`)."""
+        if int(batch_size) != 1:
+            raise ValueError("the per-ray path renders one frame at a time (BaseRender.py:336 asserts batch 1)")
+        if self.training:
+            raise L.GpnerfError("the HIP volume builder folds BatchNorm running statistics: call .eval() first")
+        if not code.is_cuda:
+            raise L.GpnerfError("the HIP volume builder needs GPU tensors (no CPU fallback)")
+        lib = L.lib()
+        dev = code.device
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        I3 = C.c_int32 * 3
+
+        def conv(strided, mod, bn, x, in_grid, in_dims, coords, m_dev, m_cap):
+            w = mod.weight.detach().float().contiguous()
+            scale, shift = self._folded_bn(bn)
+            out = torch.empty((m_cap, mod.cout), device=dev, dtype=torch.float32)
+            L.check(lib.gpnerf_sparse_conv3(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims), coords.data_ptr(),
+                                            m_dev.data_ptr() if m_dev is not None else None, m_cap, w.data_ptr(), mod.cout,
+                                            scale.data_ptr(), shift.data_ptr(), out.data_ptr(), st), "gpnerf_sparse_conv3")
+            return out
+
+        dims = tuple(int(v) for v in out_sh)
+        coords = coord[:, 1:].to(torch.int32).contiguous()
+        m_cap, m_dev = coords.shape[0], None
+        grid = torch.empty(dims, device=dev, dtype=torch.int32)
+        L.check(lib.gpnerf_sparse_index(coords.data_ptr(), None, m_cap, I3(*dims), grid.data_ptr(), st), "gpnerf_sparse_index")
+        x = code.detach().float().contiguous()
+        with torch.no_grad():
+            dc = self.net[0]                                            # double_conv at full resolution
+            x = conv(False, dc[0], dc[1], x, grid, dims, coords, m_dev, m_cap)
+            x = conv(False, dc[3], dc[4], x, grid, dims, coords, m_dev, m_cap)
+            L.check(lib.gpnerf_sparse_merge_duplicates(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_cap,
+                                                       I3(*dims), st), "gpnerf_sparse_merge_duplicates")
+            levels = []
+            for i in range(self.n_layers):
+                sc, dc = self.net[2 * i + 1], self.net[2 * i + 2]
+                odims = tuple(n // 2 for n in dims)
+                cells = odims[0] * odims[1] * odims[2]
+                ocap = int(min(cells, 8 * m_cap))                       # a fine site reaches at most 2^3 coarse sites
+                ogrid = torch.empty(odims, device=dev, dtype=torch.int32)
+                ocoords = torch.empty((ocap, 3), device=dev, dtype=torch.int32)
+                om = torch.empty((1,), device=dev, dtype=torch.int32)
+                L.check(lib.gpnerf_sparse_down_sites(coords.data_ptr(), m_dev.data_ptr() if m_dev is not None else None, m_cap,
+                                                     I3(*odims), ogrid.data_ptr(), ocoords.data_ptr(), om.data_ptr(), ocap, st),
+                        "gpnerf_sparse_down_sites")
+                x = conv(True, sc[0], sc[1], x, grid, dims, ocoords, om, ocap)
+                grid, dims, coords, m_dev, m_cap = ogrid, odims, ocoords, om, ocap
+                x = conv(False, dc[0], dc[1], x, grid, dims, coords, m_dev, m_cap)
+                x = conv(False, dc[3], dc[4], x, grid, dims, coords, m_dev, m_cap)
+                vol = torch.empty(dims + (x.shape[1],), device=dev, dtype=torch.float32)
+                L.check(lib.gpnerf_sparse_to_dense(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_dev.data_ptr(),
+                                                   m_cap, I3(*dims), vol.data_ptr(), st), "gpnerf_sparse_to_dense")
+                vol._gpnerf_ndhwc = True
+                levels.append(vol)
+        return levels
 
     def dense_levels(self, code, coord, out_sh, batch_size=1):
         """code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) ->

@@ -181,6 +181,32 @@ int gpnerf_select_pixels(const float* occ, int32_t D, int32_t H, int32_t W, floa
 int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o, const float* bounds,
                           int32_t neg_ray, const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream);
 
+/* ---- per-frame sparse convolution pyramid (gpnerf_volume.hip), replacing the external spconv v1.2.1 calls of
+ * libs/nerfheads/networks/SparseConvNet.py:22-111 (SubMConv3d / SparseConv3d + BatchNorm1d + ReLU, .dense()).
+ * A sparse tensor is: features [M][C] fp32, coords [M][3] int32 (d,h,w), and a dense int32 index grid [D][H][W]
+ * (row of the site, -1 = inactive).  Row counts may live on the device (m_dev, NULL = use m_cap) so a chain of levels
+ * needs no host synchronisation; m_cap bounds every launch.  All pointers device unless noted; dims: host int32[3].
+ * Parity unpinned: spconv is not in the reference tree. */
+/* grid <- -1, then grid[coords[i]] = i (highest row wins for duplicate voxels). */
+int gpnerf_sparse_index(const int32_t* coords, const int32_t* m_dev, int32_t m_cap, const int32_t* dims, int32_t* grid,
+                        void* stream);
+/* 3x3x3 conv + folded BatchNorm + ReLU over the sites listed in out_coords.
+ * strided = 0: submanifold (SubMConv3d; in/out share sites and grid), strided = 1: SparseConv3d(k=3, s=2, p=1) reading
+ * the finer level (in_grid/in_dims) at the coarser sites of out_coords.  weight [27][cin][cout] (spconv's [3,3,3,Ci,Co]). */
+int gpnerf_sparse_conv3(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
+                        const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const float* weight, int32_t cout,
+                        const float* bn_scale, const float* bn_shift, float* out, void* stream);
+/* Before the first strided conv: feat[owner] += feat[i] for every row i whose voxel is indexed by another row (two
+ * vertices rounded into one voxel).  spconv's strided rulebook takes every input row; its submanifold lookups one. */
+int gpnerf_sparse_merge_duplicates(float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, int32_t m,
+                                   const int32_t* dims, void* stream);
+/* Active sites of the next (half-resolution) level: out_grid / out_coords / m_out_dev from the finer level's coords. */
+int gpnerf_sparse_down_sites(const int32_t* in_coords, const int32_t* m_in_dev, int32_t m_in_cap, const int32_t* out_dims,
+                             int32_t* out_grid, int32_t* out_coords, int32_t* m_out_dev, int32_t m_out_cap, void* stream);
+/* .dense(): zero-filled [D][H][W][C] volume with the active sites' features (channels-last, as GpnerfFrame.vol wants). */
+int gpnerf_sparse_to_dense(const float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, const int32_t* m_dev,
+                           int32_t m_cap, const int32_t* dims, float* vol_ndhwc, void* stream);
+
 /* Channels-last re-layouts of the per-frame tensors (device -> device). */
 int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t H, int32_t W, void* stream);
 int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t H, int32_t W, void* stream);

@@ -191,3 +191,29 @@ def test_progressive_renderer_returns_pred_img(plugins, syn, oracle):
     ref = oracle.render(sc, 32, rays=np.concatenate([ro, rd, near[:, None], far[:, None]], 1), occ=occ)
     assert_close(ret["rgb_map"], ref["rgb_map"], TOL, "progressive rgb_map")
     assert np.abs(ret["pred_img"][~mref.reshape(H, W)]).max() == 0
+
+
+def test_hip_volume_builder_matches_dense_conv_formulation(syn):
+    """gpnerf_volume.hip (SubM / strided sparse conv + folded BN + ReLU, channels-last .dense()) against the rulebook
+    restatement in volume.py, which tests/test_volume_builder.py pins to a dense conv3d-with-mask formulation.
+    The synthetic vertices round into shared voxels, so spconv's duplicate-row semantics are exercised too."""
+    vol = importlib.import_module("gp-nerf_amd.volume")
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    net = vol.SparseConvNet(n_layers=4, in_dim=32, out_dim=[32, 32, 32, 32]).to(dev).eval()
+    for m in net.modules():                                  # non-trivial BatchNorm statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    sc = syn.make_scene(H=16, W=16, seed=3, aabb_half=(0.1, 0.14, 0.05), make_volumes=False)
+    coord = torch.from_numpy(sc["coord"][0]).to(dev)
+    coord4 = torch.cat([torch.zeros((coord.shape[0], 1), dtype=coord.dtype, device=dev), coord], 1)
+    out_sh = [int(v) for v in sc["out_sh"][0]]
+    code = torch.randn((coord.shape[0], 32), device=dev)
+    with torch.no_grad():
+        hip = net.dense_levels_hip(code, coord4, out_sh)
+        ref = net.dense_levels(code, coord4, out_sh)
+    for l, (a, b) in enumerate(zip(hip, ref)):
+        assert a.shape == tuple(b.shape[2:]) + (32,)
+        err = float((a.permute(3, 0, 1, 2) - b[0]).abs().max())
+        assert err < 2e-4 * max(1.0, float(b.abs().max())), (l, err)
+        assert float((a != 0).float().mean()) > 0
