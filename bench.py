@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--split-f16", action="store_true",
+                    help="dense layers on f16 MFMA with fp32 operands split into hi+lo (GPNERF_FLAG_SPLIT_F16)")
     ap.add_argument("--occ-cull", action="store_true",
                     help="progressive sample culling (demo_render.py semantics) on a sparse synthetic pyramid")
     ap.add_argument("--occupancy", type=float, default=None, help="fraction of coarse volume blocks that are occupied")
@@ -94,7 +96,7 @@ def main():
     def step(i=None):
         if i is not None:
             k_start[i].record()
-        out = fm.render_fused(frame, rays, S, early_term=args.early_term, term_eps=args.term_eps, want=want, ray_order=order, occ_cull=args.occ_cull)
+        out = fm.render_fused(frame, rays, S, early_term=args.early_term, term_eps=args.term_eps, want=want, ray_order=order, occ_cull=args.occ_cull, split_f16=args.split_f16)
         if i is not None:
             k_stop[i].record()
         if world > 1:
@@ -133,13 +135,33 @@ def main():
             "config": {"workload": f"{H}x{W} frame, {S} samples/ray, fused HIP render kernel, synthetic SMPL bound + random "
                                    f"feature volume (BASELINE.json configs[{2 if args.early_term else 1}])",
                        "rays_per_gpu": int(n_local), "rays_total": int(n_total), "samples_per_ray": S, "fill": args.fill, "ray_order": args.ray_order,
-                       "early_term": bool(args.early_term), "occ_cull": bool(args.occ_cull), "vol_occupancy": args.occupancy, "out_sh_dhw": [int(x) for x in sc["out_sh"][0]],
+                       "early_term": bool(args.early_term), "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "vol_occupancy": args.occupancy, "out_sh_dhw": [int(x) for x in sc["out_sh"][0]],
                        "parallelism": f"ray bands over {world} GPU(s), all-gather of rgb+depth" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(args),
                          "kernel": "render_fused_kernel", "kernel_ms": kernel_ms,
                          "flop_per_launch": flops_per_launch},
         }
+        if world == 1 and not args.split_f16:
+            # the optional split-precision mode of the same kernel (GPNERF_FLAG_SPLIT_F16), measured after the headline
+            # region: f16 hi/lo MFMAs with f32 accumulation, same parity bound; NOT part of `value`
+            for _ in range(args.warmup):
+                fm.render_fused(frame, rays, S, want=want, ray_order=order, split_f16=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.steps):
+                alt = fm.render_fused(frame, rays, S, want=want, ray_order=order, early_term=args.early_term,
+                                      term_eps=args.term_eps, occ_cull=args.occ_cull, split_f16=True)
+            e1.record()
+            torch.cuda.synchronize()
+            alt_ms = e0.elapsed_time(e1) / args.steps
+            line["split_f16_mode"] = {
+                "value": n_local / (alt_ms * 1e-3), "unit": "rays/s", "ms_per_step": alt_ms,
+                "max_abs_vs_f32_path": {"rgb": float((alt["rgb_map"] - out["rgb_map"]).abs().max()),
+                                        "depth": float((alt["depth_map"] - out["depth_map"]).abs().max())},
+                "note": "dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation; VALU/gather-bound",
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, rays_h, S, args.cpu_seconds)
             line["vs_cpu"] = value / line["cpu_baseline"]["value"]
@@ -155,7 +177,7 @@ def measured_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot run the
     profiler itself); only reported for the configuration the counters were collected on."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if (args.size == 512 and args.samples == 64 and args.fill == "full" and not args.early_term and not args.occ_cull
+    if (args.size == 512 and args.samples == 64 and args.fill == "full" and not args.early_term and not args.occ_cull and not args.split_f16
             and args.occupancy is None and os.path.exists(p)):
         return json.load(open(p))["hbm_bytes_per_launch"]
     return None

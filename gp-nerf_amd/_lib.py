@@ -28,6 +28,7 @@ class GpnerfFrame(C.Structure):
         ("bounds_min", C.c_float * 3), ("voxel", C.c_float * 3),
         ("out_sh", C.c_int32 * 3),
         ("head_blob", C.c_void_p),
+        ("head_blob_split", C.c_void_p),
         ("occ", C.c_void_p),
     ]
 
@@ -59,11 +60,14 @@ class GpnerfOutputs(C.Structure):
 FLAG_NEG_RAY = 1
 FLAG_EARLY_TERM = 2
 FLAG_OCC_CULL = 4
+FLAG_SPLIT_F16 = 8
 
 # every symbol include/gpnerf_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "gpnerf_head_blob_floats": (C.c_int64, []),
     "gpnerf_pack_head": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
+    "gpnerf_head_blob_split_floats": (C.c_int64, []),
+    "gpnerf_pack_head_split": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
     "gpnerf_render_fused": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float,
                                       C.c_void_p, C.POINTER(GpnerfOutputs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpnerf_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),

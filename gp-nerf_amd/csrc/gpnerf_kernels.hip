@@ -227,6 +227,193 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
 }
 
 // ---------------------------------------------------------------------------------------------
+// split-precision MLP core (GPNERF_FLAG_SPLIT_F16): v_mfma_f32_32x32x16_f16 on hi/lo f16 halves, see head_layout.h
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+struct Frag { h8 hi, lo; };        // one 16-deep k-step of the B operand: 8 values of this lane half, as f16 hi + lo
+
+DEV unsigned pk_rtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+
+// x = hi + lo with hi = f16(x) toward zero (never overflows to inf), lo = f16(x - hi): ~22 significant bits
+DEV Frag make_frag(const float* v) {
+    u32x4 H, Lo;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned w = pk_rtz(v[2 * p], v[2 * p + 1]);
+        const fp16x2 hv = __builtin_bit_cast(fp16x2, w);
+        H[p] = w;
+        Lo[p] = pk_rtz(v[2 * p] - (float)hv[0], v[2 * p + 1] - (float)hv[1]);
+    }
+    Frag f;
+    f.hi = __builtin_bit_cast(h8, H);
+    f.lo = __builtin_bit_cast(h8, Lo);
+    return f;
+}
+
+DEV Frag make_frag2(float a, float b) {                    // the rgb k-step: two live slots, six zero pads
+    const unsigned w = pk_rtz(a, b);
+    const fp16x2 hv = __builtin_bit_cast(fp16x2, w);
+    u32x4 H = {w, 0u, 0u, 0u}, Lo = {pk_rtz(a - (float)hv[0], b - (float)hv[1]), 0u, 0u, 0u};
+    Frag f;
+    f.hi = __builtin_bit_cast(h8, H);
+    f.lo = __builtin_bit_cast(h8, Lo);
+    return f;
+}
+
+template <int L>
+DEV const unsigned* wstep(const unsigned* lw, int m, int s) { return lw + gph::w_off(L) + (m * gph::NS[L] + s) * gph::STEP_WORDS; }
+
+template <int L>
+DEV f32x16 bias_tile_s(const unsigned* lw, int m, int half) {
+    const float* p = reinterpret_cast<const float*>(lw) + gph::b_off(L) + m * 32 + half * 16;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+        acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+    }
+    return acc;
+}
+
+// acc += W_tile[:, 16 k] . B  as  Wlo.Bhi + Whi.Blo + Whi.Bhi
+DEV void mfma_step(const unsigned* __restrict__ w, int lane, const Frag& b, f32x16& acc) {
+    const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(w + lane * 4));
+    const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(w + 256 + lane * 4));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi, acc, 0, 0, 0);
+}
+
+template <int L, int NSTEP>
+DEV void mfma_steps(const unsigned* lw, int m, int s0, int lane, const Frag* b, f32x16& acc) {
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) mfma_step(wstep<L>(lw, m, s0 + s), lane, b[s], acc);
+}
+
+// ELU of an accumulator tile -> its two B-operand k-steps (and optionally the fp32 values)
+DEV void tile_frags(const f32x16& a, Frag* out2, float* keep = nullptr, float scale = 1.f) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { t[r] = elu1(a[r]); if (keep) keep[r] = t[r]; t[r] *= scale; }
+    out2[0] = make_frag(t);
+    out2[1] = make_frag(t + 8);
+}
+
+DEV void geo_eval_s(const unsigned* __restrict__ lw, int lane, const float (&fv)[64], Frag (&sff)[4]) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    Frag in[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) in[s] = make_frag(fv + 8 * s);
+    f32x16 g0 = bias_tile_s<gpl::GEO>(lw, 0, half), g1 = bias_tile_s<gpl::GEO>(lw, 1, half);
+    mfma_steps<gpl::GEO, 8>(lw, 0, 0, lane, in, g0);
+    mfma_steps<gpl::GEO, 8>(lw, 1, 0, lane, in, g1);
+    tile_frags(g0, sff);
+    tile_frags(g1, sff + 2);
+}
+
+DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const float (&x)[NV][18], float nvalid,
+                    float& sigma, float (&rgb)[3]) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    const float* lf = reinterpret_cast<const float*>(lw);
+    // cross-view mean / variance (trainhead.py:20-24) and their k-steps: mean(2 + rgb), var(2 + rgb)
+    Frag mvf[6];
+    {
+        float mv[36];
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+            const float m = ((x[0][t] + x[1][t]) + x[2][t]) * (1.f / 3.f);
+            const float a = x[0][t] - m, b = x[1][t] - m, c = x[2][t] - m;
+            mv[t] = m;
+            mv[18 + t] = ((a * a + b * b) + c * c) * (1.f / 3.f);
+        }
+        mvf[0] = make_frag(mv); mvf[1] = make_frag(mv + 8); mvf[2] = make_frag2(mv[16], mv[17]);
+        mvf[3] = make_frag(mv + 18); mvf[4] = make_frag(mv + 26); mvf[5] = make_frag2(mv[34], mv[35]);
+    }
+    // density branch (trainhead.py:102-110,133-137)
+    {
+        f32x16 a0 = bias_tile_s<gpl::D1>(lw, 0, half), a1 = bias_tile_s<gpl::D1>(lw, 1, half);
+        mfma_steps<gpl::D1, 4>(lw, 0, 0, lane, sff, a0);
+        mfma_steps<gpl::D1, 6>(lw, 0, 4, lane, mvf, a0);
+        mfma_steps<gpl::D1, 4>(lw, 1, 0, lane, sff, a1);
+        mfma_steps<gpl::D1, 6>(lw, 1, 4, lane, mvf, a1);
+        Frag h1[4];
+        tile_frags(a0, h1);
+        tile_frags(a1, h1 + 2);
+        f32x16 a2 = bias_tile_s<gpl::D2>(lw, 0, half);
+        mfma_steps<gpl::D2, 4>(lw, 0, 0, lane, h1, a2);
+        Frag h2[2];
+        tile_frags(a2, h2);
+        f32x16 a3 = bias_tile_s<gpl::D3>(lw, 0, half);
+        mfma_steps<gpl::D3, 2>(lw, 0, 0, lane, h2, a3);
+        const float* w4 = lf + gph::D4_W + half * 8;
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part = fmaf(w4[r], elu1(a3[r]), part);
+        float s = part + __shfl_xor(part, 32) + lf[gph::D4_B];
+        s = fmaxf(s, 0.f);
+        sigma = (nvalid < 1.f) ? 0.f : s;
+    }
+    // colour branch (trainhead.py:85-100,131,139-143)
+    f32x16 s0 = bias_tile_s<gpl::BS>(lw, 0, half), s1 = bias_tile_s<gpl::BS>(lw, 1, half);
+    mfma_steps<gpl::BS, 6>(lw, 0, 0, lane, mvf, s0);
+    mfma_steps<gpl::BS, 6>(lw, 1, 0, lane, mvf, s1);
+    Frag yf[6];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        asm volatile("" : "+v"(lane));
+        Frag xf[3];
+        xf[0] = make_frag(x[v]); xf[1] = make_frag(x[v] + 8); xf[2] = make_frag2(x[v][16], x[v][17]);
+        f32x16 a0 = s0, a1 = s1;
+        mfma_steps<gpl::BV, 3>(lw, 0, 0, lane, xf, a0);
+        mfma_steps<gpl::BV, 3>(lw, 1, 0, lane, xf, a1);
+        Frag h1[4];
+        tile_frags(a0, h1);
+        tile_frags(a1, h1 + 2);
+        f32x16 a2 = bias_tile_s<gpl::B2>(lw, 0, half);
+        mfma_steps<gpl::B2, 4>(lw, 0, 0, lane, h1, a2);
+        float xb[16];
+        Frag xs[2];
+        tile_frags(a2, xs, xb, 1.f / 3.f);                    // x * 1.0 / num_views
+        f32x16 t1 = bias_tile_s<gpl::V1>(lw, 0, half);
+        mfma_steps<gpl::V1, 2>(lw, 0, 0, lane, xs, t1);
+        Frag u1[2];
+        tile_frags(t1, u1);
+        f32x16 t2 = bias_tile_s<gpl::V2>(lw, 0, half);
+        mfma_steps<gpl::V2, 2>(lw, 0, 0, lane, u1, t2);
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = xb[r] + elu1(t2[r]);
+        yf[2 * v] = make_frag(y);
+        yf[2 * v + 1] = make_frag(y + 8);
+    }
+    {
+        f32x16 c1 = bias_tile_s<gpl::R1>(lw, 0, half);
+        mfma_steps<gpl::R1, 6>(lw, 0, 0, lane, yf, c1);
+        Frag h1[2];
+        tile_frags(c1, h1);
+        f32x16 c2 = bias_tile_s<gpl::R2>(lw, 0, half);
+        mfma_steps<gpl::R2, 2>(lw, 0, 0, lane, h1, c2);
+        float e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) e[r] = elu1(c2[r]);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float* w3 = lf + gph::R3_W + o * 16 + half * 8;
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) part = fmaf(w3[r], e[r], part);
+            const float s = part + __shfl_xor(part, 32) + lf[gph::R3_B + o];
+            rgb[o] = 1.f / (1.f + fast_exp(-s));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // feature gathers (channels-last sources)
 // ---------------------------------------------------------------------------------------------
 struct Axis {
@@ -360,6 +547,7 @@ struct FrameK {           // GpnerfFrame by value (kernel argument; lands in SGP
     float Rh[9], Th[3], bounds_min[3], voxel[3];
     float out_sh[3];      // as float
     const float* head_blob;
+    const float* head_blob_split;   // f16 hi/lo image (GPNERF_FLAG_SPLIT_F16) or nullptr
     const float* occ;     // level-1-sized occupancy volume or nullptr
 };
 
@@ -398,16 +586,18 @@ DEV void grid_coords(const FrameK& fr, float px, float py, float pz, float& gx, 
 #ifndef GPNERF_MAX_WAVES
 #define GPNERF_MAX_WAVES 8
 #endif
+template <bool SPLIT>
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
                     const unsigned flags, const float term_eps, const OutK out, const int split, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(fr.head_blob);
+        const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? fr.head_blob_split : fr.head_blob);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < gpl::BLOB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (SPLIT ? gph::BLOB_WORDS : gpl::BLOB_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
+    const unsigned* const lw = reinterpret_cast<const unsigned*>(lds);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, half = lane >> 5;
@@ -480,7 +670,9 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         }
         STAMP(st, 0);
         float sf[32];
-        geo_eval(lds, lane, fv, sf);
+        Frag sff[4];
+        if constexpr (SPLIT) geo_eval_s(lw, lane, fv, sff);
+        else geo_eval(lds, lane, fv, sf);
         STAMP(st, 1);
 
         // Projector.compute (:326-363)
@@ -501,7 +693,8 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
 
         STAMP(st, 2);
         float sigma, rgb[3];
-        mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
+        if constexpr (SPLIT) mlp_eval_s(lw, lane, sff, x, nvalid, sigma, rgb);
+        else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
         if (cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
@@ -930,6 +1123,18 @@ constexpr int FUSED_WAVES = GPNERF_FUSED_WAVES;
 
 int col_ok(int c, int n_in) { return c >= 0 && c < n_in; }
 
+// f16(x) rounded toward zero (what v_cvt_pkrtz_f16_f32 does on the device), on the host
+_Float16 f16_rtz(float v) {
+    _Float16 h = (_Float16)v;                                  // round to nearest
+    if (v == v && (float)h != v && ((float)h > v) == (v > 0.f)) {   // rounded away from zero: step one ulp back
+        uint16_t b;
+        memcpy(&b, &h, 2);
+        b -= 1;                                                // magnitude bits decrease toward zero for either sign
+        memcpy(&h, &b, 2);
+    }
+    return h;
+}
+
 void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, float* blob) {
     for (int m = 0; m < gpl::MT[L]; ++m) {
         float* wt = blob + gpl::w_off(L) + m * gpl::NT[L] * 64;
@@ -1011,6 +1216,7 @@ bool to_framek(const GpnerfFrame* f, FrameK& k, bool need_vol, bool need_img) {
     memcpy(k.voxel, f->voxel, sizeof(k.voxel));
     for (int a = 0; a < 3; ++a) k.out_sh[a] = (float)f->out_sh[a];
     k.head_blob = f->head_blob;
+    k.head_blob_split = f->head_blob_split;
     k.occ = f->occ;
     return true;
 }
@@ -1098,6 +1304,54 @@ int gpnerf_pack_head(const GpnerfHeadParams* p, float* blob) {
     return GPNERF_OK;
 }
 
+int64_t gpnerf_head_blob_split_floats(void) { return gph::BLOB_WORDS; }
+
+int gpnerf_pack_head_split(const GpnerfHeadParams* p, float* blob) {
+    if (!p || !blob) return GPNERF_E_ARG;
+    const float* const* all = reinterpret_cast<const float* const*>(p);
+    for (size_t i = 0; i < sizeof(GpnerfHeadParams) / sizeof(float*); ++i)
+        if (!all[i]) return GPNERF_E_ARG;
+    memset(blob, 0, sizeof(float) * gph::BLOB_WORDS);
+    struct Spec { int L; const float *W, *b; int n_out, n_in; };
+    const Spec specs[] = {{gpl::GEO, p->geo_w, p->geo_b, 64, 128}, {gpl::D1, p->d1_w, p->d1_b, 64, 134}, {gpl::D2, p->d2_w, p->d2_b, 32, 64},
+                          {gpl::D3, p->d3_w, p->d3_b, 16, 32},    {gpl::BS, p->b1_w, p->b1_b, 64, 105}, {gpl::BV, p->b1_w, nullptr, 64, 105},
+                          {gpl::B2, p->b2_w, p->b2_b, 32, 64},    {gpl::V1, p->v1_w, p->v1_b, 32, 32},  {gpl::V2, p->v2_w, p->v2_b, 32, 32},
+                          {gpl::R1, p->r1_w, p->r1_b, 32, 96},    {gpl::R2, p->r2_w, p->r2_b, 16, 32}};
+    uint16_t* halfs = reinterpret_cast<uint16_t*>(blob);
+    for (const Spec& sp : specs) {
+        for (int m = 0; m < gph::MT[sp.L]; ++m) {
+            for (int st = 0; st < gph::NS[sp.L]; ++st) {
+                const size_t base = ((size_t)gph::w_off(sp.L) + (size_t)(m * gph::NS[sp.L] + st) * gph::STEP_WORDS) * 2;   // in halfs
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = 32 * m + (lane & 31), h = lane >> 5, c = gph::col_of(sp.L, st, j, h);
+                        const float v = (row < sp.n_out && c >= 0 && c < sp.n_in) ? sp.W[(size_t)row * sp.n_in + c] : 0.f;
+                        const _Float16 hi = f16_rtz(v);
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        uint16_t hb, lb;
+                        memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+                        halfs[base + lane * 8 + j] = hb;
+                        halfs[base + 512 + lane * 8 + j] = lb;
+                    }
+            }
+            float* bt = blob + gph::b_off(sp.L) + m * 32;
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * m + gpl::ft(r, h);
+                    bt[h * 16 + r] = (sp.b && row < sp.n_out) ? sp.b[row] : 0.f;
+                }
+        }
+    }
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 8; ++r) {
+            blob[gph::D4_W + h * 8 + r] = p->d4_w[gpl::ft(r, h)];
+            for (int o = 0; o < 3; ++o) blob[gph::R3_W + o * 16 + h * 8 + r] = p->r3_w[o * 16 + gpl::ft(r, h)];
+        }
+    blob[gph::D4_B] = p->d4_b[0];
+    for (int o = 0; o < 3; ++o) blob[gph::R3_B + o] = p->r3_b[o];
+    return GPNERF_OK;
+}
+
 int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, uint32_t flags,
                         float term_eps, const int32_t* ray_order, const GpnerfOutputs* out, void* workspace,
                         size_t workspace_bytes, void* stream) {
@@ -1108,10 +1362,15 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (!to_framek(f, k, true, true)) return GPNERF_E_ARG;
     const int64_t tiles = (n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
+    const bool split16 = (flags & GPNERF_FLAG_SPLIT_F16) != 0;
+    if (split16 && !f->head_blob_split) return GPNERF_E_ARG;
+    const size_t lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split) != hipSuccess)
             return GPNERF_E_DEVICE;
         attr_set = true;
     }
@@ -1119,8 +1378,12 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const Geometry g = choose_geometry(tiles, n_samples, may_split, workspace ? workspace_bytes : 0, n_rays);
     const int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
     const OutK ok = to_outk(out, ray_order);
-    hipLaunchKernelGGL(render_fused_kernel, dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), k, rays,
-                       (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, ok, g.split, (float*)workspace);
+    if (split16)
+        hipLaunchKernelGGL(render_fused_kernel<true>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), k, rays,
+                           (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, ok, g.split, (float*)workspace);
+    else
+        hipLaunchKernelGGL(render_fused_kernel<false>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), k, rays,
+                           (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, ok, g.split, (float*)workspace);
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),

@@ -64,3 +64,59 @@ constexpr int col_of(int l, int t, int h) {
 }
 
 }  // namespace gpl
+
+// ------------------------------------------------------------------------------------------------------------------
+// Split-precision image (GPNERF_FLAG_SPLIT_F16): the same layers on v_mfma_f32_32x32x16_f16 with every fp32 operand
+// written as hi + lo in f16 (hi = f16(x) toward zero, lo = f16(x - hi)) and three MFMAs per k-step:
+//   W.h ~= Whi.hhi + Whi.hlo + Wlo.hhi        (the dropped lo.lo term is ~2^-22 relative; f32 accumulation)
+// which keeps ~fp32 accuracy (measured 1e-6 on rgb) at 3/16 of the fp32-MFMA cost.
+//   A operand: lane l holds W[row l&31][k = 8*(l>>5) + j], j = 0..7      (8 halfs = one ds_read_b128)
+//   B operand: lane l holds H[k = 8*(l>>5) + j][ray l&31]
+//   C/D      : as the fp32 form, feature ft(r,h) in accumulator register r of half h
+// A 32-feature accumulator tile feeds the next layer as two 16-deep k-steps: step u takes registers 8u..8u+7.
+// ------------------------------------------------------------------------------------------------------------------
+namespace gph {
+
+using gpl::GEO; using gpl::D1; using gpl::D2; using gpl::D3; using gpl::BS; using gpl::BV; using gpl::B2;
+using gpl::V1; using gpl::V2; using gpl::R1; using gpl::R2; using gpl::NLAYER; using gpl::MT; using gpl::ft;
+
+//                              GEO  D1  D2  D3  BS  BV  B2  V1  V2  R1  R2      k-steps of 16
+constexpr int NS[NLAYER] = {8, 10, 4, 2, 6, 3, 4, 2, 2, 6, 2};
+constexpr int STEP_WORDS = 512;          // one k-step of one tile: 64 lanes x 8 halfs hi (256 words) + the same for lo
+
+constexpr int w_off(int l) {             // in 32-bit words
+    int o = 0;
+    for (int j = 0; j < l; ++j) o += NS[j] * MT[j] * STEP_WORDS;
+    return o;
+}
+constexpr int W_TOTAL = w_off(NLAYER);
+constexpr int b_off(int l) {             // fp32 biases, [tile][half][16] as in the fp32 image
+    int o = W_TOTAL;
+    for (int j = 0; j < l; ++j) o += MT[j] * 32;
+    return o;
+}
+constexpr int B_END = b_off(NLAYER);
+constexpr int D4_W = B_END, D4_B = D4_W + 16, R3_W = D4_B + 4, R3_B = R3_W + 48;
+constexpr int BLOB_WORDS = R3_B + 4;
+static_assert(BLOB_WORDS % 4 == 0, "image is copied as 16-byte pieces");
+static_assert(BLOB_WORDS * 4 <= 160 * 1024, "split image must fit the 160 KiB LDS of one CU");
+
+// slot of the 35-vector [r,g,b, feat0..31] held by half h at (k-step u of 3, element j); -1 = zero pad
+constexpr int x35(int u, int j, int h) {
+    return u < 2 ? 3 + 16 * h + 8 * u + j : (j == 0 ? (h == 0 ? 0 : 1) : (j == 1 ? (h == 0 ? 2 : -1) : -1));
+}
+constexpr int off_or_pad(int base, int idx) { return idx < 0 ? -1 : base + idx; }
+constexpr int tile_col(int s, int j, int h) { return 32 * (s >> 1) + ft(8 * (s & 1) + j, h); }
+
+// PyTorch weight column consumed at (layer l, k-step s, element j, half h); -1: zero
+constexpr int col_of(int l, int s, int j, int h) {
+    switch (l) {
+        case GEO: return 32 * (s >> 1) + 16 * h + 8 * (s & 1) + j;
+        case D1:  return s < 4 ? tile_col(s, j, h) : (s < 7 ? off_or_pad(64, x35(s - 4, j, h)) : off_or_pad(99, x35(s - 7, j, h)));
+        case BS:  return s < 3 ? off_or_pad(0, x35(s, j, h)) : off_or_pad(35, x35(s - 3, j, h));
+        case BV:  return off_or_pad(70, x35(s, j, h));
+        default:  return tile_col(s, j, h);          // D2 B2 R1 (several tiles) and D3 V1 V2 R2 (one tile)
+    }
+}
+
+}  // namespace gph

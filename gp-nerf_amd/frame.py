@@ -42,7 +42,13 @@ def pack_head(state, device):
     n = int(lib.gpnerf_head_blob_floats())
     blob = np.zeros(n, np.float32)
     L.check(lib.gpnerf_pack_head(C.byref(params), blob.ctypes.data_as(L.FP)), "gpnerf_pack_head")
-    return torch.from_numpy(blob).to(device)
+    out = torch.from_numpy(blob).to(device)
+    # the f16 hi/lo image for GPNERF_FLAG_SPLIT_F16 rides along as an attribute of the fp32 one
+    ns = int(lib.gpnerf_head_blob_split_floats())
+    sblob = np.zeros(ns, np.float32)
+    L.check(lib.gpnerf_pack_head_split(C.byref(params), sblob.ctypes.data_as(L.FP)), "gpnerf_pack_head_split")
+    out._gpnerf_split = torch.from_numpy(sblob).to(device)
+    return out
 
 
 class Frame:
@@ -111,6 +117,8 @@ class Frame:
             f.out_sh[i] = int(osh[i])
         self.head_blob = head_blob
         f.head_blob = head_blob.data_ptr()
+        self.head_blob_split = getattr(head_blob, "_gpnerf_split", None)
+        f.head_blob_split = self.head_blob_split.data_ptr() if self.head_blob_split is not None else None
         self.c = f
 
     def _set_volumes(self, f, volumes, keep):
@@ -183,10 +191,12 @@ def patch_order(mask_at_box, H, W, patch_w=32, patch_h=8):
 
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
-                 want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True):
+                 want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
+                 split_f16=False):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     ray_order: optional int32 device tensor [N], a permutation that groups rays into cache-friendly tiles.
-    load_balance: lend the kernel a workspace so small frames can split a tile's samples over several wavefronts."""
+    load_balance: lend the kernel a workspace so small frames can split a tile's samples over several wavefronts.
+    split_f16: dense layers on f16 MFMA with fp32 operands split into hi + lo (GPNERF_FLAG_SPLIT_F16)."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()
@@ -214,6 +224,10 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         res["raw"] = torch.empty((N, S, 4), device=dev)
         o.raw = res["raw"].data_ptr()
     flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
+    if split_f16:
+        if not frame.c.head_blob_split:
+            raise L.GpnerfError("split_f16 needs the f16 hi/lo head image (build the frame from pack_head()'s tensor)")
+        flags |= L.FLAG_SPLIT_F16
     if occ_cull:
         if not frame.c.occ:
             frame.build_occupancy()

@@ -40,6 +40,9 @@ extern "C" {
 /* flags of gpnerf_render_fused */
 #define GPNERF_FLAG_NEG_RAY 1u     /* Projector(neg_ray=True) + raw2outputs(neg=True): BaseRender.py:86-88,317-320 */
 #define GPNERF_FLAG_EARLY_TERM 2u  /* stop a 32-ray wave tile once every ray has T < term_eps (not in the reference) */
+#define GPNERF_FLAG_SPLIT_F16 8u   /* dense layers on f16 MFMA with every fp32 operand split into f16 hi + lo (three MFMAs per
+                                      k-step, f32 accumulation): ~fp32 accuracy (1e-6 on rgb), 3/16 of the fp32 MFMA cost.
+                                      Needs frame->head_blob_split; operands must stay below the f16 range (65504) */
 #define GPNERF_FLAG_OCC_CULL 4u    /* progressive sample culling of libs/renders/demo_render.py:270-283,317-347: a sample is
                                       evaluated only where the occupancy volume (frame->occ) interpolates to > 0; culled
                                       samples carry alpha = 0, and colour is kept only where alpha > 1e-14 */
@@ -61,6 +64,7 @@ typedef struct GpnerfFrame {
     float voxel[3];                         /* cfg.dataset.voxel_size (applied in d,h,w order); BaseRender.py:67 */
     int32_t out_sh[3];                      /* batch['out_sh'] d,h,w; BaseRender.py:69-70 */
     const float* head_blob;                 /* device; gpnerf_pack_head() image, gpnerf_head_blob_floats() floats */
+    const float* head_blob_split;           /* device or NULL; gpnerf_pack_head_split() image (GPNERF_FLAG_SPLIT_F16) */
     const float* occ;                       /* device or NULL; [D_1][H_1][W_1] occupancy `masks3d` at level-1 size
                                                (SparseConvNet.py:135-139), read only with GPNERF_FLAG_OCC_CULL */
 } GpnerfFrame;
@@ -103,6 +107,10 @@ int64_t gpnerf_head_blob_floats(void);
  * (MFMA A-operand order).  Host-side, model-load time.
  * Replaces nothing in the reference; it is what load_state_dict is to nn.Linear. */
 int gpnerf_pack_head(const GpnerfHeadParams* params_host, float* blob_host);
+
+/* The same parameters as f16 hi/lo pairs in v_mfma_f32_32x32x16_f16 A-operand order (GPNERF_FLAG_SPLIT_F16). */
+int64_t gpnerf_head_blob_split_floats(void);
+int gpnerf_pack_head_split(const GpnerfHeadParams* params_host, float* blob_host);
 
 /* Fused sample -> gather -> MLP -> composite over N rays.
  * Replaces Renderer.batchify_rays + render_rays with is_train=False

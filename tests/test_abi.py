@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header(pkg):
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(GpnerfFrame), offsetof(GpnerfFrame, vol_dhw), offsetof(GpnerfFrame, featmaps),
          offsetof(GpnerfFrame, proj), offsetof(GpnerfFrame, out_sh), offsetof(GpnerfFrame, head_blob), offsetof(GpnerfFrame, imgs));
-  printf("%zu\n", offsetof(GpnerfFrame, occ));
+  printf("%zu %zu\n", offsetof(GpnerfFrame, occ), offsetof(GpnerfFrame, head_blob_split));
   printf("%zu %zu\n", sizeof(GpnerfHeadParams), sizeof(GpnerfOutputs));
   return 0;
 }'''
@@ -50,7 +50,7 @@ int main(void) {
     F = L.GpnerfFrame
     assert [int(x) for x in a.split()] == [C.sizeof(F), F.vol_dhw.offset, F.featmaps.offset, F.proj.offset, F.out_sh.offset,
                                            F.head_blob.offset, F.imgs.offset]
-    assert int(occ_off) == F.occ.offset
+    assert [int(x) for x in occ_off.split()] == [F.occ.offset, F.head_blob_split.offset]
     assert [int(x) for x in b.split()] == [C.sizeof(L.GpnerfHeadParams), C.sizeof(L.GpnerfOutputs)]
 
 

@@ -208,3 +208,21 @@ def test_progressive_ray_selection_matches_restatement(fm, oracle, syn):
     assert_close(rays[:, 3:6], rd, 1e-5, "ray_d")
     assert_close(rays[:, 6], near, 2e-5, "near")
     assert_close(rays[:, 7], far, 2e-5, "far")
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_split_f16_mode_matches_reference_golden(name, fm):
+    """GPNERF_FLAG_SPLIT_F16 (f16 hi/lo MFMA, fp32 accumulation) stays inside north_star's 1e-4 on every golden vector."""
+    z, meta = load(name)
+    sc = scene_of(meta)
+    S = meta["n_samples"]
+    fr = build_frame(fm, sc)
+    got = cpu(fm.render_fused(fr, rays_of(sc), S, neg_ray=meta["neg_ray"], split_f16=True, want=("weights", "rgb_in", "raw", "ray_mask")))
+    assert_close(got["rgb_map"], z["rgb_map"], TOL, "rgb_map")
+    assert_close(got["depth_map"], z["depth_map"], TOL, "depth_map")
+    assert_close(got["acc_map"], z["acc_map"], TOL, "acc_map")
+    assert_close(got["rgb_in_map"], z["rgb_in_map"], TOL, "rgb_in_map")
+    if "weights" in z:
+        assert_close(got["weights"], z["weights"], TOL, "weights")
+    if "st_raw" in z:
+        assert_close(got["raw"][: z["st_raw"].shape[0]], z["st_raw"], TOL, "raw")

@@ -148,3 +148,139 @@ def test_pack_rejects_missing_tensors(pkg):
     L = pkg._lib
     blob = np.zeros(L.lib().gpnerf_head_blob_floats(), np.float32)
     assert L.lib().gpnerf_pack_head(C.byref(L.GpnerfHeadParams()), blob.ctypes.data_as(L.FP)) == -1
+
+
+# ---- split-precision image (GPNERF_FLAG_SPLIT_F16) ------------------------------------------------------------------
+NS16 = [8, 10, 4, 2, 6, 3, 4, 2, 2, 6, 2]
+MT16 = [2, 2, 1, 1, 2, 2, 1, 1, 1, 1, 1]
+
+
+def split16(v):
+    """hi = f16 toward zero, lo = f16(v - hi), as make_frag does on the device."""
+    v = np.asarray(v, np.float32)
+    hi = v.astype(np.float16)
+    away = (np.abs(hi.astype(np.float32)) > np.abs(v))
+    hi = np.where(away, (hi.view(np.uint16) - 1).view(np.float16), hi)
+    lo = (v - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float32), lo.astype(np.float32)
+
+
+class Wave16:
+    """v_mfma_f32_32x32x16_f16 operand maps: A/B lane l holds k = 8*(l>>5)+j; C/D feature ft(r,h) in register r."""
+
+    def __init__(self, blob):
+        self.words = blob
+        self.halfs = blob.view(np.float16)
+        off, self.w_off = 0, {}
+        for n, ns, mt in zip(NAMES, NS16, MT16):
+            self.w_off[n] = off
+            off += ns * mt * 512
+        self.b_off = {}
+        for n, mt in zip(NAMES, MT16):
+            self.b_off[n] = off
+            off += mt * 32
+        self.d4w, self.d4b, self.r3w, self.r3b = off, off + 16, off + 20, off + 68
+
+    def bias_tile(self, name, m):
+        acc = np.zeros((16, 64), np.float32)
+        bo = self.b_off[name]
+        for h in range(2):
+            acc[:, 32 * h:32 * h + 32] = self.words[bo + m * 32 + h * 16: bo + m * 32 + h * 16 + 16][:, None]
+        return acc
+
+    def steps(self, name, m, s0, frags, acc):
+        """frags: list of [8][64] fp32 slot arrays (one per k-step)."""
+        ns = NS16[NAMES.index(name)]
+        D = np.zeros((32, 32), np.float64)
+        for i, fr in enumerate(frags):
+            base = (self.w_off[name] + (m * ns + s0 + i) * 512) * 2
+            ah = self.halfs[base: base + 512].astype(np.float32).reshape(64, 8)
+            al = self.halfs[base + 512: base + 1024].astype(np.float32).reshape(64, 8)
+            bh, bl = split16(fr)                                   # [8][64]
+            for h in range(2):
+                A_h, A_l = ah[32 * h:32 * h + 32], al[32 * h:32 * h + 32]          # [row][j]
+                B_h, B_l = bh[:, 32 * h:32 * h + 32], bl[:, 32 * h:32 * h + 32]    # [j][col]
+                D += A_l.astype(np.float64) @ B_h + A_h.astype(np.float64) @ B_l + A_h.astype(np.float64) @ B_h
+        out = acc.copy()
+        for r in range(16):
+            for h in range(2):
+                out[r, 32 * h:32 * h + 32] += D[ft(r, h), :].astype(np.float32)
+        return out
+
+
+def emulate_split(blob, vol_feat, rgb_feat, mask):
+    w = Wave16(blob)
+    lane_s, lane_h = np.arange(64) % 32, np.arange(64) // 32
+    fv = np.stack([vol_feat[lane_s, 32 * (t >> 4) + 16 * lane_h + (t & 15)] for t in range(64)], 0)
+    x = np.zeros((3, 18, 64), np.float32)
+    for v in range(3):
+        for t in range(16):
+            x[v, t] = rgb_feat[lane_s, v, 3 + 16 * lane_h + t]
+        x[v, 16] = np.where(lane_h == 1, rgb_feat[lane_s, v, 1], rgb_feat[lane_s, v, 0])
+        x[v, 17] = np.where(lane_h == 1, 0.0, rgb_feat[lane_s, v, 2])
+    nvalid = mask.sum(1)[lane_s]
+    z6 = np.zeros((6, 64), np.float32)
+    tile2 = lambda a: [a[0:8], a[8:16]]
+    x3 = lambda a: [a[0:8], a[8:16], np.concatenate([a[16:18], z6], 0)]
+    fvf = [fv[8 * s: 8 * s + 8] for s in range(8)]
+    g0 = w.steps("GEO", 0, 0, fvf, w.bias_tile("GEO", 0))
+    g1 = w.steps("GEO", 1, 0, fvf, w.bias_tile("GEO", 1))
+    sff = tile2(elu(g0)) + tile2(elu(g1))
+    m = (x[0] + x[1] + x[2]) * np.float32(1 / 3)
+    var = ((x[0] - m) ** 2 + (x[1] - m) ** 2 + (x[2] - m) ** 2) * np.float32(1 / 3)
+    mvf = x3(m) + x3(var)
+    a0 = w.steps("D1", 0, 4, mvf, w.steps("D1", 0, 0, sff, w.bias_tile("D1", 0)))
+    a1 = w.steps("D1", 1, 4, mvf, w.steps("D1", 1, 0, sff, w.bias_tile("D1", 1)))
+    a2 = w.steps("D2", 0, 0, tile2(elu(a0)) + tile2(elu(a1)), w.bias_tile("D2", 0))
+    a3 = w.steps("D3", 0, 0, tile2(elu(a2)), w.bias_tile("D3", 0))
+    e3 = elu(a3)
+    part = sum(blob[w.d4w + lane_h * 8 + r] * e3[r] for r in range(8)).astype(np.float32)
+    s = part + part[(np.arange(64) + 32) % 64] + blob[w.d4b]
+    sigma = np.where(nvalid < 1, 0.0, np.maximum(s, 0))
+    s0 = w.steps("BS", 0, 0, mvf, w.bias_tile("BS", 0))
+    s1 = w.steps("BS", 1, 0, mvf, w.bias_tile("BS", 1))
+    yf = []
+    for v in range(3):
+        b0 = w.steps("BV", 0, 0, x3(x[v]), s0)
+        b1 = w.steps("BV", 1, 0, x3(x[v]), s1)
+        xb = elu(w.steps("B2", 0, 0, tile2(elu(b0)) + tile2(elu(b1)), w.bias_tile("B2", 0)))
+        t1 = elu(w.steps("V1", 0, 0, tile2(xb * np.float32(1 / 3)), w.bias_tile("V1", 0)))
+        t2 = elu(w.steps("V2", 0, 0, tile2(t1), w.bias_tile("V2", 0)))
+        yf += tile2(xb + t2)
+    c1 = elu(w.steps("R1", 0, 0, yf, w.bias_tile("R1", 0)))
+    c2 = elu(w.steps("R2", 0, 0, tile2(c1), w.bias_tile("R2", 0)))
+    rgb = []
+    for o in range(3):
+        part = sum(blob[w.r3w + o * 16 + lane_h * 8 + r] * c2[r] for r in range(8)).astype(np.float32)
+        s = part + part[(np.arange(64) + 32) % 64] + blob[w.r3b + o]
+        rgb.append(1 / (1 + np.exp(-s)))
+    raw = np.stack(rgb + [sigma], 1)
+    assert np.array_equal(raw[:32], raw[32:])
+    return raw[:32].astype(np.float32)
+
+
+def test_split_head_image_reproduces_the_reference_head(pkg, oracle, syn):
+    L = pkg._lib
+    lib = L.lib()
+    head = syn.make_head_weights(seed=4, bias_std=0.2)
+    params = L.GpnerfHeadParams()
+    keep = []
+    for short, name in L.HEAD_FIELDS:
+        for suf, fld in (("weight", "_w"), ("bias", "_b")):
+            a = np.ascontiguousarray(head[f"{name}.{suf}"], np.float32)
+            keep.append(a)
+            setattr(params, short + fld, a.ctypes.data_as(L.FP))
+    n = lib.gpnerf_head_blob_split_floats()
+    assert n * 4 <= 160 * 1024
+    blob = np.zeros(n, np.float32)
+    assert lib.gpnerf_pack_head_split(C.byref(params), blob.ctypes.data_as(L.FP)) == 0
+    g = np.random.Generator(np.random.PCG64(13))
+    vol = g.standard_normal((32, 128), dtype=np.float32) * 2
+    feat = g.standard_normal((32, 3, 35), dtype=np.float32)
+    feat[..., :3] = g.random((32, 3, 3), dtype=np.float32)
+    mask = (g.random((32, 3)) > 0.4).astype(np.float32)
+    mask[:3] = 0
+    got = emulate_split(blob, vol, feat, mask)
+    ref = oracle.head_forward(head, vol, feat, mask)
+    err = np.abs(got - ref).max()
+    assert err < 3e-5, err          # hi/lo split keeps ~22 significant bits: fp32-class accuracy
