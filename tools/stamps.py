@@ -17,6 +17,7 @@ fm = importlib.import_module("gp-nerf_amd.frame")
 syn = importlib.import_module("gp-nerf_amd.synthetic")
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+split = len(sys.argv) > 2 and sys.argv[2] == "split"
 S = 64
 dev = torch.device("cuda:0")
 sc = syn.make_scene(H=size, W=size, seed=0, fill="full", pose="identity")
@@ -27,12 +28,12 @@ rays = t(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None],
 lib = L.lib()
 lib.gpnerf_debug_read_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
 buf = (C.c_ulonglong * 16)()
-fm.render_fused(fr, rays, S, want=())
+fm.render_fused(fr, rays, S, want=(), split_f16=split)
 torch.cuda.synchronize()
 lib.gpnerf_debug_read_stamps(buf)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-fm.render_fused(fr, rays, S, want=())
+fm.render_fused(fr, rays, S, want=(), split_f16=split)
 e1.record()
 torch.cuda.synchronize()
 lib.gpnerf_debug_read_stamps(buf)
