@@ -239,15 +239,26 @@ struct Frag { h8 hi, lo; };        // one 16-deep k-step of the B operand: 8 val
 
 DEV unsigned pk_rtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 
+// x - f16_half(w): v_fma_mix_f32 reads the f16 half of w directly (no conversion back to f32 first)
+DEV float minus_lo_half(unsigned w, float x) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(x));
+    return r;
+}
+DEV float minus_hi_half(unsigned w, float x) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(x));
+    return r;
+}
+
 // x = hi + lo with hi = f16(x) toward zero (never overflows to inf), lo = f16(x - hi): ~22 significant bits
 DEV Frag make_frag(const float* v) {
     u32x4 H, Lo;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const unsigned w = pk_rtz(v[2 * p], v[2 * p + 1]);
-        const fp16x2 hv = __builtin_bit_cast(fp16x2, w);
         H[p] = w;
-        Lo[p] = pk_rtz(v[2 * p] - (float)hv[0], v[2 * p + 1] - (float)hv[1]);
+        Lo[p] = pk_rtz(minus_lo_half(w, v[2 * p]), minus_hi_half(w, v[2 * p + 1]));
     }
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
@@ -257,8 +268,7 @@ DEV Frag make_frag(const float* v) {
 
 DEV Frag make_frag2(float a, float b) {                    // the rgb k-step: two live slots, six zero pads
     const unsigned w = pk_rtz(a, b);
-    const fp16x2 hv = __builtin_bit_cast(fp16x2, w);
-    u32x4 H = {w, 0u, 0u, 0u}, Lo = {pk_rtz(a - (float)hv[0], b - (float)hv[1]), 0u, 0u, 0u};
+    u32x4 H = {w, 0u, 0u, 0u}, Lo = {pk_rtz(minus_lo_half(w, a), minus_hi_half(w, b)), 0u, 0u, 0u};
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
     f.lo = __builtin_bit_cast(h8, Lo);

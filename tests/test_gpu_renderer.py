@@ -86,6 +86,19 @@ def test_build_render_and_render_match_reference(name, plugins):
     assert (ret2["rgb_map"] - ret["rgb_map"]).abs().max() > 1e-3
 
 
+def test_fast_plugin_uses_the_split_mode_and_keeps_parity(plugins):
+    fast = importlib.import_module("hip_render_fast")
+    z, meta = load("base_s64")
+    sc = scene_of(meta)
+    r = fast.build_render(cfg(n_samples=64)).to("cuda:0").eval()
+    assert r.split_f16 is True
+    load_head(r, sc)
+    with torch.no_grad():
+        ret = r.render(batch_of(sc))
+    assert_close(ret["rgb_map"][0].cpu().numpy(), z["rgb_map"], TOL, "rgb_map (split mode)")
+    assert_close(ret["depth_map"][0, :, 0].cpu().numpy(), z["depth_map"], TOL, "depth_map (split mode)")
+
+
 def test_head_forward_matches_reference(plugins):
     _, hip_head = plugins
     z, meta = load("base_s32")
