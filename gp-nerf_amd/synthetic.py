@@ -87,52 +87,43 @@ def rot_y(theta):
 
 
 def rays_numpy(H, W, K, R, T, world_bounds):
-    """Pixel rays + AABB slab test, restating data_utils.py:47-63 and :96-130.
+    """Pixel rays and their entry / exit distances through the padded world AABB, with the semantics of
+    data_utils.py:47-63 (get_rays) and :96-130 (get_near_far): un-normalised directions, +1e-5 clamp of small direction
+    components, box padded by 1 cm, a ray is kept iff exactly two of its six plane hits lie on the box, distances signed
+    by the first hit.  Returns ray_o [N,3], ray_d [N,3], near [N], far [N], mask_at_box [H*W] (raster order)."""
+    Kinv = np.linalg.inv(np.asarray(K, np.float64))
+    Rinv = np.linalg.inv(np.asarray(R, np.float64))
+    centre = -(Rinv @ np.asarray(T, np.float64).reshape(3))
+    cols, rows = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    pix = np.stack([cols.ravel(), rows.ravel(), np.ones(H * W, np.float32)], 1)
+    world = (pix @ Kinv.T) @ Rinv.T + centre
+    origin = np.broadcast_to(centre, world.shape).astype(np.float32)
+    direction = (world - centre).astype(np.float32)
+    direction[np.abs(direction) < 1e-5] = 1e-5
 
-    Returns ray_o [N,3], ray_d [N,3] (un-normalised, with the +1e-5 clamp applied
-    in place as the reference does), near [N], far [N], mask_at_box [H*W] bool.
-    """
-    K = np.asarray(K, np.float64)
-    R = np.asarray(R, np.float64)
-    T = np.asarray(T, np.float64).reshape(3, 1)
-    R_inv = np.linalg.inv(R)
-    Tw = -R_inv @ T
-    rays_o = Tw.ravel()
-    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy")
-    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
-    pixel_camera = np.dot(xy1, np.linalg.inv(K).T)
-    pixel_world = (pixel_camera @ R_inv.T) + Tw.ravel()[None, None]
-    rays_d = pixel_world - rays_o[None, None]
-    rays_o = np.broadcast_to(rays_o, rays_d.shape)
-    ray_o = rays_o.reshape(-1, 3).astype(np.float32)
-    ray_d = rays_d.reshape(-1, 3).astype(np.float32)
-
-    bounds = np.asarray(world_bounds, np.float32) + np.array([-0.01, 0.01], np.float64)[:, None]
-    nominator = bounds[None] - ray_o[:, None]
-    ray_d = ray_d.copy()
-    ray_d[np.abs(ray_d) < 1e-5] = 1e-5
-    d_intersect = (nominator / ray_d[:, None]).reshape(-1, 6)
-    p_intersect = d_intersect[..., None] * ray_d[:, None] + ray_o[:, None]
-    min_x, min_y, min_z, max_x, max_y, max_z = bounds.ravel()
-    eps = 1e-6
-    p_mask = (
-        (p_intersect[..., 0] >= (min_x - eps))
-        * (p_intersect[..., 0] <= (max_x + eps))
-        * (p_intersect[..., 1] >= (min_y - eps))
-        * (p_intersect[..., 1] <= (max_y + eps))
-        * (p_intersect[..., 2] >= (min_z - eps))
-        * (p_intersect[..., 2] <= (max_z + eps))
-    )
-    mask_at_box = p_mask.sum(-1) == 2
-    p_int = p_intersect[mask_at_box][p_mask[mask_at_box]].reshape(-1, 2, 3)
-    o = ray_o[mask_at_box]
-    d = ray_d[mask_at_box]
-    norm_ray = np.linalg.norm(d, axis=1)
-    sign = np.array(((p_int[:, 0] - o) * d).sum(axis=1) < 0.0, dtype=np.int64) * -2 + 1
-    d0 = np.linalg.norm(p_int[:, 0] - o, axis=1) / norm_ray * sign
-    d1 = np.linalg.norm(p_int[:, 1] - o, axis=1) / norm_ray * sign
-    near = np.minimum(d0, d1).astype(np.float32)
-    far = np.maximum(d0, d1).astype(np.float32)
+    box = np.asarray(world_bounds, np.float32).astype(np.float64)
+    lo, hi = box[0] - 0.01, box[1] + 0.01
+    tol = 1e-6
+    hits, on_box = [], []
+    for plane in (lo, hi):                      # plane order: x/y/z of the low corner, then of the high corner
+        for axis in range(3):
+            t = (plane[axis] - origin[:, axis]) / direction[:, axis]
+            pt = origin + t[:, None] * direction
+            hits.append(pt)
+            on_box.append(np.all((pt >= lo - tol) & (pt <= hi + tol), axis=1))
+    hits, on_box = np.stack(hits, 1), np.stack(on_box, 1)          # [P,6,3], [P,6]
+    mask_at_box = on_box.sum(1) == 2
+    sel_hits, sel_on = hits[mask_at_box], on_box[mask_at_box]
+    first = sel_on.argmax(1)
+    second = 5 - sel_on[:, ::-1].argmax(1)
+    idx = np.arange(sel_hits.shape[0])
+    p_a, p_b = sel_hits[idx, first], sel_hits[idx, second]
+    o, d = origin[mask_at_box], direction[mask_at_box]
+    length = np.linalg.norm(d, axis=1)
+    sign = np.where(((p_a - o) * d).sum(1) < 0.0, -1.0, 1.0)       # both distances take the first hit's sign
+    t_a = np.linalg.norm(p_a - o, axis=1) / length * sign
+    t_b = np.linalg.norm(p_b - o, axis=1) / length * sign
+    near, far = np.minimum(t_a, t_b).astype(np.float32), np.maximum(t_a, t_b).astype(np.float32)
     return o.astype(np.float32), d.astype(np.float32), near, far, mask_at_box
 
 
