@@ -58,12 +58,13 @@ def test_fused_matches_reference_golden(name, fm):
         assert np.array_equal(got["ray_mask"][:k].astype(bool), z["st_ray_mask"])
 
 
+@pytest.mark.parametrize("split_f16", [False, True])
 @pytest.mark.parametrize("S,n_rays", [(1, 5), (2, 33), (7, 31), (64, 100), (128, 64)])
-def test_fused_matches_oracle_ragged(S, n_rays, fm, oracle, syn):
+def test_fused_matches_oracle_ragged(S, n_rays, split_f16, fm, oracle, syn):
     sc = syn.make_scene(H=16, W=16, seed=100 + S, fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1,
                         max_rays=n_rays)
     fr = build_frame(fm, sc)
-    got = cpu(fm.render_fused(fr, rays_of(sc), S, want=("weights", "z_vals", "rgb_in", "ray_mask", "raw")))
+    got = cpu(fm.render_fused(fr, rays_of(sc), S, want=("weights", "z_vals", "rgb_in", "ray_mask", "raw"), split_f16=split_f16))
     ref = oracle.render(sc, S, stages=True)
     for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map", "weights"):
         assert_close(got[k], ref[k], TOL, k)

@@ -161,6 +161,10 @@ def test_full_size_parity_on_a_ray_sample_and_invariants(full_scene, oracle):
     ref = oracle.render(sc, S, rays=rays_h[idx])
     for k in ("rgb_map", "depth_map", "acc_map", "weights", "rgb_in_map"):
         assert_close(got[k][idx], ref[k], TOL, f"full-size {k}")
+    fast = {k: v.cpu().numpy() for k, v in fm.render_fused(fr, rays, S, split_f16=True).items()}
+    for k in ("rgb_map", "depth_map", "acc_map", "weights", "rgb_in_map"):
+        assert_close(fast[k][idx], ref[k], TOL, f"full-size {k} (split mode)")
+    assert np.abs(fast["rgb_map"] - got["rgb_map"]).max() < 2e-5 and np.abs(fast["depth_map"] - got["depth_map"]).max() < 1e-4
     # (2) size-independent properties over all 262144 rays
     w = got["weights"]
     assert (w >= 0).all() and np.abs(w.sum(1) - got["acc_map"]).max() < 1e-5
