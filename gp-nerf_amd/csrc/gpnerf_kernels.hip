@@ -59,13 +59,9 @@ struct Stamps { DEV void start() {} DEV void flush(int) {} };
 #endif
 
 DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }       // v_exp_f32
-#ifdef GPNERF_ABLATE_ELU
-DEV float elu1(float x) { return x; }
-#else
 // nn.ELU(alpha=1) = x > 0 ? x : exp(x) - 1.  exp(x) - 1 >= x everywhere and has x's sign, so the select is the median
 // of (x, exp(x) - 1, 0): one v_med3_f32 instead of a compare and a conditional move
 DEV float elu1(float x) { return __builtin_amdgcn_fmed3f(x, fast_exp(x) - 1.f, 0.f); }
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // dense layers on v_mfma_f32_32x32x2_f32
@@ -1124,10 +1120,7 @@ __global__ void images_to_nhwc4_kernel(const float* __restrict__ src, float* __r
 // C ABI
 // =============================================================================================
 namespace {
-#ifndef GPNERF_FUSED_WAVES
-#define GPNERF_FUSED_WAVES 8
-#endif
-constexpr int FUSED_WAVES = GPNERF_FUSED_WAVES;
+constexpr int FUSED_WAVES = 8;      // waves per workgroup of head_forward_kernel
 
 int col_ok(int c, int n_in) { return c >= 0 && c < n_in; }
 
