@@ -670,7 +670,8 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         for (int l = 0; l < GPNERF_LEVELS; ++l)
         {
             gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
-            __builtin_amdgcn_sched_barrier(0);      // one level's 32 loads in flight at a time (register pressure)
+            if (l & 1) __builtin_amdgcn_sched_barrier(0);    // at most two levels' 64 loads in flight (register pressure)
+
         }
         STAMP(st, 0);
         float sf[32];
