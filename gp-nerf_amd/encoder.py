@@ -1,0 +1,119 @@
+"""`build_encoder(cfg)` / `ResUNet`: the per-frame image encoder with the reference's interface and
+state_dict keys (libs/encoders/UNet.py:133-242), so `load_state_dict(strict=True)` of a reference checkpoint works.
+
+Per frame, not per ray: V=3 source images [V,3,H,W] -> feature maps [V,32,H/4,W/4], ~16 GFLOP of 3x3 convolutions at
+512x512.  The convolutions are plain library calls (MIOpen through torch, channels-last); what is built for this path is
+the hand-over: the result leaves with channels-last strides (logical NCHW, physical NHWC), which is the layout the render
+kernel gathers from, so `Frame` takes it as is, without the NCHW -> NHWC re-layout launch.
+
+Network (UNet.py:154-234): 7x7/2 stem -> three residual stages of [3,4,6] two-conv units at 64/128/256 channels, every stage
+entered with stride 2 (there is no max-pool), all 3x3 / 7x7 convolutions reflect-padded, every normalisation an affine
+InstanceNorm without running statistics -> two (bilinear x2, align_corners) + conv + concat-skip decoder steps with
+InstanceNorm + ELU -> 1x1 output convolution.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# UNet.py:151 fixes the stage depths to [3,4,6] whatever the name says.  The names resnet50/101/152 only widen the decoder's
+# expected skip channels (UNet.py:142-145) while the stages stay 64/128/256 wide, so the reference's own forward fails
+# on them; they are rejected here at construction.
+_NAMES = ("resnet18", "resnet34")
+
+
+def _inorm(ch):
+    return nn.InstanceNorm2d(ch, track_running_stats=False, affine=True)
+
+
+def _conv(cin, cout, k, stride=1, bias=False):
+    return nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=bias, padding_mode="reflect")
+
+
+class ResidualUnit(nn.Module):
+    """Two 3x3 convolutions + identity / projected shortcut (UNet.py:17-53).  Attribute names are the checkpoint's."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(cin, cout, 3, stride), _inorm(cout)
+        self.conv2, self.bn2 = _conv(cout, cout, 3), _inorm(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), _inorm(cout))
+
+    def forward(self, x):
+        y = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class ConvNormELU(nn.Module):
+    """conv (with bias, reflect pad) -> InstanceNorm -> ELU (UNet.py:107-120); sub-modules `conv`, `bn`."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv, self.bn = _conv(cin, cout, k, bias=True), _inorm(cout)
+
+    def forward(self, x):
+        return F.elu(self.bn(self.conv(x)))
+
+
+class UpsampleConv(nn.Module):
+    """bilinear x`scale` (align_corners) then ConvNormELU (UNet.py:123-131); the conv block is the sub-module `conv`."""
+
+    def __init__(self, cin, cout, k, scale):
+        super().__init__()
+        self.scale = scale
+        self.conv = ConvNormELU(cin, cout, k)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=True))
+
+
+def _stage(cin, cout, n):
+    return nn.Sequential(*[ResidualUnit(cin if i == 0 else cout, cout, 2 if i == 0 else 1) for i in range(n)])
+
+
+def _concat_skip(skip, up):
+    """Zero-pad the skip tensor (centred, extra on the far side) to the upsampled size, then [up, skip] on channels
+    (UNet.py:199-211)."""
+    dy, dx = up.shape[2] - skip.shape[2], up.shape[3] - skip.shape[3]
+    if dy or dx:
+        skip = F.pad(skip, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+    return torch.cat([up, skip], dim=1)
+
+
+class ResUNet(nn.Module):
+    def __init__(self, encoder="resnet34", out_ch=32, norm_layer=None):
+        super().__init__()
+        if encoder not in _NAMES:
+            raise ValueError(f"encoder type {encoder!r}: only {_NAMES} give a runnable network")
+        if norm_layer is not None:
+            raise ValueError("the reference always runs InstanceNorm here (UNet.py:152-153); other norms are not built")
+        n1, n2, n3 = 3, 4, 6
+        skip1, skip2, deep = 64, 128, 256
+        self.conv1, self.bn1 = _conv(3, 64, 7, stride=2), _inorm(64)
+        self.layer1, self.layer2, self.layer3 = _stage(64, 64, n1), _stage(64, 128, n2), _stage(128, 256, n3)
+        self.upconv3 = UpsampleConv(deep, 128, 3, 2)
+        self.iconv3 = ConvNormELU(skip2 + 128, 128, 3)
+        self.upconv2 = UpsampleConv(128, 64, 3, 2)
+        self.iconv2 = ConvNormELU(skip1 + 64, out_ch, 3)
+        self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
+
+    def forward(self, x):
+        """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the whole net runs channels-last and the result keeps
+        channels-last strides, which `Frame` recognises (no re-layout launch)."""
+        on_gpu = x.is_cuda
+        if on_gpu:
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x1 = self.layer1(x)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
+        x = self.iconv3(_concat_skip(x2, self.upconv3(x3)))
+        x = self.iconv2(_concat_skip(x1, self.upconv2(x)))
+        x = self.out_conv(x)
+        return x.contiguous(memory_format=torch.channels_last) if on_gpu else x
+
+
+def build_encoder(cfg):
+    """Same cfg keys as UNet.py:236-242."""
+    return ResUNet(encoder=cfg.encoder.name, out_ch=cfg.encoder.out_ch)

@@ -80,10 +80,15 @@ class Frame:
         src = src_imgs.contiguous().float()
         self.imgs = torch.empty((V, H, W, 4), device=dev, dtype=torch.float32)
         L.check(lib.gpnerf_relayout_images(src.data_ptr(), self.imgs.data_ptr(), V, H, W, st), "gpnerf_relayout_images")
-        fm = featmaps.contiguous().float()
-        fh, fw = fm.shape[-2:]
-        self.featmaps = torch.empty((V, fh, fw, L.CH), device=dev, dtype=torch.float32)
-        L.check(lib.gpnerf_relayout_featmaps(fm.data_ptr(), self.featmaps.data_ptr(), V, fh, fw, st), "gpnerf_relayout_featmaps")
+        fh, fw = featmaps.shape[-2:]
+        if (featmaps.dtype == torch.float32 and not featmaps.is_contiguous()
+                and featmaps.is_contiguous(memory_format=torch.channels_last)):
+            fm = featmaps                       # physical [V,h,w,32] already (encoder.ResUNet on the GPU): no copy
+            self.featmaps = featmaps.permute(0, 2, 3, 1)
+        else:
+            fm = featmaps.contiguous().float()
+            self.featmaps = torch.empty((V, fh, fw, L.CH), device=dev, dtype=torch.float32)
+            L.check(lib.gpnerf_relayout_featmaps(fm.data_ptr(), self.featmaps.data_ptr(), V, fh, fw, st), "gpnerf_relayout_featmaps")
         keep = [src, fm]
         self._set_volumes(f, volumes, keep)
         self._keep = keep  # sources stay alive until the re-layout kernels have run (stream order)

@@ -70,6 +70,58 @@ def make_head_weights(seed=0, bias_std=0.0, sigma_bias=0.0):
     return sd
 
 
+
+def encoder_param_shapes(out_ch=32):
+    """(state_dict key, shape) of every parameter of the image encoder, in the checkpoint's naming
+    (libs/encoders/UNet.py:154-176): stem, three residual stages of 3/4/6 units, two decoder steps, output conv."""
+    t = [("conv1.weight", (64, 3, 7, 7)), ("bn1.weight", (64,)), ("bn1.bias", (64,))]
+    cin = 64
+    for stage, (width, units) in enumerate(((64, 3), (128, 4), (256, 6)), start=1):
+        for u in range(units):
+            p = f"layer{stage}.{u}."
+            t += [(p + "conv1.weight", (width, cin if u == 0 else width, 3, 3)), (p + "bn1.weight", (width,)),
+                  (p + "bn1.bias", (width,)), (p + "conv2.weight", (width, width, 3, 3)), (p + "bn2.weight", (width,)),
+                  (p + "bn2.bias", (width,))]
+            if u == 0:       # every stage is entered with stride 2 -> projected shortcut
+                t += [(p + "downsample.0.weight", (width, cin, 1, 1)), (p + "downsample.1.weight", (width,)),
+                      (p + "downsample.1.bias", (width,))]
+        cin = width
+    for name, ci, co in (("upconv3.conv", 256, 128), ("iconv3", 256, 128), ("upconv2.conv", 128, 64), ("iconv2", 128, out_ch)):
+        t += [(name + ".conv.weight", (co, ci, 3, 3)), (name + ".conv.bias", (co,)), (name + ".bn.weight", (co,)),
+              (name + ".bn.bias", (co,))]
+    t += [("out_conv.weight", (out_ch, out_ch, 1, 1)), ("out_conv.bias", (out_ch,))]
+    return t
+
+
+def make_encoder_weights(seed=0, out_ch=32):
+    """Seeded encoder parameters: conv kernels ~ N(0, 2/fan_in), norm scales ~ 1 + 0.1 N, every bias ~ 0.1 N (so that the
+    affine and bias paths are exercised).  Drawn in `encoder_param_shapes()` order from PCG64([seed, 303])."""
+    g = _rng(seed, 303)
+    sd = OrderedDict()
+    for key, shape in encoder_param_shapes(out_ch):
+        x = g.standard_normal(shape, dtype=np.float32)
+        if len(shape) == 4:
+            x *= np.float32(math.sqrt(2.0 / (shape[1] * shape[2] * shape[3])))
+        elif key.endswith("weight"):
+            x = np.float32(1.0) + np.float32(0.1) * x
+        else:
+            x *= np.float32(0.1)
+        sd[key] = x.astype(np.float32)
+    return sd
+
+
+def make_encoder_images(H, W, seed=0, views=3):
+    """Source images as the dataset hands them over: [V,3,H,W] in [-1,1], smooth + noise so that InstanceNorm sees structure."""
+    g = _rng(seed, 304)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H, dtype=np.float32), np.linspace(-1, 1, W, dtype=np.float32), indexing="ij")
+    out = np.empty((views, 3, H, W), np.float32)
+    for v in range(views):
+        for c in range(3):
+            a, b, ph = g.uniform(1.0, 6.0, 3).astype(np.float32)
+            out[v, c] = 0.6 * np.sin(a * xx + b * yy + ph) + 0.4 * g.uniform(-1, 1, (H, W)).astype(np.float32)
+    return np.clip(out, -1, 1).astype(np.float32)
+
+
 def rodrigues(rvec):
     rvec = np.asarray(rvec, np.float64)
     th = np.linalg.norm(rvec)

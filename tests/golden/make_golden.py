@@ -12,6 +12,7 @@ What executes here is the reference's own code:
   * libs/nerfheads/networks/SparseConvNet.py SparseConvNet.forward (the
     F.grid_sample + cat + view lines :105-124)
   * libs/datasets/data_utils.py get_rays / get_near_far
+  * libs/encoders/UNet.py ResUNet.forward (encoder_* vectors only)
 
 What is NOT the reference: `spconv` (v1.2.1, not in the tree, not installed) is
 replaced by inert stand-ins so the modules import and construct; the sparse
@@ -258,6 +259,29 @@ CASES = [
 ]
 
 
+def run_encoder_case(name, H, W, seed):
+    """libs/encoders/UNet.py ResUNet.forward on seeded images with seeded parameters.  The parameters
+    come from gp-nerf_amd/synthetic.py by state_dict key, and are loaded strict=True into the reference's module, so the
+    vector also pins the key/shape map."""
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    UNet = importlib.import_module("UNet")
+    state = syn.make_encoder_weights(seed)
+    net = UNet.ResUNet(encoder="resnet34", out_ch=32)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    net.eval()
+    imgs = syn.make_encoder_images(H, W, seed)
+    with torch.no_grad():
+        out = net(torch.from_numpy(imgs)).numpy()
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(imgs).tobytes())
+    for k in sorted(state):
+        h.update(np.ascontiguousarray(state[k]).tobytes())
+    meta = dict(name=name, H=H, W=W, seed=seed, inputs_sha256=h.hexdigest(), torch=torch.__version__,
+                reference="libs/encoders/UNet.py ResUNet(resnet34, out_ch=32).forward, eval, CPU fp32")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), featmaps=out.astype(np.float32), meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    print(name, out.shape, float(np.abs(out).max()))
+
+
 def main():
     _install_stubs()
     _paths()
@@ -270,6 +294,9 @@ def main():
         run_case(name, kw, S, **extra)
     if not only or "rays_48" in only:
         run_rays_case("rays_48", 48, 48, 11)
+    for name, H, W, seed in (("encoder_64x64", 64, 64, 3), ("encoder_72x88", 72, 88, 4)):
+        if not only or name in only:
+            run_encoder_case(name, H, W, seed)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-frame producers timed on the GPU: sparse volume builder (gp-nerf_amd/volume.py), re-layout, occupancy."""
+"""Per-frame producers timed on the GPU: sparse volume builder (gp-nerf_amd/volume.py), re-layout, occupancy, image encoder."""
 import importlib
 import os
 import sys
@@ -42,3 +42,14 @@ ms, fr = timed(lambda: fm.Frame.for_volumes(vols, blob))
 print(f"re-layout of the pyramid: {ms:.2f} ms")
 ms, _ = timed(lambda: fr.build_occupancy())
 print(f"occupancy volume: {ms:.2f} ms")
+
+# image encoder (gp-nerf_amd/encoder.py): 3 source views 512x512 -> [3,32,128,128], channels-last out
+enc = importlib.import_module("gp-nerf_amd.encoder")
+net = enc.ResUNet().to(dev).eval()
+net.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_encoder_weights(0).items()}, strict=True)
+imgs = torch.from_numpy(syn.make_encoder_images(512, 512, 0)).to(dev)
+with torch.no_grad():
+    for _ in range(3):
+        net(imgs)                      # MIOpen picks its algorithms on the first calls
+    ms, out = timed(lambda: net(imgs), n=10)
+print(f"encoder (ResUNet, MIOpen channels-last): {ms:.2f} ms per frame; out {tuple(out.shape)} strides {out.stride()}")
