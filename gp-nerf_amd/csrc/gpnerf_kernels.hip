@@ -60,8 +60,35 @@ struct Stamps { DEV void start() {} DEV void flush(int) {} };
 
 DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }       // v_exp_f32
 // nn.ELU(alpha=1) = x > 0 ? x : exp(x) - 1.  exp(x) - 1 >= x everywhere and has x's sign, so the select is the median
-// of (x, exp(x) - 1, 0): one v_med3_f32 instead of a compare and a conditional move
-DEV float elu1(float x) { return __builtin_amdgcn_fmed3f(x, fast_exp(x) - 1.f, 0.f); }
+// of (x, exp(x) - 1, 0): one v_med3_f32 instead of a compare and a conditional move.
+// The dense layers run in a scaled domain: every MFMA accumulator holds x' = log2(e) * (W h + b) and every activation
+// h' = log2(e) * ELU(x) = med3(x', (2^x' - 1) * log2(e), 0) -- v_exp_f32 on the accumulator as it is, one FMA, one
+// median.  A layer fed by scaled activations needs W h' + log2(e) b, i.e. its weights unchanged and its bias scaled; the
+// packers (pack_scale) scale the biases, the weight columns that multiply raw inputs, and the two VALU tails by ln 2.
+DEV float elus(float xs) { return __builtin_amdgcn_fmed3f(xs, fmaf(__builtin_amdgcn_exp2f(xs), LOG2E, -LOG2E), 0.f); }
+// N accumulator registers at once, stage by stage: the v_exp_f32 results are not consumed back to back (a transcendental
+// feeding the next instruction costs a wait state) and the FMAs pair up as v_pk_fma_f32
+template <int N>
+DEV void elus_n(f32x16& a, float* out) {
+    asm volatile("" : "+v"(a));          // not before the MFMA groups issued so far (see the note at the end)
+    float e[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) e[r] = __builtin_amdgcn_exp2f(a[r]);
+#pragma unroll
+    for (int r = 0; r < N; r += 2) {
+        const f32x2 m = __builtin_elementwise_fma(f32x2{e[r], e[r + 1]}, f32x2{LOG2E, LOG2E}, f32x2{-LOG2E, -LOG2E});
+        e[r] = m[0]; e[r + 1] = m[1];
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) out[r] = __builtin_amdgcn_fmed3f(a[r], e[r], 0.f);
+    // All N results exist before anything that follows in program order: left alone, the scheduler threads these VALU
+    // instructions between the next layer's MFMAs, and every MFMA -> VALU -> MFMA switch inside one wave idles the matrix
+    // pipe for ~20 cycles (tools/micro/mfma_chains.hip).  One burst per layer, then an uninterrupted MFMA run.
+    static_assert(N == 8 || N == 16, "");
+    asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]), "+v"(out[4]), "+v"(out[5]), "+v"(out[6]), "+v"(out[7]));
+    if constexpr (N == 16)
+        asm volatile("" : "+v"(out[8]), "+v"(out[9]), "+v"(out[10]), "+v"(out[11]), "+v"(out[12]), "+v"(out[13]), "+v"(out[14]), "+v"(out[15]));
+}
 
 // ---------------------------------------------------------------------------------------------
 // dense layers on v_mfma_f32_32x32x2_f32
@@ -71,18 +98,32 @@ DEV float elu1(float x) { return __builtin_amdgcn_fmed3f(x, fast_exp(x) - 1.f, 0
 template <int NT>
 DEV void mfma_tile(const float* __restrict__ w, int lane, const float (&b)[NT], f32x16& acc) {
     constexpr int NG = NT / 4;
+    // Software-pipelined weight reads: group g+1's ds_read_b128 is issued before group g's four MFMAs, so its LDS
+    // latency hides behind 256 cycles of matrix work.  (Left to itself the compiler reuses one register quad: read,
+    // wait ~100 cycles, 4 MFMAs, read, wait ...)  The empty asm orders the read ahead of the MFMAs -- it "modifies" the
+    // offset the read used (so the read cannot sink below it) and the accumulator (so the MFMAs cannot rise above it) --
+    // without consuming the loaded value, i.e. without a wait.
+    typedef const __attribute__((address_space(3))) float* lds_ptr;      // 32-bit LDS address: one VGPR to launder
+    lds_ptr p = (lds_ptr)w + lane * 4;
+    f32x4 a = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(p);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(w + (g * 64 + lane) * 4);
+        f32x4 an = a;
+        f32x2 at = {0.f, 0.f};
+        if (g + 1 < NG) an = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(p + (g + 1) * 256);
+        else if constexpr (NT % 4 == 2) at = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>((lds_ptr)w + NG * 256 + lane * 2);
+        asm volatile("" : "+v"(p), "+v"(acc));
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * g + 0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * g + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[4 * g + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[4 * g + 3], acc, 0, 0, 0);
-    }
-    if constexpr (NT % 4 == 2) {
-        const f32x2 a = *reinterpret_cast<const f32x2*>(w + NG * 256 + lane * 2);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * NG + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * NG + 1], acc, 0, 0, 0);
+        a = an;
+        if constexpr (NT % 4 == 2) {
+            if (g + 1 == NG) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[0], b[4 * NG + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[1], b[4 * NG + 1], acc, 0, 0, 0);
+            }
+        }
     }
 }
 
@@ -114,8 +155,8 @@ DEV void geo_eval(const float* __restrict__ lds, int lane, const float (&fv)[64]
     f32x16 g0 = bias_tile<gpl::GEO>(lds, 0, half), g1 = bias_tile<gpl::GEO>(lds, 1, half);
     mfma_tile<64>(wtile<gpl::GEO>(lds, 0), lane, fv, g0);
     mfma_tile<64>(wtile<gpl::GEO>(lds, 1), lane, fv, g1);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sf[r] = elu1(g0[r]); sf[16 + r] = elu1(g1[r]); }
+    elus_n<16>(g0, sf);
+    elus_n<16>(g1, sf + 16);
 }
 
 // The rest of NeRFHead.forward (libs/nerfheads/trainhead.py:118-145,159-163) for 32 samples.
@@ -148,20 +189,19 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
         mfma_tile<68>(wtile<gpl::D1>(lds, 0), lane, d1in, a0);
         mfma_tile<68>(wtile<gpl::D1>(lds, 1), lane, d1in, a1);
         float h1[32];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { h1[r] = elu1(a0[r]); h1[16 + r] = elu1(a1[r]); }
+        elus_n<16>(a0, h1);
+        elus_n<16>(a1, h1 + 16);
         f32x16 a2 = bias_tile<gpl::D2>(lds, 0, half);
         mfma_tile<32>(wtile<gpl::D2>(lds, 0), lane, h1, a2);
         float h2[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h2[r] = elu1(a2[r]);
+        elus_n<16>(a2, h2);
         f32x16 a3 = bias_tile<gpl::D3>(lds, 0, half);
         mfma_tile<16>(wtile<gpl::D3>(lds, 0), lane, h2, a3);
         // 16 -> 1 on the VALU: this half holds features ft(r,h), r < 8
         const float* w4 = lds + gpl::D4_W + half * 8;
         float part = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) part = fmaf(w4[r], elu1(a3[r]), part);
+        for (int r = 0; r < 8; ++r) part = fmaf(w4[r], elus(a3[r]), part);
         float s = part + __shfl_xor(part, 32) + lds[gpl::D4_B];
         s = fmaxf(s, 0.f);                              // nn.ReLU
         sigma = (nvalid < 1.f) ? 0.f : s;               // masked_fill(num_valid_obs < 1, 0)
@@ -182,35 +222,34 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
         mfma_tile<18>(wtile<gpl::BV>(lds, 0), lane, x[v], a0);
         mfma_tile<18>(wtile<gpl::BV>(lds, 1), lane, x[v], a1);
         float h1[32];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { h1[r] = elu1(a0[r]); h1[16 + r] = elu1(a1[r]); }
+        elus_n<16>(a0, h1);
+        elus_n<16>(a1, h1 + 16);
         f32x16 a2 = bias_tile<gpl::B2>(lds, 0, half);
         mfma_tile<32>(wtile<gpl::B2>(lds, 0), lane, h1, a2);
         float xb[16], xs[16];
+        elus_n<16>(a2, xb);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { xb[r] = elu1(a2[r]); xs[r] = xb[r] * (1.f / 3.f); }   // x * 1.0 / num_views
+        for (int r = 0; r < 16; ++r) xs[r] = xb[r] * (1.f / 3.f);                          // x * 1.0 / num_views
         f32x16 t1 = bias_tile<gpl::V1>(lds, 0, half);
         mfma_tile<16>(wtile<gpl::V1>(lds, 0), lane, xs, t1);
         float u1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u1[r] = elu1(t1[r]);
+        elus_n<16>(t1, u1);
         f32x16 t2 = bias_tile<gpl::V2>(lds, 0, half);
         mfma_tile<16>(wtile<gpl::V2>(lds, 0), lane, u1, t2);
+        elus_n<16>(t2, y + 16 * v);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[16 * v + r] = xb[r] + elu1(t2[r]);                  // x = x + x_vis
+        for (int r = 0; r < 16; ++r) y[16 * v + r] += xb[r];                                // x = x + x_vis
     }
     STAMP(st, 4);
     {
         f32x16 c1 = bias_tile<gpl::R1>(lds, 0, half);
         mfma_tile<48>(wtile<gpl::R1>(lds, 0), lane, y, c1);
         float h1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h1[r] = elu1(c1[r]);
+        elus_n<16>(c1, h1);
         f32x16 c2 = bias_tile<gpl::R2>(lds, 0, half);
         mfma_tile<16>(wtile<gpl::R2>(lds, 0), lane, h1, c2);
         float e[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) e[r] = elu1(c2[r]);
+        elus_n<8>(c2, e);
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const float* w3 = lds + gpl::R3_W + o * 16 + half * 8;
@@ -302,10 +341,11 @@ DEV void mfma_steps(const unsigned* lw, int m, int s0, int lane, const Frag* b, 
 }
 
 // ELU of an accumulator tile -> its two B-operand k-steps (and optionally the fp32 values)
-DEV void tile_frags(const f32x16& a, Frag* out2, float* keep = nullptr, float scale = 1.f) {
+DEV void tile_frags(f32x16& a, Frag* out2, float* keep = nullptr, float scale = 1.f) {
     float t[16];
+    elus_n<16>(a, t);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { t[r] = elu1(a[r]); if (keep) keep[r] = t[r]; t[r] *= scale; }
+    for (int r = 0; r < 16; ++r) { if (keep) keep[r] = t[r]; t[r] *= scale; }
     out2[0] = make_frag(t);
     out2[1] = make_frag(t + 8);
 }
@@ -361,7 +401,7 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
         const float* w4 = lf + gph::D4_W + half * 8;
         float part = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) part = fmaf(w4[r], elu1(a3[r]), part);
+        for (int r = 0; r < 8; ++r) part = fmaf(w4[r], elus(a3[r]), part);
         float s = part + __shfl_xor(part, 32) + lf[gph::D4_B];
         s = fmaxf(s, 0.f);
         sigma = (nvalid < 1.f) ? 0.f : s;
@@ -394,8 +434,9 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
         f32x16 t2 = bias_tile_s<gpl::V2>(lw, 0, half);
         mfma_steps<gpl::V2, 2>(lw, 0, 0, lane, u1, t2);
         float y[16];
+        elus_n<16>(t2, y);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = xb[r] + elu1(t2[r]);
+        for (int r = 0; r < 16; ++r) y[r] += xb[r];
         yf[2 * v] = make_frag(y);
         yf[2 * v + 1] = make_frag(y + 8);
     }
@@ -407,8 +448,7 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
         f32x16 c2 = bias_tile_s<gpl::R2>(lw, 0, half);
         mfma_steps<gpl::R2, 2>(lw, 0, 0, lane, h1, c2);
         float e[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) e[r] = elu1(c2[r]);
+        elus_n<8>(c2, e);
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const float* w3 = lf + gph::R3_W + o * 16 + half * 8;
@@ -445,14 +485,17 @@ DEV Axis axis_taps(float g, int size) {
     return a;
 }
 
-// (v_pk_fma_f32 here was measured slower than 16 scalar FMAs, 15.3 vs 15.0 ms/frame)
+// 16 channels of one tap: 8 v_pk_fma_f32 (the tap weight is broadcast by op_sel)
 DEV void fma16(const float* __restrict__ p, float w, float* f) {
     const f32x4* q = reinterpret_cast<const f32x4*>(p);
     const f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
-    f[0] = fmaf(a[0], w, f[0]);   f[1] = fmaf(a[1], w, f[1]);   f[2] = fmaf(a[2], w, f[2]);   f[3] = fmaf(a[3], w, f[3]);
-    f[4] = fmaf(b[0], w, f[4]);   f[5] = fmaf(b[1], w, f[5]);   f[6] = fmaf(b[2], w, f[6]);   f[7] = fmaf(b[3], w, f[7]);
-    f[8] = fmaf(c[0], w, f[8]);   f[9] = fmaf(c[1], w, f[9]);   f[10] = fmaf(c[2], w, f[10]); f[11] = fmaf(c[3], w, f[11]);
-    f[12] = fmaf(d[0], w, f[12]); f[13] = fmaf(d[1], w, f[13]); f[14] = fmaf(d[2], w, f[14]); f[15] = fmaf(d[3], w, f[15]);
+    const f32x2 w2 = {w, w};
+    const f32x2 src[8] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}, {c[0], c[1]}, {c[2], c[3]}, {d[0], d[1]}, {d[2], d[3]}};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x2 r = __builtin_elementwise_fma(src[i], w2, f32x2{f[2 * i], f[2 * i + 1]});
+        f[2 * i] = r[0]; f[2 * i + 1] = r[1];
+    }
 }
 
 // trilinear sample of one level [D][H][W][32] at normalised (gx,gy,gz) -> this half's 16 channels
@@ -499,7 +542,8 @@ struct ViewSample {
 
 // Projector.compute for one view (libs/renders/BaseRender.py:301-324,296-299,283-294,352-362):
 // project p, bilinear RGB from imgs[v] (NHWC4) and 16 feature channels from featmaps[v] (NHWC32).
-DEV ViewSample gather_view(const float* __restrict__ M, const float* __restrict__ img, int ih, int iw,
+template <class MP>
+DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
                            const float* __restrict__ fm, int fh, int fw, float px, float py, float pz, bool neg,
                            int half, float* f) {
     const float hx = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3];
@@ -561,6 +605,18 @@ struct OutK {
     const int32_t* order;     // optional: slot i of the launch renders ray order[i] (locality-friendly tiling)
 };
 
+struct KArgs {            // the fused kernel's only argument (see render_fused_kernel on why it is one struct)
+    FrameK fr;
+    const float* rays;
+    long n_rays;
+    int S;
+    unsigned flags;
+    float term_eps;
+    OutK out;
+    int split;
+    float* part;
+};
+
 // bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
 // contiguous run of tiles so neighbouring ray tiles hit the same L2 (speed only, never correctness)
 DEV int xcd_remap(int bid, int nb) {
@@ -575,7 +631,8 @@ DEV float linspace01(int k, int S, float step) {
 
 // pts_to_can_pts (BaseRender.py:52-60): (p - Th) @ Rh, then get_grid_coords (:62-73): voxel-normalised
 // coordinate in [-1,1], dhw arithmetic, returned in xyz order.
-DEV void grid_coords(const FrameK& fr, float px, float py, float pz, float& gx, float& gy, float& gz) {
+template <class FR>
+DEV void grid_coords(const FR& fr, float px, float py, float pz, float& gx, float& gy, float& gz) {
     const float qx0 = px - fr.Th[0], qy0 = py - fr.Th[1], qz0 = pz - fr.Th[2];
     const float qx = (qx0 * fr.Rh[0] + qy0 * fr.Rh[3]) + qz0 * fr.Rh[6];
     const float qy = (qx0 * fr.Rh[1] + qy0 * fr.Rh[4]) + qz0 * fr.Rh[7];
@@ -592,11 +649,20 @@ DEV void grid_coords(const FrameK& fr, float px, float py, float pz, float& gx, 
 #endif
 template <bool SPLIT>
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
-render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long n_rays, const int S,
-                    const unsigned flags, const float term_eps, const OutK out, const int split, float* __restrict__ part) {
+render_fused_kernel(const KArgs ka) {
+    // Everything the sample loop reads from the arguments is re-read from the kernarg segment (scalar loads, scalar
+    // cache) at the top of every iteration through `kp`, a pointer the optimiser cannot see through.  Held in SGPRs
+    // across the loop instead, the ~130 argument dwords spill to VGPR lanes and come back as v_readlane_b32 -- VALU
+    // instructions in the middle of the MFMA chains, which stall the matrix pipe (tools/micro/mfma_chains.hip).
+    typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
+    const long n_rays = ka.n_rays;
+    const int S = ka.S;
+    const unsigned flags = ka.flags;
+    const float term_eps = ka.term_eps;
+    const int split = ka.split;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? fr.head_blob_split : fr.head_blob);
+        const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : ka.fr.head_blob);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         for (int i = threadIdx.x; i < (SPLIT ? gph::BLOB_WORDS : gpl::BLOB_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
     }
@@ -614,13 +680,13 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
     if (ray0 >= n_rays) return;
     const bool active = (ray0 + n) < n_rays;
     const long slot = active ? ray0 + n : n_rays - 1;
-    const long ray = out.order ? (long)out.order[slot] : slot;
+    const long ray = ka.out.order ? (long)ka.out.order[slot] : slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;
     const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
-    const bool cull = (flags & GPNERF_FLAG_OCC_CULL) != 0 && fr.occ != nullptr;
+    const bool cull = (flags & GPNERF_FLAG_OCC_CULL) != 0 && ka.fr.occ != nullptr;
 
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rays + ray * 8);
-    const f32x4 r1 = *reinterpret_cast<const f32x4*>(rays + ray * 8 + 4);
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(ka.rays + ray * 8);
+    const f32x4 r1 = *reinterpret_cast<const f32x4*>(ka.rays + ray * 8 + 4);
     const float ox = r0[0], oy = r0[1], oz = r0[2], dx = r0[3], dy = r1[0], dz = r1[1], near = r1[2], far = r1[3];
 
     float T = 1.f, c_r = 0.f, c_g = 0.f, c_b = 0.f, depth = 0.f, acc = 0.f;
@@ -631,11 +697,19 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0);
 
+#ifdef GPNERF_X_STAGGER    // experiment: start the second wave of every SIMD late
+    if (wave & GPNERF_X_STAGBIT)
+        for (int i = 0; i < GPNERF_X_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     Stamps st;
     st.start();
     const int k_end = (int)(((long)S * (seg + 1)) / split);
     int k = (int)(((long)S * seg) / split);
     for (; k < k_end; ++k) {
+        kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const __attribute__((address_space(4))) FrameK& fr = kp->fr;
+        const __attribute__((address_space(4))) OutK& out = kp->out;
         // raw2outputs(neg=True) flips rgb and sigma along the ray but not z (BaseRender.py:86-88,101):
         // composite step k consumes the network output of sample S-1-k.
         const int ks = neg ? (S - 1 - k) : k;
@@ -669,15 +743,23 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
 #pragma unroll
         for (int l = 0; l < GPNERF_LEVELS; ++l)
         {
+#ifdef GPNERF_X_NOGATHER   // experiment: MLP phases only
+            for (int c = 0; c < 16; ++c) fv[16 * l + c] = gx * (float)(c + 1) + gy * (float)(l + 1);
+#else
             gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
             if (l & 1) __builtin_amdgcn_sched_barrier(0);    // at most two levels' 64 loads in flight (register pressure)
+#endif
 
         }
         STAMP(st, 0);
         float sf[32];
         Frag sff[4];
+#ifdef GPNERF_X_NOMLP      // experiment: gather phases only
+        for (int c = 0; c < 32; ++c) sf[c] = fv[c] + fv[32 + c];
+#else
         if constexpr (SPLIT) geo_eval_s(lw, lane, fv, sff);
         else geo_eval(lds, lane, fv, sf);
+#endif
         STAMP(st, 1);
 
         // Projector.compute (:326-363)
@@ -686,9 +768,15 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         float vrgb[NV][3];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
+#ifdef GPNERF_X_NOGATHER
+            ViewSample s;
+            s.valid = 1.f; s.rgb[0] = px * 0.1f; s.rgb[1] = py * 0.1f; s.rgb[2] = pz * 0.1f;
+            for (int c = 0; c < 16; ++c) x[v][c] = px * (float)(c + 1) + pz * (float)(v + 1);
+#else
             const ViewSample s = gather_view(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
                                              fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
                                              px, py, pz, neg, half, x[v]);
+#endif
             x[v][16] = half ? s.rgb[1] : s.rgb[0];
             x[v][17] = half ? 0.f : s.rgb[2];
             vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
@@ -698,8 +786,15 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
 
         STAMP(st, 2);
         float sigma, rgb[3];
+#ifdef GPNERF_X_NOMLP
+        sigma = nvalid; rgb[0] = rgb[1] = rgb[2] = 0.f;
+        for (int c = 0; c < 32; ++c) sigma += sf[c];
+        for (int v = 0; v < NV; ++v)
+            for (int c = 0; c < 18; ++c) rgb[v] += x[v][c];
+#else
         if constexpr (SPLIT) mlp_eval_s(lw, lane, sff, x, nvalid, sigma, rgb);
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
+#endif
         if (cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
@@ -752,6 +847,10 @@ render_fused_kernel(const FrameK fr, const float* __restrict__ rays, const long 
         if (early && __all(T < term_eps)) { ++k; break; }
     }
     st.flush(lane);
+    kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const __attribute__((address_space(4))) OutK& out = kp->out;
+    float* const part = kp->part;
     if (writer && split > 1) {
         // partial composite of this segment: rgb, depth, acc, segment transmittance, rgb_in, #samples with >1 valid view
         float* p = part + ((size_t)ray * split + seg) * 16;
@@ -1137,6 +1236,17 @@ _Float16 f16_rtz(float v) {
     return h;
 }
 
+// scaled-domain packing (see elus()): factor on weight column c of MFMA layer L -- log2(e) where the column multiplies a
+// raw input (volume features, cross-view mean / variance, per-view features), 1 where it multiplies a scaled activation
+constexpr float PACK_LOG2E = 1.4426950408889634f, PACK_LN2 = 0.6931471805599453f;
+float pack_scale(int L, int c) {
+    switch (L) {
+        case gpl::GEO: case gpl::BS: case gpl::BV: return PACK_LOG2E;
+        case gpl::D1: return c >= 64 ? PACK_LOG2E : 1.f;
+        default: return 1.f;
+    }
+}
+
 void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, float* blob) {
     for (int m = 0; m < gpl::MT[L]; ++m) {
         float* wt = blob + gpl::w_off(L) + m * gpl::NT[L] * 64;
@@ -1145,7 +1255,7 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
             for (int lane = 0; lane < 64; ++lane) {
                 const int row = 32 * m + (lane & 31), h = lane >> 5;
                 const int c = gpl::col_of(L, t, h);
-                const float v = (row < n_out && col_ok(c, n_in)) ? W[(size_t)row * n_in + c] : 0.f;
+                const float v = (row < n_out && col_ok(c, n_in)) ? W[(size_t)row * n_in + c] * pack_scale(L, c) : 0.f;
                 const int g = t / 4;
                 if (g < NG) wt[(g * 64 + lane) * 4 + (t & 3)] = v;
                 else wt[NG * 256 + lane * 2 + (t - 4 * NG)] = v;
@@ -1154,7 +1264,7 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
         for (int h = 0; h < 2; ++h)
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * m + gpl::ft(r, h);
-                bt[h * 16 + r] = (b && row < n_out) ? b[row] : 0.f;
+                bt[h * 16 + r] = (b && row < n_out) ? b[row] * PACK_LOG2E : 0.f;
             }
     }
 }
@@ -1298,8 +1408,8 @@ int gpnerf_pack_head(const GpnerfHeadParams* p, float* blob) {
     pack_layer(gpl::R2, p->r2_w, p->r2_b, 16, 32, blob);
     for (int h = 0; h < 2; ++h)
         for (int r = 0; r < 8; ++r) {
-            blob[gpl::D4_W + h * 8 + r] = p->d4_w[gpl::ft(r, h)];
-            for (int o = 0; o < 3; ++o) blob[gpl::R3_W + o * 16 + h * 8 + r] = p->r3_w[o * 16 + gpl::ft(r, h)];
+            blob[gpl::D4_W + h * 8 + r] = p->d4_w[gpl::ft(r, h)] * PACK_LN2;
+            for (int o = 0; o < 3; ++o) blob[gpl::R3_W + o * 16 + h * 8 + r] = p->r3_w[o * 16 + gpl::ft(r, h)] * PACK_LN2;
         }
     blob[gpl::D4_B] = p->d4_b[0];
     for (int o = 0; o < 3; ++o) blob[gpl::R3_B + o] = p->r3_b[o];
@@ -1327,7 +1437,7 @@ int gpnerf_pack_head_split(const GpnerfHeadParams* p, float* blob) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int row = 32 * m + (lane & 31), h = lane >> 5, c = gph::col_of(sp.L, st, j, h);
-                        const float v = (row < sp.n_out && c >= 0 && c < sp.n_in) ? sp.W[(size_t)row * sp.n_in + c] : 0.f;
+                        const float v = (row < sp.n_out && c >= 0 && c < sp.n_in) ? sp.W[(size_t)row * sp.n_in + c] * pack_scale(sp.L, c) : 0.f;
                         const _Float16 hi = f16_rtz(v);
                         const _Float16 lo = (_Float16)(v - (float)hi);
                         uint16_t hb, lb;
@@ -1340,14 +1450,14 @@ int gpnerf_pack_head_split(const GpnerfHeadParams* p, float* blob) {
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * m + gpl::ft(r, h);
-                    bt[h * 16 + r] = (sp.b && row < sp.n_out) ? sp.b[row] : 0.f;
+                    bt[h * 16 + r] = (sp.b && row < sp.n_out) ? sp.b[row] * PACK_LOG2E : 0.f;
                 }
         }
     }
     for (int h = 0; h < 2; ++h)
         for (int r = 0; r < 8; ++r) {
-            blob[gph::D4_W + h * 8 + r] = p->d4_w[gpl::ft(r, h)];
-            for (int o = 0; o < 3; ++o) blob[gph::R3_W + o * 16 + h * 8 + r] = p->r3_w[o * 16 + gpl::ft(r, h)];
+            blob[gph::D4_W + h * 8 + r] = p->d4_w[gpl::ft(r, h)] * PACK_LN2;
+            for (int o = 0; o < 3; ++o) blob[gph::R3_W + o * 16 + h * 8 + r] = p->r3_w[o * 16 + gpl::ft(r, h)] * PACK_LN2;
         }
     blob[gph::D4_B] = p->d4_b[0];
     for (int o = 0; o < 3; ++o) blob[gph::R3_B + o] = p->r3_b[o];
@@ -1380,12 +1490,13 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const Geometry g = choose_geometry(tiles, n_samples, may_split, workspace ? workspace_bytes : 0, n_rays);
     const int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
     const OutK ok = to_outk(out, ray_order);
+    KArgs ka;
+    ka.fr = k; ka.rays = rays; ka.n_rays = (long)n_rays; ka.S = (int)n_samples; ka.flags = (unsigned)flags; ka.term_eps = term_eps;
+    ka.out = ok; ka.split = g.split; ka.part = (float*)workspace;
     if (split16)
-        hipLaunchKernelGGL(render_fused_kernel<true>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), k, rays,
-                           (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, ok, g.split, (float*)workspace);
+        hipLaunchKernelGGL(render_fused_kernel<true>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
     else
-        hipLaunchKernelGGL(render_fused_kernel<false>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), k, rays,
-                           (long)n_rays, (int)n_samples, (unsigned)flags, term_eps, ok, g.split, (float*)workspace);
+        hipLaunchKernelGGL(render_fused_kernel<false>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),

@@ -52,8 +52,14 @@ class Wave:
         return out
 
 
+LOG2E = np.float32(1.4426950408889634)
+
+
 def elu(x):
-    return np.where(x > 0, x, np.expm1(np.minimum(x, 0))).astype(np.float32)
+    """The kernels' scaled-domain ELU (elus() in gpnerf_kernels.hip): accumulators hold log2(e) * (W h + b), activations
+    log2(e) * ELU(.) -- the packers scale biases, raw-input weight columns and the VALU tails to match."""
+    x = x.astype(np.float32)
+    return np.where(x > 0, x, (np.exp2(np.minimum(x, 0)) - np.float32(1)) * LOG2E).astype(np.float32)
 
 
 def emulate(blob, table, vol_feat, rgb_feat, mask):

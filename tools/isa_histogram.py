@@ -8,7 +8,7 @@ path, key = sys.argv[1], sys.argv[2]
 rows = open(path).read().split("\n")
 start = next(i for i, l in enumerate(rows) if re.match(r"^_Z\w*:", l) and key in l.split(":")[0])
 end = next(i for i in range(start, len(rows)) if "s_endpgm" in rows[i])
-if len(sys.argv) > 4:
+if len(sys.argv) > 4 and int(sys.argv[4]) > 0:
     start, end = int(sys.argv[3]), int(sys.argv[4])
 c = collections.Counter()
 for l in rows[start:end]:

@@ -5,29 +5,36 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int MODE>   // 0: MFMA waves only, 1: MFMA + VALU(fma) partner, 2: MFMA + VALU(v_exp) partner, 3: bf16 MFMA + VALU partner
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// MODE 0: MFMA waves only, 1: + v_fma_f32 partner, 2: + v_exp_f32 partner, 3: + v_pk_fma_f32 partner,
+//      4: v_fma_f32 waves only (no MFMA), 5: v_pk_fma_f32 waves only, 6: two MFMA waves per SIMD
+template <int MODE>
 __global__ void __launch_bounds__(512, 2) k(const float* g, float* out, int iters, long long* cyc) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float a = g[lane], b = g[lane + 64];
     float r = 0;
     long long t0 = __builtin_amdgcn_s_memtime();
-    if (wave < 4) {
+    if ((wave < 4 && MODE < 4) || MODE == 6) {   // MFMA waves
         f32x16 acc = {0};
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 64; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         for (int i = 0; i < 16; ++i) r += acc[i];
-    } else if (MODE > 0) {
+    } else if ((wave >= 4 || MODE == 7 || MODE == 8) && MODE > 0 && MODE != 6) {
         float v[8] = {a, b, a, b, a, b, a, b};
+        f32x2 p[4] = {{a, b}, {b, a}, {a, a}, {b, b}};
+        const f32x2 pa = {a, b}, pb = {b, a};
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 1024; ++i) {
-                if (MODE == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i & 7]) : "v"(a), "v"(b));
-                else asm volatile("v_exp_f32 %0, %0" : "+v"(v[i & 7]));
+                if (MODE == 1 || MODE == 4 || MODE == 7) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i & 7]) : "v"(a), "v"(b));
+                else if (MODE == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i & 7]));
+                else asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i & 3]) : "v"(pa), "v"(pb));
             }
         }
         for (int i = 0; i < 8; ++i) r += v[i];
+        for (int i = 0; i < 4; ++i) r += p[i][0] + p[i][1];
     }
     long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 512 + threadIdx.x] = r;
@@ -57,5 +64,11 @@ int main() {
     run<0>(g, out, cyc, "f32 MFMA waves alone");
     run<1>(g, out, cyc, "f32 MFMA + v_fma_f32 partner");
     run<2>(g, out, cyc, "f32 MFMA + v_exp_f32 partner");
+    run<3>(g, out, cyc, "f32 MFMA + v_pk_fma_f32 partner");
+    run<4>(g, out, cyc, "v_fma_f32 waves alone");
+    run<5>(g, out, cyc, "v_pk_fma_f32 waves alone");
+    run<6>(g, out, cyc, "two f32 MFMA waves per SIMD");
+    run<7>(g, out, cyc, "two v_fma_f32 waves per SIMD");
+    run<8>(g, out, cyc, "two v_pk_fma_f32 waves per SIMD");
     return 0;
 }
