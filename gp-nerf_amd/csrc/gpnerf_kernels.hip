@@ -697,10 +697,6 @@ render_fused_kernel(const KArgs ka) {
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0);
 
-#ifdef GPNERF_X_STAGGER    // experiment: start the second wave of every SIMD late
-    if (wave & GPNERF_X_STAGBIT)
-        for (int i = 0; i < GPNERF_X_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     Stamps st;
     st.start();
     const int k_end = (int)(((long)S * (seg + 1)) / split);
@@ -743,23 +739,15 @@ render_fused_kernel(const KArgs ka) {
 #pragma unroll
         for (int l = 0; l < GPNERF_LEVELS; ++l)
         {
-#ifdef GPNERF_X_NOGATHER   // experiment: MLP phases only
-            for (int c = 0; c < 16; ++c) fv[16 * l + c] = gx * (float)(c + 1) + gy * (float)(l + 1);
-#else
             gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
             if (l & 1) __builtin_amdgcn_sched_barrier(0);    // at most two levels' 64 loads in flight (register pressure)
-#endif
 
         }
         STAMP(st, 0);
         float sf[32];
         Frag sff[4];
-#ifdef GPNERF_X_NOMLP      // experiment: gather phases only
-        for (int c = 0; c < 32; ++c) sf[c] = fv[c] + fv[32 + c];
-#else
         if constexpr (SPLIT) geo_eval_s(lw, lane, fv, sff);
         else geo_eval(lds, lane, fv, sf);
-#endif
         STAMP(st, 1);
 
         // Projector.compute (:326-363)
@@ -768,15 +756,9 @@ render_fused_kernel(const KArgs ka) {
         float vrgb[NV][3];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-#ifdef GPNERF_X_NOGATHER
-            ViewSample s;
-            s.valid = 1.f; s.rgb[0] = px * 0.1f; s.rgb[1] = py * 0.1f; s.rgb[2] = pz * 0.1f;
-            for (int c = 0; c < 16; ++c) x[v][c] = px * (float)(c + 1) + pz * (float)(v + 1);
-#else
             const ViewSample s = gather_view(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
                                              fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
                                              px, py, pz, neg, half, x[v]);
-#endif
             x[v][16] = half ? s.rgb[1] : s.rgb[0];
             x[v][17] = half ? 0.f : s.rgb[2];
             vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
@@ -786,15 +768,8 @@ render_fused_kernel(const KArgs ka) {
 
         STAMP(st, 2);
         float sigma, rgb[3];
-#ifdef GPNERF_X_NOMLP
-        sigma = nvalid; rgb[0] = rgb[1] = rgb[2] = 0.f;
-        for (int c = 0; c < 32; ++c) sigma += sf[c];
-        for (int v = 0; v < NV; ++v)
-            for (int c = 0; c < 18; ++c) rgb[v] += x[v][c];
-#else
         if constexpr (SPLIT) mlp_eval_s(lw, lane, sff, x, nvalid, sigma, rgb);
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
-#endif
         if (cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
