@@ -465,8 +465,8 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
 // feature gathers (channels-last sources)
 // ---------------------------------------------------------------------------------------------
 struct Axis {
-    int i0, i1;     // clamped tap indices
-    float w0, w1;   // weights, zeroed for out-of-range taps (padding_mode='zeros')
+    unsigned i0, i1;   // clamped tap indices
+    float w0, w1;      // weights, zeroed for out-of-range taps (padding_mode='zeros')
 };
 
 // F.grid_sample coordinate handling, align_corners=True: index = ((g + 1) / 2) * (size - 1)
@@ -478,11 +478,19 @@ DEV Axis axis_taps(float g, int size) {
     const bool v0 = (f0 >= 0.f) && (f0 <= sm1);          // false for NaN / +-huge
     const bool v1 = (f1 >= 0.f) && (f1 <= sm1);
     Axis a;
-    a.i0 = v0 ? (int)f0 : 0;
-    a.i1 = v1 ? (int)f1 : 0;
+    a.i0 = v0 ? (unsigned)f0 : 0u;
+    a.i1 = v1 ? (unsigned)f1 : 0u;
     a.w0 = v0 ? 1.f - t : 0.f;
     a.w1 = v1 ? t : 0.f;
     return a;
+}
+
+// Tap addresses are 32-bit BYTE offsets from a uniform base (to_framek() guarantees every tensor is below 4 GiB and every
+// index factor below 2^24): the products are v_mad_u32_u24 (full rate; v_mul_lo_u32 is quarter rate) and the loads take
+// the base from SGPRs plus a 32-bit VGPR offset, so no 64-bit address arithmetic runs on the VALU.
+DEV unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
+DEV const float* at_byte(const float* base, unsigned byte_off) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // 16 channels of one tap: 8 v_pk_fma_f32 (the tap weight is broadcast by op_sel)
@@ -505,25 +513,24 @@ DEV void gather_volume(const float* __restrict__ vol, int D, int H, int W, float
     const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
 #pragma unroll
     for (int c = 0; c < 16; ++c) f[c] = 0.f;
-    const int ch = half * 16;
-    const int zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1}, xi[2] = {ax.i0, ax.i1};
+    const unsigned zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1};
     const float zw[2] = {az.w0, az.w1}, yw[2] = {ay.w0, ay.w1}, xw[2] = {ax.w0, ax.w1};
+    const unsigned row_bytes = (unsigned)W * 128u;                              // one x-row: W voxels x 32 channels x 4 B
+    const unsigned xb[2] = {ax.i0 * 128u + (unsigned)half * 64u, ax.i1 * 128u + (unsigned)half * 64u};
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            const unsigned rowb = __umul24(mad24(zi[a], (unsigned)H, yi[b]), row_bytes);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float w = (xw[e] * yw[b]) * zw[a];
-                const int off = ((zi[a] * H + yi[b]) * W + xi[e]) * 32 + ch;
-                fma16(vol + off, w, f);
-            }
+            for (int e = 0; e < 2; ++e) fma16(at_byte(vol, rowb + xb[e]), (xw[e] * yw[b]) * zw[a], f);
+        }
 }
 
 // F.grid_sample of the single-channel occupancy volume (demo_render.py:274-279), same coordinates as the features
 DEV float sample_occupancy(const float* __restrict__ occ, int D, int H, int W, float gx, float gy, float gz) {
     const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
-    const int zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1}, xi[2] = {ax.i0, ax.i1};
+    const unsigned zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1}, xi[2] = {ax.i0, ax.i1};
     const float zw[2] = {az.w0, az.w1}, yw[2] = {ay.w0, ay.w1}, xw[2] = {ax.w0, ax.w1};
     float v = 0.f;
 #pragma unroll
@@ -531,7 +538,8 @@ DEV float sample_occupancy(const float* __restrict__ occ, int D, int H, int W, f
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) v = fmaf(occ[(zi[a] * H + yi[b]) * W + xi[e]], (xw[e] * yw[b]) * zw[a], v);
+            for (int e = 0; e < 2; ++e)
+                v = fmaf(*at_byte(occ, (__umul24(mad24(zi[a], (unsigned)H, yi[b]), (unsigned)W) + xi[e]) * 4u), (xw[e] * yw[b]) * zw[a], v);
     return v;
 }
 
@@ -560,10 +568,12 @@ DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
     s.valid = (front && inb) ? 1.f : 0.f;
     {   // RGB from the full-resolution image
         const Axis ax = axis_taps(nx, iw), ay = axis_taps(ny, ih);
-        const f32x4 nw = *reinterpret_cast<const f32x4*>(img + (ay.i0 * iw + ax.i0) * 4);
-        const f32x4 ne = *reinterpret_cast<const f32x4*>(img + (ay.i0 * iw + ax.i1) * 4);
-        const f32x4 sw = *reinterpret_cast<const f32x4*>(img + (ay.i1 * iw + ax.i0) * 4);
-        const f32x4 se = *reinterpret_cast<const f32x4*>(img + (ay.i1 * iw + ax.i1) * 4);
+        const unsigned r0 = __umul24(ay.i0, (unsigned)iw * 16u), r1 = __umul24(ay.i1, (unsigned)iw * 16u);
+        const unsigned x0 = ax.i0 * 16u, x1 = ax.i1 * 16u;
+        const f32x4 nw = *reinterpret_cast<const f32x4*>(at_byte(img, r0 + x0));
+        const f32x4 ne = *reinterpret_cast<const f32x4*>(at_byte(img, r0 + x1));
+        const f32x4 sw = *reinterpret_cast<const f32x4*>(at_byte(img, r1 + x0));
+        const f32x4 se = *reinterpret_cast<const f32x4*>(at_byte(img, r1 + x1));
         const float wnw = ax.w0 * ay.w0, wne = ax.w1 * ay.w0, wsw = ax.w0 * ay.w1, wse = ax.w1 * ay.w1;
 #pragma unroll
         for (int c = 0; c < 3; ++c) s.rgb[c] = fmaf(se[c], wse, fmaf(sw[c], wsw, fmaf(ne[c], wne, nw[c] * wnw)));
@@ -572,11 +582,12 @@ DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
         const Axis ax = axis_taps(nx, fw), ay = axis_taps(ny, fh);
 #pragma unroll
         for (int c = 0; c < 16; ++c) f[c] = 0.f;
-        const int ch = half * 16;
-        fma16(fm + (ay.i0 * fw + ax.i0) * 32 + ch, ax.w0 * ay.w0, f);
-        fma16(fm + (ay.i0 * fw + ax.i1) * 32 + ch, ax.w1 * ay.w0, f);
-        fma16(fm + (ay.i1 * fw + ax.i0) * 32 + ch, ax.w0 * ay.w1, f);
-        fma16(fm + (ay.i1 * fw + ax.i1) * 32 + ch, ax.w1 * ay.w1, f);
+        const unsigned r0 = __umul24(ay.i0, (unsigned)fw * 128u), r1 = __umul24(ay.i1, (unsigned)fw * 128u);
+        const unsigned x0 = ax.i0 * 128u + (unsigned)half * 64u, x1 = ax.i1 * 128u + (unsigned)half * 64u;
+        fma16(at_byte(fm, r0 + x0), ax.w0 * ay.w0, f);
+        fma16(at_byte(fm, r0 + x1), ax.w1 * ay.w0, f);
+        fma16(at_byte(fm, r1 + x0), ax.w0 * ay.w1, f);
+        fma16(at_byte(fm, r1 + x1), ax.w1 * ay.w1, f);
     }
     return s;
 }
@@ -1282,10 +1293,15 @@ int launch_status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNER
 // GpnerfFrame -> kernel argument; need_vol / need_img say which tensors the launch will touch
 bool to_framek(const GpnerfFrame* f, FrameK& k, bool need_vol, bool need_img) {
     memset(&k, 0, sizeof(k));
-    // tap offsets are 32-bit float indices inside the kernels
-    for (int l = 0; l < GPNERF_LEVELS; ++l)
-        if (f->vol[l] && (int64_t)f->vol_dhw[l][0] * f->vol_dhw[l][1] * f->vol_dhw[l][2] * GPNERF_CH >= (int64_t)1 << 31) return false;
-    if ((int64_t)f->img_h * f->img_w * 4 >= (int64_t)1 << 31 || (int64_t)f->feat_h * f->feat_w * GPNERF_CH >= (int64_t)1 << 31) return false;
+    // tap addresses are 32-bit byte offsets built from 24-bit factors inside the kernels (gather_volume / gather_view)
+    const int64_t lim_bytes = (int64_t)1 << 32, lim24 = (int64_t)1 << 24;
+    for (int l = 0; l < GPNERF_LEVELS; ++l) {
+        if (!f->vol[l]) continue;
+        const int64_t D = f->vol_dhw[l][0], H = f->vol_dhw[l][1], W = f->vol_dhw[l][2];
+        if (D * H * W * GPNERF_CH * 4 >= lim_bytes || D * H >= lim24 || W * GPNERF_CH * 4 >= lim24) return false;
+    }
+    if ((int64_t)f->img_h * f->img_w * 16 >= lim_bytes || (int64_t)f->img_w * 16 >= lim24 || f->img_h >= lim24) return false;
+    if ((int64_t)f->feat_h * f->feat_w * GPNERF_CH * 4 >= lim_bytes || (int64_t)f->feat_w * GPNERF_CH * 4 >= lim24 || f->feat_h >= lim24) return false;
     if (need_vol)
         for (int l = 0; l < GPNERF_LEVELS; ++l)
             if (!f->vol[l] || f->vol_dhw[l][0] < 1 || f->vol_dhw[l][1] < 1 || f->vol_dhw[l][2] < 1) return false;
