@@ -295,6 +295,7 @@ DEV Frag make_frag(const float* v) {
         H[p] = w;
         Lo[p] = pk_rtz(minus_lo_half(w, v[2 * p]), minus_hi_half(w, v[2 * p + 1]));
     }
+    asm volatile("" : "+v"(H), "+v"(Lo));      // complete before the MFMA run that follows (no VALU between MFMAs)
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
     f.lo = __builtin_bit_cast(h8, Lo);
@@ -325,19 +326,28 @@ DEV f32x16 bias_tile_s(const unsigned* lw, int m, int half) {
     return acc;
 }
 
-// acc += W_tile[:, 16 k] . B  as  Wlo.Bhi + Whi.Blo + Whi.Bhi
-DEV void mfma_step(const unsigned* __restrict__ w, int lane, const Frag& b, f32x16& acc) {
-    const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(w + lane * 4));
-    const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(w + 256 + lane * 4));
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi, acc, 0, 0, 0);
-}
-
+// acc += W_tile[:, 16 k] . B  as  Wlo.Bhi + Whi.Blo + Whi.Bhi, NSTEP k-steps in one uninterrupted MFMA run: the next
+// step's hi/lo weight reads are issued before this step's three MFMAs (same ordering device as mfma_tile)
 template <int L, int NSTEP>
 DEV void mfma_steps(const unsigned* lw, int m, int s0, int lane, const Frag* b, f32x16& acc) {
+    typedef const __attribute__((address_space(3))) unsigned* lds_ptr;
+    typedef const __attribute__((address_space(3))) u32x4* lds_vec;
+    lds_ptr p = (lds_ptr)wstep<L>(lw, m, s0) + lane * 4;
+    u32x4 ah = *reinterpret_cast<lds_vec>(p), al = *reinterpret_cast<lds_vec>(p + 256);
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) mfma_step(wstep<L>(lw, m, s0 + s), lane, b[s], acc);
+    for (int s = 0; s < NSTEP; ++s) {
+        u32x4 nh = ah, nl = al;
+        if (s + 1 < NSTEP) {
+            nh = *reinterpret_cast<lds_vec>(p + (s + 1) * gph::STEP_WORDS);
+            nl = *reinterpret_cast<lds_vec>(p + (s + 1) * gph::STEP_WORDS + 256);
+        }
+        asm volatile("" : "+v"(p), "+v"(acc));
+        const h8 wh = __builtin_bit_cast(h8, ah), wl = __builtin_bit_cast(h8, al);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b[s].hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[s].lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[s].hi, acc, 0, 0, 0);
+        ah = nh; al = nl;
+    }
 }
 
 // ELU of an accumulator tile -> its two B-operand k-steps (and optionally the fp32 values)
