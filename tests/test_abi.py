@@ -82,3 +82,45 @@ def test_cpu_tensors_are_refused(pkg):
     fm = importlib.import_module("gp-nerf_amd.frame")
     with pytest.raises(pkg.GpnerfError, match="no CPU fallback"):
         fm.render_fused(None, torch.zeros(4, 8), 8)
+
+
+def _frame(L, dhw=(8, 8, 8), img=(16, 16), feat=(4, 4)):
+    """A GpnerfFrame whose pointers are non-null dummies: argument checks run on the host before any launch."""
+    f = L.GpnerfFrame()
+    for l in range(L.LEVELS):
+        f.vol[l] = 0x1000
+        for a in range(3):
+            f.vol_dhw[l][a] = dhw[a]
+    f.featmaps, f.feat_h, f.feat_w = 0x1000, feat[0], feat[1]
+    f.imgs, f.img_h, f.img_w = 0x1000, img[0], img[1]
+    f.head_blob = 0x1000
+    return f
+
+
+def test_render_fused_rejects_bad_arguments_on_the_host(pkg):
+    """gpnerf_render_fused returns GPNERF_E_ARG (never launches, never throws) for frames its 32-bit / 24-bit tap
+    addressing cannot cover and for missing tensors; an empty ray list is a no-op."""
+    L = pkg._lib
+    lib = L.lib()
+    out = L.GpnerfOutputs()
+    out.rgb = out.depth = out.acc = out.disp = 0x1000
+
+    def call(frame, n_rays=64, n_samples=8, rays=0x1000, o=out):
+        return lib.gpnerf_render_fused(C.byref(frame), rays, n_rays, n_samples, 0, 1e-4, None, C.byref(o), None, 0, None)
+
+    assert call(_frame(L), n_rays=0) == 0                                   # nothing to do
+    assert call(_frame(L), n_samples=0) == -1
+    assert call(_frame(L), rays=None) == -1
+    assert call(_frame(L), o=L.GpnerfOutputs()) == -1                       # rgb / depth / acc / disp are required
+    assert call(_frame(L, dhw=(4096, 4096, 8))) == -1                       # D*H >= 2^24
+    assert call(_frame(L, dhw=(8, 8, 1 << 17))) == -1                       # one x-row >= 2^24 bytes
+    assert call(_frame(L, dhw=(1024, 1024, 1024))) == -1                    # level >= 4 GiB
+    assert call(_frame(L, img=(8, 1 << 20))) == -1                          # image row >= 2^24 bytes
+    assert call(_frame(L, feat=(1 << 12, 1 << 13))) == -1                   # feature maps >= 4 GiB per view
+    f = _frame(L)
+    f.vol[2] = None
+    assert call(f) == -1
+    f = _frame(L)
+    f.head_blob = None
+    assert call(f) == -1
+    assert lib.gpnerf_strerror(-1) == b"invalid argument"
