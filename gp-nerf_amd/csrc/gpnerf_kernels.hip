@@ -274,15 +274,13 @@ struct Frag { h8 hi, lo; };        // one 16-deep k-step of the B operand: 8 val
 
 DEV unsigned pk_rtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 
-// x - f16_half(w): v_fma_mix_f32 reads the f16 half of w directly (no conversion back to f32 first)
-DEV float minus_lo_half(unsigned w, float x) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(x));
-    return r;
-}
-DEV float minus_hi_half(unsigned w, float x) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(x));
+// lo pair of (x0, x1) given their packed hi halves w: f16(x0 - w.lo) in the low half, f16(x1 - w.hi) in the high half.
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 read the f16 half of w directly, subtract in f32 and write the rounded f16 result
+// into one half of the destination -- no conversion back to f32, no separate pack.
+DEV unsigned lo_pair(unsigned w, float x0, float x1) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(w), "v"(x1));
     return r;
 }
 
@@ -293,7 +291,7 @@ DEV Frag make_frag(const float* v) {
     for (int p = 0; p < 4; ++p) {
         const unsigned w = pk_rtz(v[2 * p], v[2 * p + 1]);
         H[p] = w;
-        Lo[p] = pk_rtz(minus_lo_half(w, v[2 * p]), minus_hi_half(w, v[2 * p + 1]));
+        Lo[p] = lo_pair(w, v[2 * p], v[2 * p + 1]);
     }
     asm volatile("" : "+v"(H), "+v"(Lo));      // complete before the MFMA run that follows (no VALU between MFMAs)
     Frag f;
@@ -304,7 +302,7 @@ DEV Frag make_frag(const float* v) {
 
 DEV Frag make_frag2(float a, float b) {                    // the rgb k-step: two live slots, six zero pads
     const unsigned w = pk_rtz(a, b);
-    u32x4 H = {w, 0u, 0u, 0u}, Lo = {pk_rtz(minus_lo_half(w, a), minus_hi_half(w, b)), 0u, 0u, 0u};
+    u32x4 H = {w, 0u, 0u, 0u}, Lo = {lo_pair(w, a, b), 0u, 0u, 0u};
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
     f.lo = __builtin_bit_cast(h8, Lo);
