@@ -62,11 +62,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GPNERF_BENCH_BACKEND=gloo is a dry run of the N>1 flow on a box with fewer GPUs than ranks (ranks share devices and
+    # the all-gather is staged through the host); every measured run uses "nccl" (= RCCL) with one GPU per rank.
+    backend = os.environ.get("GPNERF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     fm = importlib.import_module("gp-nerf_amd.frame")
     syn = importlib.import_module("gp-nerf_amd.synthetic")
@@ -89,7 +96,7 @@ def main():
     torch.cuda.synchronize()
 
     want = ()                              # headline outputs only: rgb, depth, acc, disp
-    gathered = torch.empty((world, n_local, 4), device=dev) if world > 1 else None
+    gathered = torch.empty((world, n_local, 4), device=dev if backend == "nccl" else "cpu") if world > 1 else None
     k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
@@ -100,7 +107,10 @@ def main():
         if i is not None:
             k_stop[i].record()
         if world > 1:
-            par.all_gather_pixels(out, gathered)
+            if backend == "nccl":
+                par.all_gather_pixels(out, gathered)
+            else:
+                par.all_gather_pixels({k: v.cpu() for k, v in out.items() if k in ("rgb_map", "depth_map")}, gathered)
         return out
 
     for _ in range(args.warmup):
