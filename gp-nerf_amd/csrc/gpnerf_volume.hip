@@ -127,6 +127,68 @@ hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 int status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
 bool bad(const int32_t* dims) { return !dims || dims[0] < 1 || dims[1] < 1 || dims[2] < 1; }
 
+
+// Vertex-code attention (libs/nerfheads/trainhead.py:48-52 through networks/MultiHeadAttention.py:61-98, sum=False):
+// per SMPL vertex, query = its code (length 1), keys = values = its features in the V source views.  One wavefront walks
+// vertices; lane j < d_model owns output column j of every projection, its four weight rows live in registers.
+//   qh = Wq q / sqrt(d_k);  kh_v = Wk f_v;  vh_v = Wv f_v;  per head: softmax_v(qh . kh_v);  out = sum_v a_v vh_v;  y = Wfc out
+constexpr int ATT_MAX = 64;     // d_model, kv_dim <= 64
+template <int DMAX>             // 32 when d_model, kv_dim <= 32 (the weight rows fit the register file), else 64
+__global__ void __launch_bounds__(256, 1) vertex_attention_kernel(const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ wq,
+                                        const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ wfc,
+                                        const int n, const int d_model, const int kv_dim, const int n_head, const int views,
+                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane < d_model ? lane : 0;
+    const int d_k = d_model / n_head;
+    const float inv_t = 1.f / sqrtf((float)d_k);
+    float rq[DMAX], rk[DMAX], rv[DMAX], rf[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {
+        rq[i] = i < d_model ? wq[j * d_model + i] : 0.f;
+        rf[i] = i < d_model ? wfc[j * d_model + i] : 0.f;
+        rk[i] = i < kv_dim ? wk[j * kv_dim + i] : 0.f;
+        rv[i] = i < kv_dim ? wv[j * kv_dim + i] : 0.f;
+    }
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long v = wave; v < n; v += n_waves) {
+        const float qx = lane < d_model ? q[v * d_model + lane] : 0.f;
+        float qh = 0.f;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) qh = fmaf(rq[i], __shfl(qx, i), qh);
+        qh *= inv_t;
+        float score[4], val[4];                 // views <= 4
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            score[s] = -INFINITY; val[s] = 0.f;
+            if (s < views) {
+                const float fx = lane < kv_dim ? kv[(v * views + s) * kv_dim + lane] : 0.f;
+                float kh = 0.f, vh = 0.f;
+#pragma unroll
+                for (int i = 0; i < DMAX; ++i) {
+                    const float f = __shfl(fx, i);
+                    kh = fmaf(rk[i], f, kh);
+                    vh = fmaf(rv[i], f, vh);
+                }
+                float p = qh * kh;              // sum over the d_k lanes of this head (d_k is a power of two)
+                for (int o = 1; o < d_k; o <<= 1) p += __shfl_xor(p, o);
+                score[s] = p; val[s] = vh;
+            }
+        }
+        float m = fmaxf(fmaxf(score[0], score[1]), fmaxf(score[2], score[3]));
+        float den = 0.f, acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float e = s < views ? __expf(score[s] - m) : 0.f;
+            den += e; acc = fmaf(e, val[s], acc);
+        }
+        const float o = lane < d_model ? acc / den : 0.f;
+        float y = 0.f;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) y = fmaf(rf[i], __shfl(o, i), y);
+        if (lane < d_model) out[v * d_model + lane] = y;
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -195,6 +257,24 @@ int gpnerf_sparse_to_dense(const float* feat, int32_t channels, const int32_t* c
     hipLaunchKernelGGL(dense_kernel, dim3((m_cap + 7) / 8), dim3(256), 0, S_(stream), feat, (int)channels, coords, grid,
                        (const int*)m_dev, (int)m_cap, s, vol_ndhwc);
     return status();
+}
+
+int gpnerf_vertex_attention(const float* q, const float* kv, const float* wq, const float* wk, const float* wv, const float* wfc,
+                            int32_t n, int32_t d_model, int32_t kv_dim, int32_t n_head, int32_t views, float* out, void* stream) {
+    if (n == 0) return GPNERF_OK;
+    if (!q || !kv || !wq || !wk || !wv || !wfc || !out || n < 0) return GPNERF_E_ARG;
+    if (d_model < 1 || d_model > ATT_MAX || kv_dim < 1 || kv_dim > ATT_MAX || n_head < 1 || d_model % n_head || views < 1 || views > 4)
+        return GPNERF_E_ARG;
+    const int d_k = d_model / n_head;
+    if (d_k & (d_k - 1)) return GPNERF_E_ARG;          // the per-head reduction is a butterfly
+    const int blocks = n < 4096 ? (n + 3) / 4 : 1024;
+    if (d_model <= 32 && kv_dim <= 32)
+        hipLaunchKernelGGL(vertex_attention_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q,
+                           kv, wq, wk, wv, wfc, (int)n, (int)d_model, (int)kv_dim, (int)n_head, (int)views, out);
+    else
+        hipLaunchKernelGGL(vertex_attention_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q,
+                           kv, wq, wk, wv, wfc, (int)n, (int)d_model, (int)kv_dim, (int)n_head, (int)views, out);
+    return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH;
 }
 
 }  // extern "C"

@@ -45,9 +45,10 @@ class NeRFSigmaHead(nn.Module):
         (trainhead.py:48-56, SparseConvNet.py:105-111).  Per frame, not per ray."""
         code = self.c(torch.arange(0, self.n_smpl, device=smpl_feat_sampled.device))
         feat = smpl_feat_sampled.flatten(0, 1)
-        fused = self.xyzc_attn(code.unsqueeze(1), feat, feat)[0].squeeze(1)
-        if fused.is_cuda and not self.training:
+        if feat.is_cuda and not self.training:
+            fused = self.xyzc_attn.fuse_vertices(code, feat)
             return self.xyzc_net.dense_levels_hip(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
+        fused = self.xyzc_attn(code.unsqueeze(1), feat, feat)[0].squeeze(1)
         return self.xyzc_net.dense_levels(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
 
 

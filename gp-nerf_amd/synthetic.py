@@ -122,6 +122,22 @@ def make_encoder_images(H, W, seed=0, views=3):
     return np.clip(out, -1, 1).astype(np.float32)
 
 
+
+def make_attention_case(n, code_dim, seed=0, views=3, kv_dim=32):
+    """Seeded inputs of the vertex-code attention (trainhead.py:48-52): parameters by state_dict key, vertex codes [n,d],
+    per-view vertex features [n,V,32]."""
+    g = _rng(seed, 404)
+    sd = OrderedDict()
+    for key, shape in (("w_qs.weight", (code_dim, code_dim)), ("w_ks.weight", (code_dim, kv_dim)), ("w_vs.weight", (code_dim, kv_dim)),
+                       ("fc.weight", (code_dim, code_dim))):
+        sd[key] = (g.standard_normal(shape, dtype=np.float32) * np.float32(math.sqrt(1.0 / shape[1]))).astype(np.float32)
+    sd["layer_norm.weight"] = np.ones((code_dim,), np.float32)
+    sd["layer_norm.bias"] = np.zeros((code_dim,), np.float32)
+    code = g.standard_normal((n, code_dim), dtype=np.float32)
+    feat = (g.standard_normal((n, views, kv_dim), dtype=np.float32) * np.float32(1.5)).astype(np.float32)
+    return sd, code, feat
+
+
 def rodrigues(rvec):
     rvec = np.asarray(rvec, np.float64)
     th = np.linalg.norm(rvec)

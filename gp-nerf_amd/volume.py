@@ -49,6 +49,20 @@ class MultiHeadAttention(nn.Module):
             out = self.layer_norm(out + residual)
         return out, attn
 
+    def fuse_vertices(self, code, feat):
+        """The call the volume builder makes (trainhead.py:48-52): code [N,d_model], feat [N,V,kv_dim] -> [N,d_model],
+        as ONE HIP launch (gpnerf_vertex_attention) instead of ~12 library calls.  GPU, inference, sum=False only."""
+        if self.sum_flag or self.training or not code.is_cuda:
+            raise L.GpnerfError("fuse_vertices is the inference form of the sum=False attention on the GPU")
+        code, feat = code.contiguous().float(), feat.contiguous().float()
+        n, d = code.shape
+        out = torch.empty((n, d), device=code.device, dtype=torch.float32)
+        w = [m.weight.detach().contiguous().float() for m in (self.w_qs, self.w_ks, self.w_vs, self.fc)]
+        L.check(L.lib().gpnerf_vertex_attention(code.data_ptr(), feat.data_ptr(), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(),
+                                                w[3].data_ptr(), n, d, feat.shape[2], self.n_head, feat.shape[1], out.data_ptr(),
+                                                torch.cuda.current_stream(code.device).cuda_stream), "gpnerf_vertex_attention")
+        return out
+
 
 # ------------------------------------------------------------------------------------------------
 # sparse 3-D convolution by rulebook

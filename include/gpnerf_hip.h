@@ -215,6 +215,14 @@ int gpnerf_sparse_down_sites(const int32_t* in_coords, const int32_t* m_in_dev, 
 int gpnerf_sparse_to_dense(const float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, const int32_t* m_dev,
                            int32_t m_cap, const int32_t* dims, float* vol_ndhwc, void* stream);
 
+/* Vertex-code attention of the volume builder (libs/nerfheads/trainhead.py:48-52, networks/MultiHeadAttention.py:61-98 with
+ * sum=False): q [n][d_model] vertex codes, kv [n][views][kv_dim] the vertices' per-view features, weights in PyTorch
+ * layout (w_qs [d_model][d_model], w_ks / w_vs [d_model][kv_dim], fc [d_model][d_model]); out [n][d_model].  All device.
+ * d_model, kv_dim <= 64, views <= 4, d_model / n_head a power of two. */
+int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, const float* w_ks, const float* w_vs,
+                            const float* fc, int32_t n, int32_t d_model, int32_t kv_dim, int32_t n_head, int32_t views,
+                            float* out, void* stream);
+
 /* Channels-last re-layouts of the per-frame tensors (device -> device). */
 int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t H, int32_t W, void* stream);
 int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t H, int32_t W, void* stream);

@@ -12,7 +12,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("rays_", "encoder_")))
+                  if not os.path.basename(p).startswith(("rays_", "encoder_", "attention_")))
+
+
+def attention_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "attention_*.npz")))
 
 
 def encoder_case_names():
