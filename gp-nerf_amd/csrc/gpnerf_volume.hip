@@ -62,6 +62,57 @@ __global__ void __launch_bounds__(256) conv_kernel(const float* __restrict__ in,
     if (co < cout) out[(size_t)site * cout + co] = fmaxf(fmaf(acc, scale[co], shift[co]), 0.f);
 }
 
+
+// The same convolution on the matrix cores, for cin a multiple of 8 (gpnerf_sparse_conv3_mfma).  One wavefront = 32 output
+// sites, transposed like the render kernel's MLP: out[co][site] += W_k[ci][co] . x[neighbour_k(site)][ci] on
+// v_mfma_f32_32x32x2_f32 with A = packed weights (gpnerf_sparse_pack_weight: [tap][cin/8][64 lanes][4], lane = co + 32*half,
+// half h owning input channels h*cin/2 ...), B = the neighbour row's channels loaded straight from the feature matrix
+// (lane = site + 32*half), 27 * cin/2 MFMAs per tile.  The VALU form above walks cin*27 dependent FMAs per site.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+template <bool STRIDED>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict__ in, const int cin, const int32_t* __restrict__ in_grid,
+                                                        const Dims in_dims, const int32_t* __restrict__ out_coords,
+                                                        const int* __restrict__ m_ptr, const int m_cap, const float* __restrict__ Wp,
+                                                        const int cout, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, s = lane & 31, half = lane >> 5;
+    const int m = m_ptr ? min(*m_ptr, m_cap) : m_cap;
+    const int site = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + s;
+    if (site - s >= m) return;                                  // whole tile past the end (wave-uniform)
+    const bool valid = site < m;
+    const int od = valid ? out_coords[3 * site] : 0, oh = valid ? out_coords[3 * site + 1] : 0, ow = valid ? out_coords[3 * site + 2] : 0;
+    const int half_c = cin >> 1, ng = cin >> 3;
+    f32x16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < KV; ++k) {
+        const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
+        const int d = (STRIDED ? 2 * od : od) - 1 + kd, h = (STRIDED ? 2 * oh : oh) - 1 + kh, w = (STRIDED ? 2 * ow : ow) - 1 + kw;
+        const bool inb = valid && d >= 0 && d < in_dims.d && h >= 0 && h < in_dims.h && w >= 0 && w < in_dims.w;
+        const int j = inb ? in_grid[cell_of(in_dims, d, h, w)] : -1;
+        if (!__any(j >= 0)) continue;                           // no site of the tile has this neighbour
+        const float* x = in + (size_t)(j < 0 ? 0 : j) * cin + half * half_c;
+        const float* wk = Wp + ((size_t)k * ng * 64 + lane) * 4;
+#pragma unroll 4
+        for (int g = 0; g < ng; ++g) {
+            f32x4v b = {0.f, 0.f, 0.f, 0.f};
+            if (j >= 0) b = *reinterpret_cast<const f32x4v*>(x + 4 * g);
+            const f32x4v a = *reinterpret_cast<const f32x4v*>(wk + (size_t)g * 256);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;       // 32x32 accumulator: row of register r in lane half `half`
+        if (co < cout) out[(size_t)site * cout + co] = fmaxf(fmaf(acc[r], scale[co], shift[co]), 0.f);
+    }
+}
+
 // spconv's strided rulebook takes EVERY input row, so two vertices rounded into one voxel both contribute, while its
 // submanifold lookups find one row per voxel.  Fold the former into the grid formulation: add the features of the other
 // rows of a voxel onto the indexed row (only the vertex level can hold duplicates).
@@ -218,6 +269,38 @@ int gpnerf_sparse_conv3(int32_t strided, const float* in, int32_t cin, const int
     else
         hipLaunchKernelGGL(conv_kernel<false>, grid, block, 0, S_(stream), in, (int)cin, in_grid, s, out_coords, (const int*)m_dev,
                            (int)m_cap, weight, (int)cout, bn_scale, bn_shift, out);
+    return status();
+}
+
+int64_t gpnerf_sparse_packed_weight_floats(int32_t cin) { return cin >= 8 && cin <= 32 && cin % 8 == 0 ? (int64_t)KV * (cin / 8) * 256 : 0; }
+
+int gpnerf_sparse_pack_weight(const float* weight, int32_t cin, int32_t cout, float* packed) {
+    if (!weight || !packed || cin < 8 || cin > 32 || cin % 8 || cout < 1 || cout > 32) return GPNERF_E_ARG;
+    const int ng = cin / 8, half_c = cin / 2;
+    for (int k = 0; k < KV; ++k)
+        for (int g = 0; g < ng; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    const int co = lane & 31, ci = (lane >> 5) * half_c + 4 * g + i;
+                    packed[(((size_t)k * ng + g) * 64 + lane) * 4 + i] = co < cout ? weight[((size_t)k * cin + ci) * cout + co] : 0.f;
+                }
+    return GPNERF_OK;
+}
+
+int gpnerf_sparse_conv3_mfma(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
+                             const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const float* packed_weight, int32_t cout,
+                             const float* bn_scale, const float* bn_shift, float* out, void* stream) {
+    if (!in || !in_grid || bad(in_dims) || !out_coords || !packed_weight || !bn_scale || !bn_shift || !out) return GPNERF_E_ARG;
+    if (cin < 8 || cin > 32 || cin % 8 || cout < 1 || cout > 32 || m_cap < 0) return GPNERF_E_ARG;
+    if (m_cap == 0) return GPNERF_OK;
+    const Dims s{in_dims[0], in_dims[1], in_dims[2]};
+    const dim3 grid((unsigned)((m_cap + 127) / 128)), block(256);
+    if (strided)
+        hipLaunchKernelGGL(conv_mfma_kernel<true>, grid, block, 0, S_(stream), in, (int)cin, in_grid, s, out_coords, (const int*)m_dev,
+                           (int)m_cap, packed_weight, (int)cout, bn_scale, bn_shift, out);
+    else
+        hipLaunchKernelGGL(conv_mfma_kernel<false>, grid, block, 0, S_(stream), in, (int)cin, in_grid, s, out_coords, (const int*)m_dev,
+                           (int)m_cap, packed_weight, (int)cout, bn_scale, bn_shift, out);
     return status();
 }
 

@@ -13,6 +13,7 @@ w_qs, w_ks, w_vs, fc, layer_norm).
 """
 import ctypes as C
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -191,6 +192,21 @@ class SparseConvNet(nn.Module):
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
         return scale.float().contiguous(), (bn.bias - bn.running_mean * scale).float().contiguous()
 
+    def _packed_weight(self, mod, dev):
+        """gpnerf_sparse_pack_weight image of a conv's [3,3,3,Cin,Cout] weight on `dev`, re-packed when the parameter changes."""
+        key = (str(dev), mod.weight.data_ptr(), mod.weight._version)
+        cache = self.__dict__.setdefault("_wp_cache", {})
+        hit = cache.get(id(mod))
+        if hit is None or hit[0] != key:
+            lib = L.lib()
+            w = np.ascontiguousarray(mod.weight.detach().float().cpu().numpy().reshape(27, mod.cin, mod.cout))
+            packed = np.zeros(int(lib.gpnerf_sparse_packed_weight_floats(mod.cin)), np.float32)
+            L.check(lib.gpnerf_sparse_pack_weight(w.ctypes.data_as(L.FP), mod.cin, mod.cout, packed.ctypes.data_as(L.FP)),
+                    "gpnerf_sparse_pack_weight")
+            hit = (key, torch.from_numpy(packed).to(dev))
+            cache[id(mod)] = hit
+        return hit[1]
+
     def dense_levels_hip(self, code, coord, out_sh, batch_size=1):
         """Same result as dense_levels(), computed by the HIP sparse-convolution kernels and returned directly in the
         render kernel's channels-last layout: a list of 4 tensors [D_k,H_k,W_k,C] (tagged `_gpnerf_ndhwc`)."""
@@ -206,12 +222,19 @@ class SparseConvNet(nn.Module):
         I3 = C.c_int32 * 3
 
         def conv(strided, mod, bn, x, in_grid, in_dims, coords, m_dev, m_cap):
-            w = mod.weight.detach().float().contiguous()
             scale, shift = self._folded_bn(bn)
             out = torch.empty((m_cap, mod.cout), device=dev, dtype=torch.float32)
-            L.check(lib.gpnerf_sparse_conv3(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims), coords.data_ptr(),
-                                            m_dev.data_ptr() if m_dev is not None else None, m_cap, w.data_ptr(), mod.cout,
-                                            scale.data_ptr(), shift.data_ptr(), out.data_ptr(), st), "gpnerf_sparse_conv3")
+            mp = m_dev.data_ptr() if m_dev is not None else None
+            if mod.cin % 8 == 0 and mod.cin <= 32 and mod.cout <= 32:          # matrix-core form
+                wp = self._packed_weight(mod, dev)
+                L.check(lib.gpnerf_sparse_conv3_mfma(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims),
+                                                     coords.data_ptr(), mp, m_cap, wp.data_ptr(), mod.cout, scale.data_ptr(),
+                                                     shift.data_ptr(), out.data_ptr(), st), "gpnerf_sparse_conv3_mfma")
+            else:
+                w = mod.weight.detach().float().contiguous()
+                L.check(lib.gpnerf_sparse_conv3(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims), coords.data_ptr(),
+                                                mp, m_cap, w.data_ptr(), mod.cout, scale.data_ptr(), shift.data_ptr(),
+                                                out.data_ptr(), st), "gpnerf_sparse_conv3")
             return out
 
         dims = tuple(int(v) for v in out_sh)

@@ -204,6 +204,15 @@ int gpnerf_sparse_index(const int32_t* coords, const int32_t* m_dev, int32_t m_c
 int gpnerf_sparse_conv3(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
                         const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const float* weight, int32_t cout,
                         const float* bn_scale, const float* bn_shift, float* out, void* stream);
+/* The same convolution on the matrix cores (32 output sites per wavefront, v_mfma_f32_32x32x2_f32; cin a multiple of 8,
+ * cin, cout <= 32).  packed_weight: device copy of gpnerf_sparse_pack_weight()'s image of the [27][cin][cout] weight
+ * (host side, model-load time; gpnerf_sparse_packed_weight_floats(cin) floats).  Same result as gpnerf_sparse_conv3 up to
+ * fp32 summation order. */
+int64_t gpnerf_sparse_packed_weight_floats(int32_t cin);
+int gpnerf_sparse_pack_weight(const float* weight_host, int32_t cin, int32_t cout, float* packed_host);
+int gpnerf_sparse_conv3_mfma(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
+                             const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const float* packed_weight,
+                             int32_t cout, const float* bn_scale, const float* bn_shift, float* out, void* stream);
 /* Before the first strided conv: feat[owner] += feat[i] for every row i whose voxel is indexed by another row (two
  * vertices rounded into one voxel).  spconv's strided rulebook takes every input row; its submanifold lookups one. */
 int gpnerf_sparse_merge_duplicates(float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, int32_t m,

@@ -210,14 +210,15 @@ def test_progressive_renderer_returns_pred_img(plugins, syn, oracle):
     assert np.abs(ret["pred_img"][~mref.reshape(H, W)]).max() == 0
 
 
-def test_hip_volume_builder_matches_dense_conv_formulation(syn):
+@pytest.mark.parametrize("in_dim", [32, 16, 12])      # 32, 16: every conv on the matrix cores; 12: the first one on the VALU form
+def test_hip_volume_builder_matches_dense_conv_formulation(in_dim, syn):
     """gpnerf_volume.hip (SubM / strided sparse conv + folded BN + ReLU, channels-last .dense()) against the rulebook
     restatement in volume.py, which tests/test_volume_builder.py pins to a dense conv3d-with-mask formulation.
     The synthetic vertices round into shared voxels, so spconv's duplicate-row semantics are exercised too."""
     vol = importlib.import_module("gp-nerf_amd.volume")
     torch.manual_seed(0)
     dev = "cuda:0"
-    net = vol.SparseConvNet(n_layers=4, in_dim=32, out_dim=[32, 32, 32, 32]).to(dev).eval()
+    net = vol.SparseConvNet(n_layers=4, in_dim=in_dim, out_dim=[32, 32, 32, 32]).to(dev).eval()
     for m in net.modules():                                  # non-trivial BatchNorm statistics
         if isinstance(m, torch.nn.BatchNorm1d):
             m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
@@ -225,7 +226,7 @@ def test_hip_volume_builder_matches_dense_conv_formulation(syn):
     coord = torch.from_numpy(sc["coord"][0]).to(dev)
     coord4 = torch.cat([torch.zeros((coord.shape[0], 1), dtype=coord.dtype, device=dev), coord], 1)
     out_sh = [int(v) for v in sc["out_sh"][0]]
-    code = torch.randn((coord.shape[0], 32), device=dev)
+    code = torch.randn((coord.shape[0], in_dim), device=dev)
     with torch.no_grad():
         hip = net.dense_levels_hip(code, coord4, out_sh)
         ref = net.dense_levels(code, coord4, out_sh)
