@@ -84,6 +84,8 @@ SYMBOLS = {
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "gpnerf_instance_norm_act": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gpnerf_upsample2x": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_vertex_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p]),
     "gpnerf_build_occupancy": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_void_p]),
     "gpnerf_sparse_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),

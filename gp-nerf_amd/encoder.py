@@ -2,9 +2,11 @@
 state_dict keys (libs/encoders/UNet.py:133-242), so `load_state_dict(strict=True)` of a reference checkpoint works.
 
 Per frame, not per ray: V=3 source images [V,3,H,W] -> feature maps [V,32,H/4,W/4], ~16 GFLOP of 3x3 convolutions at
-512x512.  The convolutions are plain library calls (MIOpen through torch, channels-last); what is built for this path is
-the hand-over: the result leaves with channels-last strides (logical NCHW, physical NHWC), which is the layout the render
-kernel gathers from, so `Frame` takes it as is, without the NCHW -> NHWC re-layout launch.
+512x512.  The convolutions are plain library calls (MIOpen through torch).  Built for this path: (1) on the GPU at
+inference every InstanceNorm runs fused with the residual add and activation behind it, and the two bilinear upsamplings run
+as one launch each (gpnerf_instance_norm_act / gpnerf_upsample2x in csrc/gpnerf_encoder.hip; stock torch spends ~180 tiny
+launches there); (2) the hand-over: the result leaves with channels-last strides (logical NCHW, physical NHWC), which is
+the layout the render kernel gathers from, so `Frame` takes it as is, without the NCHW -> NHWC re-layout launch.
 
 Network (UNet.py:154-234): 7x7/2 stem -> three residual stages of [3,4,6] two-conv units at 64/128/256 channels, every stage
 entered with stride 2 (there is no max-pool), all 3x3 / 7x7 convolutions reflect-padded, every normalisation an affine
@@ -14,6 +16,8 @@ InstanceNorm + ELU -> 1x1 output convolution.
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib as L
 
 # UNet.py:151 fixes the stage depths to [3,4,6] whatever the name says.  The names resnet50/101/152 only widen the decoder's
 # expected skip channels (UNet.py:142-145) while the stages stay 64/128/256 wide, so the reference's own forward fails
@@ -29,6 +33,33 @@ def _conv(cin, cout, k, stride=1, bias=False):
     return nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=bias, padding_mode="reflect")
 
 
+def _fused(x, training):
+    """The HIP glue kernels serve GPU inference; training and CPU tensors take the torch operators."""
+    return x.is_cuda and not training and not torch.is_grad_enabled()
+
+
+def _norm_act(norm, x, act, residual=None):
+    """act(InstanceNorm(x) [+ residual]) as one launch; act: 0 none, 1 ReLU, 2 ELU."""
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    res = residual.contiguous() if residual is not None else None
+    L.check(L.lib().gpnerf_instance_norm_act(x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(),
+                                             res.data_ptr() if res is not None else None, n, c, h * w, float(norm.eps), act,
+                                             out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+            "gpnerf_instance_norm_act")
+    return out
+
+
+def _upsample2x(x):
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, 2 * h, 2 * w), device=x.device, dtype=x.dtype)
+    L.check(L.lib().gpnerf_upsample2x(x.data_ptr(), n * c, h, w, out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+            "gpnerf_upsample2x")
+    return out
+
+
 class ResidualUnit(nn.Module):
     """Two 3x3 convolutions + identity / projected shortcut (UNet.py:17-53).  Attribute names are the checkpoint's."""
 
@@ -41,6 +72,10 @@ class ResidualUnit(nn.Module):
             self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), _inorm(cout))
 
     def forward(self, x):
+        if _fused(x, self.training):
+            y = self.conv2(_norm_act(self.bn1, self.conv1(x), 1))
+            idn = x if self.downsample is None else _norm_act(self.downsample[1], self.downsample[0](x), 0)
+            return _norm_act(self.bn2, y, 1, residual=idn)
         y = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
         return F.relu(y + (x if self.downsample is None else self.downsample(x)))
 
@@ -53,6 +88,8 @@ class ConvNormELU(nn.Module):
         self.conv, self.bn = _conv(cin, cout, k, bias=True), _inorm(cout)
 
     def forward(self, x):
+        if _fused(x, self.training):
+            return _norm_act(self.bn, self.conv(x), 2)
         return F.elu(self.bn(self.conv(x)))
 
 
@@ -65,6 +102,8 @@ class UpsampleConv(nn.Module):
         self.conv = ConvNormELU(cin, cout, k)
 
     def forward(self, x):
+        if self.scale == 2 and x.dtype == torch.float32 and _fused(x, self.training):
+            return self.conv(_upsample2x(x))
         return self.conv(F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=True))
 
 
@@ -99,12 +138,10 @@ class ResUNet(nn.Module):
         self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
 
     def forward(self, x):
-        """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the whole net runs channels-last and the result keeps
-        channels-last strides, which `Frame` recognises (no re-layout launch)."""
+        """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the result leaves with channels-last strides, which `Frame`
+        recognises (no re-layout launch)."""
         on_gpu = x.is_cuda
-        if on_gpu:
-            x = x.contiguous(memory_format=torch.channels_last)
-        x = F.relu(self.bn1(self.conv1(x)))
+        x = _norm_act(self.bn1, self.conv1(x), 1) if _fused(x, self.training) else F.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)

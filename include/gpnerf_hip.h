@@ -232,6 +232,14 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
                             const float* fc, int32_t n, int32_t d_model, int32_t kv_dim, int32_t n_head, int32_t views,
                             float* out, void* stream);
 
+/* Image-encoder glue (libs/encoders/UNet.py), NCHW device tensors.
+ * instance_norm_act: out = act(InstanceNorm2d(x; gamma, beta, eps, biased variance, no running statistics) [+ residual]),
+ *   act 0 = none (UNet.py:180-183 shortcut), 1 = ReLU (:38-53), 2 = ELU (:117-120); residual may be NULL.
+ * upsample2x: F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (UNet.py:129) on [planes][h][w]. */
+int gpnerf_instance_norm_act(const float* x, const float* gamma, const float* beta, const float* residual, int32_t n, int32_t c,
+                             int64_t hw, float eps, int32_t act, float* out, void* stream);
+int gpnerf_upsample2x(const float* x, int64_t planes, int32_t h, int32_t w, float* out, void* stream);
+
 /* Channels-last re-layouts of the per-frame tensors (device -> device). */
 int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t H, int32_t W, void* stream);
 int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t H, int32_t W, void* stream);
