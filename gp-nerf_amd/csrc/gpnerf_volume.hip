@@ -86,24 +86,43 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict_
     f32x16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // all 27 neighbour rows first (independent loads, one round trip), then the taps with the next tap's channels in
+    // flight while this tap's MFMAs run
+    int nbr[KV];
+#pragma unroll
     for (int k = 0; k < KV; ++k) {
         const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
         const int d = (STRIDED ? 2 * od : od) - 1 + kd, h = (STRIDED ? 2 * oh : oh) - 1 + kh, w = (STRIDED ? 2 * ow : ow) - 1 + kw;
         const bool inb = valid && d >= 0 && d < in_dims.d && h >= 0 && h < in_dims.h && w >= 0 && w < in_dims.w;
-        const int j = inb ? in_grid[cell_of(in_dims, d, h, w)] : -1;
-        if (!__any(j >= 0)) continue;                           // no site of the tile has this neighbour
+        nbr[k] = inb ? in_grid[cell_of(in_dims, d, h, w)] : -1;
+    }
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tap = [&](int k, f32x4v (&b)[4]) {
+        const int j = nbr[k];
         const float* x = in + (size_t)(j < 0 ? 0 : j) * cin + half * half_c;
-        const float* wk = Wp + ((size_t)k * ng * 64 + lane) * 4;
-#pragma unroll 4
-        for (int g = 0; g < ng; ++g) {
-            f32x4v b = {0.f, 0.f, 0.f, 0.f};
-            if (j >= 0) b = *reinterpret_cast<const f32x4v*>(x + 4 * g);
-            const f32x4v a = *reinterpret_cast<const f32x4v*>(wk + (size_t)g * 256);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = (g < ng && j >= 0) ? *reinterpret_cast<const f32x4v*>(x + 4 * g) : zero4;
+    };
+    f32x4v cur[4], nxt[4];
+    load_tap(0, cur);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        if (k + 1 < KV) load_tap(k + 1, nxt);
+        if (__any(nbr[k] >= 0)) {                               // some site of the tile has this neighbour
+            const float* wk = Wp + ((size_t)k * ng * 64 + lane) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < ng) {
+                    const f32x4v a = *reinterpret_cast<const f32x4v*>(wk + (size_t)g * 256);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], cur[g][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], cur[g][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], cur[g][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], cur[g][3], acc, 0, 0, 0);
+                }
+            }
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cur[g] = nxt[g];
     }
     if (!valid) return;
 #pragma unroll

@@ -186,11 +186,19 @@ class SparseConvNet(nn.Module):
         self.net = nn.ModuleList(net)
 
     # ---- the MI355X-native path: gpnerf_volume.hip ---------------------------------------------------------
-    @staticmethod
-    def _folded_bn(bn):
-        """inference-mode BatchNorm1d as y = x * scale + shift"""
-        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-        return scale.float().contiguous(), (bn.bias - bn.running_mean * scale).float().contiguous()
+    def _folded_bn(self, bn):
+        """inference-mode BatchNorm1d as y = x * scale + shift; cached until a parameter or running statistic changes
+        (five tiny launches per convolution otherwise, every frame)."""
+        ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        cache = self.__dict__.setdefault("_bn_cache", {})
+        hit = cache.get(id(bn))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                hit = (key, scale.float().contiguous(), (bn.bias - bn.running_mean * scale).float().contiguous())
+            cache[id(bn)] = hit
+        return hit[1], hit[2]
 
     def _packed_weight(self, mod, dev):
         """gpnerf_sparse_pack_weight image of a conv's [3,3,3,Cin,Cout] weight on `dev`, re-packed when the parameter changes."""
