@@ -12,6 +12,7 @@ import torch
 import torch.distributed as dist
 
 TILE = 32  # rays one wavefront renders together; shard boundaries stay tile-aligned
+INTERLEAVE_BAND = 2048  # rays per round-robin band of render_sharded: 64 tiles = 8 workgroups of the fused kernel
 
 
 def shard_bounds(n_rays, world, tile=TILE):
@@ -50,19 +51,46 @@ def all_gather_ragged(local, bounds, group=None):
     return torch.cat([p[: e - s] for p, (s, e) in zip(parts, bounds)], dim=0)
 
 
-def render_sharded(render_fn, rays, keys=("rgb_map", "depth_map", "acc_map", "disp_map"), group=None):
-    """Strong scaling of one frame: every rank renders its block of `rays` with `render_fn(rays_block) -> dict`
-    and receives the full maps.  With no process group this is just render_fn(rays)."""
+def interleaved_indices(n_rays, world, band=INTERLEAVE_BAND):
+    """Round-robin bands of `band` rays (a multiple of the 32-ray tile): rank r owns bands r, r + world, ...  Per-ray cost
+    varies smoothly over the image (empty space, early termination, culling), so interleaving evens the ranks' work where
+    contiguous blocks do not.  Returns one index tensor per rank; together they cover 0..n_rays-1 once."""
+    idx = torch.arange(n_rays)
+    owner = (idx // band) % world
+    return [idx[owner == r] for r in range(world)]
+
+
+def render_sharded(render_fn, rays, keys=("rgb_map", "depth_map", "acc_map", "disp_map"), group=None, interleave=True):
+    """Strong scaling of one frame: every rank renders its share of `rays` with `render_fn(rays_share) -> dict`
+    and receives the full maps.  With no process group this is just render_fn(rays).
+    interleave: round-robin bands (load balance) instead of one contiguous block per rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return render_fn(rays)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    bounds = shard_bounds(rays.shape[0], world)
-    s, e = bounds[rank]
-    local = render_fn(rays[s:e])
+    n = rays.shape[0]
+    if interleave:
+        shares = interleaved_indices(n, world)
+        mine = shares[rank].to(rays.device)
+        local = render_fn(rays.index_select(0, mine))
+        sizes, start = [int(s.numel()) for s in shares], 0
+        bounds = []
+        for sz in sizes:
+            bounds.append((start, start + sz))
+            start += sz
+        order = torch.cat(shares).to(rays.device)              # gathered row i holds ray order[i]
+    else:
+        bounds = shard_bounds(n, world)
+        s, e = bounds[rank]
+        local = render_fn(rays[s:e])
+        order = None
     full = {}
     for k in keys:
         v = local[k]
         v2 = v if v.dim() > 1 else v[:, None]
         g = all_gather_ragged(v2.contiguous(), bounds, group)
+        if order is not None:
+            out = torch.empty_like(g)
+            out.index_copy_(0, order, g)
+            g = out
         full[k] = g if v.dim() > 1 else g[:, 0]
     return full

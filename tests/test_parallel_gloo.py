@@ -23,6 +23,21 @@ def test_shard_bounds_are_tile_aligned_and_cover():
             assert max(sizes) - min(sizes) <= 32 + 31
 
 
+def test_interleaved_bands_partition_the_rays():
+    par = importlib.import_module("gp-nerf_amd.parallel")
+    for n in (0, 1, 2047, 2048, 2049, 10000, 262144):
+        for world in (1, 2, 3, 8):
+            shares = par.interleaved_indices(n, world)
+            assert len(shares) == world
+            allidx = torch.cat(shares)
+            assert allidx.numel() == n and torch.equal(torch.sort(allidx).values, torch.arange(n))
+            for r, sh in enumerate(shares):
+                assert bool(((sh // par.INTERLEAVE_BAND) % world == r).all())
+            if n >= world * par.INTERLEAVE_BAND * 4:
+                sizes = [s.numel() for s in shares]
+                assert max(sizes) - min(sizes) <= par.INTERLEAVE_BAND
+
+
 def _fake_render(rays):
     # any per-ray function stands in for the kernel: shard-invariance is what is under test
     s = rays.sum(1)
@@ -35,9 +50,11 @@ def _worker(rank, world, port, n, q):
     par = importlib.import_module("gp-nerf_amd.parallel")
     g = torch.Generator().manual_seed(7)
     rays = torch.rand((n, 8), generator=g)
-    full = par.render_sharded(_fake_render, rays)
     ref = _fake_render(rays)
-    ok = all(torch.equal(full[k], ref[k]) for k in ref)
+    ok = True
+    for interleave in (True, False):
+        full = par.render_sharded(_fake_render, rays, interleave=interleave)
+        ok = ok and all(torch.equal(full[k], ref[k]) for k in ref)
     # equal-sized shards, the bench's collective
     s, e = par.shard_bounds(n - n % (32 * world), world)[rank]
     local = _fake_render(rays[s:e])
@@ -50,7 +67,7 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [667, 4096])
+@pytest.mark.parametrize("n", [667, 4096, 9000])
 def test_render_sharded_equals_unsharded_world2(n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
