@@ -1268,6 +1268,7 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
 // (32 rays x S samples) is long, so a grid that is not many times 256 workgroups quantises badly.  Choose the waves per
 // workgroup and, when the caller lends a workspace, how many waves share the samples of one tile (split), minimising
 // rounds x step time x samples per unit.  GPNERF_WAVES / GPNERF_SPLIT override (diagnostics).
+constexpr int GPNERF_MAX_SPLIT = 8;     // waves that may share one tile's samples
 struct Geometry { int waves, split; };
 
 Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, int64_t n_rays) {
@@ -1279,14 +1280,14 @@ Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, 
     const int64_t cus = 256;
     Geometry best{8, 1};
     double best_t = 1e300;
-    for (int split = 1; split <= 4; split *= 2) {
+    for (int split = 1; split <= GPNERF_MAX_SPLIT; split *= 2) {
         if (split > 1 && (!may_split || S / split < 8 || ws_bytes < (size_t)n_rays * split * 16 * sizeof(float))) continue;
         if (f_split > 0 && split != f_split && !(split == 1 && f_split > 1 && !may_split)) continue;
         for (int w = GPNERF_MAX_WAVES; w >= 1; --w) {
             if (f_waves > 0 && w != f_waves) continue;
             const int64_t blocks = (tiles * split + w - 1) / w;
             const int64_t rounds = (blocks + cus - 1) / cus;
-            const double step = w <= 4 ? 85.7 : (w <= 8 ? 134.0 : 190.0);  // kilo-cycles per 32-sample step
+            const double step = w <= 4 ? 82.0 : (w <= 8 ? 133.0 : 190.0);  // kilo-cycles per 32-sample step (measured)
             const double t = (double)rounds * step * ((double)S / split) + (split > 1 ? 60.0 : 0.0);
             if (t < best_t * 0.97) { best_t = t; best = Geometry{w, split}; }   // ties: wider workgroup, no split
         }
@@ -1506,8 +1507,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
 
 size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples) {
     (void)n_samples;
-    // room for 4 sample segments per ray, 16 floats each; only frames small enough to profit from splitting
-    return n_rays > 0 && n_rays <= 131072 ? (size_t)n_rays * 4 * 16 * sizeof(float) : 0;
+    // room for GPNERF_MAX_SPLIT sample segments per ray, 16 floats each; only frames small enough to profit from splitting
+    return n_rays > 0 && n_rays <= 131072 ? (size_t)n_rays * GPNERF_MAX_SPLIT * 16 * sizeof(float) : 0;
 }
 
 int gpnerf_sample_points(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, float* pts,
