@@ -125,6 +125,10 @@ def lib():
             raise GpnerfError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C gp-nerf_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
+        # torch first: it bundles its own HIP runtime, and the one that is loaded first serves the whole process.  Loaded the
+        # other way round, this library binds to the system runtime while torch's streams and allocations live in another
+        # one, and every launch fails.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the ABI and the header drift apart
