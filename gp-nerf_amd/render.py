@@ -133,7 +133,11 @@ class Renderer(nn.Module):
         pred_img[mask_np.reshape(H, W)] = rgb.cpu().numpy()
         t4 = time.time()
         return {"rgb_map": rgb.cpu().numpy(), "pred_img": pred_img, "mask_at_box": mask_np.reshape(-1),
-                "time_slots": {"frame": t1 - t0, "ray_select": t2 - t1, "render": t3 - t2, "bc_render": t4 - t3},
+                # this path's own phases, plus the reference's ten keys (demo_render.py:97-357) so that consumers indexing them
+                # keep working: its per-frame phases collapse into `sp_encode`, its sigma / rgb passes into `sigma_f`
+                "time_slots": {"frame": t1 - t0, "ray_select": t2 - t1, "render": t3 - t2, "bc_render": t4 - t3,
+                               "bc_time": t2 - t1, "sigma_c": 0.0, "bc_attn": 0.0, "sigma_attn": 0.0, "sp_encode": t1 - t0,
+                               "bf_sigma": 0.0, "sigma_f": t3 - t2, "bf_rgb": 0.0, "rgb_f": 0.0},
                 "etime": t1 - t0, "rtime": t4 - t0}
 
     # ---- the hot path ---------------------------------------------------------------------------------
