@@ -252,3 +252,17 @@ def test_random_scene_sweep_matches_oracle(fm, oracle, syn):
                 worst = max(worst, float(np.nanmax(np.abs(got[k].astype(np.float64) - ref[k])))) if got[k].size else worst
             assert np.array_equal(got["ray_mask"], ref["ray_mask"])
     assert worst < 2e-5, worst
+
+
+@pytest.mark.parametrize("split_f16", [False, True])
+def test_render_is_deterministic(split_f16, fm, syn):
+    """No atomics, no order-dependent reductions on the per-ray path: two launches give identical bits (also with the
+    sample-split launch geometry, whose segment merge runs in a fixed order)."""
+    sc = syn.make_scene(H=48, W=48, seed=9, fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1)
+    fr = build_frame(fm, sc)
+    rays = rays_of(sc)
+    for lb in (False, True):
+        a = fm.render_fused(fr, rays, 32, split_f16=split_f16, load_balance=lb)
+        b = fm.render_fused(fr, rays, 32, split_f16=split_f16, load_balance=lb)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, lb)
