@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--occupancy", type=float, default=None, help="fraction of coarse volume blocks that are occupied")
     ap.add_argument("--ray-order", default="patch", choices=["patch", "raster"],
                     help="patch: 32x8-pixel workgroup tiles (gpnerf_render_fused's ray_order); raster: the list as given")
+    ap.add_argument("--patch", default="32x8", help="WxH of the patches of --ray-order patch (W*H a multiple of 32: one patch row or one whole patch per wavefront)")
     return ap.parse_args()
 
 
@@ -91,7 +92,8 @@ def main():
     n_local = rays.shape[0]
     order = None
     if args.ray_order == "patch":
-        order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], H, W)).to(dev)
+        pw, ph = (int(v) for v in args.patch.split("x"))
+        order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], H, W, patch_w=pw, patch_h=ph)).to(dev)
     n_total = n_local * world
     torch.cuda.synchronize()
 

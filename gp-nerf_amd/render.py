@@ -123,8 +123,9 @@ class Renderer(nn.Module):
                                     batch["bounds"][0, 0], batch["Rh"][0], batch["Th"][0], neg_ray=neg)
         torch.cuda.synchronize(dev)
         t2 = time.time()
+        order = F_.patch_order_device(mask, H, W) if rays.shape[0] else None     # compact wave tiles: cull whole tiles
         o = F_.render_fused(frame, rays, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
-                            occ_cull=True, want=(), split_f16=self.split_f16)
+                            occ_cull=True, want=(), split_f16=self.split_f16, ray_order=order)
         rgb = o["rgb_map"]
         torch.cuda.synchronize(dev)
         t3 = time.time()

@@ -36,3 +36,17 @@ def test_renderer_refuses_training_mode():
     head = importlib.import_module("gp-nerf_amd.head")
     with pytest.raises(Exception, match="inference-only"):
         render.Renderer(None, head.NeRFHead(code_dim=32), is_train=True)
+
+
+def test_patch_order_device_equals_host_version():
+    """frame.patch_order_device (torch ops, used by the progressive renderer) is the same permutation as patch_order."""
+    import importlib
+    import numpy as np
+    import torch
+    fm = importlib.import_module("gp-nerf_amd.frame")
+    g = np.random.Generator(np.random.PCG64(1))
+    for H, W in ((16, 16), (33, 40), (24, 7)):
+        m = g.random((H * W,)) < 0.6
+        a = fm.patch_order(m, H, W, patch_w=4, patch_h=8)
+        b = fm.patch_order_device(torch.from_numpy(m), H, W).numpy()
+        assert np.array_equal(a, b) and sorted(a.tolist()) == list(range(int(m.sum())))
