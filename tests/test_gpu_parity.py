@@ -173,23 +173,28 @@ def test_ray_order_changes_tiling_not_results(fm, syn):
             assert torch.equal(torch.nan_to_num(got[k].float()), torch.nan_to_num(base[k].float())), k
 
 
-def test_progressive_sample_culling_matches_restatement(fm, oracle, syn):
-    """demo_render.py's occupancy / alpha culling (parity unpinned: restated, the CUDA-only reference path cannot run)."""
+@pytest.mark.parametrize("neg,split_f16,lb", [(False, False, False), (True, False, False), (False, True, False), (False, False, True),
+                                              (True, True, True)])
+def test_progressive_sample_culling_matches_restatement(neg, split_f16, lb, fm, oracle, syn):
+    """demo_render.py's occupancy / alpha culling (parity unpinned: restated, the CUDA-only reference path cannot run).
+    The kernel walks a per-lane sample cursor here, so neg_ray, both forms and the sample-split geometry are all covered."""
     sc = syn.make_scene(H=24, W=24, seed=77, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1,
-                        vol_occupancy=0.35)
+                        vol_occupancy=0.35, neg_cams=neg)
     S = 48
     fr = build_frame(fm, sc)
     occ = fr.build_occupancy().cpu().numpy()
     occ_ref = oracle.build_occupancy(sc)
     assert_close(occ, occ_ref, 1e-4, "masks3d")
     assert 0.2 < (occ_ref > 0).mean() < 0.8
-    got = cpu(fm.render_fused(fr, rays_of(sc), S, occ_cull=True, want=("weights", "raw", "z_vals")))
-    ref = oracle.render(sc, S, stages=True, occ=occ_ref)
-    for k in ("rgb_map", "acc_map", "depth_map", "weights"):
+    got = cpu(fm.render_fused(fr, rays_of(sc), S, neg_ray=neg, occ_cull=True, split_f16=split_f16, load_balance=lb,
+                              want=("weights", "raw", "z_vals", "rgb_in")))
+    ref = oracle.render(sc, S, neg_ray=neg, stages=True, occ=occ_ref)
+    for k in ("rgb_map", "acc_map", "depth_map", "weights", "rgb_in_map"):
         assert_close(got[k], ref[k], TOL, k)
+    assert_close(got["z_vals"], ref["z_vals"], 1e-6, "z_vals")
     assert_close(got["raw"], ref["st_raw"], TOL, "raw")
     culled = (ref["st_raw"][..., 3] == 0).mean()
-    dense = cpu(fm.render_fused(fr, rays_of(sc), S))
+    dense = cpu(fm.render_fused(fr, rays_of(sc), S, neg_ray=neg))
     assert culled > 0.3 and np.abs(dense["acc_map"] - got["acc_map"]).max() > 1e-3, "the scene does not exercise culling"
 
 
