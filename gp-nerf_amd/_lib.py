@@ -61,6 +61,7 @@ FLAG_NEG_RAY = 1
 FLAG_EARLY_TERM = 2
 FLAG_OCC_CULL = 4
 FLAG_SPLIT_F16 = 8
+FLAG_FLIP_SAMPLES = 16
 
 # every symbol include/gpnerf_hip.h declares: (restype, argtypes)
 SYMBOLS = {
@@ -82,8 +83,7 @@ SYMBOLS = {
     "gpnerf_make_rays": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_select_pixels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, FP, FP, FP, FP, FP, FP, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p]),
+    "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_instance_norm_act": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_upsample2x": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_vertex_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p]),

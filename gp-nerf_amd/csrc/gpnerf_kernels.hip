@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/gpnerf_hip.h"
 #include "head_layout.h"
 
@@ -700,7 +702,8 @@ render_fused_kernel(const KArgs ka) {
     const bool active = (ray0 + n) < n_rays;
     const long slot = active ? ray0 + n : n_rays - 1;
     const long ray = ka.out.order ? (long)ka.out.order[slot] : slot;
-    const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;
+    const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;             // Projector front test
+    const bool flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;       // raw2outputs(neg=True)
     const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
     const bool cull = (flags & GPNERF_FLAG_OCC_CULL) != 0 && ka.fr.occ != nullptr;
 
@@ -727,7 +730,7 @@ render_fused_kernel(const KArgs ka) {
         const __attribute__((address_space(4))) OutK& out = kp->out;
         // raw2outputs(neg=True) flips rgb and sigma along the ray but not z (BaseRender.py:86-88,101):
         // composite step k consumes the network output of sample S-1-k.
-        const int ks = neg ? (S - 1 - k) : k;
+        const int ks = flip ? (S - 1 - k) : k;
         // get_sampling_points (BaseRender.py:37-38,48), jitter off
         const float t = (S > 1) ? linspace01(ks, S, step) : 0.f;
         const float z = near * (1.f - t) + far * t;
@@ -783,7 +786,7 @@ render_fused_kernel(const KArgs ka) {
             vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
             nvalid += s.valid;
         }
-        if (nvalid > 1.f) ++n_two;                      // pixel_mask (:139)
+        if (nvalid > 1.f && keep) ++n_two;              // pixel_mask (:139); culled samples never count
 
         STAMP(st, 2);
         float sigma, rgb[3];
@@ -802,7 +805,7 @@ render_fused_kernel(const KArgs ka) {
         // rgb_in_map (:147) pairs weight k with the UN-flipped rgb_in of sample k
         float irgb[NV][3];
         float zk = z;
-        if (neg) {
+        if (flip) {
             const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
             zk = near * (1.f - tk) + far * tk;
             const float ax_ = ox + dx * zk, ay_ = oy + dy * zk, az_ = oz + dz * zk;
@@ -1058,7 +1061,10 @@ __global__ void composite_kernel(const float* __restrict__ raw, const float* __r
 // ---------------------------------------------------------------------------------------------
 // get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130), one lane per pixel
 // ---------------------------------------------------------------------------------------------
-struct RayCam { float Kinv[9], Rinv[9], o[3], bmin[3], bmax[3]; };
+struct RayCam { float Kinv[9], Rinv[9], o[3], bmin[3], bmax[3], T[3]; };
+
+// one length-3 row of torch's CPU `@` (sgemm): k = 0, 1, 2 accumulated with fused multiply-adds (oracle: MM3)
+DEV float mm3(float a0, float b0, float a1, float b1, float a2, float b2) { return fmaf(a2, b2, fmaf(a1, b1, a0 * b0)); }
 
 // demo != 0: the inference renderer's variant (libs/renders/demo_render.py:201-239): box used as given, no small-|d|
 // clamp, d1 negated under neg_ray instead of the sign test; sel (optional) restricts the pixels considered (:179-200)
@@ -1069,14 +1075,23 @@ __global__ void make_rays_kernel(const int H, const int W, const RayCam cam, con
     if (sel && !sel[idx]) { hit[idx] = 0; return; }
     const float i = (float)(idx % W), j = (float)(idx / W);
     float pc[3], d[3];
+    if (demo) {
+        // pixel_camera = xy1 @ K_inv^T; pixel_world = (pixel_camera - T) @ R; rays_d = pixel_world - rays_o (demo_render.py:204-210)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) pc[a] = (i * cam.Kinv[a * 3 + 0] + j * cam.Kinv[a * 3 + 1]) + cam.Kinv[a * 3 + 2];   // xy1 @ K^-T
+        for (int a = 0; a < 3; ++a) pc[a] = mm3(i, cam.Kinv[a * 3 + 0], j, cam.Kinv[a * 3 + 1], 1.f, cam.Kinv[a * 3 + 2]);
+        const float t0 = pc[0] - cam.T[0], t1 = pc[1] - cam.T[1], t2 = pc[2] - cam.T[2];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float pw = ((pc[0] * cam.Rinv[a * 3 + 0] + pc[1] * cam.Rinv[a * 3 + 1]) + pc[2] * cam.Rinv[a * 3 + 2]) + cam.o[a];
-        float da = pw - cam.o[a];
-        if (!demo && fabsf(da) < 1e-5f) da = 1e-5f;   // ray_d[np.abs(ray_d) < 1e-5] = 1e-5 (:101)
-        d[a] = da;
+        for (int a = 0; a < 3; ++a) d[a] = mm3(t0, cam.Rinv[a * 3 + 0], t1, cam.Rinv[a * 3 + 1], t2, cam.Rinv[a * 3 + 2]) - cam.o[a];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pc[a] = (i * cam.Kinv[a * 3 + 0] + j * cam.Kinv[a * 3 + 1]) + cam.Kinv[a * 3 + 2];   // xy1 @ K^-T
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float pw = ((pc[0] * cam.Rinv[a * 3 + 0] + pc[1] * cam.Rinv[a * 3 + 1]) + pc[2] * cam.Rinv[a * 3 + 2]) + cam.o[a];
+            float da = pw - cam.o[a];
+            if (fabsf(da) < 1e-5f) da = 1e-5f;   // ray_d[np.abs(ray_d) < 1e-5] = 1e-5 (:101)
+            d[a] = da;
+        }
     }
     const float eps = 1e-6f;
     float p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
@@ -1099,12 +1114,16 @@ __global__ void make_rays_kernel(const int H, const int W, const RayCam cam, con
     hit[idx] = (uint8_t)keep;
     float near = 0.f, far = 0.f;
     if (keep) {
-        const float nd = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        // the demo renderer's torch.norm(dim=1) is sqrt(fma(z, z, fma(y, y, x*x))) on the CPU path (demo_render.py:232-234)
+        const auto norm3 = [demo](float x, float y, float z) {
+            return demo ? sqrtf(fmaf(z, z, fmaf(y, y, x * x))) : sqrtf((x * x + y * y) + z * z);
+        };
+        const float nd = norm3(d[0], d[1], d[2]);
         const float v0x = p0[0] - cam.o[0], v0y = p0[1] - cam.o[1], v0z = p0[2] - cam.o[2];
         const float v1x = p1[0] - cam.o[0], v1y = p1[1] - cam.o[1], v1z = p1[2] - cam.o[2];
         const float sg = (!demo && ((v0x * d[0] + v0y * d[1]) + v0z * d[2]) < 0.f) ? -1.f : 1.f;     // both from p0 (:123,126)
-        const float d0 = sqrtf((v0x * v0x + v0y * v0y) + v0z * v0z) / nd * sg;
-        const float d1 = sqrtf((v1x * v1x + v1y * v1y) + v1z * v1z) / nd * ((demo && neg) ? -1.f : sg);
+        const float d0 = norm3(v0x, v0y, v0z) / nd * sg;
+        const float d1 = norm3(v1x, v1y, v1z) / nd * ((demo && neg) ? -1.f : sg);
         near = fminf(d0, d1); far = fmaxf(d0, d1);
     }
     f32x4 a, b;
@@ -1133,14 +1152,14 @@ __global__ void select_pixels_kernel(const float* __restrict__ occ, const int D,
                 sz = (float)d * 2.f * g.voxel[2] + g.bmin[2];
     float p[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) p[a] = ((sx * g.Rh[a * 3 + 0] + sy * g.Rh[a * 3 + 1]) + sz * g.Rh[a * 3 + 2]) + g.Th[a];
+    for (int a = 0; a < 3; ++a) p[a] = mm3(sx, g.Rh[a * 3 + 0], sy, g.Rh[a * 3 + 1], sz, g.Rh[a * 3 + 2]) + g.Th[a];
 #pragma unroll
     for (int a = 0; a < 3; ++a) { atomicMin(mm + a, ordered_int(p[a])); atomicMax(mm + 3 + a, ordered_int(p[a])); }
     float c[3], q[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) c[a] = ((p[0] * g.pose[a * 4 + 0] + p[1] * g.pose[a * 4 + 1]) + p[2] * g.pose[a * 4 + 2]) + g.pose[a * 4 + 3];
+    for (int a = 0; a < 3; ++a) c[a] = mm3(p[0], g.pose[a * 4 + 0], p[1], g.pose[a * 4 + 1], p[2], g.pose[a * 4 + 2]) + g.pose[a * 4 + 3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) q[a] = (c[0] * g.K[a * 3 + 0] + c[1] * g.K[a * 3 + 1]) + c[2] * g.K[a * 3 + 2];
+    for (int a = 0; a < 3; ++a) q[a] = mm3(c[0], g.K[a * 3 + 0], c[1], g.K[a * 3 + 1], c[2], g.K[a * 3 + 2]);
     const float fx = q[0] / q[2], fy = q[1] / q[2];
     if (!(fabsf(fx) < 1e9f) || !(fabsf(fy) < 1e9f)) return;            // .long() of inf/nan is undefined in the reference
     int x0 = (int)fx, y0 = (int)fy;                                     // .long(): truncation toward zero
@@ -1173,6 +1192,10 @@ __global__ void __launch_bounds__(256) cfirst_to_clast32_kernel(const float* __r
         const long p = p0 + pp;
         if (p < P) d[(size_t)p * 32 + c] = tile[c][pp];
     }
+}
+
+__global__ void init_minmax_kernel(int* __restrict__ mm) {
+    if (threadIdx.x < 6) mm[threadIdx.x] = threadIdx.x < 3 ? 0x7FFFFFFF : (int)0x80000000;
 }
 
 // SparseConvNet.encode's masks3d (SparseConvNet.py:135-139): one lane per level-1 voxel
@@ -1271,13 +1294,13 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
 constexpr int GPNERF_MAX_SPLIT = 8;     // waves that may share one tile's samples
 struct Geometry { int waves, split; };
 
-Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, int64_t n_rays) {
+Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, int64_t n_rays, int n_cus) {
     static int f_waves = -1, f_split = -1;
     if (f_waves < 0) {
         const char* e = getenv("GPNERF_WAVES"); f_waves = e ? atoi(e) : 0;
         const char* g = getenv("GPNERF_SPLIT"); f_split = g ? atoi(g) : 0;
     }
-    const int64_t cus = 256;
+    const int64_t cus = n_cus > 0 ? n_cus : 256;
     Geometry best{8, 1};
     double best_t = 1e300;
     for (int split = 1; split <= GPNERF_MAX_SPLIT; split *= 2) {
@@ -1296,6 +1319,41 @@ Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, 
 }
 
 hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Per-device facts and one-time setup, keyed by the CURRENT device of the calling thread: the architecture check
+// (GPNERF_E_DEVICE on anything but gfx950), the CU count the launch geometry balances over, and the opt-in to > 64 KB of
+// dynamic LDS, which is a per-device function attribute (a process that renders on a second GPU needs it there too).
+struct DeviceState { bool probed = false, ok = false; int cus = 0; };
+constexpr int MAX_DEVICES = 64;
+DeviceState g_devices[MAX_DEVICES];
+std::mutex g_devices_mutex;
+
+
+// returns GPNERF_OK and fills *cus, or GPNERF_E_DEVICE
+int device_ready(int* cus) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return GPNERF_E_DEVICE;
+    std::lock_guard<std::mutex> lock(g_devices_mutex);
+    DeviceState& d = g_devices[dev];
+    if (!d.probed) {
+        d.probed = true;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) {
+            d.cus = prop.multiProcessorCount;
+            const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS, lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
+            d.ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+        }
+        (void)hipGetLastError();
+    }
+    if (!d.ok) return GPNERF_E_DEVICE;
+    if (cus) *cus = d.cus;
+    return GPNERF_OK;
+}
 
 int launch_status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
 
@@ -1477,17 +1535,11 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const bool split16 = (flags & GPNERF_FLAG_SPLIT_F16) != 0;
     if (split16 && !f->head_blob_split) return GPNERF_E_ARG;
     const size_t lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split) != hipSuccess)
-            return GPNERF_E_DEVICE;
-        attr_set = true;
-    }
+    int n_cus = 0;
+    if (device_ready(&n_cus) != GPNERF_OK) return GPNERF_E_DEVICE;
+    if (flags & GPNERF_FLAG_OCC_CULL) k.voxel[0] = k.voxel[1] = k.voxel[2] = 0.005f;   // demo_render.py:91 `xyz / 0.005`
     const bool may_split = workspace && !(flags & GPNERF_FLAG_EARLY_TERM);
-    const Geometry g = choose_geometry(tiles, n_samples, may_split, workspace ? workspace_bytes : 0, n_rays);
+    const Geometry g = choose_geometry(tiles, n_samples, may_split, workspace ? workspace_bytes : 0, n_rays, n_cus);
     const int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
     const OutK ok = to_outk(out, ray_order);
     KArgs ka;
@@ -1551,13 +1603,7 @@ int gpnerf_head_forward(const float* head_blob, const float* vol_feat, const flo
     if (n_points == 0) return GPNERF_OK;
     if (!head_blob || !vol_feat || !rgb_feat || !mask || !raw || n_points < 0) return GPNERF_E_ARG;
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return GPNERF_E_DEVICE;
-        attr_set = true;
-    }
+    if (device_ready(nullptr) != GPNERF_OK) return GPNERF_E_DEVICE;
     const int64_t tiles = (n_points + 31) / 32;
     int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
     if (blocks > 1024) blocks = 1024;
@@ -1584,6 +1630,7 @@ int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv,
     memcpy(c.Kinv, Kinv, sizeof(c.Kinv));
     memcpy(c.Rinv, Rinv, sizeof(c.Rinv));
     memcpy(c.o, cam_o, sizeof(c.o));
+    c.T[0] = c.T[1] = c.T[2] = 0.f;
     for (int a = 0; a < 3; ++a) {   // bounds + [-0.01, 0.01] (data_utils.py:98)
         c.bmin[a] = (float)((double)bounds[a] - 0.01);
         c.bmax[a] = (float)((double)bounds[3 + a] + 0.01);
@@ -1608,21 +1655,24 @@ int gpnerf_select_pixels(const float* occ, int32_t D, int32_t H, int32_t W, floa
     memcpy(g.pose, pose, sizeof(g.pose));
     memcpy(g.K, K, sizeof(g.K));
     if (hipMemsetAsync(pixel_sel, 0, (size_t)img_h * img_w, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
-    const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-    if (hipMemcpyAsync(world_minmax, init, sizeof(init), hipMemcpyHostToDevice, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+    hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(64), 0, S_(stream), (int*)world_minmax);
     const long n = (long)D * H * W;
     hipLaunchKernelGGL(select_pixels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), occ, (int)D, (int)H,
                        (int)W, threshold, g, (int)img_h, (int)img_w, pixel_sel, (int*)world_minmax);
     return launch_status();
 }
 
-int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o, const float* bounds,
-                          int32_t neg_ray, const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream) {
-    if (!Kinv || !Rinv || !cam_o || !bounds || !rays || !hit || H < 1 || W < 1) return GPNERF_E_ARG;
+int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* pose, const float* bounds, int32_t neg_ray,
+                          const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream) {
+    if (!Kinv || !pose || !bounds || !rays || !hit || H < 1 || W < 1) return GPNERF_E_ARG;
     RayCam c;
     memcpy(c.Kinv, Kinv, sizeof(c.Kinv));
-    memcpy(c.Rinv, Rinv, sizeof(c.Rinv));
-    memcpy(c.o, cam_o, sizeof(c.o));
+    for (int a = 0; a < 3; ++a) {
+        for (int k = 0; k < 3; ++k) c.Rinv[a * 3 + k] = pose[k * 4 + a];              // column a of R: (x @ R)[a] = sum_k x[k] R[k][a]
+        c.T[a] = pose[a * 4 + 3];
+    }
+    // ori_rays_o = (-R^T) @ T, a [3,3] @ [3,1] product accumulated like every CPU `@` (demo_render.py:203)
+    for (int a = 0; a < 3; ++a) c.o[a] = fmaf(-pose[2 * 4 + a], pose[11], fmaf(-pose[1 * 4 + a], pose[7], (-pose[0 * 4 + a]) * pose[3]));
     for (int a = 0; a < 3; ++a) { c.bmin[a] = bounds[a]; c.bmax[a] = bounds[3 + a]; }   // used as given (demo_render.py:215)
     const int n = H * W, bs = 256;
     hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, 1, (int)neg_ray,

@@ -211,8 +211,11 @@ def patch_order_device(mask, H, W, patch_w=4, patch_h=8):
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
-                 split_f16=False):
+                 split_f16=False, flip=None):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
+    neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); defaults to neg_ray for the dense renderer
+    (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
+    (demo_render.py:329-344).
     ray_order: optional int32 device tensor [N], a permutation that groups rays into cache-friendly tiles.
     load_balance: lend the kernel a workspace so small frames can split a tile's samples over several wavefronts.
     split_f16: dense layers on f16 MFMA with fp32 operands split into hi + lo (GPNERF_FLAG_SPLIT_F16)."""
@@ -242,7 +245,9 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     if "raw" in want:
         res["raw"] = torch.empty((N, S, 4), device=dev)
         o.raw = res["raw"].data_ptr()
-    flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
+    if flip is None:
+        flip = bool(neg_ray) and not occ_cull
+    flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_FLIP_SAMPLES if flip else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
     if split_f16:
         if not frame.c.head_blob_split:
             raise L.GpnerfError("split_f16 needs the f16 hi/lo head image (build the frame from pack_head()'s tensor)")
@@ -353,7 +358,8 @@ def project_gather(frame, pts, neg_ray=False):
     return feat, mask
 
 
-def select_rays(frame, target_K, target_pose, H, W, voxel_size, bounds_min, Rh, Th, neg_ray=False, threshold=0.1):
+def select_rays(frame, target_K, target_pose, H, W, voxel_size, bounds_min, Rh, Th, neg_ray=False, threshold=0.1,
+                target_K_inv=None):
     """Progressive ray selection of the inference renderer (demo_render.py:166-247) on the device:
     occupied voxels -> marked pixels (gpnerf_select_pixels) -> rays with near/far (gpnerf_make_rays_demo).
     Returns (rays [n,8] in raster order of the kept pixels, mask_at_box [H*W] bool)."""
@@ -377,14 +383,12 @@ def select_rays(frame, target_K, target_pose, H, W, voxel_size, bounds_min, Rh, 
     box = bits.view(np.float32).copy()
     box[2] -= np.float32(0.05)
     box[5] += np.float32(0.05)
-    R, T = pose.reshape(3, 4)[:, :3], pose.reshape(3, 4)[:, 3]
-    Kinv = np.ascontiguousarray(np.linalg.inv(K.reshape(3, 3).astype(np.float64)).astype(np.float32))
-    Rinv = np.ascontiguousarray(R.T.astype(np.float32))           # the reference multiplies by R, i.e. uses R^T as the inverse
-    o = np.ascontiguousarray((-(R.T @ T)).astype(np.float32))
-    # pixel_world = (pixel_camera - T) @ R = R^T pixel_camera + o
+    # batch["target_K_inv"] is what the reference multiplies by (demo_render.py:204; the dataset makes it with
+    # np.linalg.inv on the float32 K, ZjumocapDataset.py:480); without it, do the same here
+    Kinv = f32(target_K_inv, 9) if target_K_inv is not None else np.ascontiguousarray(np.linalg.inv(K.reshape(3, 3)).astype(np.float32).ravel())
     rays = torch.empty((H * W, 8), device=dev)
     hit = torch.empty((H * W,), device=dev, dtype=torch.uint8)
-    L.check(lib.gpnerf_make_rays_demo(H, W, p(Kinv), p(Rinv), p(o), p(np.ascontiguousarray(box)), int(bool(neg_ray)),
+    L.check(lib.gpnerf_make_rays_demo(H, W, p(Kinv), p(pose), p(np.ascontiguousarray(box)), int(bool(neg_ray)),
                                       sel.data_ptr(), rays.data_ptr(), hit.data_ptr(), st), "gpnerf_make_rays_demo")
     mask = hit.bool()
     return rays[mask], mask

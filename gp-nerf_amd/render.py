@@ -54,8 +54,19 @@ class Renderer(nn.Module):
 
     # ---- helpers the reference exposes as methods (stage entry points) ----------------------------
     def _neg_ray(self, batch):
-        # BaseRender.py:165-168
-        return self.neg_ray_val if batch["body_msk"].shape[-1] > self.n_rays else self.neg_ray_train
+        # BaseRender.py:165-168; the progressive renderer guards the key lookup (demo_render.py:380-384)
+        if "body_msk" in batch and batch["body_msk"].shape[-1] > self.n_rays:
+            return self.neg_ray_val
+        return self.neg_ray_train
+
+    def encode(self, batch):
+        """`featmaps = self.encoder(src_imgs.squeeze(0))` (BaseRender.py:222, demo_render.py:441): the part of a frame the
+        reference's demo renderer reports as `etime`."""
+        src_imgs = batch["src_imgs"]
+        if src_imgs.shape[0] != 1:
+            raise L.GpnerfError("only batch_size=1 is supported (as BaseRender.py:336 asserts)")
+        featmaps = batch["featmaps"] if "featmaps" in batch else self.encoder(src_imgs.squeeze(0))
+        return featmaps[0] if featmaps.dim() == 5 else featmaps
 
     def prepare_sp_input(self, batch):
         """BaseRender.py:187-209 (the fields the volume builder reads)."""
@@ -70,15 +81,11 @@ class Renderer(nn.Module):
             sp["volumes"] = batch["volumes"]
         return sp
 
-    def build_frame(self, batch):
-        """Per-frame work: encoder, volume pyramid, channels-last re-layout, weight image."""
-        src_imgs = batch["src_imgs"]
-        dev = src_imgs.device
-        if src_imgs.shape[0] != 1:
-            raise L.GpnerfError("only batch_size=1 is supported (as BaseRender.py:336 asserts)")
-        featmaps = batch["featmaps"] if "featmaps" in batch else self.encoder(src_imgs.squeeze(0))  # BaseRender.py:222
-        if featmaps.dim() == 5:
-            featmaps = featmaps[0]
+    def build_frame(self, batch, featmaps=None):
+        """Per-frame work after the encoder: volume pyramid, channels-last re-layout, weight image."""
+        dev = batch["src_imgs"].device
+        if featmaps is None:
+            featmaps = self.encode(batch)
         blob = self.nerfhead.head_blob(dev)
         if "volumes" in batch:
             return F_.Frame.from_batch(batch, featmaps, batch["volumes"], self.voxel_size, blob)
@@ -113,14 +120,18 @@ class Renderer(nn.Module):
         dev = batch["src_imgs"].device
         H, W = batch["src_imgs"].shape[-2:]
         torch.cuda.synchronize(dev)
-        t0 = time.time()
-        frame = self.build_frame(batch)
+        te = time.time()
+        featmaps = self.encode(batch)
+        torch.cuda.synchronize(dev)
+        t0 = time.time()                                     # the reference restarts its clock here (demo_render.py:443-446)
+        frame = self.build_frame(batch, featmaps)
         frame.build_occupancy()
         torch.cuda.synchronize(dev)
         t1 = time.time()
-        neg = self.neg_ray_val
+        neg = self._neg_ray(batch)
         rays, mask = F_.select_rays(frame, batch["target_K"][0], batch["target_pose"][0], H, W, self.voxel_size,
-                                    batch["bounds"][0, 0], batch["Rh"][0], batch["Th"][0], neg_ray=neg)
+                                    batch["bounds"][0, 0], batch["Rh"][0], batch["Th"][0], neg_ray=neg,
+                                    target_K_inv=batch["target_K_inv"][0] if "target_K_inv" in batch else None)
         torch.cuda.synchronize(dev)
         t2 = time.time()
         order = F_.patch_order_device(mask, H, W) if rays.shape[0] else None     # compact wave tiles: cull whole tiles
@@ -139,7 +150,9 @@ class Renderer(nn.Module):
                 "time_slots": {"frame": t1 - t0, "ray_select": t2 - t1, "render": t3 - t2, "bc_render": t4 - t3,
                                "bc_time": t2 - t1, "sigma_c": 0.0, "bc_attn": 0.0, "sigma_attn": 0.0, "sp_encode": t1 - t0,
                                "bf_sigma": 0.0, "sigma_f": t3 - t2, "bf_rgb": 0.0, "rgb_f": 0.0},
-                "etime": t1 - t0, "rtime": t4 - t0}
+                # etime = the encoder alone, rtime = everything after it, as demo_render.py:441-446,494-497 measures them
+                # (libs/trainers/BaseTrainer.py:276 sums rtime into the reported render time)
+                "etime": t0 - te, "rtime": t4 - t0}
 
     # ---- the hot path ---------------------------------------------------------------------------------
     def render(self, batch):
@@ -149,10 +162,11 @@ class Renderer(nn.Module):
             raise L.GpnerfError("mesh extraction (use_rgbhead=False, BaseRender.py:255-272) is outside the per-ray render path")
         dev = batch["ray_o"].device
         torch.cuda.synchronize(dev)
-        t0 = time.time()
-        frame = self.build_frame(batch)
+        te = time.time()
+        featmaps = self.encode(batch)
         torch.cuda.synchronize(dev)
-        t1 = time.time()
+        t0 = time.time()
+        frame = self.build_frame(batch, featmaps)
         rays = torch.cat([batch["ray_o"], batch["ray_d"], batch["near"].unsqueeze(-1), batch["far"].unsqueeze(-1)], dim=-1)[0]
         neg = self._neg_ray(batch)
 
@@ -170,7 +184,9 @@ class Renderer(nn.Module):
             "acc_map": o["acc_map"].view(1, n, 1), "depth_map": o["depth_map"].view(1, n, 1),
             "alpha": o["weights"].view(1, n, -1), "z_vals": o["z_vals"].view(1, n, -1),
             "rgb_in_map": o["rgb_in_map"].view(1, n, 9),
-            "etime": t1 - t0, "rtime": t2 - t0,
+            # BaseRender.render returns neither; the evaluation loop reads ret["rtime"] (BaseTrainer.py:276), which only the
+            # demo renderer provides: encoder time and everything after it, each on its own clock (demo_render.py:441-446,494-497)
+            "etime": t0 - te, "rtime": t2 - t0,
         }
 
 

@@ -220,6 +220,7 @@ def make_scene(
     make_volumes=True,
     neg_cams=False,
     vol_occupancy=None,
+    neg_target=False,
 ):
     """Build one synthetic frame.
 
@@ -328,7 +329,10 @@ def make_scene(
         "src_Ks": src_Ks[None],
         "src_poses": src_poses[None],
         "target_K": K[None],
-        "target_pose": np.concatenate([R, T], 1)[None].astype(np.float32),
+        # neg_target: the target camera in the negated (THuman-style) convention as well; only the progressive renderer
+        # derives rays from target_pose (demo_render.py:201-239), ray_o/ray_d above stay those of the un-negated camera
+        "target_pose": (np.concatenate([R, T], 1)[None] * (-1.0 if neg_target else 1.0)).astype(np.float32),
+        "target_K_inv": np.linalg.inv(K)[None],          # float32, as ZjumocapDataset.py:480 makes it
         "feature": np.concatenate([verts, np.zeros_like(verts)], 1)[None].astype(np.float32),
         "coord": coord[None],
         "bounds": bounds[None],

@@ -38,14 +38,20 @@ extern "C" {
 #define GPNERF_E_DEVICE (-3)   /* not a gfx950 device / no device */
 
 /* flags of gpnerf_render_fused */
-#define GPNERF_FLAG_NEG_RAY 1u     /* Projector(neg_ray=True) + raw2outputs(neg=True): BaseRender.py:86-88,317-320 */
+#define GPNERF_FLAG_NEG_RAY 1u     /* Projector(neg_ray=True): a sample is in front of a source view iff h_z < 0
+                                      (BaseRender.py:317-320, demo_render.py:550-553).  The dense renderer pairs it with
+                                      GPNERF_FLAG_FLIP_SAMPLES; the progressive renderer's integral never flips */
+#define GPNERF_FLAG_FLIP_SAMPLES 16u /* raw2outputs(neg=True): rgb and sigma reversed along the ray before compositing, z not
+                                      (BaseRender.py:86-88,101); rgb_in_map pairs the weights with the un-flipped rgb_in (:147) */
 #define GPNERF_FLAG_EARLY_TERM 2u  /* stop a 32-ray wave tile once every ray has T < term_eps (not in the reference) */
 #define GPNERF_FLAG_SPLIT_F16 8u   /* dense layers on f16 MFMA with every fp32 operand split into f16 hi + lo (three MFMAs per
                                       k-step, f32 accumulation): ~fp32 accuracy (1e-6 on rgb), 3/16 of the fp32 MFMA cost.
                                       Needs frame->head_blob_split; operands must stay below the f16 range (65504) */
-#define GPNERF_FLAG_OCC_CULL 4u    /* progressive sample culling of libs/renders/demo_render.py:270-283,317-347: a sample is
-                                      evaluated only where the occupancy volume (frame->occ) interpolates to > 0; culled
-                                      samples carry alpha = 0, and colour is kept only where alpha > 1e-14 */
+#define GPNERF_FLAG_OCC_CULL 4u    /* the progressive renderer's per-sample rules (libs/renders/demo_render.py): grid coordinates
+                                      with its literal voxel size 0.005 instead of frame->voxel (:87-95), a sample is evaluated
+                                      only where the occupancy volume (frame->occ) interpolates to > 0 (:270-283), culled
+                                      samples carry alpha = 0, colour is kept only where alpha > 1e-14 (:317,:329-341);
+                                      ray_mask counts kept samples only */
 
 /* Per-frame constants (everything render_rays reads that does not depend on the ray).
  * Layouts are channels-last so that one bilinear / trilinear tap is one contiguous
@@ -183,11 +189,14 @@ int gpnerf_build_occupancy(const GpnerfFrame* frame, float* occ, void* stream);
 int gpnerf_select_pixels(const float* occ, int32_t D, int32_t H, int32_t W, float threshold, const float* voxel_xyz,
                          const float* bounds_min, const float* Rh, const float* Th, const float* pose, const float* K,
                          int32_t img_h, int32_t img_w, uint8_t* pixel_sel, int32_t* world_minmax, void* stream);
-/* The inference renderer's on-device get_rays / near-far (libs/renders/demo_render.py:201-239): like gpnerf_make_rays
- * but the box is used as given (no +-0.01), directions are not clamped, and under neg_ray the second distance is negated.
- * pixel_sel: optional device [H*W] mask of the pixels to consider (others get hit = 0). */
-int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o, const float* bounds,
-                          int32_t neg_ray, const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream);
+/* The inference renderer's on-device get_rays / near-far (libs/renders/demo_render.py:201-239): pixel_camera = xy1 @ Kinv^T,
+ * pixel_world = (pixel_camera - T) @ R, rays_o = (-R^T) @ T, with every length-3 product accumulated as torch's CPU `@` does
+ * (fused multiply-adds over k = 0,1,2), the box used as given (no +-0.01), directions not clamped, distances by torch.norm's
+ * formula, and under neg_ray the second distance negated.  Kinv: host 3x3 (batch['target_K_inv']); pose: host 3x4 row-major
+ * [R|T] (batch['target_pose']); bounds: host [2][3].  pixel_sel: optional device [H*W] mask of the pixels to consider
+ * (others get hit = 0).  Bit-exact against the reference's CPU run (tests/golden/demo_*.npz). */
+int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* pose, const float* bounds, int32_t neg_ray,
+                          const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream);
 
 /* ---- per-frame sparse convolution pyramid (gpnerf_volume.hip), replacing the external spconv v1.2.1 calls of
  * libs/nerfheads/networks/SparseConvNet.py:22-111 (SubMConv3d / SparseConv3d + BatchNorm1d + ReLU, .dense()).

@@ -8,7 +8,7 @@
  * Parity status: PINNED against outputs of the reference itself, generated in
  * the build container by tests/golden/make_golden.py (which runs the reference's
  * Renderer.render / NeRFHead.forward / SparseConvNet.forward / get_rays /
- * get_near_far) and committed as tests/golden/*.npz.  The sparse-convolution
+ * get_near_far) and committed as tests/golden/ (.npz files).  The sparse-convolution
  * volume builder (external spconv v1.2.1, absent from the tree) is NOT restated:
  * the 4 dense feature levels are inputs here, as they are in the golden vectors.
  *
@@ -182,14 +182,20 @@ static void head_forward(const OracleFrame *f, const float *vol_feat /*128*/, co
     raw[3] = sg;
 }
 
-/* Renderer.render_rays for one ray (BaseRender.py:110-157) with is_train=False. */
-/* flags: bit 0 = neg_ray; bit 2 (value 4) = progressive sample culling, restating
- * libs/renders/demo_render.py:270-283 (keep a sample iff grid_sample(masks3d) > 0), :317 (colour only where
- * alpha > 1e-14) and :336-344 (culled samples carry alpha = 0, rgb = 0).  demo_render.py hard-codes CUDA and
- * cannot be run in the build container: this branch is a restatement WITHOUT a golden vector (parity unpinned). */
+/* Renderer.render_rays for one ray (BaseRender.py:110-157) with is_train=False.
+ * flags: bit 0 (1)  = neg_ray as the Projector sees it: a point is in front of a view iff h_z < 0 (BaseRender.py:317-320,
+ *                     demo_render.py:550-553);
+ *        bit 1 (2)  = raw2outputs(neg=True): rgb and sigma are flipped along the ray before compositing, z is not
+ *                     (BaseRender.py:86-88).  The dense renderer sets bits 0 and 1 together; the progressive renderer's
+ *                     integral (demo_render.py:329-344) never flips, so it sets bit 0 alone;
+ *        bit 2 (4)  = the progressive renderer's per-sample rules, libs/renders/demo_render.py: grid coordinates with its
+ *                     literal 0.005 (:87-95), keep a sample iff grid_sample(masks3d) > 0 (:270-283), colour only where
+ *                     alpha > 1e-14 (:317), culled samples carry alpha = 0, rgb = 0 (:329-341).  PINNED: tests/golden/demo_*.npz
+ *                     are outputs of that file's Renderer.render (tests/golden/make_golden.py run_demo_case).
+ *                     ray_mask (which that renderer does not return) counts kept samples only. */
 static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near far*/, int S, int flags,
                            int64_t r, OracleOut *o, float *scratch /* S*(4+9+1) */) {
-    const int neg_ray = flags & 1, cull = (flags & 4) && f->occ;
+    const int neg_ray = flags & 1, flip = (flags & 2) != 0, cull = (flags & 4) && f->occ;
     float *raw = scratch;            /* [S][4] */
     float *rin = scratch + 4 * S;    /* [S][9] */
     float *zv = scratch + 13 * S;    /* [S] */
@@ -212,7 +218,7 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
         float g[3];
         for (int a = 0; a < 3; ++a) {       /* a indexes dhw; xyz component is 2-a */
             float v = q[2 - a] - f->bounds_min[2 - a];
-            v = v / f->voxel[a];
+            v = v / (cull ? 0.005f : f->voxel[a]);      /* demo_render.py:91 divides by the literal */
             v = v / (float)f->out_sh[a] * 2.f - 1.f;
             g[2 - a] = v;
         }
@@ -243,12 +249,16 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
         }
         if (o->st_rgb_feat) memcpy(o->st_rgb_feat + ((size_t)r * S + k) * NV * XF, x, sizeof(x));
         if (o->st_mask) memcpy(o->st_mask + ((size_t)r * S + k) * NV, mask, sizeof(mask));
-        if (mask[0] + mask[1] + mask[2] > 1.f) ++n_two;             /* pixel_mask :139 */
+        int kept = 1;
+        float occv = 0.f;
+        if (cull) {
+            grid_sample3d(f->occ, 1, f->vol_dhw[0][0], f->vol_dhw[0][1], f->vol_dhw[0][2], g[0], g[1], g[2], &occv);
+            kept = occv > 0.f;
+        }
+        if (kept && mask[0] + mask[1] + mask[2] > 1.f) ++n_two;     /* pixel_mask :139 */
         head_forward(f, vf, x, mask, raw + 4 * k, rin + 9 * k);
         if (cull) {
-            float occv;
-            grid_sample3d(f->occ, 1, f->vol_dhw[0][0], f->vol_dhw[0][1], f->vol_dhw[0][2], g[0], g[1], g[2], &occv);
-            if (!(occv > 0.f)) raw[4 * k + 3] = 0.f;
+            if (!kept) raw[4 * k + 3] = 0.f;
             if (!(1.f - expf(-raw[4 * k + 3]) > 1e-14f)) raw[4 * k] = raw[4 * k + 1] = raw[4 * k + 2] = 0.f;
         }
         if (o->st_raw) memcpy(o->st_raw + ((size_t)r * S + k) * 4, raw + 4 * k, 4 * sizeof(float));
@@ -256,7 +266,7 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
     /* raw2outputs :75-107 */
     float T = 1.f, rgb[3] = {0, 0, 0}, depth = 0.f, acc = 0.f, rgbin[9] = {0};
     for (int k = 0; k < S; ++k) {
-        int src = neg_ray ? (S - 1 - k) : k;           /* torch.flip of rgb and sigma only :86-88 */
+        int src = flip ? (S - 1 - k) : k;              /* torch.flip of rgb and sigma only :86-88 */
         float alpha = 1.f - expf(-raw[4 * src + 3]);
         float w = alpha * T;
         T = T * (1.f - alpha + 1e-10f);
@@ -422,9 +432,13 @@ int oracle_build_occupancy(const OracleFrame *f, float *occ) {
 }
 
 /* Progressive ray selection + on-device rays of the inference renderer, restating
- * libs/renders/demo_render.py:166-247 (parity unpinned: the file hard-codes CUDA and cannot run in the build container).
+ * libs/renders/demo_render.py:166-247.  PINNED: mask_at_box bit-exact, rays and near/far bit-exact against
+ * tests/golden/demo_*.npz (outputs of that file's Renderer.render on CPU tensors, see tests/golden/make_golden.py).
  * occ [D,H,W] = masks3d; voxel (xyz), bmin = bounds[0,0], Rh row-major, Th; pose 3x4 row-major [R|T]; K, Kinv 3x3.
  * Outputs sized ih*iw; returns the number of rays kept (raster order); mask[ih*iw] = final mask_at_box. */
+/* A length-3 row of torch's CPU `@` (sgemm) accumulates k = 0, 1, 2 with fused multiply-adds:
+ * fma(a2, b2, fma(a1, b1, a0 * b0)) -- checked bit-exact against torch 2.10 on [n,3] @ [3,3] for n = 7 .. 46080. */
+#define MM3(a0, b0, a1, b1, a2, b2) fmaf((a2), (b2), fmaf((a1), (b1), (a0) * (b0)))
 int64_t oracle_select_rays(const float *occ, int D, int H, int W, float thr, const float *voxel, const float *bmin,
                            const float *Rh, const float *Th, const float *pose, const float *K, const float *Kinv,
                            int ih, int iw, int neg_ray, float *ray_o, float *ray_d, float *near, float *far, uint8_t *mask) {
@@ -437,10 +451,10 @@ int64_t oracle_select_rays(const float *occ, int D, int H, int W, float thr, con
                 float s[3] = {(float)w * 2.f * voxel[0] + bmin[0], (float)h * 2.f * voxel[1] + bmin[1],
                               (float)d * 2.f * voxel[2] + bmin[2]};                    /* :166 */
                 float p[3], c[3], q[3];
-                for (int a = 0; a < 3; ++a) p[a] = s[0] * Rh[a * 3] + s[1] * Rh[a * 3 + 1] + s[2] * Rh[a * 3 + 2] + Th[a];   /* :167 */
+                for (int a = 0; a < 3; ++a) p[a] = MM3(s[0], Rh[a * 3], s[1], Rh[a * 3 + 1], s[2], Rh[a * 3 + 2]) + Th[a];   /* :167 */
                 for (int a = 0; a < 3; ++a) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
-                for (int a = 0; a < 3; ++a) c[a] = p[0] * pose[a * 4] + p[1] * pose[a * 4 + 1] + p[2] * pose[a * 4 + 2] + pose[a * 4 + 3]; /* :179 */
-                for (int a = 0; a < 3; ++a) q[a] = c[0] * K[a * 3] + c[1] * K[a * 3 + 1] + c[2] * K[a * 3 + 2];           /* :180 */
+                for (int a = 0; a < 3; ++a) c[a] = MM3(p[0], pose[a * 4], p[1], pose[a * 4 + 1], p[2], pose[a * 4 + 2]) + pose[a * 4 + 3]; /* :179 */
+                for (int a = 0; a < 3; ++a) q[a] = MM3(c[0], K[a * 3], c[1], K[a * 3 + 1], c[2], K[a * 3 + 2]);           /* :180 */
                 float fx = q[0] / q[2], fy = q[1] / q[2];
                 if (!(fabsf(fx) < 1e9f) || !(fabsf(fy) < 1e9f)) continue;
                 int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;               /* .long() :182-183 */
@@ -450,7 +464,7 @@ int64_t oracle_select_rays(const float *occ, int D, int H, int W, float thr, con
             }
     mn[2] -= 0.05f; mx[2] += 0.05f;                                                     /* :172-174 */
     float o[3];
-    for (int a = 0; a < 3; ++a) o[a] = -(pose[0 * 4 + a] * pose[3] + pose[1 * 4 + a] * pose[7] + pose[2 * 4 + a] * pose[11]);  /* -R^T T :203 */
+    for (int a = 0; a < 3; ++a) o[a] = MM3(-pose[0 * 4 + a], pose[3], -pose[1 * 4 + a], pose[7], -pose[2 * 4 + a], pose[11]);  /* (-R^T) T :203 */
     const float eps = 1e-6f;
     int64_t n = 0;
     for (int j = 0; j < ih; ++j)
@@ -458,10 +472,10 @@ int64_t oracle_select_rays(const float *occ, int D, int H, int W, float thr, con
             mask[(size_t)j * iw + i] = 0;
             if (!sel[(size_t)j * iw + i]) continue;
             float pc[3], pw[3], dd[3];
-            for (int a = 0; a < 3; ++a) pc[a] = (float)i * Kinv[a * 3] + (float)j * Kinv[a * 3 + 1] + Kinv[a * 3 + 2];   /* :205 */
+            for (int a = 0; a < 3; ++a) pc[a] = MM3((float)i, Kinv[a * 3], (float)j, Kinv[a * 3 + 1], 1.f, Kinv[a * 3 + 2]);   /* :205 */
             for (int a = 0; a < 3; ++a) {                                                                             /* :206-208 */
                 float t0 = pc[0] - pose[3], t1 = pc[1] - pose[7], t2 = pc[2] - pose[11];
-                pw[a] = t0 * pose[0 * 4 + a] + t1 * pose[1 * 4 + a] + t2 * pose[2 * 4 + a];
+                pw[a] = MM3(t0, pose[0 * 4 + a], t1, pose[1 * 4 + a], t2, pose[2 * 4 + a]);
                 dd[a] = pw[a] - o[a];
             }
             float hit[2][3]; int cnt = 0;
@@ -475,10 +489,12 @@ int64_t oracle_select_rays(const float *occ, int D, int H, int W, float thr, con
             }
             if (cnt != 2) continue;                                                     /* :227 */
             mask[(size_t)j * iw + i] = 1;
-            float nd = sqrtf(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+            /* torch.norm(x, dim=1) on CPU evaluates sqrt(fma(z, z, fma(y, y, x*x))) (checked bit-exact on 200k vectors) :232-234 */
+#define NORM3(v) sqrtf(fmaf((v)[2], (v)[2], fmaf((v)[1], (v)[1], (v)[0] * (v)[0])))
+            float nd = NORM3(dd);
             float v0[3] = {hit[0][0] - o[0], hit[0][1] - o[1], hit[0][2] - o[2]}, v1[3] = {hit[1][0] - o[0], hit[1][1] - o[1], hit[1][2] - o[2]};
-            float d0 = sqrtf(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]) / nd;
-            float d1 = sqrtf(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) / nd;
+            float d0 = NORM3(v0) / nd;
+            float d1 = NORM3(v1) / nd;
             if (neg_ray) d1 = -d1;                                                      /* :236-237 */
             for (int a = 0; a < 3; ++a) { ray_o[3 * n + a] = o[a]; ray_d[3 * n + a] = dd[a]; }
             near[n] = fminf(d0, d1); far[n] = fmaxf(d0, d1);

@@ -177,9 +177,13 @@ def build_occupancy(scene):
     return occ
 
 
-def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None, want_weights=True, occ=None):
+def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None, want_weights=True, occ=None, flip=None):
     """Run the oracle over all rays of a synthetic scene; returns a dict of numpy arrays.
-    occ: masks3d -> progressive sample culling (demo_render.py semantics, parity unpinned)."""
+    neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); default = neg_ray for the dense renderer
+    and False for the progressive one, which never flips (demo_render.py:329-344).
+    occ: masks3d -> the progressive renderer's per-sample rules (pinned by tests/golden/demo_*.npz)."""
+    if flip is None:
+        flip = bool(neg_ray) and occ is None
     fr = Frame(scene)
     if occ is not None:
         occ = _f32(occ)
@@ -210,7 +214,7 @@ def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None
     if stages:
         for k in ("st_grid", "st_vol_feat", "st_rgb_feat", "st_mask", "st_raw"):
             setattr(o, k, _p(res[k]))
-    rc = lib().oracle_render(C.byref(fr.c), _p(rays), N, S, int(bool(neg_ray)) | (4 if occ is not None else 0), C.byref(o), int(n_threads))
+    rc = lib().oracle_render(C.byref(fr.c), _p(rays), N, S, int(bool(neg_ray)) | (2 if flip else 0) | (4 if occ is not None else 0), C.byref(o), int(n_threads))
     assert rc == 0
     return res
 
@@ -242,10 +246,11 @@ def max_threads():
     return int(lib().oracle_max_threads())
 
 
-def select_rays(occ, voxel, bmin, Rh, Th, pose, K, ih, iw, neg_ray=False, thr=0.1):
-    """demo_render.py:166-247: occupied voxels -> pixel set -> rays / near / far (parity unpinned restatement)."""
+def select_rays(occ, voxel, bmin, Rh, Th, pose, K, ih, iw, neg_ray=False, thr=0.1, Kinv=None):
+    """demo_render.py:166-247: occupied voxels -> pixel set -> rays / near / far (pinned by tests/golden/demo_*.npz)."""
     occ, voxel, bmin, Rh, Th, pose, K = (_f32(a) for a in (occ, voxel, bmin, Rh, Th, pose, K))
-    Kinv = _f32(np.linalg.inv(K.astype(np.float64)))
+    # batch['target_K_inv'] = np.linalg.inv(target_K) on the float32 K (ZjumocapDataset.py:480)
+    Kinv = _f32(np.linalg.inv(K)) if Kinv is None else _f32(Kinv)
     n = ih * iw
     ro, rd, near, far = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
     mask = np.zeros(n, np.uint8)

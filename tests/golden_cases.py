@@ -12,7 +12,15 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("rays_", "encoder_", "attention_")))
+                  if not os.path.basename(p).startswith(("rays_", "encoder_", "attention_", "demo_", "e2e_")))
+
+
+def demo_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "demo_*.npz")))
+
+
+def rays_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "rays_*.npz")))
 
 
 def attention_case_names():

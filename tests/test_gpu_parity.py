@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import assert_close, case_names, load, scene_of
+from golden_cases import assert_close, case_names, demo_case_names, load, scene_of
 
 pytestmark = pytest.mark.gpu
 
@@ -176,8 +176,9 @@ def test_ray_order_changes_tiling_not_results(fm, syn):
 @pytest.mark.parametrize("neg,split_f16,lb", [(False, False, False), (True, False, False), (False, True, False), (False, False, True),
                                               (True, True, True)])
 def test_progressive_sample_culling_matches_restatement(neg, split_f16, lb, fm, oracle, syn):
-    """demo_render.py's occupancy / alpha culling (parity unpinned: restated, the CUDA-only reference path cannot run).
-    The kernel walks a per-lane sample cursor here, so neg_ray, both forms and the sample-split geometry are all covered."""
+    """demo_render.py's occupancy / alpha culling against the oracle's restatement (itself pinned to outputs of that file,
+    tests/golden/demo_*.npz): neg_ray (front test only -- the progressive integral never flips), both kernel forms and the
+    sample-split launch geometry."""
     sc = syn.make_scene(H=24, W=24, seed=77, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1,
                         vol_occupancy=0.35, neg_cams=neg)
     S = 48
@@ -199,7 +200,7 @@ def test_progressive_sample_culling_matches_restatement(neg, split_f16, lb, fm, 
 
 
 def test_progressive_ray_selection_matches_restatement(fm, oracle, syn):
-    """demo_render.py:166-247 (unpinned restatement): occupied voxels -> pixel set -> rays."""
+    """demo_render.py:166-247 on a non-512 frame against the oracle (pinned by tests/golden/demo_*.npz): index work, bit-exact."""
     H = W = 48
     sc = syn.make_scene(H=H, W=W, seed=78, focal_mul=6.0, pose="random", aabb_half=(0.2, 0.3, 0.12), vol_occupancy=0.3)
     fr = build_frame(fm, sc)
@@ -210,10 +211,26 @@ def test_progressive_ray_selection_matches_restatement(fm, oracle, syn):
     rays, mask = rays.cpu().numpy(), mask.cpu().numpy()
     assert 50 < mref.sum() < H * W
     assert np.array_equal(mask, mref)
-    assert_close(rays[:, 0:3], ro, 1e-5, "ray_o")
-    assert_close(rays[:, 3:6], rd, 1e-5, "ray_d")
-    assert_close(rays[:, 6], near, 2e-5, "near")
-    assert_close(rays[:, 7], far, 2e-5, "far")
+    assert np.array_equal(rays[:, 0:3], ro) and np.array_equal(rays[:, 3:6], rd), "rays"
+    assert np.array_equal(rays[:, 6], near) and np.array_equal(rays[:, 7], far), "near / far"
+
+
+@pytest.mark.parametrize("name", demo_case_names())
+def test_progressive_ray_selection_matches_reference_fixtures(name, fm):
+    """gpnerf_build_occupancy + gpnerf_select_pixels + gpnerf_make_rays_demo against values captured inside the reference's
+    demo_render.py run: masks3d, mask_at_box, and the rays / near / far it handed to get_sampling_points -- bit-exact."""
+    z, meta = load(name)
+    sc = scene_of(meta)
+    fr = build_frame(fm, sc)
+    occ = fr.build_occupancy().cpu().numpy()
+    assert_close(occ, z["masks3d"], 1e-4, "masks3d")
+    assert int((occ > 0.1).sum()) == int(z["n_mask_xyz"])
+    rays, mask = fm.select_rays(fr, sc["target_K"][0], sc["target_pose"][0], 512, 512, sc["voxel_size"], sc["bounds"][0, 0],
+                                sc["Rh"][0], sc["Th"][0], neg_ray=meta["neg_ray"], target_K_inv=z["target_K_inv"][0])
+    rays, mask = rays.cpu().numpy(), mask.cpu().numpy()
+    assert np.array_equal(mask, np.unpackbits(z["mask_at_box_bits"]).astype(bool)), "mask_at_box"
+    assert np.array_equal(rays[:, 0:3], z["ray_o"]) and np.array_equal(rays[:, 3:6], z["ray_d"]), "rays"
+    assert np.array_equal(rays[:, 6], z["near"]) and np.array_equal(rays[:, 7], z["far"]), "near / far"
 
 
 @pytest.mark.parametrize("name", case_names())

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_cases import GOLDEN_DIR, assert_close, case_names, load, scene_of, sha_inputs
+from golden_cases import GOLDEN_DIR, assert_close, case_names, demo_case_names, load, scene_of, sha_inputs
 
 # fp32 re-association only: the reference's own fp32-vs-fp64 spread is 6.5e-7
 TOL = 2e-5
@@ -54,3 +54,30 @@ def test_synthetic_rays_agree_with_oracle(oracle, syn):
     assert np.array_equal(mask, sc["mask_at_box"][0])
     assert_close(near, sc["near"][0], 1e-5, "near")
     assert_close(far, sc["far"][0], 1e-5, "far")
+
+
+# ---- the progressive renderer (libs/renders/demo_render.py), fixtures = outputs of its Renderer.render ----------------
+@pytest.mark.parametrize("name", demo_case_names())
+def test_oracle_matches_the_progressive_renderer(name, oracle):
+    z, meta = load(name)
+    sc = scene_of(meta)
+    assert sha_inputs(sc) == meta["sha256_inputs"], "synthetic inputs are not byte-identical to the golden run"
+    assert np.array_equal(sc["target_K_inv"], z["target_K_inv"]), "np.linalg.inv(float32 K) differs on this host"
+    # SparseConvNet.encode: masks3d and the occupied-voxel list (SparseConvNet.py:135-141)
+    occ = oracle.build_occupancy(sc)
+    assert_close(occ, z["masks3d"], 1e-4, "masks3d")          # sums of ~128 values of magnitude ~1: fp32 order only
+    assert int((occ > 0.1).sum()) == int(z["n_mask_xyz"])
+    # ray selection + near/far (demo_render.py:166-239): index work, bit-exact
+    mask_ref = np.unpackbits(z["mask_at_box_bits"]).astype(bool)
+    ro, rd, near, far, mask = oracle.select_rays(occ, sc["voxel_size"], sc["bounds"][0, 0], sc["Rh"][0], sc["Th"][0],
+                                                 sc["target_pose"][0], sc["target_K"][0], 512, 512, neg_ray=meta["neg_ray"])
+    assert np.array_equal(mask, mask_ref), "mask_at_box"
+    assert np.array_equal(ro, z["ray_o"]) and np.array_equal(rd, z["ray_d"]), "rays"
+    assert np.array_equal(near, z["near"]) and np.array_equal(far, z["far"]), "near / far"
+    # culled render + the un-flipped integral (:270-344), on the oracle's own rays
+    res = oracle.render(sc, meta["n_samples"], neg_ray=meta["neg_ray"], occ=occ,
+                        rays=np.concatenate([ro, rd, near[:, None], far[:, None]], 1))
+    assert_close(res["rgb_map"], z["rgb_map"], TOL, "rgb_map")
+    if meta["neg_ray"]:      # the fixture discriminates the two readings of neg_ray: flipping the samples is far off
+        bad = oracle.render(sc, meta["n_samples"], neg_ray=True, flip=True, occ=occ, rays=np.concatenate([ro, rd, near[:, None], far[:, None]], 1))
+        assert np.abs(bad["rgb_map"] - z["rgb_map"]).max() > 1e-2
