@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libgpnerf_hip.so")
 
 VIEWS, CH, LEVELS = 3, 32, 4
 FP = C.POINTER(C.c_float)
+DP = C.POINTER(C.c_double)
 U8P = C.POINTER(C.c_uint8)
 
 
@@ -80,7 +81,7 @@ SYMBOLS = {
     "gpnerf_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gpnerf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.POINTER(GpnerfOutputs), C.c_void_p]),
-    "gpnerf_make_rays": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, FP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_make_rays": (C.c_int, [C.c_int32, C.c_int32, DP, DP, DP, FP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_select_pixels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, FP, FP, FP, FP, FP, FP, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

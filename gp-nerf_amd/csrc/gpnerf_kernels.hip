@@ -1061,73 +1061,113 @@ __global__ void composite_kernel(const float* __restrict__ raw, const float* __r
 // ---------------------------------------------------------------------------------------------
 // get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130), one lane per pixel
 // ---------------------------------------------------------------------------------------------
-struct RayCam { float Kinv[9], Rinv[9], o[3], bmin[3], bmax[3], T[3]; };
+struct RayCam {
+    float Kinv[9], Rinv[9], o[3], bmin[3], bmax[3], T[3];      // the inference renderer's float32 pipeline (demo = 1)
+    double Kinv_d[9], Rinv_d[9], o_d[3], bmin_d[3], bmax_d[3];  // the dataset's float64 pipeline (demo = 0)
+};
 
 // one length-3 row of torch's CPU `@` (sgemm): k = 0, 1, 2 accumulated with fused multiply-adds (oracle: MM3)
 DEV float mm3(float a0, float b0, float a1, float b1, float a2, float b2) { return fmaf(a2, b2, fmaf(a1, b1, a0 * b0)); }
 
-// demo != 0: the inference renderer's variant (libs/renders/demo_render.py:201-239): box used as given, no small-|d|
-// clamp, d1 negated under neg_ray instead of the sign test; sel (optional) restricts the pixels considered (:179-200)
-__global__ void make_rays_kernel(const int H, const int W, const RayCam cam, const int demo, const int neg,
-                                 const uint8_t* __restrict__ sel, float* __restrict__ rays, uint8_t* __restrict__ hit) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= H * W) return;
-    if (sel && !sel[idx]) { hit[idx] = 0; return; }
-    const float i = (float)(idx % W), j = (float)(idx / W);
-    float pc[3], d[3];
-    if (demo) {
-        // pixel_camera = xy1 @ K_inv^T; pixel_world = (pixel_camera - T) @ R; rays_d = pixel_world - rays_o (demo_render.py:204-210)
+// demo = 0: the dataset's get_rays + get_near_far in the precision numpy runs them in (data_utils.py:47-63,96-130 via sample_ray
+// :294-300): float64 camera products (dgemm order: fused multiply-adds over k = 0,1,2) rounded once to float32 rays; float64
+// plane hits and on-box tests on those float32 values against float64 bounds (+-0.01 added in float64, :98); norm_ray in
+// float32; the two float64 distances rounded to float32.  Bit-exact against tests/golden/rays_*.npz.
+DEV void dataset_ray(const RayCam& cam, const float i, const float j, float (&o)[3], float (&d)[3], bool& keep, float& near, float& far) {
+    double pc[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) pc[a] = mm3(i, cam.Kinv[a * 3 + 0], j, cam.Kinv[a * 3 + 1], 1.f, cam.Kinv[a * 3 + 2]);
-        const float t0 = pc[0] - cam.T[0], t1 = pc[1] - cam.T[1], t2 = pc[2] - cam.T[2];
+    for (int a = 0; a < 3; ++a) pc[a] = fma(1.0, cam.Kinv_d[a * 3 + 2], fma((double)j, cam.Kinv_d[a * 3 + 1], (double)i * cam.Kinv_d[a * 3 + 0]));
 #pragma unroll
-        for (int a = 0; a < 3; ++a) d[a] = mm3(t0, cam.Rinv[a * 3 + 0], t1, cam.Rinv[a * 3 + 1], t2, cam.Rinv[a * 3 + 2]) - cam.o[a];
-    } else {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) pc[a] = (i * cam.Kinv[a * 3 + 0] + j * cam.Kinv[a * 3 + 1]) + cam.Kinv[a * 3 + 2];   // xy1 @ K^-T
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float pw = ((pc[0] * cam.Rinv[a * 3 + 0] + pc[1] * cam.Rinv[a * 3 + 1]) + pc[2] * cam.Rinv[a * 3 + 2]) + cam.o[a];
-            float da = pw - cam.o[a];
-            if (fabsf(da) < 1e-5f) da = 1e-5f;   // ray_d[np.abs(ray_d) < 1e-5] = 1e-5 (:101)
-            d[a] = da;
-        }
+    for (int a = 0; a < 3; ++a) {
+        const double pw = fma(pc[2], cam.Rinv_d[a * 3 + 2], fma(pc[1], cam.Rinv_d[a * 3 + 1], pc[0] * cam.Rinv_d[a * 3 + 0])) + cam.o_d[a];
+        o[a] = (float)cam.o_d[a];
+        float da = (float)(pw - cam.o_d[a]);
+        if (fabsf(da) < 1e-5f) da = 1e-5f;             // ray_d[np.abs(ray_d) < 1e-5] = 1e-5 (:101), on the float32 array
+        d[a] = da;
     }
-    const float eps = 1e-6f;
-    float p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+    const double eps = 1e-6;
+    double p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
     int cnt = 0;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {                     // order: min_x,min_y,min_z,max_x,max_y,max_z (:99-103)
+    for (int m = 0; m < 6; ++m) {                      // order: min_x,min_y,min_z,max_x,max_y,max_z (:99-103)
         const int a = m % 3;
-        const float bd = (m < 3) ? cam.bmin[a] : cam.bmax[a];
-        const float tt = (bd - cam.o[a]) / d[a];
-        const float hx = tt * d[0] + cam.o[0], hy = tt * d[1] + cam.o[1], hz = tt * d[2] + cam.o[2];
-        const bool ok = hx >= cam.bmin[0] - eps && hx <= cam.bmax[0] + eps && hy >= cam.bmin[1] - eps &&
-                        hy <= cam.bmax[1] + eps && hz >= cam.bmin[2] - eps && hz <= cam.bmax[2] + eps;
+        const double bd = (m < 3) ? cam.bmin_d[a] : cam.bmax_d[a];
+        const double tt = (bd - (double)o[a]) / (double)d[a];
+        const double hx = tt * (double)d[0] + (double)o[0], hy = tt * (double)d[1] + (double)o[1], hz = tt * (double)d[2] + (double)o[2];
+        const bool ok = hx >= cam.bmin_d[0] - eps && hx <= cam.bmax_d[0] + eps && hy >= cam.bmin_d[1] - eps &&
+                        hy <= cam.bmax_d[1] + eps && hz >= cam.bmin_d[2] - eps && hz <= cam.bmax_d[2] + eps;
         if (ok) {
             if (cnt == 0) { p0[0] = hx; p0[1] = hy; p0[2] = hz; }
             else if (cnt == 1) { p1[0] = hx; p1[1] = hy; p1[2] = hz; }
             ++cnt;
         }
     }
-    const bool keep = (cnt == 2);
-    hit[idx] = (uint8_t)keep;
-    float near = 0.f, far = 0.f;
+    keep = (cnt == 2);
+    near = 0.f; far = 0.f;
     if (keep) {
-        // the demo renderer's torch.norm(dim=1) is sqrt(fma(z, z, fma(y, y, x*x))) on the CPU path (demo_render.py:232-234)
-        const auto norm3 = [demo](float x, float y, float z) {
-            return demo ? sqrtf(fmaf(z, z, fmaf(y, y, x * x))) : sqrtf((x * x + y * y) + z * z);
-        };
-        const float nd = norm3(d[0], d[1], d[2]);
-        const float v0x = p0[0] - cam.o[0], v0y = p0[1] - cam.o[1], v0z = p0[2] - cam.o[2];
-        const float v1x = p1[0] - cam.o[0], v1y = p1[1] - cam.o[1], v1z = p1[2] - cam.o[2];
-        const float sg = (!demo && ((v0x * d[0] + v0y * d[1]) + v0z * d[2]) < 0.f) ? -1.f : 1.f;     // both from p0 (:123,126)
-        const float d0 = norm3(v0x, v0y, v0z) / nd * sg;
-        const float d1 = norm3(v1x, v1y, v1z) / nd * ((demo && neg) ? -1.f : sg);
-        near = fminf(d0, d1); far = fmaxf(d0, d1);
+        const float nd = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);          // np.linalg.norm on float32 (:120)
+        const double v0x = p0[0] - o[0], v0y = p0[1] - o[1], v0z = p0[2] - o[2];
+        const double v1x = p1[0] - o[0], v1y = p1[1] - o[1], v1z = p1[2] - o[2];
+        const double sg = ((v0x * d[0] + v0y * d[1]) + v0z * d[2]) < 0.0 ? -1.0 : 1.0;   // both from p0 (:123,126)
+        const double d0 = sqrt((v0x * v0x + v0y * v0y) + v0z * v0z) / (double)nd * sg;
+        const double d1 = sqrt((v1x * v1x + v1y * v1y) + v1z * v1z) / (double)nd * sg;
+        near = (float)fmin(d0, d1); far = (float)fmax(d0, d1);
     }
+}
+
+// demo = 1: the inference renderer's variant (libs/renders/demo_render.py:201-239), float32 throughout: box used as given,
+// no small-|d| clamp, d1 negated under neg_ray instead of the sign test; sel (optional) restricts the pixels (:179-200)
+__global__ void make_rays_kernel(const int H, const int W, const RayCam cam, const int demo, const int neg,
+                                 const uint8_t* __restrict__ sel, float* __restrict__ rays, uint8_t* __restrict__ hit) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    if (sel && !sel[idx]) { hit[idx] = 0; return; }
+    const float i = (float)(idx % W), j = (float)(idx / W);
+    float o[3], d[3], near = 0.f, far = 0.f;
+    bool keep;
+    if (!demo) {
+        dataset_ray(cam, i, j, o, d, keep, near, far);
+    } else {
+        // pixel_camera = xy1 @ K_inv^T; pixel_world = (pixel_camera - T) @ R; rays_d = pixel_world - rays_o (demo_render.py:204-210)
+        float pc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pc[a] = mm3(i, cam.Kinv[a * 3 + 0], j, cam.Kinv[a * 3 + 1], 1.f, cam.Kinv[a * 3 + 2]);
+        const float t0 = pc[0] - cam.T[0], t1 = pc[1] - cam.T[1], t2 = pc[2] - cam.T[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            o[a] = cam.o[a];
+            d[a] = mm3(t0, cam.Rinv[a * 3 + 0], t1, cam.Rinv[a * 3 + 1], t2, cam.Rinv[a * 3 + 2]) - cam.o[a];
+        }
+        const float eps = 1e-6f;
+        float p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+        int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {                     // order: min_x,min_y,min_z,max_x,max_y,max_z (:211-214)
+            const int a = m % 3;
+            const float bd = (m < 3) ? cam.bmin[a] : cam.bmax[a];
+            const float tt = (bd - o[a]) / d[a];
+            const float hx = tt * d[0] + o[0], hy = tt * d[1] + o[1], hz = tt * d[2] + o[2];
+            const bool ok = hx >= cam.bmin[0] - eps && hx <= cam.bmax[0] + eps && hy >= cam.bmin[1] - eps &&
+                            hy <= cam.bmax[1] + eps && hz >= cam.bmin[2] - eps && hz <= cam.bmax[2] + eps;
+            if (ok) {
+                if (cnt == 0) { p0[0] = hx; p0[1] = hy; p0[2] = hz; }
+                else if (cnt == 1) { p1[0] = hx; p1[1] = hy; p1[2] = hz; }
+                ++cnt;
+            }
+        }
+        keep = (cnt == 2);
+        if (keep) {
+            // torch.norm(dim=1) is sqrt(fma(z, z, fma(y, y, x*x))) on the reference's CPU path (demo_render.py:232-234)
+            const auto norm3 = [](float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); };
+            const float nd = norm3(d[0], d[1], d[2]);
+            const float d0 = norm3(p0[0] - o[0], p0[1] - o[1], p0[2] - o[2]) / nd;
+            const float d1 = norm3(p1[0] - o[0], p1[1] - o[1], p1[2] - o[2]) / nd * (neg ? -1.f : 1.f);
+            near = fminf(d0, d1); far = fmaxf(d0, d1);
+        }
+    }
+    hit[idx] = (uint8_t)keep;
     f32x4 a, b;
-    a[0] = cam.o[0]; a[1] = cam.o[1]; a[2] = cam.o[2]; a[3] = d[0];
+    a[0] = o[0]; a[1] = o[1]; a[2] = o[2]; a[3] = d[0];
     b[0] = d[1]; b[1] = d[2]; b[2] = near; b[3] = far;
     *reinterpret_cast<f32x4*>(rays + (size_t)idx * 8) = a;
     *reinterpret_cast<f32x4*>(rays + (size_t)idx * 8 + 4) = b;
@@ -1623,17 +1663,17 @@ int gpnerf_composite(const float* raw, const float* z_vals, const float* nvalid,
     return launch_status();
 }
 
-int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o, const float* bounds,
+int gpnerf_make_rays(int32_t H, int32_t W, const double* Kinv, const double* Rinv, const double* cam_o, const float* bounds,
                      float* rays, uint8_t* hit, void* stream) {
     if (!Kinv || !Rinv || !cam_o || !bounds || !rays || !hit || H < 1 || W < 1) return GPNERF_E_ARG;
     RayCam c;
-    memcpy(c.Kinv, Kinv, sizeof(c.Kinv));
-    memcpy(c.Rinv, Rinv, sizeof(c.Rinv));
-    memcpy(c.o, cam_o, sizeof(c.o));
-    c.T[0] = c.T[1] = c.T[2] = 0.f;
-    for (int a = 0; a < 3; ++a) {   // bounds + [-0.01, 0.01] (data_utils.py:98)
-        c.bmin[a] = (float)((double)bounds[a] - 0.01);
-        c.bmax[a] = (float)((double)bounds[3 + a] + 0.01);
+    memset(&c, 0, sizeof(c));
+    memcpy(c.Kinv_d, Kinv, sizeof(c.Kinv_d));
+    memcpy(c.Rinv_d, Rinv, sizeof(c.Rinv_d));
+    memcpy(c.o_d, cam_o, sizeof(c.o_d));
+    for (int a = 0; a < 3; ++a) {   // bounds + [-0.01, 0.01] in float64 (data_utils.py:98)
+        c.bmin_d[a] = (double)bounds[a] + -0.01;
+        c.bmax_d[a] = (double)bounds[3 + a] + 0.01;
     }
     const int n = H * W, bs = 256;
     hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, 0, 0,
@@ -1666,6 +1706,7 @@ int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* 
                           const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream) {
     if (!Kinv || !pose || !bounds || !rays || !hit || H < 1 || W < 1) return GPNERF_E_ARG;
     RayCam c;
+    memset(&c, 0, sizeof(c));
     memcpy(c.Kinv, Kinv, sizeof(c.Kinv));
     for (int a = 0; a < 3; ++a) {
         for (int k = 0; k < 3; ++k) c.Rinv[a * 3 + k] = pose[k * 4 + a];              // column a of R: (x @ R)[a] = sum_k x[k] R[k][a]

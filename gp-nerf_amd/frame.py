@@ -301,20 +301,20 @@ def composite(raw, z_vals, nvalid=None, neg=False):
 
 
 def make_rays(H, W, K, R, T, bounds, device):
-    """gpnerf_make_rays: get_rays + get_near_far (data_utils.py:47-63,96-130) on the device.
+    """gpnerf_make_rays: get_rays + get_near_far (data_utils.py:47-63,96-130) on the device, bit-exact against numpy's run.
+    K, R, T are used in the dtype they come in (the dataset reads them as float64, ZjumocapDataset.py:360-380): the
+    inverses are np.linalg.inv in that dtype, as get_rays takes them (:49-51,57).
 
     Returns (rays [n,8] packed in raster order of the hit pixels, mask_at_box [H*W] bool)."""
     lib = L.lib()
-    K = np.asarray(K, np.float32)
-    R = np.asarray(R, np.float32)
-    T = np.asarray(T, np.float32).ravel()
-    Kinv = np.ascontiguousarray(np.linalg.inv(K).astype(np.float32))
-    Rinv = np.ascontiguousarray(np.linalg.inv(R).astype(np.float32))
-    o = np.ascontiguousarray((-(Rinv @ T)).astype(np.float32))
+    K, R, T = np.asarray(K), np.asarray(R), np.asarray(T).reshape(3, 1)
+    R_inv = np.linalg.inv(R)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    Kinv, Rinv, o = f64(np.linalg.inv(K)), f64(R_inv), f64((-R_inv @ T).ravel())
     b = np.ascontiguousarray(np.asarray(bounds, np.float32))
     rays = torch.empty((H * W, 8), device=device)
     hit = torch.empty((H * W,), device=device, dtype=torch.uint8)
-    L.check(lib.gpnerf_make_rays(H, W, Kinv.ctypes.data_as(L.FP), Rinv.ctypes.data_as(L.FP), o.ctypes.data_as(L.FP),
+    L.check(lib.gpnerf_make_rays(H, W, Kinv.ctypes.data_as(L.DP), Rinv.ctypes.data_as(L.DP), o.ctypes.data_as(L.DP),
                                  b.ctypes.data_as(L.FP), rays.data_ptr(), hit.data_ptr(), _stream_ptr(rays.device)),
             "gpnerf_make_rays")
     mask = hit.bool()

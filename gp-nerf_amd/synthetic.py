@@ -195,6 +195,36 @@ def rays_numpy(H, W, K, R, T, world_bounds):
     return o.astype(np.float32), d.astype(np.float32), near, far, mask_at_box
 
 
+def make_ray_camera(kind, H=512, W=512):
+    """Target cameras for the ray-generation vectors, float64 as the dataset reads them from annots.npy
+    (ZjumocapDataset.py:360-380), with the world box of the identity-pose scene (float32, as prepare_input makes it).
+      axis    : R = I, principal point on a pixel centre: the centre row / column have a zero direction component, which
+                get_near_far replaces by +1e-5 (data_utils.py:101)
+      edge    : R = I, focal length chosen so that pixel column W/2 + 100 passes exactly through the front-right edge of the
+                padded box (two plane hits coincide), i.e. grazing rays on both sides of the eps = 1e-6 test (:107-115)
+      oblique : generic rotation / translation / intrinsics with no float32-representable entries
+    Returns K [3,3], R [3,3], T [3] (float64) and bounds [2,3] (float32)."""
+    bounds = np.array([[-0.5, -0.9, -0.3], [0.5, 0.9, 0.3]], np.float32)
+    if kind == "axis":
+        K = np.array([[1.05 * W, 0, W / 2.0], [0, 1.05 * W, H / 2.0], [0, 0, 1]], np.float64)
+        R, T = np.eye(3), np.array([0.0, 0.0, 3.0])
+    elif kind == "edge":
+        f = 100.0 * (3.0 - (float(np.float32(0.3)) + 0.01)) / (float(np.float32(0.5)) + 0.01)
+        K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], np.float64)
+        R, T = np.eye(3), np.array([0.0, 0.0, 3.0])
+    elif kind == "oblique":
+        rv = np.array([0.31, -0.52, 0.17])
+        th = np.linalg.norm(rv)
+        k = rv / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + math.sin(th) * Kx + (1 - math.cos(th)) * (Kx @ Kx)
+        T = np.array([0.137, -0.211, 2.9031])
+        K = np.array([[W * 0.9137, 0, W / 2.0 + 3.37], [0, W * 0.9291, H / 2.0 - 5.11], [0, 0, 1]], np.float64)
+    else:
+        raise ValueError(kind)
+    return K, R, T, bounds
+
+
 def out_shape_dhw(bounds_smpl, voxel):
     """ZjumocapDataset.py:243-254: ceil(extent/voxel) rounded up to the next x32."""
     mn = bounds_smpl[0][[2, 1, 0]].astype(np.float64)

@@ -167,12 +167,15 @@ int gpnerf_head_forward(const float* head_blob, const float* vol_feat, const flo
 int gpnerf_composite(const float* raw, const float* z_vals, const float* nvalid, int64_t n_rays, int32_t n_samples,
                      int32_t neg, const GpnerfOutputs* out, void* stream);
 
-/* get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130) for one target camera.
- *   Kinv, Rinv: host 3x3 row-major fp32 inverses; cam_o: host [3] camera centre (-R^-1 T);
- *   bounds: host [2][3] world AABB (un-padded).
+/* get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130) for one target camera, in the precision the dataset
+ * runs them in (sample_ray's test branch, :294-300): float64 camera products rounded once to float32 rays, float64 plane hits
+ * and on-box tests (`bounds + [-0.01, 0.01]` promotes them, :98), float32 norm_ray, distances rounded to float32.
+ * mask_at_box, rays, near and far are bit-exact against the reference's numpy run (tests/golden/rays_*.npz).
+ *   Kinv, Rinv: host 3x3 row-major float64 inverses (np.linalg.inv of K, R); cam_o: host [3] float64 camera centre -Rinv @ T;
+ *   bounds: host [2][3] float32 world AABB (un-padded).
  *   rays: device [H*W][8]; hit: device [H*W] uint8 (mask_at_box).  Rays are written at their
  *   pixel index; the caller keeps the hit ones in raster order. */
-int gpnerf_make_rays(int32_t H, int32_t W, const float* Kinv, const float* Rinv, const float* cam_o,
+int gpnerf_make_rays(int32_t H, int32_t W, const double* Kinv, const double* Rinv, const double* cam_o,
                      const float* bounds, float* rays, uint8_t* hit, void* stream);
 
 /* SparseConvNet.encode's occupancy volume (libs/nerfheads/networks/SparseConvNet.py:135-139):

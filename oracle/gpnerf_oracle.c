@@ -339,41 +339,40 @@ int oracle_composite(const float *raw, const float *z, const float *nvalid, int6
     return 0;
 }
 
-/* get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130).
- * K,R row-major 3x3 fp32, T[3], bounds[2][3] world AABB (un-padded).
+/* get_rays + get_near_far (libs/datasets/data_utils.py:47-63,96-130) in the precision the reference runs them in.
+ * The dataset hands get_rays float64 K, R, T (annots.npy lists -> np.array, ZjumocapDataset.py:360-380), so pixel_camera /
+ * pixel_world / rays_d are float64 products (np.dot / @ = dgemm: k accumulated 0,1,2 with fused multiply-adds) and
+ * sample_ray rounds ray_o / ray_d to float32 once (:297-298).  get_near_far then mixes precisions: `bounds + np.array(...)`
+ * is float64 (:98), so the six plane hits and the on-box test are float64 arithmetic on the float32 ray values; norm_ray is
+ * np.linalg.norm of the float32 ray_d, i.e. float32 sqrt(x*x + y*y + z*z) summed left to right (:120); the two distances are
+ * float64 norms divided by it, signed by the first hit (:121-127), and rounded to float32 by the caller (:299-300).
+ * Kinv, Rinv: row-major 3x3 inverses (np.linalg.inv), cam_o = -Rinv @ T, all double; bounds[2][3] float32 world AABB.
  * Outputs sized H*W; returns the number of rays kept (raster order); mask[H*W]. */
-int64_t oracle_make_rays(int H, int W, const float *K, const float *R, const float *T, const float *bounds,
+#define MM3D(a0, b0, a1, b1, a2, b2) fma((a2), (b2), fma((a1), (b1), (a0) * (b0)))
+int64_t oracle_make_rays(int H, int W, const double *Kinv, const double *Rinv, const double *cam_o, const float *bounds,
                          float *ray_o, float *ray_d, float *near, float *far, uint8_t *mask) {
-    /* inverses in double, then the reference's float32 pipeline */
-    double Kd[9], Ki[9], Rd[9], Ri[9];
-    for (int i = 0; i < 9; ++i) { Kd[i] = K[i]; Rd[i] = R[i]; }
-#define INV3(A, B) do { \
-    double det = A[0]*(A[4]*A[8]-A[5]*A[7]) - A[1]*(A[3]*A[8]-A[5]*A[6]) + A[2]*(A[3]*A[7]-A[4]*A[6]); \
-    B[0]=(A[4]*A[8]-A[5]*A[7])/det; B[1]=(A[2]*A[7]-A[1]*A[8])/det; B[2]=(A[1]*A[5]-A[2]*A[4])/det; \
-    B[3]=(A[5]*A[6]-A[3]*A[8])/det; B[4]=(A[0]*A[8]-A[2]*A[6])/det; B[5]=(A[2]*A[3]-A[0]*A[5])/det; \
-    B[6]=(A[3]*A[7]-A[4]*A[6])/det; B[7]=(A[1]*A[6]-A[0]*A[7])/det; B[8]=(A[0]*A[4]-A[1]*A[3])/det; } while (0)
-    INV3(Kd, Ki);
-    INV3(Rd, Ri);
-    float Kif[9], Rif[9], o[3];
-    for (int i = 0; i < 9; ++i) { Kif[i] = (float)Ki[i]; Rif[i] = (float)Ri[i]; }
-    for (int i = 0; i < 3; ++i) o[i] = -(Rif[i * 3 + 0] * T[0] + Rif[i * 3 + 1] * T[1] + Rif[i * 3 + 2] * T[2]); /* :50-51 */
-    float bmin[3], bmax[3];
-    for (int i = 0; i < 3; ++i) { bmin[i] = (float)((double)bounds[i] - 0.01); bmax[i] = (float)((double)bounds[3 + i] + 0.01); } /* :98 */
-    const float eps = 1e-6f;
+    double bmin[3], bmax[3];
+    for (int i = 0; i < 3; ++i) { bmin[i] = (double)bounds[i] + -0.01; bmax[i] = (double)bounds[3 + i] + 0.01; }   /* :98 */
+    const double eps = 1e-6;
     int64_t n = 0;
     for (int j = 0; j < H; ++j)
         for (int i = 0; i < W; ++i) {
-            float xy1[3] = {(float)i, (float)j, 1.f}, pc[3], pw[3], d[3];
-            for (int a = 0; a < 3; ++a) pc[a] = xy1[0] * Kif[a * 3 + 0] + xy1[1] * Kif[a * 3 + 1] + xy1[2] * Kif[a * 3 + 2]; /* xy1 @ K^-T :56-57 */
-            for (int a = 0; a < 3; ++a) pw[a] = pc[0] * Rif[a * 3 + 0] + pc[1] * Rif[a * 3 + 1] + pc[2] * Rif[a * 3 + 2] + o[a]; /* :58 */
-            for (int a = 0; a < 3; ++a) { d[a] = pw[a] - o[a]; if (fabsf(d[a]) < 1e-5f) d[a] = 1e-5f; }  /* :60, :101 */
-            float hit[6][3]; int ok[6], cnt = 0;
+            double pc[3];
+            float o[3], d[3];
+            for (int a = 0; a < 3; ++a) pc[a] = MM3D((double)i, Kinv[a * 3 + 0], (double)j, Kinv[a * 3 + 1], 1.0, Kinv[a * 3 + 2]); /* :56-57 */
+            for (int a = 0; a < 3; ++a) {
+                double pw = MM3D(pc[0], Rinv[a * 3 + 0], pc[1], Rinv[a * 3 + 1], pc[2], Rinv[a * 3 + 2]) + cam_o[a];           /* :58 */
+                o[a] = (float)cam_o[a];
+                d[a] = (float)(pw - cam_o[a]);                                        /* :60, then .astype(np.float32) :297-298 */
+                if (fabsf(d[a]) < 1e-5f) d[a] = 1e-5f;                                /* :101, in place on the float32 array */
+            }
+            double hit[6][3]; int ok[6], cnt = 0;
             for (int s = 0; s < 2; ++s)
                 for (int a = 0; a < 3; ++a) {
-                    float bd = s ? bmax[a] : bmin[a];
-                    float tt = (bd - o[a]) / d[a];                                   /* :102 */
+                    double bd = s ? bmax[a] : bmin[a];
+                    double tt = (bd - (double)o[a]) / (double)d[a];                    /* :99-102 */
                     int m = s * 3 + a;
-                    for (int c = 0; c < 3; ++c) hit[m][c] = tt * d[c] + o[c];        /* :104 */
+                    for (int c = 0; c < 3; ++c) hit[m][c] = tt * (double)d[c] + (double)o[c];   /* :104 */
                     ok[m] = hit[m][0] >= bmin[0] - eps && hit[m][0] <= bmax[0] + eps && hit[m][1] >= bmin[1] - eps &&
                             hit[m][1] <= bmax[1] + eps && hit[m][2] >= bmin[2] - eps && hit[m][2] <= bmax[2] + eps;
                     cnt += ok[m];
@@ -381,15 +380,15 @@ int64_t oracle_make_rays(int H, int W, const float *K, const float *R, const flo
             int keep = (cnt == 2);                                                   /* :116 */
             mask[(size_t)j * W + i] = (uint8_t)keep;
             if (!keep) continue;
-            float *p0 = NULL, *p1 = NULL;
+            double *p0 = NULL, *p1 = NULL;
             for (int m = 0; m < 6; ++m) if (ok[m]) { if (!p0) p0 = hit[m]; else p1 = hit[m]; }
-            float nd = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-            float v0[3] = {p0[0] - o[0], p0[1] - o[1], p0[2] - o[2]}, v1[3] = {p1[0] - o[0], p1[1] - o[1], p1[2] - o[2]};
-            float sg = (v0[0] * d[0] + v0[1] * d[1] + v0[2] * d[2]) < 0.f ? -1.f : 1.f;   /* both use p0 :123,126 */
-            float d0 = sqrtf(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]) / nd * sg;
-            float d1 = sqrtf(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) / nd * sg;
+            float nd = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);                /* np.linalg.norm(float32) :120 */
+            double v0[3] = {p0[0] - o[0], p0[1] - o[1], p0[2] - o[2]}, v1[3] = {p1[0] - o[0], p1[1] - o[1], p1[2] - o[2]};
+            double sg = (v0[0] * d[0] + v0[1] * d[1] + v0[2] * d[2]) < 0.0 ? -1.0 : 1.0;   /* both use p0 :123,126 */
+            double d0 = sqrt(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]) / (double)nd * sg;
+            double d1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) / (double)nd * sg;
             for (int a = 0; a < 3; ++a) { ray_o[3 * n + a] = o[a]; ray_d[3 * n + a] = d[a]; }
-            near[n] = fminf(d0, d1); far[n] = fmaxf(d0, d1);
+            near[n] = (float)fmin(d0, d1); far[n] = (float)fmax(d0, d1);
             ++n;
         }
     return n;

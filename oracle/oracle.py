@@ -63,7 +63,8 @@ def lib():
         _lib.oracle_render.restype = C.c_int
         _lib.oracle_render.argtypes = [C.POINTER(OracleFrame), FP, C.c_int64, C.c_int, C.c_int, C.POINTER(OracleOut), C.c_int]
         _lib.oracle_make_rays.restype = C.c_int64
-        _lib.oracle_make_rays.argtypes = [C.c_int, C.c_int, FP, FP, FP, FP, FP, FP, FP, FP, C.POINTER(C.c_uint8)]
+        DP = C.POINTER(C.c_double)
+        _lib.oracle_make_rays.argtypes = [C.c_int, C.c_int, DP, DP, DP, FP, FP, FP, FP, FP, C.POINTER(C.c_uint8)]
         _lib.oracle_composite.restype = C.c_int
         _lib.oracle_composite.argtypes = [FP, FP, FP, C.c_int64, C.c_int, C.c_int, FP, FP, FP, FP, FP, C.POINTER(C.c_uint8)]
         _lib.oracle_max_threads.restype = C.c_int
@@ -219,14 +220,26 @@ def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None
     return res
 
 
+def camera_inverses(K, R, T):
+    """What get_rays derives from the camera (data_utils.py:49-51,57), in the dtype it is handed (the dataset: float64),
+    returned as float64 for the C side: inv(K), inv(R), -inv(R) @ T."""
+    K, R, T = np.asarray(K), np.asarray(R), np.asarray(T).reshape(3, 1)
+    R_inv = np.linalg.inv(R)
+    o = (-R_inv @ T).ravel()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    return f64(np.linalg.inv(K)), f64(R_inv), f64(o)
+
+
 def make_rays(H, W, K, R, T, bounds):
-    K, R, T, bounds = _f32(K), _f32(R), _f32(T).ravel(), _f32(bounds)
+    Kinv, Rinv, o = camera_inverses(K, R, T)
+    bounds = _f32(bounds)
     n = H * W
     ro, rd = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
     near, far = np.zeros(n, np.float32), np.zeros(n, np.float32)
     mask = np.zeros(n, np.uint8)
-    k = lib().oracle_make_rays(H, W, _p(K), _p(R), _p(T), _p(bounds), _p(ro), _p(rd), _p(near), _p(far),
-                               mask.ctypes.data_as(C.POINTER(C.c_uint8)))
+    DP = C.POINTER(C.c_double)
+    k = lib().oracle_make_rays(H, W, Kinv.ctypes.data_as(DP), Rinv.ctypes.data_as(DP), o.ctypes.data_as(DP), _p(bounds), _p(ro), _p(rd),
+                               _p(near), _p(far), mask.ctypes.data_as(C.POINTER(C.c_uint8)))
     return ro[:k], rd[:k], near[:k], far[:k], mask.astype(bool)
 
 

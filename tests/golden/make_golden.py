@@ -228,25 +228,31 @@ def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays
           f"acc mean={out['acc_map'].mean():.4f} depth mean={out['depth_map'].mean():.4f} -> {os.path.getsize(path)} B")
 
 
-def run_rays_case(name, H, W, seed):
-    """get_rays + get_near_far (data_utils.py:47-63,96-130) on a synthetic camera/box."""
+def run_rays_case(name, H, W, kind):
+    """get_rays + get_near_far (data_utils.py:47-63,96-130) as sample_ray's test branch chains them (:294-300): float64
+    camera (the dataset's dtype) -> float64 rays rounded to float32 -> get_near_far on the float32 rays."""
     du = importlib.import_module("data_utils")
     syn = importlib.import_module("gp-nerf_amd.synthetic")
-    sc = syn.make_scene(H=H, W=W, seed=seed, fill="survey", pose="random", make_volumes=False)
-    K = sc["target_K"][0]
-    R = sc["target_pose"][0][:, :3]
-    T = sc["target_pose"][0][:, 3]  # (3,) as ZjumocapDataset.py:410 passes it
+    K, R, T, bounds = syn.make_ray_camera(kind, H, W)
     ray_o, ray_d = du.get_rays(H, W, K, R, T)
+    assert ray_d.dtype == np.float64
     ray_o = ray_o.reshape(-1, 3).astype(np.float32)
     ray_d = ray_d.reshape(-1, 3).astype(np.float32)
-    near, far, mask_at_box = du.get_near_far(sc["can_bounds"][0], ray_o, ray_d)
-    out = {"K": K, "R": R, "T": T, "bounds": sc["can_bounds"][0], "H": np.int32(H), "W": np.int32(W),
-           "ray_o": ray_o[mask_at_box], "ray_d": ray_d[mask_at_box],
-           "near": near.astype(np.float32), "far": far.astype(np.float32), "mask_at_box": mask_at_box}
+    n_clamped = int((np.abs(ray_d) < 1e-5).sum())
+    near, far, mask_at_box = du.get_near_far(bounds, ray_o, ray_d)            # clamps ray_d in place (:101)
+    assert near.dtype == np.float64
+    ray_o, ray_d = ray_o[mask_at_box], ray_d[mask_at_box]
+    near, far = near.astype(np.float32), far.astype(np.float32)
+    step = max(1, ray_d.shape[0] // 4096)
+    out = {"K": K, "R": R, "T": T, "bounds": bounds, "H": np.int32(H), "W": np.int32(W), "kind": np.frombuffer(kind.encode(), np.uint8),
+           "mask_at_box_bits": np.packbits(mask_at_box), "n_rays": np.int64(mask_at_box.sum()),
+           "near": near, "far": far, "ray_o": ray_o[0], "ray_d_stride": np.int64(step), "ray_d_sub": ray_d[::step],
+           "ray_d_sha256": np.frombuffer(hashlib.sha256(np.ascontiguousarray(ray_d).tobytes()).digest(), np.uint8),
+           "n_clamped": np.int64(n_clamped), "n_degenerate": np.int64((near == far).sum())}
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"{name}: {int(mask_at_box.sum())}/{H*W} rays hit -> {os.path.getsize(path)} B")
-
+    print(f"{name}: {int(mask_at_box.sum())}/{H*W} rays hit, {n_clamped} clamped components, {int((near == far).sum())} rays with near == far "
+          f"-> {os.path.getsize(path)} B")
 
 class _device_shim:
     """`.to("cuda")` -> `.to("cpu")` and a no-op torch.cuda.synchronize while the reference's demo renderer runs."""
@@ -425,8 +431,10 @@ def main():
     for name, kw, S, extra in DEMO_CASES:
         if not only or name in only:
             run_demo_case(name, kw, S, **extra)
-    if not only or "rays_48" in only:
-        run_rays_case("rays_48", 48, 48, 11)
+    for name, H, W, kind in (("rays_48", 48, 48, "oblique"), ("rays_512_axis", 512, 512, "axis"), ("rays_512_edge", 512, 512, "edge"),
+                             ("rays_512_oblique", 512, 512, "oblique")):
+        if not only or name in only:
+            run_rays_case(name, H, W, kind)
     for name, n, d, seed in (("attention_d16", 257, 16, 5), ("attention_d32", 300, 32, 6)):
         if not only or name in only:
             run_attention_case(name, n, d, seed)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import assert_close, case_names, demo_case_names, load, scene_of
+from golden_cases import assert_close, case_names, demo_case_names, load, rays_case_names, scene_of
 
 pytestmark = pytest.mark.gpu
 
@@ -107,17 +107,18 @@ def test_composite_matches_oracle(fm, oracle):
         assert np.array_equal(got["ray_mask"].astype(bool), ref["ray_mask"])
 
 
-def test_make_rays_matches_oracle_and_golden(fm, oracle, syn):
+@pytest.mark.parametrize("name", rays_case_names())
+def test_make_rays_matches_reference_golden(name, fm, syn):
+    """gpnerf_make_rays against numpy's run of get_rays + get_near_far (three 512x512 cameras incl. the +1e-5 clamp and
+    rays through the box edge): mask_at_box, rays, near, far bit-exact."""
     import os
     from golden_cases import GOLDEN_DIR
-    z = np.load(os.path.join(GOLDEN_DIR, "rays_48.npz"))
-    rays, mask = fm.make_rays(int(z["H"]), int(z["W"]), z["K"], z["R"], z["T"], z["bounds"], torch.device("cuda:0"))
+    from test_oracle_golden import check_rays_against_golden
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    K, R, T, bounds = syn.make_ray_camera(bytes(z["kind"]).decode(), int(z["H"]), int(z["W"]))
+    rays, mask = fm.make_rays(int(z["H"]), int(z["W"]), K, R, T, bounds, torch.device("cuda:0"))
     rays, mask = rays.cpu().numpy(), mask.cpu().numpy()
-    assert np.array_equal(mask, z["mask_at_box"])
-    assert_close(rays[:, 0:3], z["ray_o"], 1e-6, "ray_o")
-    assert_close(rays[:, 3:6], z["ray_d"], 1e-6, "ray_d")
-    assert_close(rays[:, 6], z["near"], 1e-5, "near")
-    assert_close(rays[:, 7], z["far"], 1e-5, "far")
+    check_rays_against_golden(z, rays[:, 0:3], rays[:, 3:6], rays[:, 6], rays[:, 7], mask)
 
 
 def test_early_termination_stays_within_bound(fm, oracle, syn):

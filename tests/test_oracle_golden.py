@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_cases import GOLDEN_DIR, assert_close, case_names, demo_case_names, load, scene_of, sha_inputs
+from golden_cases import GOLDEN_DIR, assert_close, case_names, demo_case_names, load, rays_case_names, scene_of, sha_inputs
 
 # fp32 re-association only: the reference's own fp32-vs-fp64 spread is 6.5e-7
 TOL = 2e-5
@@ -37,14 +37,27 @@ def test_oracle_matches_reference_outputs(name, oracle):
         assert np.array_equal(res["ray_mask"][:k].astype(bool), z["st_ray_mask"]), "ray mask"
 
 
-def test_oracle_rays_match_reference(oracle):
-    z = np.load(os.path.join(GOLDEN_DIR, "rays_48.npz"))
-    ro, rd, near, far, mask = oracle.make_rays(int(z["H"]), int(z["W"]), z["K"], z["R"], z["T"], z["bounds"])
-    assert np.array_equal(mask, z["mask_at_box"])
-    assert_close(ro, z["ray_o"], 1e-6, "ray_o")
-    assert_close(rd, z["ray_d"], 1e-6, "ray_d")
-    assert_close(near, z["near"], 1e-5, "near")
-    assert_close(far, z["far"], 1e-5, "far")
+def check_rays_against_golden(z, ro, rd, near, far, mask):
+    """mask_at_box, rays, near and far of a rays_* vector: index work and correctly-rounded arithmetic -> bit-exact."""
+    import hashlib
+    n = int(z["H"]) * int(z["W"])
+    assert np.array_equal(mask, np.unpackbits(z["mask_at_box_bits"])[:n].astype(bool)), "mask_at_box"
+    assert np.array_equal(ro, np.broadcast_to(z["ray_o"], ro.shape)), "ray_o"
+    assert np.array_equal(rd[::int(z["ray_d_stride"])], z["ray_d_sub"]), "ray_d (subset)"
+    assert hashlib.sha256(np.ascontiguousarray(rd).tobytes()).digest() == bytes(z["ray_d_sha256"]), "ray_d (all)"
+    assert np.array_equal(near, z["near"]) and np.array_equal(far, z["far"]), "near / far"
+
+
+@pytest.mark.parametrize("name", rays_case_names())
+def test_oracle_rays_match_reference(name, oracle, syn):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    K, R, T, bounds = syn.make_ray_camera(bytes(z["kind"]).decode(), int(z["H"]), int(z["W"]))
+    assert all(np.array_equal(a, z[k]) for a, k in ((K, "K"), (R, "R"), (T, "T"), (bounds, "bounds"))), "camera is not the golden run's"
+    check_rays_against_golden(z, *oracle.make_rays(int(z["H"]), int(z["W"]), K, R, T, bounds))
+    if name == "rays_512_axis":
+        assert int(z["n_clamped"]) >= 1024          # the centre row and column exercise the +1e-5 clamp
+    if name == "rays_512_edge":
+        assert int(z["n_degenerate"]) > 0           # rays through the box edge: both hits coincide
 
 
 def test_synthetic_rays_agree_with_oracle(oracle, syn):
