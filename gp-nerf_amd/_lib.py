@@ -79,6 +79,8 @@ SYMBOLS = {
     "gpnerf_project_gather": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     "gpnerf_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gpnerf_sigma_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_rgb_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gpnerf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.POINTER(GpnerfOutputs), C.c_void_p]),
     "gpnerf_make_rays": (C.c_int, [C.c_int32, C.c_int32, DP, DP, DP, FP, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -921,12 +921,15 @@ __global__ void combine_segments_kernel(const float* __restrict__ part, const lo
 }
 
 // ---------------------------------------------------------------------------------------------
-// NeRFHead.forward on pre-gathered features
+// NeRFHead.forward on pre-gathered features, and its two halves as the reference's renderers call them separately
 // ---------------------------------------------------------------------------------------------
-template <int NWAVES>
+// MODE 0: NeRFHead.forward (trainhead.py:159-163): vol_feat, rgb_feat, mask -> raw
+// MODE 1: NeRFSigmaHead.test_forward (:61-76): vol_feat, rgb_feat -> sigma_feat [P][64], globalfeat [P][134] = [sigma_feat, mean, var]
+// MODE 2: NeRFRGBHead.forward (:118-145): sigma_feat [P][64] (in place of vol_feat), rgb_feat, mask -> raw
+template <int NWAVES, int MODE>
 __global__ void __launch_bounds__(NWAVES * 64, NWAVES / 4)
 head_forward_kernel(const float* __restrict__ blob, const float* __restrict__ vol_feat, const float* __restrict__ rgb_feat,
-                    const float* __restrict__ mask, const long P, float* __restrict__ raw) {
+                    const float* __restrict__ mask, const long P, float* __restrict__ raw, float* __restrict__ globalfeat) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(blob);
@@ -939,11 +942,6 @@ head_forward_kernel(const float* __restrict__ blob, const float* __restrict__ vo
     for (long tile = (long)blockIdx.x * NWAVES + wave; tile < ntile; tile += (long)gridDim.x * NWAVES) {
         const bool active = tile * 32 + n < P;
         const long p = active ? tile * 32 + n : P - 1;
-        float fv[64];
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) fv[16 * l + c] = vol_feat[p * 128 + 32 * l + 16 * half + c];
         float x[NV][18];
         float nvalid = 0.f;
 #pragma unroll
@@ -953,16 +951,53 @@ head_forward_kernel(const float* __restrict__ blob, const float* __restrict__ vo
             for (int c = 0; c < 16; ++c) x[v][c] = xv[3 + 16 * half + c];
             x[v][16] = half ? xv[1] : xv[0];
             x[v][17] = half ? 0.f : xv[2];
-            nvalid += mask[p * NV + v];
+            if (MODE != 1) nvalid += mask[p * NV + v];
         }
         float sf[32];
-        geo_eval(lds, lane, fv, sf);
-        float sigma, rgb[3];
-        Stamps st;
-        mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
-        if (active && half == 0) {
-            f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
-            *reinterpret_cast<f32x4*>(raw + p * 4) = rw;
+        if constexpr (MODE == 2) {
+            // the accumulator layout of geo_eval's output, in the scaled domain: feature 32 m + ft(r, half) in sf[16 m + r]
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sf[16 * m + r] = vol_feat[p * 64 + 32 * m + gpl::ft(r, half)] * LOG2E;
+        } else {
+            float fv[64];
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) fv[16 * l + c] = vol_feat[p * 128 + 32 * l + 16 * half + c];
+            geo_eval(lds, lane, fv, sf);
+        }
+        if constexpr (MODE == 1) {
+            if (active) {
+                constexpr float LN2 = 0.69314718055994530942f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = sf[16 * m + r] * LN2;
+                        raw[p * 64 + 32 * m + gpl::ft(r, half)] = v;
+                        globalfeat[p * 134 + 32 * m + gpl::ft(r, half)] = v;
+                    }
+#pragma unroll
+                for (int t = 0; t < 18; ++t) {       // fused_mean_variance (trainhead.py:20-24), as mlp_eval computes it
+                    const int c = half ? gpl::idx35(t, 1) : gpl::idx35(t, 0);      // this lane's slot of the 35-vector, -1 = pad
+                    const float m_ = ((x[0][t] + x[1][t]) + x[2][t]) * (1.f / 3.f);
+                    const float a = x[0][t] - m_, b = x[1][t] - m_, cc = x[2][t] - m_;
+                    if (c >= 0) {
+                        globalfeat[p * 134 + 64 + c] = m_;
+                        globalfeat[p * 134 + 99 + c] = ((a * a + b * b) + cc * cc) * (1.f / 3.f);
+                    }
+                }
+            }
+        } else {
+            float sigma, rgb[3];
+            Stamps st;
+            mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
+            if (active && half == 0) {
+                f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
+                *reinterpret_cast<f32x4*>(raw + p * 4) = rw;
+            }
         }
     }
 }
@@ -1385,7 +1420,11 @@ int device_ready(int* cus) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES>),
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES, 0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
         }
         (void)hipGetLastError();
@@ -1437,6 +1476,19 @@ OutK to_outk(const GpnerfOutputs* o, const int32_t* order = nullptr) {
     k.rgb = o->rgb; k.depth = o->depth; k.acc = o->acc; k.disp = o->disp; k.weights = o->weights;
     k.z_vals = o->z_vals; k.rgb_in = o->rgb_in; k.raw = o->raw; k.ray_mask = o->ray_mask;
     return k;
+}
+
+template <int MODE>
+int launch_head(const float* head_blob, const float* a, const float* rgb_feat, const float* mask, int64_t n_points, float* out,
+                float* out2, void* stream) {
+    if (device_ready(nullptr) != GPNERF_OK) return GPNERF_E_DEVICE;
+    const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
+    const int64_t tiles = (n_points + 31) / 32;
+    int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL((head_forward_kernel<FUSED_WAVES, MODE>), dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
+                       head_blob, a, rgb_feat, mask, (long)n_points, out, out2);
+    return launch_status();
 }
 }  // namespace
 
@@ -1642,14 +1694,21 @@ int gpnerf_head_forward(const float* head_blob, const float* vol_feat, const flo
                         int64_t n_points, float* raw, void* stream) {
     if (n_points == 0) return GPNERF_OK;
     if (!head_blob || !vol_feat || !rgb_feat || !mask || !raw || n_points < 0) return GPNERF_E_ARG;
-    const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
-    if (device_ready(nullptr) != GPNERF_OK) return GPNERF_E_DEVICE;
-    const int64_t tiles = (n_points + 31) / 32;
-    int64_t blocks = (tiles + FUSED_WAVES - 1) / FUSED_WAVES;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(head_forward_kernel<FUSED_WAVES>, dim3((unsigned)blocks), dim3(FUSED_WAVES * 64), lds_bytes, S_(stream),
-                       head_blob, vol_feat, rgb_feat, mask, (long)n_points, raw);
-    return launch_status();
+    return launch_head<0>(head_blob, vol_feat, rgb_feat, mask, n_points, raw, nullptr, stream);
+}
+
+int gpnerf_sigma_features(const float* head_blob, const float* vol_feat, const float* rgb_feat, int64_t n_points,
+                          float* sigma_feat, float* globalfeat, void* stream) {
+    if (n_points == 0) return GPNERF_OK;
+    if (!head_blob || !vol_feat || !rgb_feat || !sigma_feat || !globalfeat || n_points < 0) return GPNERF_E_ARG;
+    return launch_head<1>(head_blob, vol_feat, rgb_feat, nullptr, n_points, sigma_feat, globalfeat, stream);
+}
+
+int gpnerf_rgb_head_forward(const float* head_blob, const float* sigma_feat, const float* rgb_feat, const float* mask,
+                            int64_t n_points, float* raw, void* stream) {
+    if (n_points == 0) return GPNERF_OK;
+    if (!head_blob || !sigma_feat || !rgb_feat || !mask || !raw || n_points < 0) return GPNERF_E_ARG;
+    return launch_head<2>(head_blob, sigma_feat, rgb_feat, mask, n_points, raw, nullptr, stream);
 }
 
 int gpnerf_composite(const float* raw, const float* z_vals, const float* nvalid, int64_t n_rays, int32_t n_samples,

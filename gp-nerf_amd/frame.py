@@ -281,6 +281,34 @@ def head_forward(head_blob, vol_feat, rgb_feat, mask):
     return raw
 
 
+def sigma_features(head_blob, vol_feat, rgb_feat):
+    """gpnerf_sigma_features: vol_feat [P,128], rgb_feat [P,V,35] -> sigma_feat [P,64], globalfeat [P,134]
+    (NeRFSigmaHead.test_forward after its volume sampling, trainhead.py:61-76)."""
+    lib = L.lib()
+    for t, w in ((vol_feat, "vol_feat"), (rgb_feat, "rgb_feat")):
+        _require_gpu(t, w)
+    vol_feat, rgb_feat = vol_feat.contiguous().float(), rgb_feat.contiguous().float()
+    P = vol_feat.shape[0]
+    sf = torch.empty((P, 64), device=vol_feat.device)
+    gf = torch.empty((P, 134), device=vol_feat.device)
+    L.check(lib.gpnerf_sigma_features(head_blob.data_ptr(), vol_feat.data_ptr(), rgb_feat.data_ptr(), P, sf.data_ptr(), gf.data_ptr(),
+                                      _stream_ptr(vol_feat.device)), "gpnerf_sigma_features")
+    return sf, gf
+
+
+def rgb_head_forward(head_blob, sigma_feat, rgb_feat, mask):
+    """gpnerf_rgb_head_forward: sigma_feat [P,64], rgb_feat [P,V,35], mask [P,V] -> raw [P,4] (NeRFRGBHead.forward, trainhead.py:118-145)."""
+    lib = L.lib()
+    for t, w in ((sigma_feat, "sigma_feat"), (rgb_feat, "rgb_feat"), (mask, "mask")):
+        _require_gpu(t, w)
+    sigma_feat, rgb_feat, mask = sigma_feat.contiguous().float(), rgb_feat.contiguous().float(), mask.contiguous().float()
+    P = sigma_feat.shape[0]
+    raw = torch.empty((P, 4), device=sigma_feat.device)
+    L.check(lib.gpnerf_rgb_head_forward(head_blob.data_ptr(), sigma_feat.data_ptr(), rgb_feat.data_ptr(), mask.data_ptr(), P,
+                                        raw.data_ptr(), _stream_ptr(sigma_feat.device)), "gpnerf_rgb_head_forward")
+    return raw
+
+
 def composite(raw, z_vals, nvalid=None, neg=False):
     """gpnerf_composite: Renderer.raw2outputs (BaseRender.py:75-107)."""
     lib = L.lib()

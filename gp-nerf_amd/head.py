@@ -52,6 +52,45 @@ class NeRFSigmaHead(nn.Module):
         return self.xyzc_net.dense_levels(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
 
 
+    def _blob(self, device):
+        """Head image carrying this module's Linear(128,64) only (the other layers zero): enough for gpnerf_sigma_features."""
+        lin = self.out_geometry_fc[0]
+        key = (str(device), lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version)
+        if self.__dict__.get("_blob_key") != key:
+            sd = {}
+            for short, name in L.HEAD_FIELDS:
+                sd[name + ".weight"] = torch.zeros(L.HEAD_SHAPES[short])
+                sd[name + ".bias"] = torch.zeros(L.HEAD_SHAPES[short][0])
+            sd["sigmahead.out_geometry_fc.0.weight"], sd["sigmahead.out_geometry_fc.0.bias"] = lin.weight, lin.bias
+            self.__dict__["_blob_t"], self.__dict__["_blob_key"] = F_.pack_head(sd, device), key
+        return self.__dict__["_blob_t"]
+
+    def _sample(self, x, grid_coords):
+        """xyzc_net(x, grid)[B,128,P] -> [P,128] rows (trainhead.py:56-57,63-68)."""
+        return self.xyzc_net(x, grid_coords[:, None, None].float()).permute(0, 2, 1).reshape(-1, 128)
+
+    def forward(self, sp_input, grid_coords, smpl_feat_sampled, mask):
+        """trainhead.py:43-59: per-frame volumes from the SMPL features, sampled at grid_coords [1,P,3], through
+        Linear(128,64)+ELU.  Returned with the reference's (odd) view [-1, n_samples, 1]."""
+        x = sp_input.get("xyzc")
+        if x is None:
+            code = self.c(torch.arange(0, self.n_smpl, device=grid_coords.device))
+            fused = self.xyzc_attn.fuse_vertices(code, smpl_feat_sampled.flatten(0, 1))
+            x = V_.SparseConvTensor(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"], sp_input.get("volumes"))
+        vol_feat = self._sample(x, grid_coords)
+        zeros = torch.zeros((vol_feat.shape[0], L.VIEWS, 35), device=vol_feat.device)
+        sigma_feat, _ = F_.sigma_features(self._blob(vol_feat.device), vol_feat, zeros)
+        return sigma_feat.view(-1, mask.shape[1], 1)
+
+    def test_forward(self, sp_input, grid_coords, rgb_feat, mask):
+        """trainhead.py:61-76: sigma_feat [R,S,64] and globalfeat [R,S,1,134] = [sigma_feat, mean_v, var_v] of rgb_feat
+        [R,S,V,35]; the volumes come from sp_input['xyzc'] (the tensor `encode` was called with, demo_render.py:154-165)."""
+        R, S = rgb_feat.shape[:2]
+        vol_feat = self._sample(sp_input["xyzc"], grid_coords)
+        sf, gf = F_.sigma_features(self._blob(vol_feat.device), vol_feat, rgb_feat.reshape(R * S, L.VIEWS, 35))
+        return sf.view(R, S, 64), gf.view(R, S, 1, 134)
+
+
 class NeRFRGBHead(nn.Module):
     """Parameters of trainhead.py:82-115: base_fc, vis_fc, rgb_fc, out_geometry_fc."""
 
@@ -67,6 +106,28 @@ class NeRFRGBHead(nn.Module):
                                              nn.Linear(32, 16), e(), nn.Linear(16, 1), nn.ReLU())
         for m in (self.out_geometry_fc, self.base_fc, self.vis_fc, self.rgb_fc):
             m.apply(weights_init)
+
+    def _blob(self, device):
+        """Head image with this module's 11 layers (Linear(128,64) of the sigma head zero): what gpnerf_rgb_head_forward stages."""
+        ps = [p for seq in (self.base_fc, self.vis_fc, self.rgb_fc, self.out_geometry_fc) for p in seq.parameters()]
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if self.__dict__.get("_blob_key") != key:
+            sd = {"sigmahead.out_geometry_fc.0.weight": torch.zeros(64, 128), "sigmahead.out_geometry_fc.0.bias": torch.zeros(64)}
+            for _, name in L.HEAD_FIELDS:
+                if name.startswith("rgbhead."):
+                    mod, idx = name[len("rgbhead."):].rsplit(".", 1)
+                    lin = getattr(self, mod)[int(idx)]
+                    sd[name + ".weight"], sd[name + ".bias"] = lin.weight, lin.bias
+            self.__dict__["_blob_t"], self.__dict__["_blob_key"] = F_.pack_head(sd, device), key
+        return self.__dict__["_blob_t"]
+
+    def forward(self, rgb_feat, sigma_feat, mask):
+        """trainhead.py:118-145: rgb_feat [R,S,V,35], sigma_feat (any view of [R,S,64]), mask [R,S,V,1] ->
+        (rgb_in [R,S,V,3], rgb_out [R,S,3], sigma_out [R,S,1])."""
+        R, S = rgb_feat.shape[:2]
+        raw = F_.rgb_head_forward(self._blob(rgb_feat.device), sigma_feat.reshape(R * S, 64), rgb_feat.reshape(R * S, L.VIEWS, 35),
+                                  mask.reshape(R * S, L.VIEWS)).view(R, S, 4)
+        return rgb_feat[..., :3], raw[..., :3], raw[..., 3:]
 
 
 class NeRFHead(nn.Module):

@@ -68,6 +68,17 @@ class MultiHeadAttention(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # sparse 3-D convolution by rulebook
 # ------------------------------------------------------------------------------------------------
+class SparseConvTensor:
+    """What the reference's renderers hand to the sparse net: `spconv.SparseConvTensor(features, indices, spatial_shape,
+    batch_size)` (trainhead.py:54, demo_render.py:154).  The net only reads these four attributes, so a real spconv tensor
+    works too.  `dense_levels` (optional): the 4 dense levels already built -- short-cuts the convolutions, like
+    sp_input['volumes'] does for NeRFHead.forward."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, dense_levels=None):
+        self.features, self.indices, self.spatial_shape, self.batch_size = features, indices, spatial_shape, batch_size
+        self.dense_levels = dense_levels
+
+
 class SparseTensor:
     """features [M,C]; coords [M,3] (d,h,w) int64; spatial shape (D,H,W).  Batch size 1."""
 
@@ -279,6 +290,42 @@ class SparseConvNet(nn.Module):
                 vol._gpnerf_ndhwc = True
                 levels.append(vol)
         return levels
+
+    # ---- the reference's two calls (SparseConvNet.py:105-143) --------------------------------------------------------
+    def _levels_of(self, x):
+        """The 4 channels-last levels of sparse tensor `x`, built once per tensor object (the reference rebuilds them on
+        every call: encode, then forward inside test_forward, demo_render.py:155,295)."""
+        hit = self.__dict__.get("_levels_cache")
+        if hit is not None and hit[0] is x:
+            return hit[1]
+        from . import frame as F_
+        pre = getattr(x, "dense_levels", None)
+        if pre is not None:
+            fr = F_.Frame.for_volumes(list(pre), None)
+        else:
+            fr = F_.Frame.for_volumes(self.dense_levels_hip(x.features, x.indices, x.spatial_shape, x.batch_size), None)
+        self.__dict__["_levels_cache"] = (x, fr)
+        return fr
+
+    def forward(self, x, grid_coords=None):
+        """SparseConvNet.forward (:105-124): with grid_coords [B,1,1,P,3] the trilinear samples of the 4 levels, [B,128,P];
+        without, the list of dense levels [1,C,D,H,W] (views of the channels-last volumes)."""
+        from . import frame as F_
+        fr = self._levels_of(x)
+        if grid_coords is None:
+            return [v.permute(3, 0, 1, 2).unsqueeze(0) for v in fr.vols]
+        P = grid_coords.shape[-2]
+        feat = F_.sample_volume(fr, grid_coords.reshape(-1, 3))
+        return feat.view(grid_coords.shape[0], P, 128).permute(0, 2, 1)
+
+    def encode(self, x, threshold=0.1):
+        """SparseConvNet.encode (:126-143): sets `features` (the dense levels), `masks3d` (occupancy at level-1 size:
+        channel sums, nearest-upsampled, summed over levels; gpnerf_build_occupancy) and `mask_xyz` (the occupied voxels'
+        (x,y,z) indices times 2, float, in torch.where's d-major order)."""
+        fr = self._levels_of(x)
+        self.features = [v.permute(3, 0, 1, 2).unsqueeze(0) for v in fr.vols]
+        self.masks3d = fr.build_occupancy()
+        self.mask_xyz = torch.stack(torch.where(self.masks3d > threshold), dim=0).permute(1, 0).flip(-1).float() * 2.0
 
     def dense_levels(self, code, coord, out_sh, batch_size=1):
         """code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) ->

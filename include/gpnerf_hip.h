@@ -162,6 +162,17 @@ int gpnerf_project_gather(const GpnerfFrame* frame, const float* pts, int64_t n_
 int gpnerf_head_forward(const float* head_blob, const float* vol_feat, const float* rgb_feat, const float* mask,
                         int64_t n_points, float* raw, void* stream);
 
+/* The two halves of the head as the reference's progressive renderer calls them (libs/renders/demo_render.py:295-326):
+ * gpnerf_sigma_features = NeRFSigmaHead.test_forward (libs/nerfheads/trainhead.py:61-76) after its volume sampling:
+ *   vol_feat [P][128], rgb_feat [P][V][35] -> sigma_feat [P][64] = ELU(Linear(vol_feat)), globalfeat [P][134] =
+ *   [sigma_feat, mean over views (35), population variance over views (35)];
+ * gpnerf_rgb_head_forward = NeRFRGBHead.forward (:118-145): sigma_feat [P][64], rgb_feat [P][V][35], mask [P][V] ->
+ *   raw [P][4] = (rgb_out, sigma_out).  All device; head_blob as in GpnerfFrame. */
+int gpnerf_sigma_features(const float* head_blob, const float* vol_feat, const float* rgb_feat, int64_t n_points,
+                          float* sigma_feat, float* globalfeat, void* stream);
+int gpnerf_rgb_head_forward(const float* head_blob, const float* sigma_feat, const float* rgb_feat, const float* mask,
+                            int64_t n_points, float* raw, void* stream);
+
 /* Renderer.raw2outputs (BaseRender.py:75-107) alone.  raw [N][S][4], z [N][S],
  * nvalid [N][S] = per-sample number of valid views (may be NULL), all device. */
 int gpnerf_composite(const float* raw, const float* z_vals, const float* nvalid, int64_t n_rays, int32_t n_samples,

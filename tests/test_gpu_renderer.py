@@ -121,6 +121,51 @@ def test_head_forward_matches_reference(plugins):
     assert_close(rgb_in.cpu().numpy(), z["st_rgb_in"], 1e-6, "rgb_in")
 
 
+@pytest.mark.parametrize("name", demo_case_names())
+def test_head_surface_of_the_progressive_renderer(name, plugins):
+    """What libs/renders/demo_render.py touches on the head: xyzc_net.encode / .masks3d / .mask_xyz,
+    sigmahead.test_forward, rgbhead.out_geometry_fc, rgbhead(...) -- against values captured inside the reference's run."""
+    _, hip_head = plugins
+    vol = importlib.import_module("gp-nerf_amd.volume")
+    z, meta = load(name)
+    sc = scene_of(meta)
+    dev = "cuda:0"
+    head = hip_head.build_head(cfg()).to(dev).eval()
+    sd = head.state_dict()
+    for k, v in sc["head"].items():
+        sd[k] = torch.from_numpy(v.copy())
+    head.load_state_dict(sd, strict=True)
+    xyzc = vol.SparseConvTensor(None, None, [int(v) for v in sc["out_sh"][0]], 1,
+                                dense_levels=[torch.from_numpy(v).to(dev) for v in sc["volumes"]])
+    net = head.sigmahead.xyzc_net
+    net.encode(xyzc, threshold=0.1)                                   # demo_render.py:155
+    assert_close(net.masks3d.cpu().numpy(), z["masks3d"], 1e-4, "masks3d")
+    assert net.mask_xyz.shape == (int(z["n_mask_xyz"]), 3) and net.mask_xyz.dtype == torch.float32
+    assert np.array_equal(net.mask_xyz[:64].cpu().numpy(), z["mask_xyz_head"]), "mask_xyz order / values"
+    assert [tuple(f.shape) for f in net.features] == [tuple(v.shape) for v in sc["volumes"]]
+    grid = torch.from_numpy(z["tf_grid"]).to(dev)[None]               # [1,P,3]
+    rgb_feat = torch.from_numpy(z["tf_rgb_feat"]).to(dev)[:, None]    # [P,1,V,35]
+    mask = torch.from_numpy(z["tf_mask"]).to(dev)[:, None, :, None]   # [P,1,V,1]
+    sigma_feat, globalfeat = head.sigmahead.test_forward({"xyzc": xyzc}, grid, rgb_feat, mask)       # :295
+    P = grid.shape[1]
+    assert sigma_feat.shape == (P, 1, 64) and globalfeat.shape == (P, 1, 1, 134)
+    assert_close(sigma_feat[:, 0].cpu().numpy(), z["tf_sigma_feat"], TOL, "sigma_feat")
+    assert_close(globalfeat[:, 0, 0].cpu().numpy(), z["tf_globalfeat"], TOL, "globalfeat")
+    # the density MLP as demo_render.py:300 runs it (stock nn.Sequential on the module's own parameters) and the colour head
+    # as :326 calls it agree with the fused head on the same points
+    sigma = head.rgbhead.out_geometry_fc(globalfeat.squeeze(2))
+    rgb_in, rgb_out, sigma_out = head.rgbhead(rgb_feat, sigma_feat, mask)
+    assert rgb_in.shape == (P, 1, 3, 3) and rgb_out.shape == (P, 1, 3) and sigma_out.shape == (P, 1, 1)
+    raw, _ = head({"volumes": xyzc.dense_levels}, grid, None, rgb_feat.view(P, 1, 3, 35), mask)
+    assert_close(rgb_out.cpu().numpy(), raw[..., :3].cpu().numpy(), 1e-6, "rgb_out")
+    assert_close(sigma_out.cpu().numpy(), raw[..., 3:].cpu().numpy(), 1e-6, "sigma_out")
+    nvalid = mask.sum(dim=2)
+    assert_close(sigma.masked_fill(nvalid < 1, 0.0).detach().cpu().numpy(), sigma_out.cpu().numpy(), 2e-5, "sigma (nn.Sequential vs HIP)")
+    # NeRFSigmaHead.forward's view (trainhead.py:58) of the same features
+    sf = head.sigmahead({"xyzc": xyzc}, grid, None, torch.zeros((P // 8, 8, 3, 1), device=dev))
+    assert sf.shape == (P * 64 // 8, 8, 1) and torch.equal(sf.reshape(P, 64), sigma_feat[:, 0])
+
+
 def test_render_with_the_volume_builder_runs(plugins, syn):
     """No pre-built pyramid in the batch: SMPL features -> attention -> sparse conv net -> fused render."""
     hip_render, _ = plugins
