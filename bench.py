@@ -4,10 +4,17 @@
     python bench.py --gpus N --steps K --warmup W
 (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL.)
 
-A "step" renders one frame's rays per GPU through gpnerf_render_fused (sample -> gather -> MLP ->
-composite) and, for N > 1, all-gathers the packed pixels (rgb + depth) of every rank.  Inputs are
-resident in HBM before the timed region.  Weak scaling: every rank renders its own 512x512x64
-band of an (N*512)x512 image, so value = N * 262144 rays / step time.
+A "step" renders ONE frame through gpnerf_render_fused (sample -> gather -> MLP -> composite) with every output
+`Renderer.render` returns (rgb, depth, acc, disp, weights, z_vals, rgb_in), in the 32x8-pixel patch order `Renderer.render`
+launches with.  Inputs are resident in HBM before the timed region.
+
+  N = 1   value = rays of the frame / step time (BASELINE.json configs[1]; --early-term --samples 128 = configs[2]).
+  N > 1   STRONG scaling (default): the same frame's rays are split over the N ranks in round-robin bands
+          (gp-nerf_amd/parallel.py ShardPlan); a step = render my share + ONE all_gather_into_tensor of the packed pixels
+          (rgb + depth, 16 B/ray) + re-assembly in ray order on every rank.  value = rays of the frame / step time, so
+          value(N) / value(1) is the speed-up on one frame (north_star: >= 6x at 8 GPUs).  After the headline region the
+          same flow is timed on a 1024x1024x64 frame (BASELINE.json configs[3]) and reported as `config4_1024`.
+          --scaling weak: every rank renders its own full frame (a band of an N-times larger image) + the same all-gather.
 
 One JSON line is printed by rank 0; see DESIGN.md for the accounting behind `roofline`.
 """
@@ -26,6 +33,7 @@ if ROOT not in sys.path:
 
 FLOP_PER_SAMPLE = 110848           # 2*MAC of the reference's dense layers, V=3, C=32
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+API_OUTPUTS = ("weights", "z_vals", "rgb_in")      # + rgb, depth, acc, disp (always written) = Renderer.render's dict
 
 
 def parse():
@@ -37,9 +45,16 @@ def parse():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--fill", default="full", choices=["full", "survey"],
                     help="full: every pixel's ray crosses the SMPL bound (N = size^2); survey: f = 1.05 W (SURVEY.md §8d)")
-    ap.add_argument("--early-term", action="store_true", help="config 3: wave-level early ray termination")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1 only")
+    ap.add_argument("--early-term", action="store_true", help="configs[2]: wave-level early ray termination")
     ap.add_argument("--term-eps", type=float, default=1e-5)
+    ap.add_argument("--sigma-bias", type=float, default=None,
+                    help="shift of the last density bias of the random-init net (default 0; 1.0 with --early-term so that rays "
+                         "become opaque, which a trained net's do and a random one's do not)")
+    ap.add_argument("--outputs", default="api", choices=["api", "light"],
+                    help="api: every map Renderer.render returns; light: rgb/depth/acc/disp only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measurements reported beside the headline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--split-f16", action="store_true",
@@ -48,9 +63,47 @@ def parse():
                     help="progressive sample culling (demo_render.py semantics) on a sparse synthetic pyramid")
     ap.add_argument("--occupancy", type=float, default=None, help="fraction of coarse volume blocks that are occupied")
     ap.add_argument("--ray-order", default="patch", choices=["patch", "raster"],
-                    help="patch: 32x8-pixel workgroup tiles (gpnerf_render_fused's ray_order); raster: the list as given")
-    ap.add_argument("--patch", default="32x8", help="WxH of the patches of --ray-order patch (W*H a multiple of 32: one patch row or one whole patch per wavefront)")
+                    help="patch: 32x8-pixel workgroup tiles (what Renderer.render passes as ray_order); raster: the list as given")
+    ap.add_argument("--patch", default="32x8", help="WxH of the patches of --ray-order patch")
     return ap.parse_args()
+
+
+class Workload:
+    """One synthetic frame resident on `dev`: frame constants, ray list, patch order."""
+
+    def __init__(self, args, size, samples, dev, sigma_bias):
+        import torch
+        fm = importlib.import_module("gp-nerf_amd.frame")
+        syn = importlib.import_module("gp-nerf_amd.synthetic")
+        self.H = self.W = size
+        self.S = samples
+        self.sc = sc = syn.make_scene(H=size, W=size, seed=args.seed, fill=args.fill, pose="identity", vol_occupancy=args.occupancy,
+                                      sigma_bias=sigma_bias)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.vols_dev = [t(v) for v in sc["volumes"]]                       # the 4 dense levels as the reference lays them out (NCDHW)
+        self.frame = fm.Frame(t(sc["src_imgs"][0]), t(sc["featmaps"]), self.vols_dev, t(sc["src_Ks"][0]),
+                              t(sc["src_poses"][0]), sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0],
+                              fm.pack_head(sc["head"], dev))
+        self.rays_h = np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32)
+        self.rays = t(self.rays_h)
+        pw, ph = (int(v) for v in args.patch.split("x"))
+        self.patch = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], size, size, patch_w=pw, patch_h=ph)).to(dev)
+        self.n = self.rays.shape[0]
+
+
+def time_launches(fn, steps, warmup):
+    """Mean HIP-event duration of fn() (events on torch's current stream, the one the kernel is launched on)."""
+    import torch
+    for _ in range(warmup):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        out = fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev])), out
 
 
 def main():
@@ -77,122 +130,220 @@ def main():
             dist.init_process_group(backend=backend)
 
     fm = importlib.import_module("gp-nerf_amd.frame")
-    syn = importlib.import_module("gp-nerf_amd.synthetic")
     par = importlib.import_module("gp-nerf_amd.parallel")
+    sigma_bias = args.sigma_bias if args.sigma_bias is not None else (1.0 if args.early_term else 0.0)
+    wl = Workload(args, args.size, args.samples, dev, sigma_bias)
+    S = wl.S
+    want = API_OUTPUTS if args.outputs == "api" else ()
+    strong = world > 1 and args.scaling == "strong"
+    kw = dict(early_term=args.early_term, term_eps=args.term_eps, occ_cull=args.occ_cull, split_f16=args.split_f16)
 
-    H = W = args.size
-    S = args.samples
-    sc = syn.make_scene(H=H, W=W, seed=args.seed, fill=args.fill, pose="identity", vol_occupancy=args.occupancy)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    blob = fm.pack_head(sc["head"], dev)
-    frame = fm.Frame(t(sc["src_imgs"][0]), t(sc["featmaps"]), [t(v) for v in sc["volumes"]], t(sc["src_Ks"][0]),
-                     t(sc["src_poses"][0]), sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0], blob)
-    rays_h = np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32)
-    rays = t(rays_h)                       # this rank's band: weak scaling, same ray count on every rank
-    n_local = rays.shape[0]
-    order = None
-    if args.ray_order == "patch":
-        pw, ph = (int(v) for v in args.patch.split("x"))
-        order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], H, W, patch_w=pw, patch_h=ph)).to(dev)
-    n_total = n_local * world
-    torch.cuda.synchronize()
+    class Flow:
+        """The timed step for one workload: single-GPU frame, strong-scaling share + gather, or weak-scaling band + gather."""
 
-    want = ()                              # headline outputs only: rgb, depth, acc, disp
-    gathered = torch.empty((world, n_local, 4), device=dev if backend == "nccl" else "cpu") if world > 1 else None
-    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    k_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    def step(i=None):
-        if i is not None:
-            k_start[i].record()
-        out = fm.render_fused(frame, rays, S, early_term=args.early_term, term_eps=args.term_eps, want=want, ray_order=order, occ_cull=args.occ_cull, split_f16=args.split_f16)
-        if i is not None:
-            k_stop[i].record()
-        if world > 1:
-            if backend == "nccl":
-                par.all_gather_pixels(out, gathered)
+        def __init__(self, wl):
+            self.wl = wl
+            if strong:
+                # the frame's ray list in patch-major order, split in round-robin bands; outputs come back in that list's order
+                self.rays_all = wl.rays.index_select(0, wl.patch.long()) if args.ray_order == "patch" else wl.rays
+                self.plan = par.plan_for(wl.n, world, dev)
+                self.rays = self.plan.take(self.rays_all, rank).contiguous()
+                self.order = None
+                self.want = ()                             # the exchange carries rgb + depth: 16 B/ray
+                self.buf = torch.empty((world * self.plan.share, 4), device=dev if backend == "nccl" else "cpu")
+                self.rays_per_step = wl.n
             else:
-                par.all_gather_pixels({k: v.cpu() for k, v in out.items() if k in ("rgb_map", "depth_map")}, gathered)
-        return out
+                self.rays, self.order, self.want = wl.rays, (wl.patch if args.ray_order == "patch" else None), want
+                self.buf = torch.empty((world, wl.n, 4), device=dev if backend == "nccl" else "cpu") if world > 1 else None
+                self.rays_per_step = wl.n * world
+            self.n_local = self.rays.shape[0]
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(k_start, k_stop)]))
+        def render(self):
+            return fm.render_fused(self.wl.frame, self.rays, self.wl.S, want=self.want, ray_order=self.order, **kw)
+
+        def step(self, events=None):
+            if events:
+                events[0].record()
+            out = self.render()
+            if events:
+                events[1].record()
+            if strong:
+                local = out if backend == "nccl" else {k: out[k].cpu() for k in par.PIXEL_KEYS}
+                out = par.gather_frame(local, self.plan if backend == "nccl" else _cpu_plan(par, self.plan), par.PIXEL_KEYS, buffer=self.buf)
+            elif world > 1:
+                par.all_gather_pixels(out if backend == "nccl" else {k: out[k].cpu() for k in par.PIXEL_KEYS}, self.buf)
+            return out
+
+        def timed(self, steps, warmup):
+            for _ in range(warmup):
+                self.step()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                out = self.step(ev[i])
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), out
+
+    flow = Flow(wl)
+    dt, kernel_ms, out = flow.timed(args.steps, args.warmup)
+
+    extras = {}
+    if world > 1 and strong and not args.no_extras and args.size != 1024:
+        # BASELINE.json configs[3]: one 1024x1024x64 frame over the same ranks, same flow
+        wl4 = Workload(args, 1024, 64, dev, 0.0)
+        f4 = Flow(wl4)
+        dt4, k4, _ = f4.timed(max(3, args.steps // 2), 2)
+        st4 = max(3, args.steps // 2)
+        extras["config4_1024"] = {"workload": "1024x1024 frame, 64 samples/ray, rays in round-robin bands over the ranks + pixel all-gather "
+                                              "(BASELINE.json configs[3])", "value": wl4.n * st4 / dt4, "unit": "rays/s", "ms_per_frame": dt4 / st4 * 1e3,
+                                  "kernel_ms_rank0": k4, "rays_per_rank": int(f4.n_local), "rays_total": int(wl4.n)}
+        del wl4, f4
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = n_total * args.steps / dt
-        flops_per_launch = float(n_local) * S * FLOP_PER_SAMPLE
+        value = flow.rays_per_step * args.steps / dt
+        flops_per_launch = float(flow.n_local) * S * FLOP_PER_SAMPLE
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        cfg_no = 2 if args.early_term else (3 if (args.size == 1024 and world > 1) else 1)
+        if world == 1:
+            parallelism = "single GPU"
+        elif strong:
+            parallelism = (f"strong: one frame's rays in round-robin bands of {par.INTERLEAVE_BAND} over {world} GPUs, one all_gather_into_tensor "
+                           f"of rgb+depth (16 B/ray) per frame")
+        else:
+            parallelism = f"weak: every one of {world} GPUs renders its own frame-sized band, all-gather of rgb+depth"
+        traffic, traffic_src = measured_traffic(args, world)
         line = {
             "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{H}x{W} frame, {S} samples/ray, fused HIP render kernel, synthetic SMPL bound + random "
-                                   f"feature volume (BASELINE.json configs[{2 if args.early_term else 1}])",
-                       "rays_per_gpu": int(n_local), "rays_total": int(n_total), "samples_per_ray": S, "fill": args.fill, "ray_order": args.ray_order,
-                       "early_term": bool(args.early_term), "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "vol_occupancy": args.occupancy, "out_sh_dhw": [int(x) for x in sc["out_sh"][0]],
-                       "parallelism": f"ray bands over {world} GPU(s), all-gather of rgb+depth" if world > 1 else "single GPU"},
+            "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{wl.H}x{wl.W} frame, {S} samples/ray, fused HIP render kernel, synthetic SMPL bound + random "
+                                   f"feature volume (BASELINE.json configs[{cfg_no}])",
+                       "rays_per_gpu": int(flow.n_local), "rays_total": int(flow.rays_per_step), "samples_per_ray": S, "fill": args.fill,
+                       "ray_order": args.ray_order, "outputs": "rgb+depth (the all-gather payload)" if strong else
+                       ("rgb,depth,acc,disp,weights,z_vals,rgb_in (Renderer.render's dict)" if args.outputs == "api" else "rgb,depth,acc,disp"),
+                       "early_term": bool(args.early_term), "term_eps": args.term_eps if args.early_term else None, "sigma_bias": sigma_bias,
+                       "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "vol_occupancy": args.occupancy,
+                       "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(args),
-                         "kernel": "render_fused_kernel", "kernel_ms": kernel_ms,
-                         "flop_per_launch": flops_per_launch},
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_per_launch},
         }
-        if world == 1 and not args.split_f16:
-            # the optional split-precision mode of the same kernel (GPNERF_FLAG_SPLIT_F16), measured after the headline
-            # region: f16 hi/lo MFMAs with f32 accumulation, same parity bound; NOT part of `value`
-            for _ in range(args.warmup):
-                fm.render_fused(frame, rays, S, want=want, ray_order=order, split_f16=True)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(args.steps):
-                alt = fm.render_fused(frame, rays, S, want=want, ray_order=order, early_term=args.early_term,
-                                      term_eps=args.term_eps, occ_cull=args.occ_cull, split_f16=True)
-            e1.record()
-            torch.cuda.synchronize()
-            alt_ms = e0.elapsed_time(e1) / args.steps
-            line["split_f16_mode"] = {
-                "value": n_local / (alt_ms * 1e-3), "unit": "rays/s", "ms_per_step": alt_ms,
-                "max_abs_vs_f32_path": {"rgb": float((alt["rgb_map"] - out["rgb_map"]).abs().max()),
-                                        "depth": float((alt["depth_map"] - out["depth_map"]).abs().max())},
-                "note": "dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation; VALU/gather-bound",
-            }
+        line.update(extras)
+        if args.early_term:
+            done = fm.render_fused(wl.frame, wl.rays, S, want=("samples_done",), ray_order=flow.order, **kw)["samples_done"]
+            line["early_term"] = {"samples_evaluated_frac": float(done.float().mean()) / S,
+                                  "note": "wave-level scan: a 32-ray tile stops once every ray has T < term_eps"}
+        if world == 1 and not args.no_extras:
+            line["beside_headline"] = beside_headline(args, fm, wl, kw, flow)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sc, rays_h, S, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(wl.sc, wl.rays_h, S, args.cpu_seconds)
             line["vs_cpu"] = value / line["cpu_baseline"]["value"]
         # sanity on the product's own output (not a parity check; tests/ do that)
-        rgb = out["rgb_map"]
-        assert bool(torch.isfinite(rgb).all()), "non-finite rgb"
+        assert bool(torch.isfinite(out["rgb_map"]).all()), "non-finite rgb"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def measured_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot run the
-    profiler itself); only reported for the configuration the counters were collected on."""
+def _cpu_plan(par, plan):
+    """gloo dry run: the same plan with host index tensors."""
+    import torch
+    return par.plan_for(plan.n_rays, plan.world, torch.device("cpu"), plan.band)
+
+
+def beside_headline(args, fm, wl, kw, flow):
+    """Measured AFTER the timed region, never part of `value`: the same launch with the light output set, in raster order,
+    in the split-precision form, and the wall time of the whole Renderer.render(batch) call on the same frame."""
+    import torch
+    S, st, wu = wl.S, args.steps, args.warmup
+    res = {}
+    head_ms = None
+    for name, want, order, extra in (("api_outputs_patch_order", API_OUTPUTS, wl.patch, {}), ("light_outputs_patch_order", (), wl.patch, {}),
+                                     ("api_outputs_raster_order", API_OUTPUTS, None, {}), ("split_f16_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True})):
+        k2 = dict(kw)
+        k2.update(extra)
+        ms, o = time_launches(lambda: fm.render_fused(wl.frame, wl.rays, S, want=want, ray_order=order, **k2), st, wu)
+        res[name] = {"kernel_ms": ms, "rays_per_sec": wl.n / (ms * 1e-3)}
+        if name == "api_outputs_patch_order":
+            head_ms, head_out = ms, o
+        if extra:
+            res[name]["max_abs_vs_f32_form"] = {"rgb": float((o["rgb_map"] - head_out["rgb_map"]).abs().max()),
+                                                "depth": float((o["depth_map"] - head_out["depth_map"]).abs().max())}
+            res[name]["note"] = "dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation"
+    try:
+        res["renderer_api"] = renderer_api_wall(args, wl)
+    except Exception as e:                       # the API timing must never take the headline down with it
+        res["renderer_api"] = {"error": repr(e)[:200]}
+    return res
+
+
+def renderer_api_wall(args, wl):
+    """Wall time of `build_render(cfg).render(batch)` (the reference's entry point, tools/inference.py:61 + BaseTrainer.py:267) on
+    the bench frame: with feature maps and volumes handed in (frame build + render + dict), and with the per-frame producers
+    (image encoder, vertex attention, sparse volume builder) running too."""
+    import torch
+    from types import SimpleNamespace as NS
+    p = os.path.join(ROOT, "gp-nerf_amd", "plugins")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    hip_render = importlib.import_module("hip_render")
+    cfg = NS(encoder=NS(file="hip_encoder", name="resnet34", out_ch=32),
+             head=NS(file="hip_head", rgb=NS(use_rgbhead=True), sigma=NS(code_dim=32, n_heads=4, n_layers=4, n_smpl=6890, outdims=[32, 32, 32, 32])),
+             dataset=NS(train=NS(name="zju_mocap", chunk=400), test=NS(name="zju_mocap", chunk=2000), voxel_size=[0.005] * 3),
+             train=NS(n_rays=1024, n_samples=wl.S), test=NS(mesh_th=50))
+    dev = wl.rays.device
+    r = hip_render.build_render(cfg).to(dev).eval()
+    sd = r.state_dict()
+    for k, v in wl.sc["head"].items():
+        sd["nerfhead." + k] = torch.from_numpy(v.copy())
+    r.load_state_dict(sd, strict=True)
+    sc = wl.sc
+    keys = ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "feature", "coord", "out_sh", "bounds", "Rh", "R", "Th", "body_msk",
+            "mask_at_box")
+    b = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in keys}
+    res = {}
+    with torch.no_grad():
+        for name, extra in (("products_in_batch", {"featmaps": torch.from_numpy(sc["featmaps"]).to(dev), "volumes": wl.vols_dev}), ("with_producers", {})):
+            bb = dict(b, **extra)
+            for _ in range(2):
+                r.render(bb)
+            ts, et = [], []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ret = r.render(bb)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+                et.append(ret["etime"] * 1e3)
+            res[name] = {"wall_ms": float(np.median(ts)), "etime_ms": float(np.median(et)), "rtime_ms": float(ret["rtime"] * 1e3),
+                         "returns": sorted(k for k in ret if k not in ("etime", "rtime"))}
+    res["note"] = ("products_in_batch: batch carries featmaps + the 4 dense levels; with_producers: hip_encoder + vertex attention + sparse "
+                   "volume builder run per frame (their volumes are sparse, the per-ray kernel's work is the same)")
+    return res
+
+
+def measured_traffic(args, world):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of the same configuration
+    (bench.py cannot run the profiler on itself); returns (bytes or None, where the number comes from)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if (args.size == 512 and args.samples == 64 and args.fill == "full" and not args.early_term and not args.occ_cull and not args.split_f16
-            and args.occupancy is None and os.path.exists(p)):
-        return json.load(open(p))["hbm_bytes_per_launch"]
-    return None
+    if (world == 1 and args.size == 512 and args.samples == 64 and args.fill == "full" and not args.early_term and not args.occ_cull
+            and not args.split_f16 and args.occupancy is None and os.path.exists(p)):
+        j = json.load(open(p))
+        return j["hbm_bytes_per_launch"], j.get("source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes, profile-derived, not measured in this run)")
+    return None, None
 
 
 def cpu_baseline(sc, rays_h, S, target_s):

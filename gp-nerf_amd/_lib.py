@@ -54,7 +54,7 @@ class GpnerfOutputs(C.Structure):
     _fields_ = [
         ("rgb", C.c_void_p), ("depth", C.c_void_p), ("acc", C.c_void_p), ("disp", C.c_void_p),
         ("weights", C.c_void_p), ("z_vals", C.c_void_p), ("rgb_in", C.c_void_p), ("ray_mask", C.c_void_p),
-        ("raw", C.c_void_p),
+        ("raw", C.c_void_p), ("samples_done", C.c_void_p),
     ]
 
 

@@ -623,6 +623,7 @@ struct FrameK {           // GpnerfFrame by value (kernel argument; lands in SGP
 struct OutK {
     float *rgb, *depth, *acc, *disp, *weights, *z_vals, *rgb_in, *raw;
     uint8_t* ray_mask;
+    int32_t* samples_done;
     const int32_t* order;     // optional: slot i of the launch renders ray order[i] (locality-friendly tiling)
 };
 
@@ -636,6 +637,8 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     OutK out;
     int split;
     float* part;
+    int dynamic;              // 1: persistent workgroups pulling tiles from `queue`
+    unsigned* queue;          // 8 counters (one per XCD), zero at launch
 };
 
 // bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
@@ -664,58 +667,50 @@ DEV void grid_coords(const FR& fr, float px, float py, float pz, float& gx, floa
 }
 
 // Launched with 1..8 waves per workgroup (blockDim.x = 64 * waves): one workgroup per CU either way (LDS), so the
-// host picks the width that balances the grid over the 256 CUs (choose_waves()).
+// host picks the width that balances the grid over the CUs (choose_geometry()).
 #ifndef GPNERF_MAX_WAVES
 #define GPNERF_MAX_WAVES 8
 #endif
+// One work unit = (32-ray tile, sample segment) rendered by one wavefront: with split > 1 the samples of a tile are divided
+// between `split` waves, whose partial composites are merged by combine_segments_kernel (finer load balance for small frames).
 template <bool SPLIT>
-__global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
-render_fused_kernel(const KArgs ka) {
+DEV void render_tile(float* lds, const int lane, const long tile, const int seg) {
     // Everything the sample loop reads from the arguments is re-read from the kernarg segment (scalar loads, scalar
     // cache) at the top of every iteration through `kp`, a pointer the optimiser cannot see through.  Held in SGPRs
     // across the loop instead, the ~130 argument dwords spill to VGPR lanes and come back as v_readlane_b32 -- VALU
     // instructions in the middle of the MFMA chains, which stall the matrix pipe (tools/micro/mfma_chains.hip).
+    // The same goes for the per-tile values: a persistent wave renders many tiles, and arguments kept in SGPRs across the
+    // tile loop spill just the same, so every tile starts from a fresh, laundered kernarg pointer.
     typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
-    const long n_rays = ka.n_rays;
-    const int S = ka.S;
-    const unsigned flags = ka.flags;
-    const float term_eps = ka.term_eps;
-    const int split = ka.split;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : ka.fr.head_blob);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < (SPLIT ? gph::BLOB_WORDS : gpl::BLOB_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
+    kargs_ptr k0 = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k0));
+    const long n_rays = k0->n_rays;
+    const int S = k0->S;
+    const unsigned flags = k0->flags;
+    const float term_eps = k0->term_eps;
+    const int split = k0->split;
     const unsigned* const lw = reinterpret_cast<const unsigned*>(lds);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, half = lane >> 5;
-    // work unit = (32-ray tile, sample segment): with split > 1 the samples of a tile are divided between `split`
-    // waves, whose partial composites are merged by combine_segments_kernel (finer load balance for small frames)
-    const long unit = (long)xcd_remap(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
-    const long tile = unit / split;
-    const int seg = (int)(unit % split);
     const long ray0 = tile * RAYS_PER_WAVE;
     if (ray0 >= n_rays) return;
     const bool active = (ray0 + n) < n_rays;
     const long slot = active ? ray0 + n : n_rays - 1;
-    const long ray = ka.out.order ? (long)ka.out.order[slot] : slot;
+    const long ray = k0->out.order ? (long)k0->out.order[slot] : slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;             // Projector front test
     const bool flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;       // raw2outputs(neg=True)
     const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
-    const bool cull = (flags & GPNERF_FLAG_OCC_CULL) != 0 && ka.fr.occ != nullptr;
+    const bool cull = (flags & GPNERF_FLAG_OCC_CULL) != 0 && k0->fr.occ != nullptr;
 
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(ka.rays + ray * 8);
-    const f32x4 r1 = *reinterpret_cast<const f32x4*>(ka.rays + ray * 8 + 4);
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(k0->rays + ray * 8);
+    const f32x4 r1 = *reinterpret_cast<const f32x4*>(k0->rays + ray * 8 + 4);
     const float ox = r0[0], oy = r0[1], oz = r0[2], dx = r0[3], dy = r1[0], dz = r1[1], near = r1[2], far = r1[3];
 
     float T = 1.f, c_r = 0.f, c_g = 0.f, c_b = 0.f, depth = 0.f, acc = 0.f;
     float rin[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) rin[i] = 0.f;
-    int n_two = 0;
+    int n_two = 0, n_done = 0;
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0);
 
@@ -756,6 +751,7 @@ render_fused_kernel(const KArgs ka) {
             }
         }
 
+        ++n_done;
         // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
         float fv[64];
 #pragma unroll
@@ -879,6 +875,56 @@ render_fused_kernel(const KArgs ka) {
             for (int i = 0; i < 9; ++i) out.rgb_in[ray * 9 + i] = rin[i];
         }
         if (out.ray_mask) out.ray_mask[ray] = (uint8_t)(n_two > 8);
+        if (out.samples_done) out.samples_done[ray] = n_done;
+    }
+}
+
+// Workgroups are persistent when the launch is `dynamic`: the head image is staged into LDS once, then every wavefront
+// pulls tiles from eight per-XCD queues (ka.queue: one counter per XCD, zeroed by the host before the launch) until all are
+// empty.  Each XCD's queue holds a contiguous run of tiles, so neighbouring tiles still share an L2; a wave whose own
+// queue is dry steals from the next XCD's.  A tile's cost varies (early termination, sample culling, padding), and with one
+// 8-wave workgroup resident per CU a static grid holds the CU until its slowest tile is done -- the queue hands the next
+// tile to whichever wave is free.  Static launches (one unit per wave, XCD-aware remap) remain for frames smaller than
+// one round and for the sample-split geometry.
+template <bool SPLIT>
+__global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
+render_fused_kernel(const KArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : ka.fr.head_blob);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < (SPLIT ? gph::BLOB_WORDS : gpl::BLOB_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int qx = blockIdx.x & 7;                    // workgroups are dealt to the XCDs round-robin
+    for (int dry = 0; dry < 8;) {
+        typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
+        kargs_ptr kq = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));            // re-read per tile rather than held across render_tile (see there)
+        long tile;
+        int seg = 0;
+        if (kq->dynamic) {
+            const long n_tiles = (kq->n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+            const long q = n_tiles >> 3, r = n_tiles & 7;
+            unsigned t = 0;
+            if (lane == 0) t = atomicAdd(kq->queue + qx, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            const long start = qx < r ? qx * (q + 1) : r * (q + 1) + (qx - r) * q;
+            const long len = q + (qx < r ? 1 : 0);
+            if ((long)t >= len) {               // this XCD's queue is dry: move on to the next one
+                qx = (qx + 1) & 7;
+                ++dry;
+                continue;
+            }
+            tile = start + t;
+        } else {                                // static launch: exactly one unit per wave
+            const long unit = (long)xcd_remap(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
+            tile = unit / kq->split;
+            seg = (int)(unit % kq->split);
+            dry = 8;
+        }
+        render_tile<SPLIT>(lds, lane, tile, seg);
     }
 }
 
@@ -1367,6 +1413,7 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
 // workgroup and, when the caller lends a workspace, how many waves share the samples of one tile (split), minimising
 // rounds x step time x samples per unit.  GPNERF_WAVES / GPNERF_SPLIT override (diagnostics).
 constexpr int GPNERF_MAX_SPLIT = 8;     // waves that may share one tile's samples
+constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue counters (one per XCD), padded
 struct Geometry { int waves, split; };
 
 Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, int64_t n_rays, int n_cus) {
@@ -1474,7 +1521,7 @@ OutK to_outk(const GpnerfOutputs* o, const int32_t* order = nullptr) {
     OutK k;
     k.order = order;
     k.rgb = o->rgb; k.depth = o->depth; k.acc = o->acc; k.disp = o->disp; k.weights = o->weights;
-    k.z_vals = o->z_vals; k.rgb_in = o->rgb_in; k.raw = o->raw; k.ray_mask = o->ray_mask;
+    k.z_vals = o->z_vals; k.rgb_in = o->rgb_in; k.raw = o->raw; k.ray_mask = o->ray_mask; k.samples_done = o->samples_done;
     return k;
 }
 
@@ -1630,13 +1677,25 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     int n_cus = 0;
     if (device_ready(&n_cus) != GPNERF_OK) return GPNERF_E_DEVICE;
     if (flags & GPNERF_FLAG_OCC_CULL) k.voxel[0] = k.voxel[1] = k.voxel[2] = 0.005f;   // demo_render.py:91 `xyz / 0.005`
-    const bool may_split = workspace && !(flags & GPNERF_FLAG_EARLY_TERM);
-    const Geometry g = choose_geometry(tiles, n_samples, may_split, workspace ? workspace_bytes : 0, n_rays, n_cus);
-    const int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
+    // workspace layout: [0, QUEUE_BYTES) the tile queue's counters, then the per-segment partial composites
+    const size_t seg_bytes = workspace && workspace_bytes > QUEUE_BYTES ? workspace_bytes - QUEUE_BYTES : 0;
+    float* const seg_part = seg_bytes ? reinterpret_cast<float*>(static_cast<char*>(workspace) + QUEUE_BYTES) : nullptr;
+    const bool may_split = seg_bytes && !(flags & GPNERF_FLAG_EARLY_TERM) && !out->samples_done;
+    const Geometry g = choose_geometry(tiles, n_samples, may_split, seg_bytes, n_rays, n_cus);
+    int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
+    // more than one round of workgroups and nothing split: persistent workgroups + tile queue (see render_fused_kernel)
+    static int f_dynamic = -1;
+    if (f_dynamic < 0) { const char* e = getenv("GPNERF_DYNAMIC"); f_dynamic = e ? atoi(e) : 1; }
+    const bool dynamic = f_dynamic && workspace && workspace_bytes >= QUEUE_BYTES && g.split == 1 && blocks > n_cus;
+    if (dynamic) {
+        if (hipMemsetAsync(workspace, 0, QUEUE_BYTES, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+        blocks = n_cus;
+    }
     const OutK ok = to_outk(out, ray_order);
     KArgs ka;
     ka.fr = k; ka.rays = rays; ka.n_rays = (long)n_rays; ka.S = (int)n_samples; ka.flags = (unsigned)flags; ka.term_eps = term_eps;
-    ka.out = ok; ka.split = g.split; ka.part = (float*)workspace;
+    ka.out = ok; ka.split = g.split; ka.part = seg_part;
+    ka.dynamic = dynamic ? 1 : 0; ka.queue = static_cast<unsigned*>(workspace);
     if (split16)
         hipLaunchKernelGGL(render_fused_kernel<true>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
     else
@@ -1644,15 +1703,17 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),
-                           (const float*)workspace, (long)n_rays, (int)n_samples, g.split, ok);
+                           (const float*)seg_part, (long)n_rays, (int)n_samples, g.split, ok);
     }
     return launch_status();
 }
 
 size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples) {
     (void)n_samples;
-    // room for GPNERF_MAX_SPLIT sample segments per ray, 16 floats each; only frames small enough to profit from splitting
-    return n_rays > 0 && n_rays <= 131072 ? (size_t)n_rays * GPNERF_MAX_SPLIT * 16 * sizeof(float) : 0;
+    if (n_rays <= 0) return 0;
+    // the tile queue's counters, plus -- only for frames small enough to profit from splitting -- room for GPNERF_MAX_SPLIT
+    // sample segments per ray, 16 floats each
+    return QUEUE_BYTES + (n_rays <= 131072 ? (size_t)n_rays * GPNERF_MAX_SPLIT * 16 * sizeof(float) : 0);
 }
 
 int gpnerf_sample_points(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, float* pts,

@@ -217,7 +217,8 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
     (demo_render.py:329-344).
     ray_order: optional int32 device tensor [N], a permutation that groups rays into cache-friendly tiles.
-    load_balance: lend the kernel a workspace so small frames can split a tile's samples over several wavefronts.
+    load_balance: lend the kernel a workspace: large frames run persistent workgroups on a tile queue, small frames split a
+    tile's samples over several wavefronts.
     split_f16: dense layers on f16 MFMA with fp32 operands split into hi + lo (GPNERF_FLAG_SPLIT_F16)."""
     lib = L.lib()
     _require_gpu(rays, "rays")
@@ -245,6 +246,9 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     if "raw" in want:
         res["raw"] = torch.empty((N, S, 4), device=dev)
         o.raw = res["raw"].data_ptr()
+    if "samples_done" in want:
+        res["samples_done"] = torch.empty((N,), device=dev, dtype=torch.int32)
+        o.samples_done = res["samples_done"].data_ptr()
     if flip is None:
         flip = bool(neg_ray) and not occ_cull
     flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_FLIP_SAMPLES if flip else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
@@ -260,7 +264,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         _require_gpu(ray_order, "ray_order")
         if ray_order.dtype != torch.int32 or ray_order.numel() != N or not ray_order.is_contiguous():
             raise L.GpnerfError("ray_order must be a contiguous int32 tensor with one entry per ray")
-    ws_bytes = int(lib.gpnerf_render_workspace_bytes(N, S)) if (load_balance and not early_term) else 0
+    ws_bytes = int(lib.gpnerf_render_workspace_bytes(N, S)) if load_balance else 0
     ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8) if ws_bytes else None
     L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), N, S, flags, float(term_eps),
                                     ray_order.data_ptr() if ray_order is not None else None, C.byref(o),

@@ -31,7 +31,7 @@ from . import parallel as P_
 class Renderer(nn.Module):
     def __init__(self, encoder, nerfhead, is_train=False, neg_ray_train=False, neg_ray_val=False, n_rays=1024,
                  n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=False, term_eps=1e-5,
-                 progressive=False, split_f16=None):
+                 progressive=False, split_f16=None, sharded_outputs="all"):
         super().__init__()
         self.encoder = encoder
         self.nerfhead = nerfhead
@@ -48,6 +48,9 @@ class Renderer(nn.Module):
         # progressive=True: the inference renderer's path (libs/renders/demo_render.py): rays are selected from the
         # occupied voxels of the frame's volume, samples are occupancy-culled, and the result is returned as `pred_img`
         self.progressive = progressive
+        # under a process group: "all" = the reference's full dict on every rank (one packed all-gather),
+        # "pixels" = rgb_map + depth_map only (16 B/ray over xGMI)
+        self.sharded_outputs = sharded_outputs
         # split_f16: dense layers on f16 MFMA with hi/lo operand pairs (GPNERF_FLAG_SPLIT_F16); same 1e-4 parity bound,
         # ~1.8x faster.  Default: exact fp32 MFMA, unless GPNERF_SPLIT_F16=1 is set in the environment.
         self.split_f16 = (os.environ.get("GPNERF_SPLIT_F16", "0") == "1") if split_f16 is None else bool(split_f16)
@@ -65,7 +68,8 @@ class Renderer(nn.Module):
         src_imgs = batch["src_imgs"]
         if src_imgs.shape[0] != 1:
             raise L.GpnerfError("only batch_size=1 is supported (as BaseRender.py:336 asserts)")
-        featmaps = batch["featmaps"] if "featmaps" in batch else self.encoder(src_imgs.squeeze(0))
+        # with a process group: one source view per rank + one all-gather of the feature maps (parallel.py)
+        featmaps = batch["featmaps"] if "featmaps" in batch else P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0))
         return featmaps[0] if featmaps.dim() == 5 else featmaps
 
     def prepare_sp_input(self, batch):
@@ -169,16 +173,33 @@ class Renderer(nn.Module):
         frame = self.build_frame(batch, featmaps)
         rays = torch.cat([batch["ray_o"], batch["ray_d"], batch["near"].unsqueeze(-1), batch["far"].unsqueeze(-1)], dim=-1)[0]
         neg = self._neg_ray(batch)
+        n = rays.shape[0]
+        sharded = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        # Which 32 rays share a wavefront is the launch's choice (results do not depend on it): when the batch says which
+        # pixels the rays are (`mask_at_box`, ZjumocapDataset.py:505), lay them out as 32x8-pixel patches so that the rays of
+        # a workgroup hit the same cache lines.  A sharded frame keeps list order (its bands are re-ordered by the plan).
+        order = None
+        if not sharded and "mask_at_box" in batch:
+            Hs, Ws = batch["src_imgs"].shape[-2:]
+            m = batch["mask_at_box"].reshape(-1)
+            if m.numel() == Hs * Ws and m.is_cuda:
+                order = F_.patch_order_device(m.bool(), Hs, Ws, patch_w=32, patch_h=8)
+                if order.numel() != n:
+                    order = None
 
         def fn(r):
             return F_.render_fused(frame, r, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
-                                   split_f16=self.split_f16)
+                                   split_f16=self.split_f16, ray_order=order, want=("weights", "z_vals", "rgb_in"))
 
-        keys = ("rgb_map", "depth_map", "acc_map", "disp_map", "weights", "z_vals", "rgb_in_map")
+        # every map of the reference's dict travels in ONE packed all-gather; sharded_outputs = "pixels" keeps the exchange at
+        # the 16 B/ray of rgb + depth (what an evaluation loop reads, libs/evaluators/if_nerf.py:50-56) and returns only those
+        all_keys = ("rgb_map", "depth_map", "acc_map", "disp_map", "weights", "z_vals", "rgb_in_map")
+        keys = P_.PIXEL_KEYS if (sharded and self.sharded_outputs == "pixels") else all_keys
         o = P_.render_sharded(fn, rays, keys=keys)
         torch.cuda.synchronize(dev)
         t2 = time.time()
-        n = rays.shape[0]
+        if keys is P_.PIXEL_KEYS:
+            return {"rgb_map": o["rgb_map"].view(1, n, 3), "depth_map": o["depth_map"].view(1, n, 1), "etime": t0 - te, "rtime": t2 - t0}
         return {
             "rgb_map": o["rgb_map"].view(1, n, 3), "disp_map": o["disp_map"].view(1, n, 1),
             "acc_map": o["acc_map"].view(1, n, 1), "depth_map": o["depth_map"].view(1, n, 1),

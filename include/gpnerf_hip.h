@@ -104,6 +104,8 @@ typedef struct GpnerfOutputs {
     float* rgb_in;     /* [N,9]  rgb_in_map (view-major, then rgb) */
     uint8_t* ray_mask; /* [N]    raw2outputs' mask: #samples with >1 valid view > 8 */
     float* raw;        /* [N,S,4] NeRFHead.forward output (rgb, sigma), un-flipped sample order */
+    int32_t* samples_done; /* [N]  diagnostic: samples the ray's wavefront evaluated (S unless early termination / culling
+                              skipped some); with it the launch never splits a tile's samples over several wavefronts */
 } GpnerfOutputs;
 
 /* Number of floats of the packed head image. */
@@ -131,10 +133,12 @@ int gpnerf_pack_head_split(const GpnerfHeadParams* params_host, float* blob_host
  *     ray_order[i]; inputs are read and outputs written at the ray's own index, so results do not depend on it.
  *     It only decides which 32 rays share a wavefront and which 256 share a workgroup: pass image patches
  *     (e.g. 32x8 pixels per workgroup) so neighbouring rays hit the same cache lines.
- *   workspace: optional device scratch of gpnerf_render_workspace_bytes() bytes (NULL = none).  With it, frames too
- *     small to fill the chip are load-balanced by letting 2 or 4 wavefronts share the samples of one 32-ray tile and
- *     merging their partial composites (second small launch); the transmittance product is then associated per
- *     segment, a ~1e-7 relative difference.  Never used with GPNERF_FLAG_EARLY_TERM. */
+ *   workspace: optional device scratch of gpnerf_render_workspace_bytes() bytes (NULL = none).  With it the launch balances
+ *     its load: frames of more than one round of workgroups run as persistent workgroups that pull 32-ray tiles from a queue
+ *     in the workspace (a tile's cost varies under early termination / culling; results are unchanged, bit for bit), and
+ *     frames too small to fill the chip let 2, 4 or 8 wavefronts share the samples of one tile and merge their partial
+ *     composites (second small launch); the transmittance product is then associated per segment, a ~1e-7 relative
+ *     difference (never with GPNERF_FLAG_EARLY_TERM).  The workspace is private to the call until the stream reaches its end. */
 int gpnerf_render_fused(const GpnerfFrame* frame, const float* rays, int64_t n_rays, int32_t n_samples,
                         uint32_t flags, float term_eps, const int32_t* ray_order, const GpnerfOutputs* out,
                         void* workspace, size_t workspace_bytes, void* stream);

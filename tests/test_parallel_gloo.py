@@ -1,9 +1,8 @@
-"""CPU: ray sharding + pixel all-gather over torch.distributed (gloo, world_size 2)."""
+"""CPU: ray sharding + the packed all-gather over torch.distributed (gloo, world_size 2 and 4)."""
 import importlib
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -23,25 +22,41 @@ def test_shard_bounds_are_tile_aligned_and_cover():
             assert max(sizes) - min(sizes) <= 32 + 31
 
 
-def test_interleaved_bands_partition_the_rays():
+def test_shard_plan_partitions_the_rays_into_equal_shares():
     par = importlib.import_module("gp-nerf_amd.parallel")
-    for n in (0, 1, 2047, 2048, 2049, 10000, 262144):
+    for n in (1, 2047, 2048, 2049, 10000, 262144, 1048576):
         for world in (1, 2, 3, 8):
-            shares = par.interleaved_indices(n, world)
-            assert len(shares) == world
-            allidx = torch.cat(shares)
-            assert allidx.numel() == n and torch.equal(torch.sort(allidx).values, torch.arange(n))
-            for r, sh in enumerate(shares):
-                assert bool(((sh // par.INTERLEAVE_BAND) % world == r).all())
-            if n >= world * par.INTERLEAVE_BAND * 4:
-                sizes = [s.numel() for s in shares]
-                assert max(sizes) - min(sizes) <= par.INTERLEAVE_BAND
+            plan = par.ShardPlan(n, world, torch.device("cpu"))
+            assert plan.index.shape == (world, plan.share) and plan.share % par.INTERLEAVE_BAND == 0
+            assert plan.share * world >= n and plan.share * world - n < world * par.INTERLEAVE_BAND + par.INTERLEAVE_BAND * world
+            assert sum(plan.n_valid) == n
+            # every ray is rendered by exactly the rank its band belongs to, and comes back to its own row
+            flat = plan.index.reshape(-1)
+            assert torch.equal(flat[plan.inverse], torch.arange(n))
+            owner = (torch.arange(n) // par.INTERLEAVE_BAND) % world
+            assert torch.equal(plan.inverse // plan.share, owner)
+            # round-trip of a payload through take -> (all-gather layout) -> unpermute
+            payload = torch.arange(n, dtype=torch.float32)[:, None] * torch.tensor([[1.0, -2.0]])
+            gathered = torch.cat([plan.take(payload, r) for r in range(world)], 0)
+            assert torch.equal(plan.unpermute(gathered), payload)
+    assert par.plan_for(1000, 4, torch.device("cpu")) is par.plan_for(1000, 4, torch.device("cpu"))      # cached per frame size
 
 
 def _fake_render(rays):
     # any per-ray function stands in for the kernel: shard-invariance is what is under test
     s = rays.sum(1)
-    return {"rgb_map": torch.stack([s, s * 2, s * 3], 1), "depth_map": s + 1, "acc_map": s * 0 + 1, "disp_map": 1 / (s + 1)}
+    S = 5
+    return {"rgb_map": torch.stack([s, s * 2, s * 3], 1), "depth_map": s + 1, "acc_map": s * 0 + 1, "disp_map": 1 / (s + 1),
+            "weights": s[:, None] * torch.arange(S)[None].float(), "z_vals": s[:, None] + torch.arange(S)[None].float(),
+            "rgb_in_map": s[:, None] * torch.ones(9)[None], "ray_mask": (s > 4).to(torch.uint8)}
+
+
+class _Enc(torch.nn.Module):
+    calls = 0
+
+    def forward(self, x):              # per-image function: [v,3,H,W] -> [v,2,H/2,W/2]
+        _Enc.calls += x.shape[0]
+        return torch.stack([x.mean(1)[:, ::2, ::2], x.amax(1)[:, ::2, ::2] - x.mean(dim=(1, 2, 3))[:, None, None]], 1)
 
 
 def _worker(rank, world, port, n, q):
@@ -52,33 +67,46 @@ def _worker(rank, world, port, n, q):
     rays = torch.rand((n, 8), generator=g)
     ref = _fake_render(rays)
     ok = True
-    for interleave in (True, False):
-        full = par.render_sharded(_fake_render, rays, interleave=interleave)
-        ok = ok and all(torch.equal(full[k], ref[k]) for k in ref)
-    # equal-sized shards, the bench's collective
+    # the 16 B/ray form, the default key set, and every map Renderer.render returns: one collective each, bit-equal
+    for keys in (par.PIXEL_KEYS, ("rgb_map", "depth_map", "acc_map", "disp_map"), tuple(ref)):
+        for band in (par.INTERLEAVE_BAND, 64):
+            full = par.render_sharded(_fake_render, rays, keys=keys, band=band)
+            ok = ok and set(full) == set(keys)
+            ok = ok and all(torch.equal(full[k], ref[k]) and full[k].dtype == ref[k].dtype and full[k].shape == ref[k].shape for k in keys)
+    # preallocated gather buffer, as the bench uses it
+    plan = par.plan_for(n, world, rays.device)
+    buf = torch.empty((world * plan.share, 4))
+    full = par.gather_frame(_fake_render(plan.take(rays, rank)), plan, par.PIXEL_KEYS, buffer=buf)
+    ok = ok and torch.equal(full["rgb_map"], ref["rgb_map"]) and torch.equal(full["depth_map"], ref["depth_map"])
+    # equal-sized contiguous shards, the weak-scaling collective
     s, e = par.shard_bounds(n - n % (32 * world), world)[rank]
     local = _fake_render(rays[s:e])
     gathered = torch.empty((world, e - s, 4))
     par.all_gather_pixels(local, gathered)
     exp = par.pack_pixels(_fake_render(rays[: (e - s) * world]))
     ok = ok and torch.equal(gathered.view(-1, 4), exp)
+    # one source view per rank
+    imgs = torch.rand((3, 3, 8, 12), generator=g)
+    enc = _Enc()
+    fm = par.encode_views_sharded(enc, imgs)
+    ok = ok and torch.equal(fm, _Enc()(imgs)) and (_Enc.calls == (1 + 3 if world >= 3 else 3 + 3))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [667, 4096, 9000])
-def test_render_sharded_equals_unsharded_world2(n):
+@pytest.mark.parametrize("world,n", [(2, 667), (2, 9000), (4, 4096), (4, 20001)])
+def test_render_sharded_equals_unsharded(world, n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
