@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libgpnerf_hip.so")
+# GPNERF_LIB_PATH: a differently built library for A/B measurements (tools/); the product always uses the in-tree build
+LIB_PATH = os.environ.get("GPNERF_LIB_PATH") or os.path.join(HERE, "csrc", "libgpnerf_hip.so")
 
 VIEWS, CH, LEVELS = 3, 32, 4
 FP = C.POINTER(C.c_float)

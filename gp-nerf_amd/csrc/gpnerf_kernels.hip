@@ -666,6 +666,23 @@ DEV void grid_coords(const FR& fr, float px, float py, float pz, float& gx, floa
     gz = ((qz - fr.bounds_min[2]) / fr.voxel[0]) / fr.out_sh[0] * 2.f - 1.f;
 }
 
+// A lane owns a ray, so an [N,S] output written sample by sample is one 4-byte store per lane at a stride of S floats, each
+// its own 64-byte write request (measured: 2 GB of requests per 512x512x64 frame for the 134 MB of weights + z_vals).
+// z_vals is a function of (near, far, k) alone, so it is written after the sample loop instead, the whole wave walking one
+// ray's row: z_vals[ray][k] for k in [k_from, k_to), 64 consecutive samples per store instruction.
+DEV void write_z_vals(float* __restrict__ z_vals, const int lane, const int ray_lo, const float near, const float far,
+                      const int n_active, const int S, const float step, const int k_from, const int k_to) {
+    for (int rr = 0; rr < n_active; ++rr) {
+        const int rid = __builtin_amdgcn_readlane(ray_lo, rr);
+        const float nr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, near), rr));
+        const float fr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, far), rr));
+        for (int kk = k_from + lane; kk < k_to; kk += 64) {
+            const float tk = (S > 1) ? linspace01(kk, S, step) : 0.f;
+            z_vals[(size_t)rid * S + kk] = nr * (1.f - tk) + fr * tk;
+        }
+    }
+}
+
 // Launched with 1..8 waves per workgroup (blockDim.x = 64 * waves): one workgroup per CU either way (LDS), so the
 // host picks the width that balances the grid over the CUs (choose_geometry()).
 #ifndef GPNERF_MAX_WAVES
@@ -696,14 +713,14 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
     if (ray0 >= n_rays) return;
     const bool active = (ray0 + n) < n_rays;
     const long slot = active ? ray0 + n : n_rays - 1;
-    const long ray = k0->out.order ? (long)k0->out.order[slot] : slot;
+    const int ray = k0->out.order ? k0->out.order[slot] : (int)slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;             // Projector front test
     const bool flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;       // raw2outputs(neg=True)
     const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
     const bool cull = (flags & GPNERF_FLAG_OCC_CULL) != 0 && k0->fr.occ != nullptr;
 
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(k0->rays + ray * 8);
-    const f32x4 r1 = *reinterpret_cast<const f32x4*>(k0->rays + ray * 8 + 4);
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(k0->rays + (size_t)ray * 8);
+    const f32x4 r1 = *reinterpret_cast<const f32x4*>(k0->rays + (size_t)ray * 8 + 4);
     const float ox = r0[0], oy = r0[1], oz = r0[2], dx = r0[3], dy = r1[0], dz = r1[1], near = r1[2], far = r1[3];
 
     float T = 1.f, c_r = 0.f, c_g = 0.f, c_b = 0.f, depth = 0.f, acc = 0.f;
@@ -718,6 +735,7 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
     st.start();
     const int k_end = (int)(((long)S * (seg + 1)) / split);
     int k = (int)(((long)S * seg) / split);
+    const int k_begin = k;
     for (; k < k_end; ++k) {
         kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
@@ -741,9 +759,7 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
             keep = sample_occupancy(fr.occ, fr.vol_dhw[0][0], fr.vol_dhw[0][1], fr.vol_dhw[0][2], gx, gy, gz) > 0.f;
             if (!__any(keep)) {
                 if (writer) {
-                    const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
                     if (out.weights) out.weights[(size_t)ray * S + k] = 0.f;
-                    if (out.z_vals) out.z_vals[(size_t)ray * S + k] = near * (1.f - tk) + far * tk;
                     if (out.raw) *reinterpret_cast<f32x4*>(out.raw + ((size_t)ray * S + ks) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 T = T * (1.f + 1e-10f);                 // cumprod(1 - alpha + 1e-10) with alpha = 0
@@ -833,7 +849,6 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
         }
         if (writer) {
             if (out.weights) out.weights[(size_t)ray * S + k] = wgt;
-            if (out.z_vals) out.z_vals[(size_t)ray * S + k] = zk;
         }
         STAMP(st, 6);
         // wavefront-level early termination (not in the reference): every ray of the tile is opaque
@@ -844,6 +859,7 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
     asm volatile("" : "+s"(kp));
     const __attribute__((address_space(4))) OutK& out = kp->out;
     float* const part = kp->part;
+    if (out.z_vals) write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_rays - ray0), S, step, k_begin, k_end);
     if (writer && split > 1) {
         // partial composite of this segment: rgb, depth, acc, segment transmittance, rgb_in, #samples with >1 valid view
         float* p = part + ((size_t)ray * split + seg) * 16;
@@ -860,12 +876,8 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
         // samples skipped by early termination carry weight 0
         for (; k < S; ++k) {
             if (out.weights) out.weights[(size_t)ray * S + k] = 0.f;
-            if (out.z_vals) {
-                const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
-                out.z_vals[(size_t)ray * S + k] = near * (1.f - tk) + far * tk;
-            }
         }
-        out.rgb[ray * 3 + 0] = c_r; out.rgb[ray * 3 + 1] = c_g; out.rgb[ray * 3 + 2] = c_b;
+        out.rgb[(size_t)ray * 3 + 0] = c_r; out.rgb[(size_t)ray * 3 + 1] = c_g; out.rgb[(size_t)ray * 3 + 2] = c_b;
         out.depth[ray] = depth;
         out.acc[ray] = acc;
         const float q = depth / acc;                    // 1 / max(1e-10, depth / acc); torch.max keeps NaN
@@ -1669,6 +1681,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (!out->rgb || !out->depth || !out->acc || !out->disp || !f->head_blob) return GPNERF_E_ARG;
     FrameK k;
     if (!to_framek(f, k, true, true)) return GPNERF_E_ARG;
+    if (n_rays >= ((int64_t)1 << 31)) return GPNERF_E_ARG;      // output rows are 32-bit values inside the kernel
     const int64_t tiles = (n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
     const bool split16 = (flags & GPNERF_FLAG_SPLIT_F16) != 0;
