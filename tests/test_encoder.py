@@ -57,8 +57,8 @@ def test_encoder_matches_reference_golden_cpu(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", encoder_case_names())
 def test_encoder_on_gpu_feeds_frame_without_relayout(name):
-    """MIOpen convolutions (other algorithms, other summation order): 2e-3 on O(5) activations; and the output is
-    physically [V,h,w,32], which Frame takes by pointer."""
+    """MIOpen convolutions (other algorithms, other summation order) stay inside north_star's 1e-4 of the reference vectors
+    (measured 3e-5 on O(5) activations); and the output is physically [V,h,w,32], which Frame takes by pointer."""
     fm = importlib.import_module("gp-nerf_amd.frame")
     z, meta = load(name)
     net, _ = _net(meta["seed"])
@@ -66,7 +66,7 @@ def test_encoder_on_gpu_feeds_frame_without_relayout(name):
     imgs = torch.from_numpy(syn.make_encoder_images(meta["H"], meta["W"], meta["seed"])).to("cuda:0")
     with torch.no_grad():
         out = net(imgs)
-    assert_close(out.cpu().numpy(), z["featmaps"], 2e-3, "featmaps")
+    assert_close(out.cpu().numpy(), z["featmaps"], 1e-4, "featmaps")
     assert out.is_contiguous(memory_format=torch.channels_last)
     sc = syn.make_scene(H=meta["H"], W=meta["W"], seed=1, aabb_half=(0.12, 0.16, 0.05))
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")

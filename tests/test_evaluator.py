@@ -75,3 +75,20 @@ def test_identical_images_and_bounding_rect():
     assert ev.mask_bounding_rect(m) == (3, 2, 3, 6)
     with pytest.raises(ValueError):
         ev.ssim_images(torch.rand(5, 20, 3), torch.rand(5, 20, 3))
+
+
+def test_psnr_matches_the_reference_evaluators_value():
+    """tests/golden/e2e_64x64_s32.npz carries the value libs/evaluators/if_nerf.py Evaluator.psnr_metric returned for the
+    reference's own render against a seeded ground truth; the device-side formula reproduces it on the same arrays."""
+    import os
+    import numpy as np
+    import torch
+    from golden_cases import GOLDEN_DIR
+    ev = importlib.import_module("gp-nerf_amd.evaluator")
+    z = np.load(os.path.join(GOLDEN_DIR, "e2e_64x64_s32.npz"))
+    got = ev.psnr_metric(torch.from_numpy(z["rgb_map"]), torch.from_numpy(z["rgb_gt"]))
+    assert abs(got - float(z["psnr"])) < 1e-4           # the reference averages in float32, this in float64
+    e = ev.Evaluator(types.SimpleNamespace(dataset=types.SimpleNamespace(H=64, W=64, ratio=1.0)), "seq")
+    e.evaluate({"rgb_map": torch.from_numpy(z["rgb_map"])[None]}, {"rgb": torch.from_numpy(z["rgb_gt"])[None], "mask_at_box": torch.ones((1, 64 * 64), dtype=torch.bool)})
+    m = e.summarize()
+    assert abs(m["psnr"] - float(z["psnr"])) < 1e-4 and abs(m["mse"] - float(z["mse"])) < 1e-8

@@ -353,3 +353,36 @@ def test_render_with_the_builtin_encoder_and_evaluator(plugins):
     e.evaluate(ret, batch_eval)
     m = e.summarize()
     assert 35.0 < m["psnr"] <= 60.0 and 0.9 < m["ssim"] <= 1.0
+
+
+def test_end_to_end_with_the_real_encoder_matches_the_reference(plugins):
+    """BASELINE.json configs[4] in miniature (the ZJU-MoCap data is not in the tree): hip_encoder -> hip_head -> hip_render on the
+    bytes of tests/golden/e2e_64x64_s32.npz, whose outputs come from the reference's ResUNet.forward + Renderer.render and whose
+    PSNR from its Evaluator.psnr_metric.  Asserts max-abs on the maps, and the PSNR difference on the device-side evaluator."""
+    hip_render, _ = plugins
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    ev = importlib.import_module("gp-nerf_amd.evaluator")
+    z, meta = load("e2e_64x64_s32")
+    sc = scene_of(meta)
+    sc["src_imgs"] = syn.make_encoder_images(64, 64, meta["seed"])[None]
+    c = cfg(n_samples=meta["n_samples"])
+    c.encoder.file = "hip_encoder"
+    r = hip_render.build_render(c).to("cuda:0").eval()
+    load_head(r, sc)
+    r.encoder.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_encoder_weights(meta["seed"]).items()}, strict=True)
+    b = batch_of(sc, with_products=False)
+    b["volumes"] = [torch.from_numpy(v).to("cuda:0") for v in sc["volumes"]]      # the 4 dense levels are inputs of the fixture
+    b["mask_at_box"] = torch.from_numpy(sc["mask_at_box"]).to("cuda:0")
+    with torch.no_grad():
+        fmaps = r.encoder(b["src_imgs"][0])
+        ret = r.render(b)
+    assert_close(fmaps.cpu().numpy(), z["featmaps"], TOL, "encoder feature maps")
+    assert_close(ret["rgb_map"][0].cpu().numpy(), z["rgb_map"], TOL, "rgb_map")
+    assert_close(ret["depth_map"][0, :, 0].cpu().numpy(), z["depth_map"], TOL, "depth_map")
+    assert_close(ret["acc_map"][0, :, 0].cpu().numpy(), z["acc_map"], TOL, "acc_map")
+    assert_close(ret["rgb_in_map"][0].cpu().numpy(), z["rgb_in_map"], TOL, "rgb_in_map")
+    assert ret["etime"] > 0 and ret["rtime"] > 0
+    e = ev.Evaluator(NS(dataset=NS(H=64, W=64, ratio=1.0)), "seq")
+    e.evaluate(ret, {"rgb": torch.from_numpy(z["rgb_gt"]).to("cuda:0")[None], "mask_at_box": b["mask_at_box"]})
+    m = e.summarize()
+    assert abs(m["psnr"] - float(z["psnr"])) < 1e-3, (m["psnr"], float(z["psnr"]))
