@@ -135,15 +135,46 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict_
 // spconv's strided rulebook takes EVERY input row, so two vertices rounded into one voxel both contribute, while its
 // submanifold lookups find one row per voxel.  Fold the former into the grid formulation: add the features of the other
 // rows of a voxel onto the indexed row (only the vertex level can hold duplicates).
-__global__ void merge_duplicates_kernel(float* __restrict__ feat, const int c, const int32_t* __restrict__ coords,
-                                        const int32_t* __restrict__ grid, const int m, const Dims s) {
-    const int site = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int ch = threadIdx.x & 31;
-    if (site >= m || ch >= c) return;
+// Two launches so that the sum is ORDERED (an atomicAdd per duplicate would add a voxel's rows in arrival order, and fp32
+// addition does not commute with that): count_duplicates_kernel counts, per indexed row, how many other rows share its voxel;
+// merge_duplicates_kernel gives every row that has company one wavefront, which scans the row list in ascending order and
+// adds the matching rows' features onto its own, lowest row index first.
+__global__ void count_duplicates_kernel(const int32_t* __restrict__ coords, const int32_t* __restrict__ grid, const int m,
+                                        const Dims s, int32_t* __restrict__ count) {
+    const int site = blockIdx.x * blockDim.x + threadIdx.x;
+    if (site >= m) return;
     const int d = coords[3 * site], h = coords[3 * site + 1], w = coords[3 * site + 2];
     if (d < 0 || d >= s.d || h < 0 || h >= s.h || w < 0 || w >= s.w) return;
     const int owner = grid[cell_of(s, d, h, w)];
-    if (owner != site) atomicAdd(feat + (size_t)owner * c + ch, feat[(size_t)site * c + ch]);
+    if (owner != site) atomicAdd(count + owner, 1);
+}
+
+__global__ void merge_duplicates_kernel(float* __restrict__ feat, const int c, const int32_t* __restrict__ coords,
+                                        const int32_t* __restrict__ grid, const int m, const Dims s,
+                                        const int32_t* __restrict__ count) {
+    const int site = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (site >= m) return;
+    const int want = count[site];
+    if (want == 0) return;
+    float acc = lane < c ? feat[(size_t)site * c + lane] : 0.f;
+    int found = 0;
+    for (int base = 0; base < m && found < want; base += 64) {
+        const int j = base + lane;
+        bool hit = false;
+        if (j < m && j != site) {
+            const int d = coords[3 * j], h = coords[3 * j + 1], w = coords[3 * j + 2];
+            hit = d >= 0 && d < s.d && h >= 0 && h < s.h && w >= 0 && w < s.w && grid[cell_of(s, d, h, w)] == site;
+        }
+        unsigned long long mask = __ballot(hit);
+        found += __popcll(mask);
+        while (mask) {
+            const int j0 = base + __ffsll((long long)mask) - 1;
+            if (lane < c) acc += feat[(size_t)j0 * c + lane];      // rows that are added are never owners: nobody writes them
+            mask &= mask - 1;
+        }
+    }
+    if (lane < c) feat[(size_t)site * c + lane] = acc;
 }
 
 // strided conv, step 1: mark every coarse site reached by an active fine site (out = (p + 1 - k) / 2 when even)
@@ -340,12 +371,14 @@ int gpnerf_sparse_down_sites(const int32_t* in_coords, const int32_t* m_in_dev, 
 }
 
 int gpnerf_sparse_merge_duplicates(float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, int32_t m,
-                                   const int32_t* dims, void* stream) {
-    if (!feat || !coords || !grid || bad(dims) || channels < 1 || channels > 32 || m < 0) return GPNERF_E_ARG;
+                                   const int32_t* dims, int32_t* scratch, void* stream) {
+    if (!feat || !coords || !grid || !scratch || bad(dims) || channels < 1 || channels > 32 || m < 0) return GPNERF_E_ARG;
     if (m == 0) return GPNERF_OK;
     const Dims s{dims[0], dims[1], dims[2]};
-    hipLaunchKernelGGL(merge_duplicates_kernel, dim3((m + 7) / 8), dim3(256), 0, S_(stream), feat, (int)channels, coords, grid,
-                       (int)m, s);
+    if (hipMemsetAsync(scratch, 0, sizeof(int32_t) * (size_t)m, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+    hipLaunchKernelGGL(count_duplicates_kernel, dim3((m + 255) / 256), dim3(256), 0, S_(stream), coords, grid, (int)m, s, scratch);
+    hipLaunchKernelGGL(merge_duplicates_kernel, dim3((m + 3) / 4), dim3(256), 0, S_(stream), feat, (int)channels, coords, grid,
+                       (int)m, s, (const int32_t*)scratch);
     return status();
 }
 

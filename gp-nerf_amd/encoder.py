@@ -33,13 +33,17 @@ def _conv(cin, cout, k, stride=1, bias=False):
     return nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=bias, padding_mode="reflect")
 
 
-def _fused(x, training):
-    """The HIP glue kernels serve GPU inference; training and CPU tensors take the torch operators."""
-    return x.is_cuda and not training and not torch.is_grad_enabled()
+def _require_gpu_inference(x, training):
+    """The encoder is built for GPU inference (MIOpen convolutions + the HIP glue kernels); there is no CPU / training path
+    in the product -- the torch-operator formulation the tests check against is oracle/producers_ref.py `encoder`."""
+    if not x.is_cuda or training:
+        raise L.GpnerfError("the HIP image encoder runs on GPU tensors in eval mode only (no CPU / training fallback)")
 
 
 def _norm_act(norm, x, act, residual=None):
     """act(InstanceNorm(x) [+ residual]) as one launch; act: 0 none, 1 ReLU, 2 ELU."""
+    if not x.is_cuda:
+        raise L.GpnerfError("the HIP image encoder runs on GPU tensors only (no CPU fallback)")
     x = x.contiguous()
     n, c, h, w = x.shape
     out = torch.empty_like(x)
@@ -72,12 +76,9 @@ class ResidualUnit(nn.Module):
             self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), _inorm(cout))
 
     def forward(self, x):
-        if _fused(x, self.training):
-            y = self.conv2(_norm_act(self.bn1, self.conv1(x), 1))
-            idn = x if self.downsample is None else _norm_act(self.downsample[1], self.downsample[0](x), 0)
-            return _norm_act(self.bn2, y, 1, residual=idn)
-        y = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
-        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+        y = self.conv2(_norm_act(self.bn1, self.conv1(x), 1))
+        idn = x if self.downsample is None else _norm_act(self.downsample[1], self.downsample[0](x), 0)
+        return _norm_act(self.bn2, y, 1, residual=idn)
 
 
 class ConvNormELU(nn.Module):
@@ -88,9 +89,7 @@ class ConvNormELU(nn.Module):
         self.conv, self.bn = _conv(cin, cout, k, bias=True), _inorm(cout)
 
     def forward(self, x):
-        if _fused(x, self.training):
-            return _norm_act(self.bn, self.conv(x), 2)
-        return F.elu(self.bn(self.conv(x)))
+        return _norm_act(self.bn, self.conv(x), 2)
 
 
 class UpsampleConv(nn.Module):
@@ -102,9 +101,9 @@ class UpsampleConv(nn.Module):
         self.conv = ConvNormELU(cin, cout, k)
 
     def forward(self, x):
-        if self.scale == 2 and x.dtype == torch.float32 and _fused(x, self.training):
-            return self.conv(_upsample2x(x))
-        return self.conv(F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=True))
+        if self.scale != 2 or x.dtype != torch.float32:
+            raise L.GpnerfError("the upsampling kernel is built for the reference's x2 bilinear steps on fp32 (UNet.py:185-188)")
+        return self.conv(_upsample2x(x))
 
 
 def _stage(cin, cout, n):
@@ -140,15 +139,15 @@ class ResUNet(nn.Module):
     def forward(self, x):
         """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the result leaves with channels-last strides, which `Frame`
         recognises (no re-layout launch)."""
-        on_gpu = x.is_cuda
-        x = _norm_act(self.bn1, self.conv1(x), 1) if _fused(x, self.training) else F.relu(self.bn1(self.conv1(x)))
+        _require_gpu_inference(x, self.training)
+        x = _norm_act(self.bn1, self.conv1(x), 1)
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
         x = self.iconv3(_concat_skip(x2, self.upconv3(x3)))
         x = self.iconv2(_concat_skip(x1, self.upconv2(x)))
         x = self.out_conv(x)
-        return x.contiguous(memory_format=torch.channels_last) if on_gpu else x
+        return x.contiguous(memory_format=torch.channels_last)
 
 
 def build_encoder(cfg):

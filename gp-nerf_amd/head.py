@@ -44,12 +44,8 @@ class NeRFSigmaHead(nn.Module):
         """Embedding -> attention over the V views -> sparse conv net -> 4 dense levels
         (trainhead.py:48-56, SparseConvNet.py:105-111).  Per frame, not per ray."""
         code = self.c(torch.arange(0, self.n_smpl, device=smpl_feat_sampled.device))
-        feat = smpl_feat_sampled.flatten(0, 1)
-        if feat.is_cuda and not self.training:
-            fused = self.xyzc_attn.fuse_vertices(code, feat)
-            return self.xyzc_net.dense_levels_hip(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
-        fused = self.xyzc_attn(code.unsqueeze(1), feat, feat)[0].squeeze(1)
-        return self.xyzc_net.dense_levels(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
+        fused = self.xyzc_attn.fuse_vertices(code, smpl_feat_sampled.flatten(0, 1))          # HIP only: raises on CPU / in training
+        return self.xyzc_net.dense_levels_hip(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
 
 
     def _blob(self, device):

@@ -1,12 +1,11 @@
 """Per-frame producers of the dense feature pyramid -- NOT on the per-ray path.
 
 The reference builds the 4 dense levels with the external spconv v1.2.1 CUDA library
-(libs/nerfheads/networks/SparseConvNet.py:22-124), which is neither in the reference tree nor
-installable here, so its arithmetic cannot be pinned ("parity unpinned" at this boundary,
-SURVEY.md §8c).  This module restates the published algorithm of submanifold / strided sparse
-convolution with a coordinate rulebook, on stock PyTorch-ROCm tensor ops (6 890 active voxels per
-frame: a few matmuls), under the reference's parameter names so reference checkpoints load with
-strict=True.  It is validated against a dense conv3d-with-mask formulation in tests/.
+(libs/nerfheads/networks/SparseConvNet.py:22-124), which is neither in the reference tree nor installable here, so its
+arithmetic cannot be pinned ("parity unpinned" at this boundary).  This module owns the reference's
+parameters under the reference's names (so reference checkpoints load with strict=True) and computes on the GPU only:
+the vertex-code attention is one HIP launch (gpnerf_vertex_attention), the sparse convolutions are gpnerf_volume.hip.
+There is no CPU / PyTorch fallback; the torch-CPU restatements the tests check against live in oracle/producers_ref.py.
 
 `MultiHeadAttention` mirrors libs/nerfheads/networks/MultiHeadAttention.py:42-98 (parameter names
 w_qs, w_ks, w_vs, fc, layer_norm).
@@ -16,7 +15,6 @@ import ctypes as C
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib as L
 
@@ -35,20 +33,12 @@ class MultiHeadAttention(nn.Module):
         self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)  # owned for checkpoint parity; used only when sum=True
 
     def forward(self, q, k, v, mask=None):
-        b, lq, lk = q.size(0), q.size(1), k.size(1)
-        residual = q
-        qh = self.w_qs(q).view(b, lq, self.n_head, self.d_k).transpose(1, 2)
-        kh = self.w_ks(k).view(k.size(0), lk, self.n_head, self.d_k).transpose(1, 2)
-        vh = self.w_vs(v).view(v.size(0), v.size(1), self.n_head, self.d_v).transpose(1, 2)
-        attn = torch.matmul(qh / (self.d_k ** 0.5), kh.transpose(2, 3))
-        if mask is not None:
-            attn = attn.masked_fill(mask.unsqueeze(1) == 0, -1e9)
-        attn = F.softmax(attn, dim=-1)
-        out = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(b, lq, -1)
-        out = self.fc(out)
-        if self.sum_flag:
-            out = self.layer_norm(out + residual)
-        return out, attn
+        """MultiHeadAttention.forward as the renderers call it (trainhead.py:51, demo_render.py:143-146): q [N,1,d_model] vertex
+        codes, k = v [N,V,kv_dim] the vertices' per-view features, no mask, sum=False -> (out [N,1,d_model], None).
+        One HIP launch; the attention weights the reference returns second are not materialised (no caller reads them)."""
+        if mask is not None or q.dim() != 3 or q.shape[1] != 1 or k is not v and not torch.equal(k, v):
+            raise L.GpnerfError("the HIP attention serves the volume builder's call: q [N,1,d], k = v [N,V,kv], no mask")
+        return self.fuse_vertices(q[:, 0], k).unsqueeze(1), None
 
     def fuse_vertices(self, code, feat):
         """The call the volume builder makes (trainhead.py:48-52): code [N,d_model], feat [N,V,kv_dim] -> [N,d_model],
@@ -79,32 +69,6 @@ class SparseConvTensor:
         self.dense_levels = dense_levels
 
 
-class SparseTensor:
-    """features [M,C]; coords [M,3] (d,h,w) int64; spatial shape (D,H,W).  Batch size 1."""
-
-    def __init__(self, features, coords, shape):
-        self.features, self.coords, self.shape = features, coords, tuple(int(s) for s in shape)
-
-    def keys(self):
-        D, H, W = self.shape
-        return (self.coords[:, 0] * H + self.coords[:, 1]) * W + self.coords[:, 2]
-
-    def dense(self):
-        """[1,C,D,H,W], zeros where inactive (spconv's .dense(), SparseConvNet.py:111)."""
-        D, H, W = self.shape
-        C = self.features.shape[1]
-        out = torch.zeros((D * H * W, C), dtype=self.features.dtype, device=self.features.device)
-        out[self.keys()] = self.features
-        return out.view(D, H, W, C).permute(3, 0, 1, 2).unsqueeze(0).contiguous()
-
-
-def _lookup(sorted_keys, order, query):
-    """index into the original rows of the entry whose key equals `query` (the highest row among duplicates), or -1."""
-    pos = (torch.searchsorted(sorted_keys, query, right=True) - 1).clamp_(min=0)
-    hit = sorted_keys[pos] == query
-    return torch.where(hit, order[pos], torch.full_like(pos, -1))
-
-
 class _SparseConv3d(nn.Module):
     """Weight [k,k,k,Cin,Cout] as spconv v1.x stores it; out[o] = sum_k W[k] in[o*stride - pad + k]."""
 
@@ -115,57 +79,14 @@ class _SparseConv3d(nn.Module):
         nn.init.kaiming_uniform_(self.weight.view(-1, cout), a=5 ** 0.5)
 
     def forward(self, x):
-        k, s = self.k, self.stride
-        pad = (k // 2) if self.subm else self.padding
-        D, H, W = x.shape
-        dev = x.coords.device
-        offs = torch.stack(torch.meshgrid(torch.arange(k), torch.arange(k), torch.arange(k), indexing="ij"), -1).view(-1, 3).to(dev)
-        Wk = self.weight.view(k * k * k, self.cin, self.cout)
-        if self.subm:
-            keys = x.keys()
-            sk, order = torch.sort(keys, stable=True)
-            out = torch.zeros((x.coords.shape[0], self.cout), dtype=x.features.dtype, device=dev)
-            for i in range(k * k * k):
-                nb = x.coords - pad + offs[i]                       # input position feeding output site through tap i
-                ok = ((nb >= 0) & (nb < torch.tensor([D, H, W], device=dev))).all(1)
-                q = (nb[:, 0] * H + nb[:, 1]) * W + nb[:, 2]
-                j = _lookup(sk, order, torch.where(ok, q, torch.full_like(q, -1)))
-                sel = (j >= 0) & ok
-                if sel.any():
-                    out[sel] += x.features[j[sel]] @ Wk[i]
-            return SparseTensor(out, x.coords, x.shape)
-        oD, oH, oW = [(n + 2 * pad - k) // s + 1 for n in (D, H, W)]
-        pairs_o, pairs_i, pairs_k = [], [], []
-        lim = torch.tensor([oD, oH, oW], device=dev)
-        for i in range(k * k * k):
-            num = x.coords + pad - offs[i]                           # o*stride = p + pad - k
-            o = torch.div(num, s, rounding_mode="floor")
-            ok = ((num % s) == 0).all(1) & ((o >= 0) & (o < lim)).all(1)
-            idx = torch.nonzero(ok).squeeze(1)
-            pairs_o.append((o[idx, 0] * oH + o[idx, 1]) * oW + o[idx, 2])
-            pairs_i.append(idx)
-            pairs_k.append(torch.full_like(idx, i))
-        okeys, iidx, kidx = torch.cat(pairs_o), torch.cat(pairs_i), torch.cat(pairs_k)
-        ukeys, inv = torch.unique(okeys, sorted=True, return_inverse=True)
-        out = torch.zeros((ukeys.numel(), self.cout), dtype=x.features.dtype, device=dev)
-        for i in range(k * k * k):
-            m = kidx == i
-            if m.any():
-                out.index_add_(0, inv[m], x.features[iidx[m]] @ Wk[i])
-        oc = torch.stack([ukeys // (oH * oW), (ukeys // oW) % oH, ukeys % oW], 1)
-        return SparseTensor(out, oc, (oD, oH, oW))
+        raise L.GpnerfError("sparse convolutions run inside SparseConvNet.dense_levels_hip (gpnerf_volume.hip); there is no torch path")
 
 
 class _SparseSequential(nn.Sequential):
-    """conv -> BatchNorm1d -> ReLU chains on the active features (spconv.SparseSequential)."""
+    """conv -> BatchNorm1d -> ReLU chains (spconv.SparseSequential): a parameter container here, see SparseConvNet."""
 
     def forward(self, x):
-        for m in self:
-            if isinstance(m, _SparseConv3d):
-                x = m(x)
-            else:
-                x = SparseTensor(m(x.features), x.coords, x.shape)
-        return x
+        raise L.GpnerfError("sparse convolutions run inside SparseConvNet.dense_levels_hip (gpnerf_volume.hip); there is no torch path")
 
 
 def _bn(c):
@@ -227,10 +148,15 @@ class SparseConvNet(nn.Module):
         return hit[1]
 
     def dense_levels_hip(self, code, coord, out_sh, batch_size=1):
-        """Same result as dense_levels(), computed by the HIP sparse-convolution kernels and returned directly in the
-        render kernel's channels-last layout: a list of 4 tensors [D_k,H_k,W_k,C] (tagged `_gpnerf_ndhwc`)."""
+        """code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) -> the 4 dense levels of
+        SparseConvNet.py:105-111, computed by the HIP sparse-convolution kernels and returned directly in the render kernel's
+        channels-last layout: a list of 4 tensors [D_k,H_k,W_k,C] (tagged `_gpnerf_ndhwc`)."""
         if int(batch_size) != 1:
             raise ValueError("the per-ray path renders one frame at a time (BaseRender.py:336 asserts batch 1)")
+        if any(int(v) % 16 for v in out_sh):
+            # the reference's datasets round out_sh up to a multiple of 32 (ZjumocapDataset.py:243-254); with odd sizes spconv's
+            # strided output shape (n - 1) // 2 + 1 and the n // 2 used below would part ways
+            raise L.GpnerfError(f"out_sh {tuple(out_sh)} must be a multiple of 16 in every dimension")
         if self.training:
             raise L.GpnerfError("the HIP volume builder folds BatchNorm running statistics: call .eval() first")
         if not code.is_cuda:
@@ -266,8 +192,9 @@ class SparseConvNet(nn.Module):
             dc = self.net[0]                                            # double_conv at full resolution
             x = conv(False, dc[0], dc[1], x, grid, dims, coords, m_dev, m_cap)
             x = conv(False, dc[3], dc[4], x, grid, dims, coords, m_dev, m_cap)
+            dup = torch.empty((m_cap,), device=dev, dtype=torch.int32)
             L.check(lib.gpnerf_sparse_merge_duplicates(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_cap,
-                                                       I3(*dims), st), "gpnerf_sparse_merge_duplicates")
+                                                       I3(*dims), dup.data_ptr(), st), "gpnerf_sparse_merge_duplicates")
             levels = []
             for i in range(self.n_layers):
                 sc, dc = self.net[2 * i + 1], self.net[2 * i + 2]
@@ -326,17 +253,3 @@ class SparseConvNet(nn.Module):
         self.features = [v.permute(3, 0, 1, 2).unsqueeze(0) for v in fr.vols]
         self.masks3d = fr.build_occupancy()
         self.mask_xyz = torch.stack(torch.where(self.masks3d > threshold), dim=0).permute(1, 0).flip(-1).float() * 2.0
-
-    def dense_levels(self, code, coord, out_sh, batch_size=1):
-        """code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) ->
-        list of 4 dense levels [1,C_k,D/2^k,H/2^k,W/2^k] (SparseConvNet.py:105-111)."""
-        if int(batch_size) != 1:
-            raise ValueError("the per-ray path renders one frame at a time (BaseRender.py:336 asserts batch 1)")
-        x = SparseTensor(code, coord[:, 1:].long(), out_sh)
-        x = self.net[0](x)
-        levels = []
-        for i in range(self.n_layers):
-            x = self.net[2 * i + 1](x)
-            x = self.net[2 * i + 2](x)
-            levels.append(x.dense())
-        return levels

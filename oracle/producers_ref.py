@@ -1,0 +1,167 @@
+"""CPU restatements of the per-frame producers (TEST INFRASTRUCTURE -- only tests/ import this; the product never does).
+
+The product computes these on the GPU only (gp-nerf_amd/volume.py, encoder.py -> HIP kernels / MIOpen).  What is here is the
+checker: plain torch-CPU formulations that read the parameters off the product's modules (same state_dict keys as the
+reference), so one set of weights drives both sides.
+
+* `attention(module, q, k, v)` -- libs/nerfheads/networks/MultiHeadAttention.py:61-98.  PINNED: tests/test_attention.py holds it
+  to vectors captured from the reference's module (tests/golden/attention_*.npz).
+* `encoder(net, x)` -- libs/encoders/UNet.py:17-53,107-131,213-234.  PINNED: tests/test_encoder.py holds it to vectors captured
+  from the reference's ResUNet (tests/golden/encoder_*.npz).
+* `dense_levels(net, code, coord, out_sh)` -- libs/nerfheads/networks/SparseConvNet.py:22-111 on the published algorithm of
+  spconv v1.2.1 (SubMConv3d / SparseConv3d by coordinate rulebook, `.dense()`).  spconv is absent from the reference tree and
+  not installable here: **parity unpinned**; tests/test_volume_builder.py checks this restatement against the dense
+  conv3d-with-mask definition it must agree with.
+"""
+import torch
+import torch.nn.functional as F
+
+
+# ---- MultiHeadAttention.forward ----------------------------------------------------------------------------------------
+def attention(m, q, k, v, mask=None):
+    """m: the product's MultiHeadAttention (parameters w_qs, w_ks, w_vs, fc, layer_norm).  Returns (out, attn)."""
+    b, lq, lk = q.size(0), q.size(1), k.size(1)
+    residual = q
+    qh = m.w_qs(q).view(b, lq, m.n_head, m.d_k).transpose(1, 2)
+    kh = m.w_ks(k).view(k.size(0), lk, m.n_head, m.d_k).transpose(1, 2)
+    vh = m.w_vs(v).view(v.size(0), v.size(1), m.n_head, m.d_v).transpose(1, 2)
+    attn = torch.matmul(qh / (m.d_k ** 0.5), kh.transpose(2, 3))
+    if mask is not None:
+        attn = attn.masked_fill(mask.unsqueeze(1) == 0, -1e9)
+    attn = F.softmax(attn, dim=-1)
+    out = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(b, lq, -1)
+    out = m.fc(out)
+    if m.sum_flag:
+        out = m.layer_norm(out + residual)
+    return out, attn
+
+
+# ---- ResUNet.forward ---------------------------------------------------------------------------------------------------
+def _unit(u, x):
+    y = u.bn2(u.conv2(F.relu(u.bn1(u.conv1(x)))))
+    return F.relu(y + (x if u.downsample is None else u.downsample(x)))
+
+
+def _cne(c, x):
+    return F.elu(c.bn(c.conv(x)))
+
+
+def _up(u, x):
+    return _cne(u.conv, F.interpolate(x, scale_factor=u.scale, mode="bilinear", align_corners=True))
+
+
+def _skip(skip, up):
+    dy, dx = up.shape[2] - skip.shape[2], up.shape[3] - skip.shape[3]
+    if dy or dx:
+        skip = F.pad(skip, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+    return torch.cat([up, skip], dim=1)
+
+
+def encoder(net, x):
+    """net: the product's ResUNet; x [V,3,H,W] -> [V,out_ch,H/4,W/4] with stock torch operators."""
+    x = F.relu(net.bn1(net.conv1(x)))
+    x1 = x
+    for u in net.layer1:
+        x1 = _unit(u, x1)
+    x2 = x1
+    for u in net.layer2:
+        x2 = _unit(u, x2)
+    x3 = x2
+    for u in net.layer3:
+        x3 = _unit(u, x3)
+    x = _cne(net.iconv3, _skip(x2, _up(net.upconv3, x3)))
+    x = _cne(net.iconv2, _skip(x1, _up(net.upconv2, x)))
+    return net.out_conv(x)
+
+
+# ---- sparse 3-D convolution by rulebook --------------------------------------------------------------------------------
+class SparseTensor:
+    """features [M,C]; coords [M,3] (d,h,w) int64; spatial shape (D,H,W).  Batch size 1."""
+
+    def __init__(self, features, coords, shape):
+        self.features, self.coords, self.shape = features, coords, tuple(int(s) for s in shape)
+
+    def keys(self):
+        D, H, W = self.shape
+        return (self.coords[:, 0] * H + self.coords[:, 1]) * W + self.coords[:, 2]
+
+    def dense(self):
+        """[1,C,D,H,W], zeros where inactive (spconv's .dense(), SparseConvNet.py:111)."""
+        D, H, W = self.shape
+        C = self.features.shape[1]
+        out = torch.zeros((D * H * W, C), dtype=self.features.dtype, device=self.features.device)
+        out[self.keys()] = self.features
+        return out.view(D, H, W, C).permute(3, 0, 1, 2).unsqueeze(0).contiguous()
+
+
+def _lookup(sorted_keys, order, query):
+    """index into the original rows of the entry whose key equals `query` (the highest row among duplicates), or -1."""
+    pos = (torch.searchsorted(sorted_keys, query, right=True) - 1).clamp_(min=0)
+    hit = sorted_keys[pos] == query
+    return torch.where(hit, order[pos], torch.full_like(pos, -1))
+
+
+def sparse_conv3d(x, weight, stride=1, padding=0, subm=False):
+    """weight [k,k,k,Cin,Cout] as spconv v1.x stores it; out[o] = sum_k W[k] in[o*stride - pad + k]."""
+    k, s = weight.shape[0], stride
+    cin, cout = weight.shape[3], weight.shape[4]
+    pad = (k // 2) if subm else padding
+    D, H, W = x.shape
+    dev = x.coords.device
+    offs = torch.stack(torch.meshgrid(torch.arange(k), torch.arange(k), torch.arange(k), indexing="ij"), -1).view(-1, 3).to(dev)
+    Wk = weight.view(k * k * k, cin, cout)
+    if subm:
+        sk, order = torch.sort(x.keys(), stable=True)
+        out = torch.zeros((x.coords.shape[0], cout), dtype=x.features.dtype, device=dev)
+        for i in range(k * k * k):
+            nb = x.coords - pad + offs[i]                       # input position feeding output site through tap i
+            ok = ((nb >= 0) & (nb < torch.tensor([D, H, W], device=dev))).all(1)
+            q = (nb[:, 0] * H + nb[:, 1]) * W + nb[:, 2]
+            j = _lookup(sk, order, torch.where(ok, q, torch.full_like(q, -1)))
+            sel = (j >= 0) & ok
+            if sel.any():
+                out[sel] += x.features[j[sel]] @ Wk[i]
+        return SparseTensor(out, x.coords, x.shape)
+    oD, oH, oW = [(n + 2 * pad - k) // s + 1 for n in (D, H, W)]
+    pairs_o, pairs_i, pairs_k = [], [], []
+    lim = torch.tensor([oD, oH, oW], device=dev)
+    for i in range(k * k * k):
+        num = x.coords + pad - offs[i]                           # o*stride = p + pad - k
+        o = torch.div(num, s, rounding_mode="floor")
+        ok = ((num % s) == 0).all(1) & ((o >= 0) & (o < lim)).all(1)
+        idx = torch.nonzero(ok).squeeze(1)
+        pairs_o.append((o[idx, 0] * oH + o[idx, 1]) * oW + o[idx, 2])
+        pairs_i.append(idx)
+        pairs_k.append(torch.full_like(idx, i))
+    okeys, iidx, kidx = torch.cat(pairs_o), torch.cat(pairs_i), torch.cat(pairs_k)
+    ukeys, inv = torch.unique(okeys, sorted=True, return_inverse=True)
+    out = torch.zeros((ukeys.numel(), cout), dtype=x.features.dtype, device=dev)
+    for i in range(k * k * k):
+        m = kidx == i
+        if m.any():
+            out.index_add_(0, inv[m], x.features[iidx[m]] @ Wk[i])
+    oc = torch.stack([ukeys // (oH * oW), (ukeys // oW) % oH, ukeys % oW], 1)
+    return SparseTensor(out, oc, (oD, oH, oW))
+
+
+def _sequential(seq, x):
+    """conv -> BatchNorm1d -> ReLU chains on the active features (spconv.SparseSequential); seq: the product's module list."""
+    for m in seq:
+        if hasattr(m, "subm"):
+            x = sparse_conv3d(x, m.weight, m.stride, m.padding, m.subm)
+        else:
+            x = SparseTensor(m(x.features), x.coords, x.shape)
+    return x
+
+
+def dense_levels(net, code, coord, out_sh):
+    """net: the product's SparseConvNet; code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) ->
+    list of 4 dense levels [1,C_k,D/2^k,H/2^k,W/2^k] (SparseConvNet.py:105-111)."""
+    x = SparseTensor(code, coord[:, 1:].long(), out_sh)
+    x = _sequential(net.net[0], x)
+    levels = []
+    for i in range(net.n_layers):
+        x = _sequential(net.net[2 * i + 1], x)
+        x = _sequential(net.net[2 * i + 2], x)
+        levels.append(x.dense())
+    return levels

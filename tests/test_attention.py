@@ -1,5 +1,6 @@
 """The volume builder's vertex-code attention (trainhead.py:48-52) against vectors captured from the reference's
-MultiHeadAttention (tests/golden/make_golden.py run_attention_case): the torch module on CPU, the fused HIP kernel on GPU."""
+MultiHeadAttention (tests/golden/make_golden.py run_attention_case): the oracle's torch restatement on CPU (which that pins),
+the fused HIP kernel -- the product's only path -- on the GPU."""
 import hashlib
 import importlib
 
@@ -26,11 +27,12 @@ def _case(meta):
 
 
 @pytest.mark.parametrize("name", attention_case_names())
-def test_attention_module_matches_reference_golden_cpu(name):
+def test_attention_restatement_matches_reference_golden_cpu(name):
+    from oracle import producers_ref as ref
     z, meta = load(name)
-    m, code, feat = _case(meta)
+    m, code, feat = _case(meta)                 # the product's module: the reference's parameter names, loaded strictly
     with torch.no_grad():
-        out = m(code.unsqueeze(1), feat, feat)[0].squeeze(1).numpy()
+        out = ref.attention(m, code.unsqueeze(1), feat, feat)[0].squeeze(1).numpy()
     assert_close(out, z["out"], 2e-6, "attention")
 
 
@@ -42,7 +44,9 @@ def test_fused_attention_kernel_matches_reference_golden(name):
     m = m.to("cuda:0")
     with torch.no_grad():
         out = m.fuse_vertices(code.to("cuda:0"), feat.to("cuda:0")).cpu().numpy()
+        out2, attn = m(code.to("cuda:0").unsqueeze(1), feat.to("cuda:0"), feat.to("cuda:0"))      # the reference's call form
     assert_close(out, z["out"], 2e-5, "attention (HIP)")
+    assert attn is None and out2.shape == (code.shape[0], 1, code.shape[1]) and np.array_equal(out2[:, 0].cpu().numpy(), out)
 
 
 def test_fused_attention_rejects_unsupported_shapes():

@@ -44,13 +44,16 @@ def test_build_encoder_cfg_keys_and_rejected_names():
 
 
 @pytest.mark.parametrize("name", encoder_case_names())
-def test_encoder_matches_reference_golden_cpu(name):
+def test_encoder_restatement_matches_reference_golden_cpu(name):
+    """The product's module (reference keys, strict load) through the oracle's torch-operator formulation: pins both the
+    parameter map and the restatement the GPU path is compared with."""
+    from oracle import producers_ref as ref
     z, meta = load(name)
     net, state = _net(meta["seed"])
     imgs = syn.make_encoder_images(meta["H"], meta["W"], meta["seed"])
     assert _sha(imgs, state) == meta["inputs_sha256"]
     with torch.no_grad():
-        out = net(torch.from_numpy(imgs)).numpy()
+        out = ref.encoder(net, torch.from_numpy(imgs)).numpy()
     assert_close(out, z["featmaps"], 1e-4, "featmaps")
 
 

@@ -295,9 +295,11 @@ def test_progressive_renderer_returns_pred_img(plugins, syn, oracle):
 
 @pytest.mark.parametrize("in_dim", [32, 16, 12])      # 32, 16: every conv on the matrix cores; 12: the first one on the VALU form
 def test_hip_volume_builder_matches_dense_conv_formulation(in_dim, syn):
-    """gpnerf_volume.hip (SubM / strided sparse conv + folded BN + ReLU, channels-last .dense()) against the rulebook
-    restatement in volume.py, which tests/test_volume_builder.py pins to a dense conv3d-with-mask formulation.
-    The synthetic vertices round into shared voxels, so spconv's duplicate-row semantics are exercised too."""
+    """gpnerf_volume.hip (SubM / strided sparse conv + folded BN + ReLU, channels-last .dense()) against the oracle's rulebook
+    restatement (oracle/producers_ref.py, torch on the CPU), which tests/test_volume_builder.py pins to a dense
+    conv3d-with-mask formulation.  The synthetic vertices round into shared voxels, so spconv's duplicate-row semantics
+    (and the ordered merge of a voxel's rows) are exercised too."""
+    from oracle import producers_ref
     vol = importlib.import_module("gp-nerf_amd.volume")
     torch.manual_seed(0)
     dev = "cuda:0"
@@ -312,10 +314,13 @@ def test_hip_volume_builder_matches_dense_conv_formulation(in_dim, syn):
     code = torch.randn((coord.shape[0], in_dim), device=dev)
     with torch.no_grad():
         hip = net.dense_levels_hip(code, coord4, out_sh)
-        ref = net.dense_levels(code, coord4, out_sh)
+        again = net.dense_levels_hip(code, coord4, out_sh)
+        cpu_net = importlib.import_module("copy").deepcopy(net).cpu()
+        ref = producers_ref.dense_levels(cpu_net, code.cpu(), coord4.cpu(), out_sh)
+    assert all(torch.equal(a, b) for a, b in zip(hip, again)), "the builder must be deterministic (ordered duplicate merge)"
     for l, (a, b) in enumerate(zip(hip, ref)):
         assert a.shape == tuple(b.shape[2:]) + (32,)
-        err = float((a.permute(3, 0, 1, 2) - b[0]).abs().max())
+        err = float((a.permute(3, 0, 1, 2).cpu() - b[0]).abs().max())
         assert err < 2e-4 * max(1.0, float(b.abs().max())), (l, err)
         assert float((a != 0).float().mean()) > 0
 

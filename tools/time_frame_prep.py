@@ -34,8 +34,6 @@ def timed(fn, n=5):
 
 with torch.no_grad():
     ms, vols = timed(lambda: h.sigmahead.build_volumes(sp, feat))
-    h.train(); ms_t, _ = timed(lambda: h.sigmahead.build_volumes(sp, feat)); h.eval()
-print(f"  (torch rulebook version of the same net: {ms_t:.1f} ms)")
 print(f"volume builder (HIP sparse conv): {ms:.1f} ms; levels {[tuple(v.shape) for v in vols]}; active level-1 voxels {(vols[0].abs().sum(-1) > 0).sum().item()}")
 blob = fm.pack_head({k: v for k, v in h.per_ray_state().items()}, dev)
 ms, fr = timed(lambda: fm.Frame.for_volumes(vols, blob))
