@@ -129,6 +129,44 @@ DEV void mfma_tile(const float* __restrict__ w, int lane, const float (&b)[NT], 
     }
 }
 
+// The same, but the sum starts from another tile's value WITHOUT copying it first: the first MFMA reads `cin` as its C operand
+// and writes a fresh accumulator (the per-view layer starts from the shared [mean,var] tile three times over).
+template <int NT>
+DEV f32x16 mfma_tile_from(const float* __restrict__ w, int lane, const float (&b)[NT], const f32x16& cin) {
+    static_assert(NT % 4 == 2 || NT % 4 == 0, "");
+    typedef const __attribute__((address_space(3))) float* lds_ptr;
+    lds_ptr p = (lds_ptr)w + lane * 4;
+    f32x4 a = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(p);
+    constexpr int NG = NT / 4;
+    f32x4 an = a;
+    f32x2 at = {0.f, 0.f};
+    if (1 < NG) an = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(p + 256);
+    else if constexpr (NT % 4 == 2) at = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>((lds_ptr)w + NG * 256 + lane * 2);
+    asm volatile("" : "+v"(p));
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], cin, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+    a = an;
+#pragma unroll
+    for (int g = 1; g < NG; ++g) {
+        an = a;
+        if (g + 1 < NG) an = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(p + (g + 1) * 256);
+        else if constexpr (NT % 4 == 2) at = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>((lds_ptr)w + NG * 256 + lane * 2);
+        asm volatile("" : "+v"(p), "+v"(acc));
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * g + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[4 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[4 * g + 3], acc, 0, 0, 0);
+        a = an;
+    }
+    if constexpr (NT % 4 == 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[0], b[4 * NG + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[1], b[4 * NG + 1], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 // accumulator initialised with the bias of tile m of layer L (image: [half][16 regs])
 template <int L>
 DEV f32x16 bias_tile(const float* __restrict__ lds, int m, int half) {
@@ -220,20 +258,17 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
     for (int v = 0; v < NV; ++v) {
         // the three views share these weights; keep the compiler from holding ~100 VGPRs of them across views
         asm volatile("" : "+v"(lane));
-        f32x16 a0 = s0, a1 = s1;
-        mfma_tile<18>(wtile<gpl::BV>(lds, 0), lane, x[v], a0);
-        mfma_tile<18>(wtile<gpl::BV>(lds, 1), lane, x[v], a1);
+        f32x16 a0 = mfma_tile_from<18>(wtile<gpl::BV>(lds, 0), lane, x[v], s0);
+        f32x16 a1 = mfma_tile_from<18>(wtile<gpl::BV>(lds, 1), lane, x[v], s1);
         float h1[32];
         elus_n<16>(a0, h1);
         elus_n<16>(a1, h1 + 16);
         f32x16 a2 = bias_tile<gpl::B2>(lds, 0, half);
         mfma_tile<32>(wtile<gpl::B2>(lds, 0), lane, h1, a2);
-        float xb[16], xs[16];
+        float xb[16];
         elus_n<16>(a2, xb);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xs[r] = xb[r] * (1.f / 3.f);                          // x * 1.0 / num_views
         f32x16 t1 = bias_tile<gpl::V1>(lds, 0, half);
-        mfma_tile<16>(wtile<gpl::V1>(lds, 0), lane, xs, t1);
+        mfma_tile<16>(wtile<gpl::V1>(lds, 0), lane, xb, t1);                               // weights carry the 1 / num_views
         float u1[16];
         elus_n<16>(t1, u1);
         f32x16 t2 = bias_tile<gpl::V2>(lds, 0, half);
@@ -436,7 +471,7 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
         mfma_steps<gpl::B2, 4>(lw, 0, 0, lane, h1, a2);
         float xb[16];
         Frag xs[2];
-        tile_frags(a2, xs, xb, 1.f / 3.f);                    // x * 1.0 / num_views
+        tile_frags(a2, xs, xb);                               // x * 1.0 / num_views rides on vis_fc.0's packed weights
         f32x16 t1 = bias_tile_s<gpl::V1>(lw, 0, half);
         mfma_steps<gpl::V1, 2>(lw, 0, 0, lane, xs, t1);
         Frag u1[2];
@@ -480,16 +515,21 @@ struct Axis {
 };
 
 // F.grid_sample coordinate handling, align_corners=True: index = ((g + 1) / 2) * (size - 1)
+// The continuous index is first clamped to [-1, size]: every tap of an index outside that range is out of bounds anyway
+// (zero weight), -1 and size themselves give the same taps and weights as before the clamp, and NaN / +-inf land on a bound
+// (v_med3_f32 returns the smallest operand when one is NaN), so the float -> int conversion below is always in range and the
+// bounds tests can be two unsigned integer compares instead of four float compares.  Indices and weights are unchanged.
 DEV Axis axis_taps(float g, int size) {
     const float sm1 = (float)(size - 1);
-    const float ix = ((g + 1.f) * 0.5f) * sm1;
-    const float f0 = floorf(ix), f1 = f0 + 1.f;
+    const float ix = __builtin_amdgcn_fmed3f(((g + 1.f) * 0.5f) * sm1, -1.f, (float)size);
+    const float f0 = floorf(ix);
     const float t = ix - f0;
-    const bool v0 = (f0 >= 0.f) && (f0 <= sm1);          // false for NaN / +-huge
-    const bool v1 = (f1 >= 0.f) && (f1 <= sm1);
+    const int j0 = (int)f0, j1 = j0 + 1;
+    const bool v0 = (unsigned)j0 < (unsigned)size;
+    const bool v1 = (unsigned)j1 < (unsigned)size;
     Axis a;
-    a.i0 = v0 ? (unsigned)f0 : 0u;
-    a.i1 = v1 ? (unsigned)f1 : 0u;
+    a.i0 = v0 ? (unsigned)j0 : 0u;
+    a.i1 = v1 ? (unsigned)j1 : 0u;
     a.w0 = v0 ? 1.f - t : 0.f;
     a.w1 = v1 ? t : 0.f;
     return a;
@@ -1393,6 +1433,7 @@ float pack_scale(int L, int c) {
     switch (L) {
         case gpl::GEO: case gpl::BS: case gpl::BV: return PACK_LOG2E;
         case gpl::D1: return c >= 64 ? PACK_LOG2E : 1.f;
+        case gpl::V1: return 1.f / 3.f;       // vis_fc(x * 1.0 / num_views) (trainhead.py:140): the 1/V rides on the weights
         default: return 1.f;
     }
 }

@@ -104,7 +104,7 @@ def emulate(blob, table, vol_feat, rgb_feat, mask):
         b1 = w.mfma_tile("BV", 1, x[v], s1)
         hh = np.concatenate([elu(b0), elu(b1)], 0)
         xb = elu(w.mfma_tile("B2", 0, hh, w.bias_tile("B2", 0)))
-        t1 = elu(w.mfma_tile("V1", 0, xb * np.float32(1 / 3), w.bias_tile("V1", 0)))
+        t1 = elu(w.mfma_tile("V1", 0, xb, w.bias_tile("V1", 0)))      # the packed weights carry the 1 / num_views
         t2 = elu(w.mfma_tile("V2", 0, t1, w.bias_tile("V2", 0)))
         y.append(xb + t2)
     y = np.concatenate(y, 0)
@@ -250,7 +250,7 @@ def emulate_split(blob, vol_feat, rgb_feat, mask):
         b0 = w.steps("BV", 0, 0, x3(x[v]), s0)
         b1 = w.steps("BV", 1, 0, x3(x[v]), s1)
         xb = elu(w.steps("B2", 0, 0, tile2(elu(b0)) + tile2(elu(b1)), w.bias_tile("B2", 0)))
-        t1 = elu(w.steps("V1", 0, 0, tile2(xb * np.float32(1 / 3)), w.bias_tile("V1", 0)))
+        t1 = elu(w.steps("V1", 0, 0, tile2(xb), w.bias_tile("V1", 0)))
         t2 = elu(w.steps("V2", 0, 0, tile2(t1), w.bias_tile("V2", 0)))
         yf += tile2(xb + t2)
     c1 = elu(w.steps("R1", 0, 0, yf, w.bias_tile("R1", 0)))
