@@ -52,3 +52,26 @@ for v in b2["volumes"]:
     v._gpnerf_ndhwc = True
 wall, e, rt = run(b2)
 print(f"featmaps + volumes given: wall {wall:.2f} ms, etime {e:.2f} ms, rtime {rt:.2f} ms")
+
+# the README command's renderer (render.file hip_demo_render): volume builder -> occupancy -> ray selection -> culled render
+hip_demo = importlib.import_module("hip_demo_render")
+rp = hip_demo.build_render(cfg).to(dev).eval()
+rp.load_state_dict(r.state_dict(), strict=True)
+bp = dict(batch)
+for k in ("target_K", "target_pose", "target_K_inv"):
+    bp[k] = torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev)
+with torch.no_grad():
+    for _ in range(3):
+        o = rp.render(bp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 8
+    acc = {}
+    for _ in range(n):
+        o = rp.render(bp)
+        for k, v in o["time_slots"].items():
+            acc[k] = acc.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n * 1e3
+print(f"progressive renderer: wall {wall:.2f} ms, etime {o['etime']*1e3:.2f} ms, rtime {o['rtime']*1e3:.2f} ms, {int(o['mask_at_box'].sum())} rays; "
+      + ", ".join(f"{k} {acc[k] / n * 1e3:.2f}" for k in ("frame", "ray_select", "render", "bc_render")))
