@@ -88,8 +88,15 @@ SYMBOLS = {
     "gpnerf_select_pixels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, FP, FP, FP, FP, FP, FP, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gpnerf_instance_norm_act": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
-    "gpnerf_upsample2x": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gpnerf_conv_packed_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gpnerf_conv_pack_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gpnerf_conv_out_tiles": (C.c_int32, [C.c_int32] * 5),
+    "gpnerf_conv2d_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_instance_norm_nhwc_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int64, C.c_int32]),
+    "gpnerf_instance_norm_act_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                                C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_upsample2x_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_vertex_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p]),
     "gpnerf_build_occupancy": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_void_p]),
     "gpnerf_sparse_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),

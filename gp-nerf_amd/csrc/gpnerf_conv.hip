@@ -1,0 +1,689 @@
+// gpnerf_conv.hip -- the image encoder's convolutions and their glue on channels-last (NHWC) activations, per frame
+// (libs/encoders/UNet.py:17-53,107-131,154-234: reflect-padded 7x7/2 stem, 3x3 stride-1/2 residual units, 1x1 shortcuts and
+// output conv, affine InstanceNorm + ReLU / ELU, bilinear x2 upsampling).
+//
+// Convolution = implicit GEMM on the matrix cores in the render kernel's transposed form,
+//     out[co][pixel] += W[co][(tap, ci)] * in[(tap, ci)][pixel],
+// with every fp32 operand written as f16 hi + lo (hi = f16(x) toward zero, lo = f16(x - hi)) and three
+// v_mfma_f32_32x32x16_f16 per 16-deep k-step (Wlo.xhi + Whi.xlo + Whi.xhi, f32 accumulation): ~22 significant bits per
+// operand at 3/16 of the fp32-MFMA cost -- the same arithmetic as GPNERF_FLAG_SPLIT_F16 (head_layout.h, namespace gph), whose
+// precondition (operands below the f16 range) holds here by construction for InstanceNorm'd / ReLU'd activations of images.
+//   A operand (weights): packed once per parameter version by pack_conv_weight_kernel into [chunk = (tap, 16 input channels)]
+//     [32-row output tile][hi 64 lanes x 8 halfs | lo 64 lanes x 8 halfs]; a workgroup streams the chunks of its output tiles
+//     through a double-buffered LDS window (one __syncthreads per chunk), every wave reads them as ds_read_b128;
+//   B operand (activations): lane (pixel = lane & 31, half = lane >> 5) loads 8 consecutive input channels of its pixel at the
+//     tap's (reflected) position -- two dwordx4 from the NHWC tensor -- and converts them to hi / lo in registers; the next
+//     chunk's loads are issued before the current chunk's MFMAs;
+//   a wave owns 2 x 32 output pixels x COT x 32 output channels (weights read from LDS are used for both pixel tiles).
+// Reflection padding is index arithmetic (no padded copy of the input, no pad launches).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gpnerf_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define DEV __device__ __forceinline__
+
+constexpr int STEP_BYTES = 2048;     // one (chunk, output tile): 64 lanes x 8 halfs hi (1 KB) + the same for lo
+constexpr int PT = 2;                // 32-pixel tiles per wave
+constexpr int WAVES = 4;             // waves per workgroup -> 256 output pixels per workgroup
+
+DEV unsigned pk_rtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+DEV unsigned lo_pair(unsigned w, float x0, float x1) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(w), "v"(x1));
+    return r;
+}
+struct Frag { h8 hi, lo; };
+DEV Frag make_frag(const f32x4 a, const f32x4 b) {
+    u32x4 H, Lo;
+    H[0] = pk_rtz(a[0], a[1]); Lo[0] = lo_pair(H[0], a[0], a[1]);
+    H[1] = pk_rtz(a[2], a[3]); Lo[1] = lo_pair(H[1], a[2], a[3]);
+    H[2] = pk_rtz(b[0], b[1]); Lo[2] = lo_pair(H[2], b[0], b[1]);
+    H[3] = pk_rtz(b[2], b[3]); Lo[3] = lo_pair(H[3], b[2], b[3]);
+    Frag f;
+    f.hi = __builtin_bit_cast(h8, H);
+    f.lo = __builtin_bit_cast(h8, Lo);
+    return f;
+}
+
+// feature index held by accumulator register r of lane-half h (32x32 C/D layout), as in head_layout.h
+DEV int ft(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// nn.Conv2d(padding_mode='reflect'): index -1 -> 1, n -> n - 2
+DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// ---- weight packing -----------------------------------------------------------------------------------------------------
+// w [Cout][Cin][KS][KS] fp32 (PyTorch) -> packed[(tap * CB + cb) * CT + ct][hi: lane][8] | [lo: lane][8] halfs,
+// lane l: row co = 32 ct + (l & 31), k = 8 (l >> 5) + j  <->  ci = 16 cb + k   (zero beyond Cin / Cout).
+// flat (inputs with fewer than 8 channels, the 3-channel stem): the K dimension is (tap, ci) flattened, k = tap * Cin + ci, cut
+// into chunks of 16 -- 10 chunks for the 7x7x3 stem instead of 49 mostly empty ones; packed[chunk * CT + ct][...].
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, const int Cout, const int Cin, const int KS, const int CB,
+                                        const int CT, const int flat, uint16_t* __restrict__ packed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one (step, lane, j)
+    const long nstep = flat ? (long)CB * CT : (long)KS * KS * CB * CT;  // flat: CB = number of 16-deep chunks of K
+    if (i >= nstep * 512) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long step = i >> 9;
+    const int ct = (int)(step % CT), cb = (int)((step / CT) % CB);
+    int tap = (int)(step / ((long)CT * CB));
+    const int co = 32 * ct + (lane & 31);
+    int ci = 16 * cb + 8 * (lane >> 5) + j;
+    bool in_k = ci < Cin;
+    if (flat) {
+        const int k = 16 * cb + 8 * (lane >> 5) + j;
+        in_k = k < KS * KS * Cin;
+        tap = k / Cin;
+        ci = k % Cin;
+    }
+    const float v = (co < Cout && in_k) ? w[((long)co * Cin + ci) * KS * KS + tap] : 0.f;
+    const unsigned hw = pk_rtz(v, 0.f);
+    const _Float16 hi = __builtin_bit_cast(_Float16, (uint16_t)(hw & 0xFFFFu));
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    uint16_t* dst = packed + step * (STEP_BYTES / 2);
+    dst[lane * 8 + j] = (uint16_t)(hw & 0xFFFFu);
+    dst[512 + lane * 8 + j] = __builtin_bit_cast(uint16_t, lo);
+}
+
+// ---- the convolution ----------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* x;           // [N][H][W][Cin]
+    const uint16_t* packed;
+    const float* bias;        // [Cout] or nullptr
+    float* y;                 // [N][Ho][Wo][Cout]
+    float* stats;             // [N][tiles][Cout][2] per-workgroup sum / sum of squares of the outputs (for the InstanceNorm behind), or nullptr
+    int H, W, Cin, Ho, Wo, Cout, CB, CT;
+};
+
+// Per-channel sum and sum of squares of a workgroup's output tile, from the accumulators (the InstanceNorm that follows every
+// convolution but the last would otherwise re-read the whole tensor for them).  Accumulator register r of half h holds channel
+// 32 c + ft(r, h) of the lane's pixel.  The wave's PT pixel tiles are added per lane; the 32 lanes of a half are summed with
+// DPP moves (rotations by 8, 4, 2, 1 inside each 16-lane row, then row_bcast15 carries row 0's total into row 1 and row 2's
+// into row 3: five VALU adds per register, no LDS traffic); lanes 16 and 48 then hold the two halves' totals, and the four
+// waves meet in LDS in a fixed order.  red: [WAVES][COT * 32][2] floats.
+template <int CTRL, int ROW_MASK>
+DEV float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+DEV float half_sum(float v) {             // valid in lanes 16..31 (half 0) and 48..63 (half 1)
+    v = dpp_add<0x128, 0xF>(v);           // row_ror:8
+    v = dpp_add<0x124, 0xF>(v);           // row_ror:4
+    v = dpp_add<0x122, 0xF>(v);           // row_ror:2
+    v = dpp_add<0x121, 0xF>(v);           // row_ror:1  -> every lane holds its row's total
+    return dpp_add<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
+}
+
+template <int COT>
+DEV void tile_stats(const f32x16 (&acc)[2][COT], const bool (&valid)[2], float* red, const ConvArgs& a, const int n, const int tile,
+                    const int ntiles, const int ct0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v0 = valid[0] ? acc[0][c][r] : 0.f, v1 = valid[1] ? acc[1][c][r] : 0.f;
+            const float s = half_sum(v0 + v1), q = half_sum(fmaf(v1, v1, v0 * v0));
+            if ((lane & 31) == 16) {
+                const int ch = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[(wave * COT * 32 + ch) * 2 + 0] = s;
+                red[(wave * COT * 32 + ch) * 2 + 1] = q;
+            }
+        }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < COT * 32; ch += WAVES * 64) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { s += red[(w * COT * 32 + ch) * 2]; q += red[(w * COT * 32 + ch) * 2 + 1]; }
+        const int co = 32 * ct0 + ch;
+        if (co < a.Cout) {
+            float* o = a.stats + (((size_t)n * ntiles + tile) * a.Cout + co) * 2;
+            o[0] = s;
+            o[1] = q;
+        }
+    }
+}
+
+// this lane's 8 input channels (16 cb + 8 half ..) of pixel (iy, ix)
+DEV void load_px(const ConvArgs& a, const int n, const int iy, const int ix, const int cb, const int half, f32x4& v0, f32x4& v1) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.Cin + 16 * cb + 8 * half);
+    v0 = q[0];
+    v1 = q[1];
+}
+
+// narrow inputs (flat K, see pack_conv_weight_kernel): this lane's 8 values k = 16 chunk + 8 half + j -> (tap, ci) of the output
+// pixel (oy, ox); eight scalar loads
+template <int KS, int STRIDE>
+DEV void load_flat(const ConvArgs& a, const int n, const int oy, const int ox, const int chunk, const int half, f32x4& v0, f32x4& v1) {
+    constexpr int PAD = KS / 2;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * chunk + 8 * half + j;
+        const int tap = k / a.Cin, ci = k - tap * a.Cin;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        v[j] = 0.f;
+        if (tap < KS * KS)
+            v[j] = a.x[(((size_t)n * a.H + reflect(oy * STRIDE + ky - PAD, a.H)) * a.W + reflect(ox * STRIDE + kx - PAD, a.W)) * a.Cin + ci];
+    }
+    v0 = f32x4{v[0], v[1], v[2], v[3]};
+    v1 = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+template <int KS, int STRIDE, int COT, bool NARROW>
+__global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs a) {
+    constexpr int PAD = KS / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][COT * STEP_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y, ct0 = blockIdx.z * COT;
+    const int howo = a.Ho * a.Wo;
+    int oy[PT], ox[PT];
+    bool valid[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int p = ((int)blockIdx.x * WAVES + wave) * (PT * 32) + t * 32 + px;
+        valid[t] = p < howo;
+        const int pc = valid[t] ? p : howo - 1;
+        oy[t] = pc / a.Wo;
+        ox[t] = pc % a.Wo;
+    }
+    f32x16 acc[PT][COT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+    const int nchunk = NARROW ? a.CB : KS * KS * a.CB;            // narrow: CB counts the chunks of the flattened K
+    // every thread moves 16 bytes of the next chunk's weights per 256-thread pass: COT * 2 KB = COT * 128 pieces
+    auto wsrc = [&](int q, int piece) {
+        return reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.packed) + ((size_t)q * a.CT + ct0) * STEP_BYTES) + piece;
+    };
+    constexpr int PIECES = COT * (STEP_BYTES / 16);
+    constexpr int WPASS = (PIECES + WAVES * 64 - 1) / (WAVES * 64);
+    u32x4 wreg[WPASS];
+    f32x4 xin[PT][2];
+    auto fetch = [&](int q) {
+#pragma unroll
+        for (int s = 0; s < WPASS; ++s) {
+            const int piece = s * (WAVES * 64) + (int)threadIdx.x;
+            if (piece < PIECES) wreg[s] = *wsrc(q, piece);
+        }
+        if constexpr (NARROW) {
+#pragma unroll
+            for (int t = 0; t < PT; ++t) load_flat<KS, STRIDE>(a, n, oy[t], ox[t], q, half, xin[t][0], xin[t][1]);
+        } else {
+            const int tap = q / a.CB, cb = q - tap * a.CB;
+            const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+            for (int t = 0; t < PT; ++t)
+                load_px(a, n, reflect(oy[t] * STRIDE + ky - PAD, a.H), reflect(ox[t] * STRIDE + kx - PAD, a.W), cb, half, xin[t][0], xin[t][1]);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < WPASS; ++s) {
+            const int piece = s * (WAVES * 64) + (int)threadIdx.x;
+            if (piece < PIECES) reinterpret_cast<u32x4*>(wbuf[buf])[piece] = wreg[s];
+        }
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int q = 0; q < nchunk; ++q) {
+        const int buf = q & 1;
+        Frag b[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) b[t] = make_frag(xin[t][0], xin[t][1]);
+        if (q + 1 < nchunk) fetch(q + 1);                 // next chunk's loads fly while this chunk's MFMAs run
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+            const u32x4* wl = reinterpret_cast<const u32x4*>(wbuf[buf] + c * STEP_BYTES);
+            const h8 wh = __builtin_bit_cast(h8, wl[lane]), wlo = __builtin_bit_cast(h8, wl[64 + lane]);
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b[t].hi, acc[t][c], 0, 0, 0);
+                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].lo, acc[t][c], 0, 0, 0);
+                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].hi, acc[t][c], 0, 0, 0);
+            }
+        }
+        if (q + 1 < nchunk) park(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: accumulator register r of half h holds output channel 32 ct + ft(r, h): four runs of 4 consecutive channels
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * (ct0 + c) + ft(r, half);
+                const float bv = co < a.Cout ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t][c][r] += bv;
+            }
+    }
+    if (a.stats) tile_stats<COT>(acc, valid, reinterpret_cast<float*>(wbuf[0]), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        if (!valid[t]) continue;
+        float* yp = a.y + ((size_t)n * howo + (size_t)oy[t] * a.Wo + ox[t]) * a.Cout;
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+            const int co0 = 32 * (ct0 + c);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + 8 * g + 4 * half;
+                if (co + 4 > a.Cout) continue;                    // Cout is a multiple of 4; the last tile may be partial
+                const f32x4 v = {acc[t][c][4 * g + 0], acc[t][c][4 * g + 1], acc[t][c][4 * g + 2], acc[t][c][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(yp + co) = v;
+            }
+        }
+    }
+}
+
+// ---- 3x3, stride 1: the bulk of the encoder (27 of its 35 convolutions) ------------------------------------------------
+// The direct kernel above pays one global-memory round trip per (tap, 16 channels) chunk for 6 MFMAs of work.  Here a
+// workgroup owns an 8-row x 32-column output tile; per 16-channel block it stages the (8+2) x (32+2) input patch ONCE into
+// LDS, already split into f16 hi / lo (so the nine taps read their B operand straight from LDS, no conversion in the loop),
+// together with the nine taps' weights, double-buffered against the MFMAs of the previous block: 54 x COT MFMAs per wave
+// between two barriers, global loads 9x fewer and all in flight together.
+constexpr int TH = 8, TW = 32;                              // output tile: rows x columns (wave w owns rows 2w, 2w + 1)
+constexpr int PW = TW + 2, PH = TH + 2;                     // input patch with its one-pixel halo
+constexpr int PPX = 80;                                     // bytes per patch pixel: 16 hi halfs | 16 lo halfs | 16 pad (bank spread)
+constexpr int PATCH_BYTES = PH * PW * PPX;                  // 27 200
+
+template <int COT>
+__global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WBYTES = 9 * COT * STEP_BYTES;
+    unsigned char* const patch0 = smem;                     // [2][PATCH_BYTES]
+    unsigned char* const wts0 = smem + 2 * PATCH_BYTES;     // [2][WBYTES]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
+    const int tiles_x = (a.Wo + TW - 1) / TW;
+    const int ty0 = ((int)blockIdx.x / tiles_x) * TH, tx0 = ((int)blockIdx.x % tiles_x) * TW;
+    const int n = blockIdx.y, ct0 = blockIdx.z * COT;
+
+    f32x16 acc[PT][COT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+    // staging work of one thread per channel block: patch items (pixel, 4-channel quad) and 16-byte weight pieces
+    constexpr int PITEMS = PH * PW * 4, PPASS = (PITEMS + WAVES * 64 - 1) / (WAVES * 64);
+    constexpr int WPIECES = 9 * COT * (STEP_BYTES / 16), WPASS = (WPIECES + WAVES * 64 - 1) / (WAVES * 64);
+    f32x4 preg[PPASS];
+    u32x4 wreg[WPASS];
+    auto fetch = [&](int cb) {
+#pragma unroll
+        for (int s = 0; s < PPASS; ++s) {
+            const int item = s * (WAVES * 64) + (int)threadIdx.x;
+            if (item < PITEMS) {
+                const int pp = item >> 2, qd = item & 3;
+                const int iy = reflect(ty0 + pp / PW - 1, a.H), ix = reflect(tx0 + pp % PW - 1, a.W);
+                // tiles may hang far over the image, where the reflection itself leaves it: clamp (those outputs are never written)
+                const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+                preg[s] = *reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + cy) * a.W + cx) * a.Cin + 16 * cb + 4 * qd);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < WPASS; ++s) {
+            const int piece = s * (WAVES * 64) + (int)threadIdx.x;
+            if (piece < WPIECES) {
+                const int tap = piece / (COT * (STEP_BYTES / 16)), rest = piece % (COT * (STEP_BYTES / 16));
+                wreg[s] = *(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.packed) +
+                                                            (((size_t)tap * a.CB + cb) * a.CT + ct0) * STEP_BYTES) + rest);
+            }
+        }
+    };
+    auto park = [&](int buf) {
+        unsigned char* const pb = patch0 + buf * PATCH_BYTES;
+#pragma unroll
+        for (int s = 0; s < PPASS; ++s) {
+            const int item = s * (WAVES * 64) + (int)threadIdx.x;
+            if (item < PITEMS) {
+                const int pp = item >> 2, qd = item & 3;
+                const f32x4 v = preg[s];
+                const unsigned h0 = pk_rtz(v[0], v[1]), h1 = pk_rtz(v[2], v[3]);
+                unsigned* d = reinterpret_cast<unsigned*>(pb + pp * PPX + qd * 8);
+                d[0] = h0; d[1] = h1;
+                d[8] = lo_pair(h0, v[0], v[1]); d[9] = lo_pair(h1, v[2], v[3]);       // lo block starts 32 bytes in
+            }
+        }
+        u32x4* const wb = reinterpret_cast<u32x4*>(wts0 + buf * WBYTES);
+#pragma unroll
+        for (int s = 0; s < WPASS; ++s) {
+            const int piece = s * (WAVES * 64) + (int)threadIdx.x;
+            if (piece < WPIECES) wb[piece] = wreg[s];
+        }
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int cb = 0; cb < a.CB; ++cb) {
+        const int buf = cb & 1;
+        if (cb + 1 < a.CB) fetch(cb + 1);                   // the next block's loads fly under this block's 54 x COT MFMAs
+        const unsigned char* const pb = patch0 + buf * PATCH_BYTES;
+        const unsigned char* const wb = wts0 + buf * WBYTES;
+        // operands of tap 0, then per tap: read the next tap's operands, run this tap's MFMAs -- the three products of one
+        // accumulator are issued COT * PT MFMAs apart (back-to-back they would wait on each other)
+        Frag b[2][PT];
+        h8 wh[2][COT], wlo[2][COT];
+        auto read_tap = [&](int tap, int slot) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const unsigned char* q = pb + ((2 * wave + t + ky) * PW + px + kx) * PPX + half * 16;
+                b[slot][t].hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q));
+                b[slot][t].lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q + 32));
+            }
+#pragma unroll
+            for (int c = 0; c < COT; ++c) {
+                const u32x4* wl = reinterpret_cast<const u32x4*>(wb + (tap * COT + c) * STEP_BYTES);
+                wh[slot][c] = __builtin_bit_cast(h8, wl[lane]);
+                wlo[slot][c] = __builtin_bit_cast(h8, wl[64 + lane]);
+            }
+        };
+        read_tap(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = tap & 1;
+            if (tap + 1 < 9) read_tap(tap + 1, cur ^ 1);
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[cur][c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cur][c], b[cur][t].lo, acc[t][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cur][c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+        }
+        if (cb + 1 < a.CB) park(buf ^ 1);
+        __syncthreads();
+    }
+    const int ox = tx0 + px;
+    bool valid[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) valid[t] = (ty0 + 2 * wave + t) < a.Ho && ox < a.Wo;
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * (ct0 + c) + ft(r, half);
+                const float bv = co < a.Cout ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t][c][r] += bv;
+            }
+    }
+    if (a.stats) tile_stats<COT>(acc, valid, reinterpret_cast<float*>(smem), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        if (!valid[t]) continue;
+        float* yp = a.y + (((size_t)n * a.Ho + ty0 + 2 * wave + t) * a.Wo + ox) * a.Cout;
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+            const int co0 = 32 * (ct0 + c);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + 8 * g + 4 * half;
+                if (co + 4 > a.Cout) continue;
+                const f32x4 v = {acc[t][c][4 * g + 0], acc[t][c][4 * g + 1], acc[t][c][4 * g + 2], acc[t][c][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(yp + co) = v;
+            }
+        }
+    }
+}
+
+// ---- InstanceNorm + residual + activation on NHWC -------------------------------------------------------------------------
+// three launches: (1) per (image, 256-pixel chunk, channel) sum and sum of squares in double; (2) per (image, channel) the
+// chunks added in a fixed order (deterministic) -> scale = gamma * rstd, shift = beta - mean * scale; (3) elementwise
+// y = act(x * scale + shift [+ residual]).
+constexpr int PCH = 256;
+
+__global__ void __launch_bounds__(256) nhwc_stats_kernel(const float* __restrict__ x, const long hw, const int C, const int nchunks,
+                                                         double* __restrict__ partial) {
+    __shared__ double red[2][256];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int c4 = C >> 2;                                  // float4 groups per pixel (C <= 1024, a multiple of 4)
+    const int lanes_per_px = c4 < 256 ? c4 : 256;
+    const int px_par = 256 / lanes_per_px;                  // pixels handled in parallel
+    const int g = threadIdx.x % lanes_per_px, pr = threadIdx.x / lanes_per_px;
+    const long p0 = (long)chunk * PCH, p1 = p0 + PCH < hw ? p0 + PCH : hw;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (pr < px_par)
+        for (long p = p0 + pr; p < p1; p += px_par) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)n * hw + p) * C + 4 * g);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += (double)v[k]; q[k] += (double)v[k] * (double)v[k]; }
+        }
+    for (int k = 0; k < 4; ++k) {                           // over the px_par pixel lanes of a channel group, fixed order
+        __syncthreads();
+        red[0][threadIdx.x] = s[k];
+        red[1][threadIdx.x] = q[k];
+        __syncthreads();
+        if (pr == 0 && g < lanes_per_px) {
+            double ts = 0, tq = 0;
+            for (int r = 0; r < px_par; ++r) { ts += red[0][r * lanes_per_px + g]; tq += red[1][r * lanes_per_px + g]; }
+            double* o = partial + (((size_t)n * nchunks + chunk) * C + 4 * g + k) * 2;
+            o[0] = ts;
+            o[1] = tq;
+        }
+    }
+}
+
+// one workgroup per (image, 32 channels): 8 chunk lanes per channel add every 8th chunk in double, then the 8 partial sums in a
+// fixed order; T = double (nhwc_stats_kernel's partials) or float (a convolution's per-tile sums)
+template <class T>
+__global__ void __launch_bounds__(256) nhwc_norm_finalize_kernel(const T* __restrict__ partial, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const long hw, const int C,
+                                                                 const int nchunks, const float eps,
+                                                                 float* __restrict__ scale_shift /* [N][2][C] */) {
+    __shared__ double red[2][256];
+    const int n = blockIdx.y, cl = threadIdx.x & 31, kl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    double ts = 0, tq = 0;
+    if (c < C)
+        for (int k = kl; k < nchunks; k += 8) {
+            const T* o = partial + (((size_t)n * nchunks + k) * C + c) * 2;
+            ts += (double)o[0];
+            tq += (double)o[1];
+        }
+    red[0][threadIdx.x] = ts;
+    red[1][threadIdx.x] = tq;
+    __syncthreads();
+    if (kl != 0 || c >= C) return;
+    ts = 0; tq = 0;
+    for (int k = 0; k < 8; ++k) { ts += red[0][k * 32 + cl]; tq += red[1][k * 32 + cl]; }
+    const double mean = ts / (double)hw;
+    double var = tq / (double)hw - mean * mean;             // biased variance, as InstanceNorm2d normalises with
+    if (var < 0) var = 0;
+    const float g = gamma[c] / sqrtf((float)var + eps);
+    scale_shift[((size_t)n * 2 + 0) * C + c] = g;
+    scale_shift[((size_t)n * 2 + 1) * C + c] = beta[c] - (float)mean * g;
+}
+
+__global__ void __launch_bounds__(256) nhwc_norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_shift,
+                                                              const float* __restrict__ residual, const long hw, const int C,
+                                                              const int act, float* __restrict__ out) {
+    const int n = blockIdx.y, c4 = C >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;           // float4 element of image n
+    if (i >= hw * c4) return;
+    const int g4 = (int)(i % c4);
+    const size_t off = (size_t)n * hw * C + (size_t)i * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale_shift + ((size_t)n * 2 + 0) * C + 4 * g4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(scale_shift + ((size_t)n * 2 + 1) * C + 4 * g4);
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (residual) r = *reinterpret_cast<const f32x4*>(residual + off);
+    f32x4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float t = fmaf(v[k], sc[k], sh[k]) + r[k];
+        if (act == 1) t = fmaxf(t, 0.f);
+        else if (act == 2) t = t > 0.f ? t : expm1f(t);
+        y[k] = t;
+    }
+    *reinterpret_cast<f32x4*>(out + off) = y;
+}
+
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) on [N][H][W][C]: src = dst * (in - 1) / (out - 1)
+__global__ void upsample2x_nhwc_kernel(const float* __restrict__ x, const int N, const int H, const int W, const int C,
+                                       float* __restrict__ out) {
+    const int OH = 2 * H, OW = 2 * W, c4 = C >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * OH * OW * c4) return;
+    const int g = (int)(i % c4);
+    const long p = i / c4;
+    const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), n = (int)(p / ((long)OW * OH));
+    const float sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f, sx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ty = fy - (float)y0, tx = fx - (float)x0;
+    auto at = [&](int yy, int xx) { return *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + yy) * W + xx) * C + 4 * g); };
+    const f32x4 a = at(y0, x0), b = at(y0, x1), c = at(y1, x0), d = at(y1, x1);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float top = a[k] * (1.f - tx) + b[k] * tx, bot = c[k] * (1.f - tx) + d[k] * tx;
+        o[k] = top * (1.f - ty) + bot * ty;
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)p * C + 4 * g) = o;
+}
+
+hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+int status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
+
+template <int KS, int STRIDE, bool NARROW>
+int launch_conv(const ConvArgs& a, int N, void* stream) {
+    const int tiles = (a.Ho * a.Wo + WAVES * PT * 32 - 1) / (WAVES * PT * 32);
+    // output tiles per workgroup: as many as still leave the chip a full round of workgroups (weights read once per COT tiles)
+    int cot = 4;
+    while (cot > 1 && (a.CT % cot != 0 || (long)tiles * N * (a.CT / cot) < 256)) cot >>= 1;
+    const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / cot));
+    if (cot == 4) hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 4, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a);
+    else if (cot == 2) hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 2, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a);
+    else hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 1, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a);
+    return status();
+}
+
+int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
+    const int tiles = ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
+    const int cot = (a.CT % 2 == 0) ? 2 : 1;
+    const size_t lds = 2 * (size_t)PATCH_BYTES + 2 * (size_t)9 * cot * STEP_BYTES;
+    const void* fn = cot == 2 ? reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<2>) : reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<1>);
+    // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
+    const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / cot));
+    if (cot == 2) hipLaunchKernelGGL(conv3x3_s1_nhwc_kernel<2>, grid, dim3(WAVES * 64), lds, S_(stream), a);
+    else hipLaunchKernelGGL(conv3x3_s1_nhwc_kernel<1>, grid, dim3(WAVES * 64), lds, S_(stream), a);
+    return status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gpnerf_conv_packed_bytes(int32_t cout, int32_t cin, int32_t ks) {
+    if (cout < 1 || cin < 1 || ks < 1) return 0;
+    const int64_t chunks = cin < 8 ? (ks * ks * cin + 15) / 16 : (int64_t)ks * ks * ((cin + 15) / 16);     // narrow inputs: flat K
+    return chunks * ((cout + 31) / 32) * STEP_BYTES;
+}
+
+int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, void* packed, void* stream) {
+    if (!weight || !packed || cout < 1 || cin < 1 || (ks != 1 && ks != 3 && ks != 7)) return GPNERF_E_ARG;
+    const int flat = cin < 8;
+    const int CB = flat ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16, CT = (cout + 31) / 32;
+    const long total = (flat ? (long)CB : (long)ks * ks * CB) * CT * 512;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_(stream), weight, (int)cout,
+                       (int)cin, (int)ks, CB, CT, flat, reinterpret_cast<uint16_t*>(packed));
+    return status();
+}
+
+// workgroup tiles per image of a convolution's output (= rows per image of its `tile_stats`)
+int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t stride) {
+    if (h < 1 || w < 1 || (ks != 1 && ks != 3 && ks != 7) || (stride != 1 && stride != 2)) return 0;
+    const int pad = ks / 2, ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
+    if (ks == 3 && stride == 1 && cin >= 8) return ((ho + TH - 1) / TH) * ((wo + TW - 1) / TW);
+    return (ho * wo + WAVES * PT * 32 - 1) / (WAVES * PT * 32);
+}
+
+int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
+                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, void* stream) {
+    if (n == 0) return GPNERF_OK;
+    if (!x || !packed || !y || n < 0 || h < 1 || w < 1 || cin < 1 || cout < 4 || (cout & 3)) return GPNERF_E_ARG;
+    if ((ks != 1 && ks != 3 && ks != 7) || (stride != 1 && stride != 2)) return GPNERF_E_ARG;
+    const int pad = ks / 2;
+    if (h <= pad || w <= pad) return GPNERF_E_ARG;                       // reflection needs pad < size
+    const bool narrow = cin < 8;
+    if (!narrow && (cin & 15)) return GPNERF_E_ARG;                       // full 16-channel chunks, 32-byte aligned loads
+    ConvArgs a;
+    a.x = x; a.packed = reinterpret_cast<const uint16_t*>(packed); a.bias = bias; a.y = y; a.stats = tile_stats;
+    a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
+    a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
+    a.CB = narrow ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16; a.CT = (cout + 31) / 32;
+    if (narrow) {
+        if (ks == 7 && stride == 2) return launch_conv<7, 2, true>(a, n, stream);
+        if (ks == 3 && stride == 1) return launch_conv<3, 1, true>(a, n, stream);
+        return GPNERF_E_ARG;
+    }
+    if (ks == 3 && stride == 1) return launch_conv3x3(a, n, stream);
+    if (ks == 3 && stride == 2) return launch_conv<3, 2, false>(a, n, stream);
+    if (ks == 1 && stride == 1) return launch_conv<1, 1, false>(a, n, stream);
+    if (ks == 1 && stride == 2) return launch_conv<1, 2, false>(a, n, stream);
+    return GPNERF_E_ARG;
+}
+
+int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c) {
+    if (n < 1 || hw < 1 || c < 1) return 0;
+    // per-chunk partial sums (double), then the [N][2][C] scale / shift table
+    return (int64_t)n * ((hw + PCH - 1) / PCH) * c * 2 * (int64_t)sizeof(double) + (int64_t)n * 2 * c * (int64_t)sizeof(float);
+}
+
+int gpnerf_instance_norm_act_nhwc(const float* x, const float* tile_stats, int32_t n_tiles, const float* gamma, const float* beta,
+                                  const float* residual, int32_t n, int64_t hw, int32_t c, float eps, int32_t act, float* out,
+                                  void* scratch, void* stream) {
+    if (n == 0 || c == 0 || hw == 0) return GPNERF_OK;
+    if (!x || !gamma || !beta || !out || !scratch || n < 0 || c < 4 || (c & 3) || c > 1024 || hw < 0 || act < 0 || act > 2) return GPNERF_E_ARG;
+    if (tile_stats && n_tiles < 1) return GPNERF_E_ARG;
+    const int nchunks = (int)((hw + PCH - 1) / PCH);
+    double* const partial = reinterpret_cast<double*>(scratch);
+    float* const table = reinterpret_cast<float*>(partial + (size_t)n * nchunks * c * 2);
+    const long elems = (long)hw * (c >> 2);
+    const dim3 fgrid((unsigned)((c + 31) / 32), (unsigned)n);
+    if (tile_stats) {
+        hipLaunchKernelGGL(nhwc_norm_finalize_kernel<float>, fgrid, dim3(256), 0, S_(stream), tile_stats, gamma, beta, (long)hw, (int)c,
+                           (int)n_tiles, eps, table);
+    } else {
+        hipLaunchKernelGGL(nhwc_stats_kernel, dim3((unsigned)nchunks, (unsigned)n), dim3(256), 0, S_(stream), x, (long)hw, (int)c, nchunks, partial);
+        hipLaunchKernelGGL(nhwc_norm_finalize_kernel<double>, fgrid, dim3(256), 0, S_(stream), (const double*)partial, gamma, beta, (long)hw,
+                           (int)c, nchunks, eps, table);
+    }
+    hipLaunchKernelGGL(nhwc_norm_apply_kernel, dim3((unsigned)((elems + 255) / 256), (unsigned)n), dim3(256), 0, S_(stream), x,
+                       (const float*)table, residual, (long)hw, (int)c, (int)act, out);
+    return status();
+}
+
+int gpnerf_upsample2x_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* out, void* stream) {
+    if (n == 0) return GPNERF_OK;
+    if (!x || !out || n < 0 || h < 1 || w < 1 || c < 4 || (c & 3)) return GPNERF_E_ARG;
+    const long total = (long)n * h * w * 4 * (c >> 2);
+    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_(stream), x, (int)n, (int)h, (int)w,
+                       (int)c, out);
+    return status();
+}
+
+}  // extern "C"

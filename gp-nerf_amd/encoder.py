@@ -1,12 +1,14 @@
 """`build_encoder(cfg)` / `ResUNet`: the per-frame image encoder with the reference's interface and
 state_dict keys (libs/encoders/UNet.py:133-242), so `load_state_dict(strict=True)` of a reference checkpoint works.
 
-Per frame, not per ray: V=3 source images [V,3,H,W] -> feature maps [V,32,H/4,W/4], ~16 GFLOP of 3x3 convolutions at
-512x512.  The convolutions are plain library calls (MIOpen through torch).  Built for this path: (1) on the GPU at
-inference every InstanceNorm runs fused with the residual add and activation behind it, and the two bilinear upsamplings run
-as one launch each (gpnerf_instance_norm_act / gpnerf_upsample2x in csrc/gpnerf_encoder.hip; stock torch spends ~180 tiny
-launches there); (2) the hand-over: the result leaves with channels-last strides (logical NCHW, physical NHWC), which is
-the layout the render kernel gathers from, so `Frame` takes it as is, without the NCHW -> NHWC re-layout launch.
+Per frame, not per ray: V=3 source images [V,3,H,W] -> feature maps [V,32,H/4,W/4], ~120 GFLOP of convolutions at 512x512.
+Everything runs in hand-written HIP kernels on channels-last activations (csrc/gpnerf_conv.hip): the convolutions as implicit
+GEMMs on the f16 matrix cores with fp32 operands split into f16 hi + lo (three MFMAs per k-step, f32 accumulation: fp32-grade
+accuracy), reflection padding as index arithmetic, InstanceNorm fused with the residual add and activation behind it, the two
+bilinear upsamplings as one launch each.  The result leaves with channels-last strides (logical NCHW, physical NHWC), which
+is the layout the render kernel gathers from, so `Frame` takes it as is, without a re-layout launch.  The nn.Conv2d /
+nn.InstanceNorm2d sub-modules are parameter containers under the reference's names; there is no torch-operator path (the
+one the tests check against is oracle/producers_ref.py `encoder`).
 
 Network (UNet.py:154-234): 7x7/2 stem -> three residual stages of [3,4,6] two-conv units at 64/128/256 channels, every stage
 entered with stride 2 (there is no max-pool), all 3x3 / 7x7 convolutions reflect-padded, every normalisation an affine
@@ -29,38 +31,91 @@ def _inorm(ch):
     return nn.InstanceNorm2d(ch, track_running_stats=False, affine=True)
 
 
-def _conv(cin, cout, k, stride=1, bias=False):
+def _mk_conv(cin, cout, k, stride=1, bias=False):
     return nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=bias, padding_mode="reflect")
 
 
 def _require_gpu_inference(x, training):
-    """The encoder is built for GPU inference (MIOpen convolutions + the HIP glue kernels); there is no CPU / training path
-    in the product -- the torch-operator formulation the tests check against is oracle/producers_ref.py `encoder`."""
+    """The encoder is built for GPU inference; there is no CPU / training path in the product -- the torch-operator
+    formulation the tests check against is oracle/producers_ref.py `encoder`."""
     if not x.is_cuda or training:
         raise L.GpnerfError("the HIP image encoder runs on GPU tensors in eval mode only (no CPU / training fallback)")
 
 
-def _norm_act(norm, x, act, residual=None):
-    """act(InstanceNorm(x) [+ residual]) as one launch; act: 0 none, 1 ReLU, 2 ELU."""
+def _st(x):
+    return torch.cuda.current_stream(x.device).cuda_stream
+
+
+def _nhwc(x):
+    """logical [N,C,H,W] with channels-last strides = physical [N,H,W,C] (a copy only if it is not laid out so already)"""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+_packed = {}      # id(conv module) -> (parameter version key, packed device image, fp32 source kept alive)
+
+
+def _packed_weight(conv):
+    """gpnerf_conv_pack_weight image of a conv's weight (f16 hi/lo, MFMA A-operand order), re-packed when the parameter changes."""
+    w = conv.weight
+    key = (str(w.device), w.data_ptr(), w._version)
+    hit = _packed.get(id(conv))
+    if hit is None or hit[0] != key:
+        lib = L.lib()
+        cout, cin, ks, _ = w.shape
+        buf = torch.empty((int(lib.gpnerf_conv_packed_bytes(cout, cin, ks)),), dtype=torch.uint8, device=w.device)
+        src = w.detach().float().contiguous()
+        L.check(lib.gpnerf_conv_pack_weight(src.data_ptr(), cout, cin, ks, buf.data_ptr(), _st(w)), "gpnerf_conv_pack_weight")
+        hit = (key, buf, src)
+        if len(_packed) > 256:
+            _packed.clear()
+        _packed[id(conv)] = hit
+    return hit[1]
+
+
+def _conv(conv, x, stats=False):
+    """nn.Conv2d(..., padding=k//2, padding_mode='reflect') on a channels-last tensor -> channels-last tensor (gpnerf_conv2d_nhwc).
+    stats=True: also returns the per-tile channel sums the InstanceNorm behind the convolution needs (`_norm_act(..., stats=)`)."""
     if not x.is_cuda:
         raise L.GpnerfError("the HIP image encoder runs on GPU tensors only (no CPU fallback)")
-    x = x.contiguous()
+    x = _nhwc(x)
+    n, cin, h, w = x.shape
+    cout, _, ks, _ = conv.weight.shape
+    stride = conv.stride[0]
+    pad = ks // 2
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    out = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+    lib = L.lib()
+    ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, cin, ks, stride)), cout, 2), device=x.device, dtype=torch.float32) if stats else None
+    L.check(lib.gpnerf_conv2d_nhwc(x.data_ptr(), n, h, w, cin, _packed_weight(conv).data_ptr(),
+                                   bias.data_ptr() if bias is not None else None, cout, ks, stride, out.data_ptr(),
+                                   ts.data_ptr() if ts is not None else None, _st(x)), "gpnerf_conv2d_nhwc")
+    return (out, ts) if stats else out
+
+
+def _norm_act(norm, x, act, residual=None, stats=None):
+    """act(InstanceNorm(x) [+ residual]) on channels-last tensors; act: 0 none, 1 ReLU, 2 ELU.  x may be the (tensor, tile sums)
+    pair `_conv(..., stats=True)` returns: the statistics then come from the convolution's epilogue instead of a pass over x."""
+    lib = L.lib()
+    if isinstance(x, tuple):
+        x, stats = x
+    x = _nhwc(x)
     n, c, h, w = x.shape
-    out = torch.empty_like(x)
-    res = residual.contiguous() if residual is not None else None
-    L.check(L.lib().gpnerf_instance_norm_act(x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(),
-                                             res.data_ptr() if res is not None else None, n, c, h * w, float(norm.eps), act,
-                                             out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
-            "gpnerf_instance_norm_act")
+    out = torch.empty_like(x, memory_format=torch.channels_last)
+    res = _nhwc(residual) if residual is not None else None
+    scratch = torch.empty((int(lib.gpnerf_instance_norm_nhwc_scratch_bytes(n, h * w, c)),), dtype=torch.uint8, device=x.device)
+    L.check(lib.gpnerf_instance_norm_act_nhwc(x.data_ptr(), stats.data_ptr() if stats is not None else None,
+                                              stats.shape[1] if stats is not None else 0, norm.weight.data_ptr(), norm.bias.data_ptr(),
+                                              res.data_ptr() if res is not None else None, n, h * w, c, float(norm.eps), act,
+                                              out.data_ptr(), scratch.data_ptr(), _st(x)), "gpnerf_instance_norm_act_nhwc")
     return out
 
 
 def _upsample2x(x):
-    x = x.contiguous()
+    x = _nhwc(x)
     n, c, h, w = x.shape
-    out = torch.empty((n, c, 2 * h, 2 * w), device=x.device, dtype=x.dtype)
-    L.check(L.lib().gpnerf_upsample2x(x.data_ptr(), n * c, h, w, out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
-            "gpnerf_upsample2x")
+    out = torch.empty((n, c, 2 * h, 2 * w), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    L.check(L.lib().gpnerf_upsample2x_nhwc(x.data_ptr(), n, h, w, c, out.data_ptr(), _st(x)), "gpnerf_upsample2x_nhwc")
     return out
 
 
@@ -69,15 +124,15 @@ class ResidualUnit(nn.Module):
 
     def __init__(self, cin, cout, stride):
         super().__init__()
-        self.conv1, self.bn1 = _conv(cin, cout, 3, stride), _inorm(cout)
-        self.conv2, self.bn2 = _conv(cout, cout, 3), _inorm(cout)
+        self.conv1, self.bn1 = _mk_conv(cin, cout, 3, stride), _inorm(cout)
+        self.conv2, self.bn2 = _mk_conv(cout, cout, 3), _inorm(cout)
         self.downsample = None
         if stride != 1 or cin != cout:
-            self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), _inorm(cout))
+            self.downsample = nn.Sequential(_mk_conv(cin, cout, 1, stride), _inorm(cout))
 
     def forward(self, x):
-        y = self.conv2(_norm_act(self.bn1, self.conv1(x), 1))
-        idn = x if self.downsample is None else _norm_act(self.downsample[1], self.downsample[0](x), 0)
+        y = _conv(self.conv2, _norm_act(self.bn1, _conv(self.conv1, x, stats=True), 1), stats=True)
+        idn = x if self.downsample is None else _norm_act(self.downsample[1], _conv(self.downsample[0], x, stats=True), 0)
         return _norm_act(self.bn2, y, 1, residual=idn)
 
 
@@ -86,10 +141,10 @@ class ConvNormELU(nn.Module):
 
     def __init__(self, cin, cout, k):
         super().__init__()
-        self.conv, self.bn = _conv(cin, cout, k, bias=True), _inorm(cout)
+        self.conv, self.bn = _mk_conv(cin, cout, k, bias=True), _inorm(cout)
 
     def forward(self, x):
-        return _norm_act(self.bn, self.conv(x), 2)
+        return _norm_act(self.bn, _conv(self.conv, x, stats=True), 2)
 
 
 class UpsampleConv(nn.Module):
@@ -128,7 +183,7 @@ class ResUNet(nn.Module):
             raise ValueError("the reference always runs InstanceNorm here (UNet.py:152-153); other norms are not built")
         n1, n2, n3 = 3, 4, 6
         skip1, skip2, deep = 64, 128, 256
-        self.conv1, self.bn1 = _conv(3, 64, 7, stride=2), _inorm(64)
+        self.conv1, self.bn1 = _mk_conv(3, 64, 7, stride=2), _inorm(64)
         self.layer1, self.layer2, self.layer3 = _stage(64, 64, n1), _stage(64, 128, n2), _stage(128, 256, n3)
         self.upconv3 = UpsampleConv(deep, 128, 3, 2)
         self.iconv3 = ConvNormELU(skip2 + 128, 128, 3)
@@ -140,14 +195,13 @@ class ResUNet(nn.Module):
         """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the result leaves with channels-last strides, which `Frame`
         recognises (no re-layout launch)."""
         _require_gpu_inference(x, self.training)
-        x = _norm_act(self.bn1, self.conv1(x), 1)
+        x = _norm_act(self.bn1, _conv(self.conv1, x.float(), stats=True), 1)
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
         x = self.iconv3(_concat_skip(x2, self.upconv3(x3)))
         x = self.iconv2(_concat_skip(x1, self.upconv2(x)))
-        x = self.out_conv(x)
-        return x.contiguous(memory_format=torch.channels_last)
+        return _conv(self.out_conv, x)
 
 
 def build_encoder(cfg):

@@ -260,13 +260,30 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
                             const float* fc, int32_t n, int32_t d_model, int32_t kv_dim, int32_t n_head, int32_t views,
                             float* out, void* stream);
 
-/* Image-encoder glue (libs/encoders/UNet.py), NCHW device tensors.
- * instance_norm_act: out = act(InstanceNorm2d(x; gamma, beta, eps, biased variance, no running statistics) [+ residual]),
- *   act 0 = none (UNet.py:180-183 shortcut), 1 = ReLU (:38-53), 2 = ELU (:117-120); residual may be NULL.
- * upsample2x: F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (UNet.py:129) on [planes][h][w]. */
-int gpnerf_instance_norm_act(const float* x, const float* gamma, const float* beta, const float* residual, int32_t n, int32_t c,
-                             int64_t hw, float eps, int32_t act, float* out, void* stream);
-int gpnerf_upsample2x(const float* x, int64_t planes, int32_t h, int32_t w, float* out, void* stream);
+/* The image encoder on channels-last activations (gpnerf_conv.hip), all tensors device fp32 [N][H][W][C].
+ * conv2d_nhwc = nn.Conv2d(cin, cout, ks, stride, padding=ks/2, padding_mode='reflect') (UNet.py:6-14,108-115,154-155) as an
+ *   implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32 operands split into f16 hi + lo (three MFMAs per k-step, f32
+ *   accumulation; operands must stay below the f16 range, which InstanceNorm'd / ReLU'd activations of images do).
+ *   ks in {1, 3, 7}, stride in {1, 2}; cin a multiple of 16, or < 8 for the 7x7/2 stem; cout a multiple of 4.
+ *   packed: gpnerf_conv_pack_weight()'s device image of the PyTorch weight [cout][cin][ks][ks] (gpnerf_conv_packed_bytes()
+ *   bytes; re-pack when the parameter changes); bias: [cout] or NULL.  y: [N][Ho][Wo][cout], Ho = (H + 2 (ks/2) - ks) / stride + 1.
+ *   tile_stats: NULL, or [N][gpnerf_conv_out_tiles()][cout][2] floats that receive every workgroup tile's per-channel sum and
+ *   sum of squares of the outputs -- the statistics the InstanceNorm behind the convolution needs, without re-reading y.
+ * instance_norm_act_nhwc = act(InstanceNorm2d(x; gamma, beta, eps, biased variance, no running statistics) [+ residual]),
+ *   act 0 none / 1 ReLU / 2 ELU (UNet.py:38-53,117-120,180-183); statistics from tile_stats (n_tiles rows per image) when
+ *   given, else from a pass over x; either way added up in double in a fixed order (deterministic);
+ *   scratch: gpnerf_instance_norm_nhwc_scratch_bytes() bytes.
+ * upsample2x_nhwc = F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (UNet.py:129). */
+int64_t gpnerf_conv_packed_bytes(int32_t cout, int32_t cin, int32_t ks);
+int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, void* packed, void* stream);
+int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t stride);
+int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
+                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, void* stream);
+int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c);
+int gpnerf_instance_norm_act_nhwc(const float* x, const float* tile_stats, int32_t n_tiles, const float* gamma, const float* beta,
+                                  const float* residual, int32_t n, int64_t hw, int32_t c, float eps, int32_t act, float* out,
+                                  void* scratch, void* stream);
+int gpnerf_upsample2x_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* out, void* stream);
 
 /* Channels-last re-layouts of the per-frame tensors (device -> device). */
 int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t H, int32_t W, void* stream);

@@ -1,0 +1,104 @@
+"""GPU: the image encoder's HIP operators on channels-last activations (csrc/gpnerf_conv.hip) against plain PyTorch fp32/fp64
+references of the same ops on the CPU: reflect-padded convolution (split-f16 MFMA implicit GEMM), InstanceNorm + residual +
+activation, bilinear x2 upsampling."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def enc():
+    return importlib.import_module("gp-nerf_amd.encoder")
+
+
+CONVS = [  # cin, cout, ks, stride, H, W, bias
+    (3, 64, 7, 2, 40, 56, False),        # stem (narrow input)
+    (64, 64, 3, 1, 33, 47, False),       # ragged pixel tiles
+    (64, 128, 3, 2, 32, 32, False),
+    (64, 128, 1, 2, 32, 32, False),      # projected shortcut
+    (128, 128, 3, 1, 16, 20, False),
+    (256, 256, 3, 1, 9, 7, False),       # smaller than one pixel tile
+    (256, 128, 3, 1, 12, 12, True),      # decoder conv with bias
+    (128, 32, 3, 1, 24, 24, True),
+    (32, 32, 1, 1, 10, 10, True),        # output conv
+    (16, 36, 3, 1, 8, 8, True),          # cout not a multiple of 32
+]
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W,bias", CONVS)
+def test_conv2d_nhwc_matches_torch(cin, cout, ks, stride, H, W, bias, enc):
+    g = torch.Generator().manual_seed(cin * 1000 + cout + ks)
+    conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=bias, padding_mode="reflect")
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    x = torch.randn((3, cin, H, W), generator=g) * 2.0 + 0.3
+    with torch.no_grad():
+        ref = conv.double()(x.double()).float()
+        conv = conv.float().to("cuda:0")
+        got = enc._conv(conv, x.to("cuda:0"))
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    err = float((got.cpu() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+    # re-packing follows parameter updates
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+        got2 = enc._conv(conv, x.to("cuda:0"))
+    ref2 = 2 * ref - (conv.bias.detach().cpu()[None, :, None, None] if bias else 0)
+    assert float((got2.cpu() - ref2).abs().max()) < 4e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("c,H,W,act,res", [(64, 37, 41, 1, False), (128, 16, 16, 1, True), (32, 24, 40, 2, False), (256, 5, 5, 0, False)])
+def test_instance_norm_act_nhwc_matches_torch(c, H, W, act, res, enc):
+    g = torch.Generator().manual_seed(c + H)
+    norm = torch.nn.InstanceNorm2d(c, track_running_stats=False, affine=True)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(c, generator=g))
+        norm.bias.copy_(0.2 * torch.randn(c, generator=g))
+    x = torch.randn((3, c, H, W), generator=g) * 3.0 + 1.5
+    r = torch.randn((3, c, H, W), generator=g) if res else None
+    with torch.no_grad():
+        y = norm.double()(x.double()) + (r.double() if res else 0)
+        ref = (F.relu(y) if act == 1 else F.elu(y) if act == 2 else y).float()
+        norm = norm.float().to("cuda:0")
+        got = enc._norm_act(norm, x.to("cuda:0"), act, residual=r.to("cuda:0") if res else None)
+    assert float((got.cpu() - ref).abs().max()) < 2e-5
+
+
+def test_norm_from_the_convolutions_tile_sums_equals_the_separate_pass(enc):
+    g = torch.Generator().manual_seed(11)
+    for cin, cout, ks, stride, H, W in ((64, 64, 3, 1, 33, 47), (64, 128, 3, 2, 32, 36), (3, 64, 7, 2, 40, 56), (128, 32, 3, 1, 24, 24)):
+        conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=True, padding_mode="reflect").to("cuda:0")
+        norm = torch.nn.InstanceNorm2d(cout, track_running_stats=False, affine=True).to("cuda:0")
+        x = (torch.randn((3, cin, H, W), generator=g) * 2 + 0.5).to("cuda:0")
+        with torch.no_grad():
+            y, ts = enc._conv(conv, x, stats=True)
+            a = enc._norm_act(norm, (y, ts), 2)
+            b = enc._norm_act(norm, y, 2)
+        assert ts.shape[0] == 3 and ts.shape[2:] == (cout, 2)
+        assert float((a - b).abs().max()) < 2e-6, (cin, cout, ks, stride)
+
+
+def test_upsample2x_nhwc_matches_torch(enc):
+    x = torch.randn((2, 64, 9, 13), generator=torch.Generator().manual_seed(5))
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    got = enc._upsample2x(x.to("cuda:0"))
+    assert got.shape == ref.shape and float((got.cpu() - ref).abs().max()) < 1e-5
+
+
+def test_conv_entry_point_rejects_unsupported_shapes():
+    L = importlib.import_module("gp-nerf_amd._lib")
+    lib = L.lib()
+    p = 0x1000
+    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 24, p, None, 32, 3, 1, p, None, None) == -1      # cin neither < 8 nor a multiple of 16
+    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 16, p, None, 32, 5, 1, p, None, None) == -1      # 5x5 is not built
+    assert lib.gpnerf_conv2d_nhwc(p, 1, 1, 8, 16, p, None, 32, 3, 1, p, None, None) == -1      # reflection needs pad < size
+    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 16, p, None, 30, 3, 1, p, None, None) == -1      # cout not a multiple of 4
+    assert lib.gpnerf_conv2d_nhwc(None, 0, 8, 8, 16, p, None, 32, 3, 1, p, None, None) == 0     # nothing to do
+    assert lib.gpnerf_conv_out_tiles(128, 128, 64, 3, 1) == 16 * 4 and lib.gpnerf_conv_out_tiles(128, 128, 64, 3, 2) == 16
+    assert lib.gpnerf_conv_packed_bytes(64, 3, 7) == 10 * 2 * 2048      # the 3-channel stem: K = 147 flattened into 10 chunks of 16
