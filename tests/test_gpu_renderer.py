@@ -391,3 +391,34 @@ def test_end_to_end_with_the_real_encoder_matches_the_reference(plugins):
     e.evaluate(ret, {"rgb": torch.from_numpy(z["rgb_gt"]).to("cuda:0")[None], "mask_at_box": b["mask_at_box"]})
     m = e.summarize()
     assert abs(m["psnr"] - float(z["psnr"])) < 1e-3, (m["psnr"], float(z["psnr"]))
+
+
+def test_patch_order_from_mask_at_box_is_only_a_launch_choice(plugins, syn):
+    """Renderer.render lays the rays out as 32x8-pixel patches when the batch carries mask_at_box; the maps it returns are in
+    the ray list's order and bit-identical to the raster-order launch."""
+    hip_render, _ = plugins
+    sc = syn.make_scene(H=48, W=64, seed=12, focal_mul=5.0, pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1)
+    r = hip_render.build_render(cfg(n_samples=24)).to("cuda:0").eval()
+    load_head(r, sc)
+    b = batch_of(sc)
+    with torch.no_grad():
+        plain = r.render(b)
+        b["mask_at_box"] = torch.from_numpy(sc["mask_at_box"]).to("cuda:0")
+        assert 0 < int(b["mask_at_box"].sum()) == sc["ray_o"].shape[1] < 48 * 64
+        tiled = r.render(b)
+    for k in ("rgb_map", "depth_map", "acc_map", "alpha", "z_vals", "rgb_in_map"):
+        assert torch.equal(torch.nan_to_num(plain[k]), torch.nan_to_num(tiled[k])), k
+
+
+def test_progressive_renderer_on_an_empty_volume(plugins, syn):
+    """No occupied voxel: no ray is selected, pred_img is all background (the reference would fail on its empty index lists)."""
+    hip_demo = importlib.import_module("hip_demo_render")
+    sc = syn.make_scene(H=32, W=32, seed=13, focal_mul=4.0, pose="random", aabb_half=(0.12, 0.16, 0.05), vol_occupancy=0.0)
+    r = hip_demo.build_render(cfg(n_samples=16)).to("cuda:0").eval()
+    load_head(r, sc)
+    b = batch_of(sc)
+    for k in ("target_K", "target_pose", "target_K_inv"):
+        b[k] = torch.from_numpy(np.ascontiguousarray(sc[k])).to("cuda:0")
+    with torch.no_grad():
+        ret = r.render(b)
+    assert ret["rgb_map"].shape == (0, 3) and not ret["mask_at_box"].any() and np.abs(ret["pred_img"]).max() == 0
