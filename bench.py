@@ -215,6 +215,12 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = flow.rays_per_step * args.steps / dt
         flops_per_launch = float(flow.n_local) * S * FLOP_PER_SAMPLE
+        evaluated = None
+        if args.early_term or args.occ_cull:
+            # the units a launch processes are the samples it evaluates: terminated / culled samples are not work done
+            done = fm.render_fused(wl.frame, flow.rays, S, want=("samples_done",), ray_order=flow.order, **kw)["samples_done"]
+            evaluated = float(done.float().mean()) / S
+            flops_per_launch *= evaluated
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         cfg_no = 2 if args.early_term else (3 if (args.size == 1024 and world > 1) else 1)
         if world == 1:
@@ -242,9 +248,12 @@ def main():
                          "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_per_launch},
         }
         line.update(extras)
+        if evaluated is not None:
+            line["roofline"]["samples_evaluated_frac"] = evaluated
+            line["roofline"]["note"] = ("flop_per_launch counts the samples the launch evaluated (32-ray tiles stop once every ray has T < term_eps / "
+                                        "skip steps whose 32 samples are all unoccupied), not the S per ray the reference would")
         if args.early_term:
-            done = fm.render_fused(wl.frame, wl.rays, S, want=("samples_done",), ray_order=flow.order, **kw)["samples_done"]
-            line["early_term"] = {"samples_evaluated_frac": float(done.float().mean()) / S,
+            line["early_term"] = {"samples_evaluated_frac": evaluated,
                                   "note": "wave-level scan: a 32-ray tile stops once every ray has T < term_eps"}
         if world == 1 and not args.no_extras:
             line["beside_headline"] = beside_headline(args, fm, wl, kw, flow)
