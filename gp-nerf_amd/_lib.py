@@ -87,7 +87,7 @@ SYMBOLS = {
     "gpnerf_make_rays": (C.c_int, [C.c_int32, C.c_int32, DP, DP, DP, FP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_select_pixels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, FP, FP, FP, FP, FP, FP, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_conv_packed_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gpnerf_conv_pack_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_conv_out_tiles": (C.c_int32, [C.c_int32] * 5),

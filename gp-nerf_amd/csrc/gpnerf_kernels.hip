@@ -902,7 +902,7 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
     if (out.z_vals) write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_rays - ray0), S, step, k_begin, k_end);
     if (writer && split > 1) {
         // partial composite of this segment: rgb, depth, acc, segment transmittance, rgb_in, #samples with >1 valid view
-        float* p = part + ((size_t)ray * split + seg) * 16;
+        float* p = part + ((size_t)slot * split + seg) * 16;      // by launch slot: `ray` may be a row of a larger array
         f32x4 a, b, c, d;
         a[0] = c_r; a[1] = c_g; a[2] = c_b; a[3] = depth;
         b[0] = acc; b[1] = T; b[2] = (float)n_two; b[3] = rin[0];
@@ -984,14 +984,15 @@ render_fused_kernel(const KArgs ka) {
 // merge the per-segment partial composites of a ray front to back: out = sum_s (prod_{j<s} T_j) * partial_s
 __global__ void combine_segments_kernel(const float* __restrict__ part, const long n_rays, const int S, const int split,
                                         const OutK out) {
-    const long ray = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ray >= n_rays) return;
+    const long slot = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_rays) return;
+    const long ray = out.order ? (long)out.order[slot] : slot;     // the row the slot's ray lives in
     float Tp = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, depth = 0.f, acc = 0.f, n_two = 0.f;
     float rin[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) rin[i] = 0.f;
     for (int s = 0; s < split; ++s) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)ray * split + s) * 16);
+        const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)slot * split + s) * 16);
         const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
         cr = fmaf(Tp, a[0], cr); cg = fmaf(Tp, a[1], cg); cb = fmaf(Tp, a[2], cb);
         depth = fmaf(Tp, a[3], depth);
@@ -1250,11 +1251,24 @@ DEV void dataset_ray(const RayCam& cam, const float i, const float j, float (&o)
 
 // demo = 1: the inference renderer's variant (libs/renders/demo_render.py:201-239), float32 throughout: box used as given,
 // no small-|d| clamp, d1 negated under neg_ray instead of the sign test; sel (optional) restricts the pixels (:179-200)
-__global__ void make_rays_kernel(const int H, const int W, const RayCam cam, const int demo, const int neg,
-                                 const uint8_t* __restrict__ sel, float* __restrict__ rays, uint8_t* __restrict__ hit) {
+__global__ void make_rays_kernel(const int H, const int W, RayCam cam, const int demo, const int neg,
+                                 const uint8_t* __restrict__ sel, const int* __restrict__ box_bits, float* __restrict__ rays,
+                                 uint8_t* __restrict__ hit) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= H * W) return;
     if (sel && !sel[idx]) { hit[idx] = 0; return; }
+    if (box_bits) {
+        // the world box of the occupied voxels as gpnerf_select_pixels left it on the device (order-preserving integer images of
+        // min xyz / max xyz), z padded by 5 cm (demo_render.py:168-175): no host round trip between the two launches
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int lo = box_bits[a], hi = box_bits[3 + a];
+            cam.bmin[a] = __int_as_float(lo >= 0 ? lo : lo ^ 0x7FFFFFFF);
+            cam.bmax[a] = __int_as_float(hi >= 0 ? hi : hi ^ 0x7FFFFFFF);
+        }
+        cam.bmin[2] -= 0.05f;
+        cam.bmax[2] += 0.05f;
+    }
     const float i = (float)(idx % W), j = (float)(idx / W);
     float o[3], d[3], near = 0.f, far = 0.f;
     bool keep;
@@ -1316,30 +1330,44 @@ DEV int ordered_int(float f) { const int i = __float_as_int(f); return i >= 0 ? 
 
 __global__ void select_pixels_kernel(const float* __restrict__ occ, const int D, const int H, const int W, const float thr,
                                      const SelGeom g, const int ih, const int iw, uint8_t* __restrict__ sel, int* __restrict__ mm) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)D * H * W) return;
-    if (!(occ[i] > thr)) return;
-    const int w = (int)(i % W), h = (int)((i / W) % H), d = (int)(i / ((long)W * H));
-    // mask_xyz = (w,h,d) * 2 (SparseConvNet.py:140-141); pts = mask_xyz * voxel_size + bounds_min; world = pts @ R^T + Th
-    const float sx = (float)w * 2.f * g.voxel[0] + g.bmin[0], sy = (float)h * 2.f * g.voxel[1] + g.bmin[1],
-                sz = (float)d * 2.f * g.voxel[2] + g.bmin[2];
-    float p[3];
+    // grid-stride over the voxels: the world box of the occupied ones is kept per lane, reduced over the wavefront at the end and
+    // merged with ONE atomic per wave and bound (same-address atomics run at ~10 ns each: one per occupied voxel was a millisecond)
+    const long total = (long)D * H * W;
+    int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (!(occ[i] > thr)) continue;
+        const int w = (int)(i % W), h = (int)((i / W) % H), d = (int)(i / ((long)W * H));
+        // mask_xyz = (w,h,d) * 2 (SparseConvNet.py:140-141); pts = mask_xyz * voxel_size + bounds_min; world = pts @ R^T + Th
+        const float sx = (float)w * 2.f * g.voxel[0] + g.bmin[0], sy = (float)h * 2.f * g.voxel[1] + g.bmin[1],
+                    sz = (float)d * 2.f * g.voxel[2] + g.bmin[2];
+        float p[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) p[a] = mm3(sx, g.Rh[a * 3 + 0], sy, g.Rh[a * 3 + 1], sz, g.Rh[a * 3 + 2]) + g.Th[a];
+        for (int a = 0; a < 3; ++a) p[a] = mm3(sx, g.Rh[a * 3 + 0], sy, g.Rh[a * 3 + 1], sz, g.Rh[a * 3 + 2]) + g.Th[a];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { atomicMin(mm + a, ordered_int(p[a])); atomicMax(mm + 3 + a, ordered_int(p[a])); }
-    float c[3], q[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], ordered_int(p[a])); hi[a] = max(hi[a], ordered_int(p[a])); }
+        float c[3], q[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) c[a] = mm3(p[0], g.pose[a * 4 + 0], p[1], g.pose[a * 4 + 1], p[2], g.pose[a * 4 + 2]) + g.pose[a * 4 + 3];
+        for (int a = 0; a < 3; ++a) c[a] = mm3(p[0], g.pose[a * 4 + 0], p[1], g.pose[a * 4 + 1], p[2], g.pose[a * 4 + 2]) + g.pose[a * 4 + 3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) q[a] = mm3(c[0], g.K[a * 3 + 0], c[1], g.K[a * 3 + 1], c[2], g.K[a * 3 + 2]);
-    const float fx = q[0] / q[2], fy = q[1] / q[2];
-    if (!(fabsf(fx) < 1e9f) || !(fabsf(fy) < 1e9f)) return;            // .long() of inf/nan is undefined in the reference
-    int x0 = (int)fx, y0 = (int)fy;                                     // .long(): truncation toward zero
-    int x1 = x0 + 1, y1 = y0 + 1;
-    x0 = min(max(x0, 0), iw - 1); x1 = min(max(x1, 0), iw - 1);        // the reference clamps to its literal W = 512
-    y0 = min(max(y0, 0), ih - 1); y1 = min(max(y1, 0), ih - 1);
-    sel[y0 * iw + x0] = 1; sel[y1 * iw + x0] = 1; sel[y0 * iw + x1] = 1; sel[y1 * iw + x1] = 1;
+        for (int a = 0; a < 3; ++a) q[a] = mm3(c[0], g.K[a * 3 + 0], c[1], g.K[a * 3 + 1], c[2], g.K[a * 3 + 2]);
+        const float fx = q[0] / q[2], fy = q[1] / q[2];
+        if (!(fabsf(fx) < 1e9f) || !(fabsf(fy) < 1e9f)) continue;          // .long() of inf/nan is undefined in the reference
+        int x0 = (int)fx, y0 = (int)fy;                                     // .long(): truncation toward zero
+        int x1 = x0 + 1, y1 = y0 + 1;
+        x0 = min(max(x0, 0), iw - 1); x1 = min(max(x1, 0), iw - 1);        // the reference clamps to its literal W = 512
+        y0 = min(max(y0, 0), ih - 1); y1 = min(max(y1, 0), ih - 1);
+        // several voxels project onto every marked pixel: look before storing
+        uint8_t* const t[4] = {sel + y0 * iw + x0, sel + y1 * iw + x0, sel + y0 * iw + x1, sel + y1 * iw + x1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!*reinterpret_cast<volatile uint8_t*>(t[k])) *t[k] = 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_xor(lo[a], o)); hi[a] = max(hi[a], __shfl_xor(hi[a], o)); }
+        if ((threadIdx.x & 63) == 0 && lo[a] <= hi[a]) { atomicMin(mm + a, lo[a]); atomicMax(mm + 3 + a, hi[a]); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1851,7 +1879,7 @@ int gpnerf_make_rays(int32_t H, int32_t W, const double* Kinv, const double* Rin
     }
     const int n = H * W, bs = 256;
     hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, 0, 0,
-                       (const uint8_t*)nullptr, rays, hit);
+                       (const uint8_t*)nullptr, (const int*)nullptr, rays, hit);
     return launch_status();
 }
 
@@ -1871,14 +1899,16 @@ int gpnerf_select_pixels(const float* occ, int32_t D, int32_t H, int32_t W, floa
     if (hipMemsetAsync(pixel_sel, 0, (size_t)img_h * img_w, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
     hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(64), 0, S_(stream), (int*)world_minmax);
     const long n = (long)D * H * W;
-    hipLaunchKernelGGL(select_pixels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), occ, (int)D, (int)H,
+    const long want_blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(select_pixels_kernel, dim3((unsigned)(want_blocks < 512 ? want_blocks : 512)), dim3(256), 0, S_(stream), occ, (int)D, (int)H,
                        (int)W, threshold, g, (int)img_h, (int)img_w, pixel_sel, (int*)world_minmax);
     return launch_status();
 }
 
-int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* pose, const float* bounds, int32_t neg_ray,
-                          const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream) {
-    if (!Kinv || !pose || !bounds || !rays || !hit || H < 1 || W < 1) return GPNERF_E_ARG;
+int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* pose, const float* bounds,
+                          const int32_t* world_minmax_dev, int32_t neg_ray, const uint8_t* pixel_sel, float* rays, uint8_t* hit,
+                          void* stream) {
+    if (!Kinv || !pose || (!bounds && !world_minmax_dev) || !rays || !hit || H < 1 || W < 1) return GPNERF_E_ARG;
     RayCam c;
     memset(&c, 0, sizeof(c));
     memcpy(c.Kinv, Kinv, sizeof(c.Kinv));
@@ -1888,10 +1918,11 @@ int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* 
     }
     // ori_rays_o = (-R^T) @ T, a [3,3] @ [3,1] product accumulated like every CPU `@` (demo_render.py:203)
     for (int a = 0; a < 3; ++a) c.o[a] = fmaf(-pose[2 * 4 + a], pose[11], fmaf(-pose[1 * 4 + a], pose[7], (-pose[0 * 4 + a]) * pose[3]));
-    for (int a = 0; a < 3; ++a) { c.bmin[a] = bounds[a]; c.bmax[a] = bounds[3 + a]; }   // used as given (demo_render.py:215)
+    if (bounds)
+        for (int a = 0; a < 3; ++a) { c.bmin[a] = bounds[a]; c.bmax[a] = bounds[3 + a]; }   // used as given (demo_render.py:215)
     const int n = H * W, bs = 256;
     hipLaunchKernelGGL(make_rays_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, S_(stream), (int)H, (int)W, c, 1, (int)neg_ray,
-                       pixel_sel, rays, hit);
+                       pixel_sel, (const int*)world_minmax_dev, rays, hit);
     return launch_status();
 }
 

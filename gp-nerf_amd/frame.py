@@ -20,6 +20,24 @@ def _require_gpu(t, what):
         raise L.GpnerfError(f"{what} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
 
 
+def fetch_host(*items):
+    """Small per-frame constants (camera matrices, Rh, Th, bounds, out_sh) as float64 numpy arrays with ONE device-to-host copy
+    for all the device tensors among them (each `.cpu()` of its own is a synchronisation: six of them cost ~0.4 ms per frame)."""
+    dev = [i for i, t in enumerate(items) if isinstance(t, torch.Tensor) and t.is_cuda]
+    out = [None] * len(items)
+    if dev:
+        flat = torch.cat([items[i].detach().reshape(-1).to(torch.float64) for i in dev]).cpu().numpy()
+        pos = 0
+        for i in dev:
+            n = items[i].numel()
+            out[i] = flat[pos:pos + n].reshape(tuple(items[i].shape))
+            pos += n
+    for i, t in enumerate(items):
+        if out[i] is None:
+            out[i] = (t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)).astype(np.float64)
+    return out
+
+
 def pack_head(state, device):
     """Pack the per-ray MLP parameters into the kernel's LDS image (gpnerf_pack_head).
 
@@ -95,31 +113,31 @@ class Frame:
         f.featmaps, f.feat_h, f.feat_w = self.featmaps.data_ptr(), fh, fw
         f.imgs, f.img_h, f.img_w = self.imgs.data_ptr(), H, W
         # K4 @ P4 in fp32, as train_intrinsics.bmm(train_poses) does (BaseRender.py:233-247,314)
+        Ks_h, poses_h, Rh_h, Th_h, bmin_h, vox_h, osh_h = fetch_host(src_Ks, src_poses, Rh, Th, bounds_min, voxel_size, out_sh)
         K4 = torch.eye(4, dtype=torch.float32).repeat(V, 1, 1)
-        K4[:, :3, :3] = src_Ks.detach().float().cpu()
+        K4[:, :3, :3] = torch.from_numpy(Ks_h.astype(np.float32)).reshape(V, 3, 3)
         P4 = torch.eye(4, dtype=torch.float32).repeat(V, 1, 1)
-        P4[:, :3, :4] = src_poses.detach().float().cpu()
+        P4[:, :3, :4] = torch.from_numpy(poses_h.astype(np.float32)).reshape(V, 3, 4)
         M = torch.bmm(K4, P4).numpy()
         for v in range(V):
             for i in range(12):
                 f.proj[v][i] = float(M[v].ravel()[i])
 
-        def flat(x, n):
-            a = x.detach().float().cpu().numpy().ravel() if isinstance(x, torch.Tensor) else np.asarray(x, np.float32).ravel()
+        def flat(a, n):
+            a = a.astype(np.float32).ravel()
             assert a.size == n, (a.shape, n)
             return a
 
-        for i, v in enumerate(flat(Rh, 9)):
+        for i, v in enumerate(flat(Rh_h, 9)):
             f.Rh[i] = float(v)
-        for i, v in enumerate(flat(Th, 3)):
+        for i, v in enumerate(flat(Th_h, 3)):
             f.Th[i] = float(v)
-        for i, v in enumerate(flat(bounds_min, 3)):
+        for i, v in enumerate(flat(bmin_h, 3)):
             f.bounds_min[i] = float(v)
-        for i, v in enumerate(flat(voxel_size, 3)):
-            f.voxel[i] = float(np.float32(v))
-        osh = out_sh.detach().cpu().numpy().ravel() if isinstance(out_sh, torch.Tensor) else np.asarray(out_sh).ravel()
+        for i, v in enumerate(flat(vox_h, 3)):
+            f.voxel[i] = float(v)
         for i in range(3):
-            f.out_sh[i] = int(osh[i])
+            f.out_sh[i] = int(osh_h.ravel()[i])
         self.head_blob = head_blob
         f.head_blob = head_blob.data_ptr()
         self.head_blob_split = getattr(head_blob, "_gpnerf_split", None)
@@ -211,7 +229,7 @@ def patch_order_device(mask, H, W, patch_w=4, patch_h=8):
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
-                 split_f16=False, flip=None):
+                 split_f16=False, flip=None, subset=False):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); defaults to neg_ray for the dense renderer
     (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
@@ -219,15 +237,23 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     ray_order: optional int32 device tensor [N], a permutation that groups rays into cache-friendly tiles.
     load_balance: lend the kernel a workspace: large frames run persistent workgroups on a tile queue, small frames split a
     tile's samples over several wavefronts.
-    split_f16: dense layers on f16 MFMA with fp32 operands split into hi + lo (GPNERF_FLAG_SPLIT_F16)."""
+    split_f16: dense layers on f16 MFMA with fp32 operands split into hi + lo (GPNERF_FLAG_SPLIT_F16).
+    subset: ray_order lists the rows of `rays` to render (any number of distinct rows); outputs keep rays' row count, rows
+    that are not listed come back zero."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()
     N, S = rays.shape[0], int(n_samples)
     dev = rays.device
+    if subset:
+        if ray_order is None:
+            raise L.GpnerfError("subset=True needs ray_order (the rows to render)")
+        alloc = torch.zeros
+    else:
+        alloc = torch.empty
     res = {
-        "rgb_map": torch.empty((N, 3), device=dev), "depth_map": torch.empty((N,), device=dev),
-        "acc_map": torch.empty((N,), device=dev), "disp_map": torch.empty((N,), device=dev),
+        "rgb_map": alloc((N, 3), device=dev), "depth_map": alloc((N,), device=dev),
+        "acc_map": alloc((N,), device=dev), "disp_map": alloc((N,), device=dev),
     }
     o = L.GpnerfOutputs()
     o.rgb, o.depth, o.acc, o.disp = (res[k].data_ptr() for k in ("rgb_map", "depth_map", "acc_map", "disp_map"))
@@ -262,11 +288,14 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         flags |= L.FLAG_OCC_CULL
     if ray_order is not None:
         _require_gpu(ray_order, "ray_order")
-        if ray_order.dtype != torch.int32 or ray_order.numel() != N or not ray_order.is_contiguous():
+        if ray_order.dtype != torch.int32 or not ray_order.is_contiguous() or (ray_order.numel() != N and not subset):
             raise L.GpnerfError("ray_order must be a contiguous int32 tensor with one entry per ray")
-    ws_bytes = int(lib.gpnerf_render_workspace_bytes(N, S)) if load_balance else 0
+    n_launch = int(ray_order.numel()) if subset else N
+    if subset and any(k in want for k in ("weights", "z_vals", "raw")):
+        raise L.GpnerfError("subset launches return the per-ray maps only")
+    ws_bytes = int(lib.gpnerf_render_workspace_bytes(n_launch, S)) if load_balance else 0
     ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8) if ws_bytes else None
-    L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), N, S, flags, float(term_eps),
+    L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), n_launch, S, flags, float(term_eps),
                                     ray_order.data_ptr() if ray_order is not None else None, C.byref(o),
                                     ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(dev)), "gpnerf_render_fused")
     return res
@@ -391,18 +420,21 @@ def project_gather(frame, pts, neg_ray=False):
 
 
 def select_rays(frame, target_K, target_pose, H, W, voxel_size, bounds_min, Rh, Th, neg_ray=False, threshold=0.1,
-                target_K_inv=None):
+                target_K_inv=None, compact=True):
     """Progressive ray selection of the inference renderer (demo_render.py:166-247) on the device:
     occupied voxels -> marked pixels (gpnerf_select_pixels) -> rays with near/far (gpnerf_make_rays_demo).
-    Returns (rays [n,8] in raster order of the kept pixels, mask_at_box [H*W] bool)."""
+    Returns (rays [n,8] in raster order of the kept pixels, mask_at_box [H*W] bool); with compact=False the rays of ALL H*W
+    pixels (rows of pixels that are not kept are unspecified) and the mask, without any host synchronisation."""
     lib = L.lib()
     if not frame.c.occ:
         frame.build_occupancy()
     occ = frame.occ
     dev = occ.device
-    f32 = lambda a, n: np.ascontiguousarray((a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)).astype(np.float32).ravel()[:n])
-    K, pose = f32(target_K, 9), f32(target_pose, 12)
-    vox, bmin, rh, th = f32(voxel_size, 3), f32(bounds_min, 3), f32(Rh, 9), f32(Th, 3)
+    items = [target_K, target_pose, voxel_size, bounds_min, Rh, Th] + ([target_K_inv] if target_K_inv is not None else [])
+    host = [np.ascontiguousarray(a.astype(np.float32).ravel()) for a in fetch_host(*items)]
+    f32 = lambda a, n: a[:n]
+    K, pose = f32(host[0], 9), f32(host[1], 12)
+    vox, bmin, rh, th = f32(host[2], 3), f32(host[3], 3), f32(host[4], 9), f32(host[5], 3)
     sel = torch.empty((H * W,), device=dev, dtype=torch.uint8)
     mm = torch.empty((6,), device=dev, dtype=torch.int32)
     D1, H1, W1 = occ.shape
@@ -410,17 +442,21 @@ def select_rays(frame, target_K, target_pose, H, W, voxel_size, bounds_min, Rh, 
     p = lambda a: a.ctypes.data_as(L.FP)
     L.check(lib.gpnerf_select_pixels(occ.data_ptr(), D1, H1, W1, float(threshold), p(vox), p(bmin), p(rh), p(th), p(pose), p(K),
                                      H, W, sel.data_ptr(), mm.data_ptr(), st), "gpnerf_select_pixels")
-    bits = mm.cpu().numpy().astype(np.int32)                      # per-frame sync: the box is a host-side constant
-    bits = np.where(bits >= 0, bits, bits ^ 0x7FFFFFFF).astype(np.int32)
-    box = bits.view(np.float32).copy()
-    box[2] -= np.float32(0.05)
-    box[5] += np.float32(0.05)
     # batch["target_K_inv"] is what the reference multiplies by (demo_render.py:204; the dataset makes it with
     # np.linalg.inv on the float32 K, ZjumocapDataset.py:480); without it, do the same here
-    Kinv = f32(target_K_inv, 9) if target_K_inv is not None else np.ascontiguousarray(np.linalg.inv(K.reshape(3, 3)).astype(np.float32).ravel())
+    Kinv = f32(host[6], 9) if target_K_inv is not None else np.ascontiguousarray(np.linalg.inv(K.reshape(3, 3)).astype(np.float32).ravel())
     rays = torch.empty((H * W, 8), device=dev)
     hit = torch.empty((H * W,), device=dev, dtype=torch.uint8)
-    L.check(lib.gpnerf_make_rays_demo(H, W, p(Kinv), p(pose), p(np.ascontiguousarray(box)), int(bool(neg_ray)),
+    # the box of the occupied voxels stays on the device (mm): no host round trip between the two launches
+    L.check(lib.gpnerf_make_rays_demo(H, W, p(Kinv), p(pose), None, mm.data_ptr(), int(bool(neg_ray)),
                                       sel.data_ptr(), rays.data_ptr(), hit.data_ptr(), st), "gpnerf_make_rays_demo")
     mask = hit.bool()
-    return rays[mask], mask
+    return (rays[mask], mask) if compact else (rays, mask)
+
+
+def patch_order_of(idx, W, patch_w=4, patch_h=8):
+    """The kept pixels idx (int64, raster order) re-ordered patch by patch (patch_w x patch_h pixel blocks, row-major inside a
+    block): one key computation and one device sort.  Returns int32 row indices for render_fused(ray_order=..., subset=True)."""
+    y, x = idx // W, idx % W
+    key = ((y // patch_h) * ((W + patch_w - 1) // patch_w) + x // patch_w) * (patch_w * patch_h) + (y % patch_h) * patch_w + x % patch_w
+    return idx[torch.argsort(key)].to(torch.int32)

@@ -118,6 +118,15 @@ class Renderer(nn.Module):
         alpha = 1.0 - torch.exp(-(torch.flip(raw[..., 3], [1]) if neg else raw[..., 3]))
         return o["rgb_map"], o["disp_map"], o["acc_map"], o["weights"], o["depth_map"], o["ray_mask"].bool(), alpha
 
+    def _host_buffers(self, H, W, dev):
+        """Pinned staging for the progressive renderer's numpy outputs (pred_img float64 [H,W,3], mask_at_box bool [H*W])."""
+        key = (H, W, str(dev))
+        if self.__dict__.get("_host_key") != key:
+            self.__dict__["_host"] = {"img": torch.empty((H, W, 3), dtype=torch.float64, pin_memory=True),
+                                      "mask": torch.empty((H * W,), dtype=torch.bool, pin_memory=True)}
+            self.__dict__["_host_key"] = key
+        return self.__dict__["_host"]
+
     def render_progressive(self, batch):
         """libs/renders/demo_render.py:429-498 + :96-376: returns `pred_img` [H,W,3] (float64 numpy, background 0),
         `mask_at_box`, `rgb_map`, `time_slots`, `rtime`, `etime` (libs/evaluators/if_nerf.py:50-56 reads pred_img[mask])."""
@@ -133,22 +142,33 @@ class Renderer(nn.Module):
         torch.cuda.synchronize(dev)
         t1 = time.time()
         neg = self._neg_ray(batch)
+        # every pixel's ray + the mask of the kept ones, no compaction and no host round trip (the box stays on the device)
         rays, mask = F_.select_rays(frame, batch["target_K"][0], batch["target_pose"][0], H, W, self.voxel_size,
                                     batch["bounds"][0, 0], batch["Rh"][0], batch["Th"][0], neg_ray=neg,
-                                    target_K_inv=batch["target_K_inv"][0] if "target_K_inv" in batch else None)
+                                    target_K_inv=batch["target_K_inv"][0] if "target_K_inv" in batch else None, compact=False)
+        idx = torch.nonzero(mask).squeeze(1)                 # kept pixels in raster order (the frame's one synchronisation)
         torch.cuda.synchronize(dev)
         t2 = time.time()
-        order = F_.patch_order_device(mask, H, W) if rays.shape[0] else None     # compact wave tiles: cull whole tiles
-        o = F_.render_fused(frame, rays, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
-                            occ_cull=True, want=(), split_f16=self.split_f16, ray_order=order)
-        rgb = o["rgb_map"]
+        if idx.numel():
+            # the kernel renders the listed rows of the H*W ray array, 4x8-pixel patches per wavefront (a compact tile is empty
+            # or full together far more often: whole tile-steps are culled), and writes each pixel's colour at its own row:
+            # the zero-initialised output IS the image
+            o = F_.render_fused(frame, rays, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
+                                occ_cull=True, want=(), split_f16=self.split_f16, ray_order=F_.patch_order_of(idx, W), subset=True)
+            img = o["rgb_map"]
+        else:
+            img = torch.zeros((H * W, 3), device=dev)
+        rgb = img.index_select(0, idx)
         torch.cuda.synchronize(dev)
         t3 = time.time()
-        mask_np = mask.cpu().numpy()
-        pred_img = np.zeros((H, W, 3))
-        pred_img[mask_np.reshape(H, W)] = rgb.cpu().numpy()
+        host = self._host_buffers(H, W, dev)
+        host["img"].copy_(img.view(H, W, 3), non_blocking=True)          # float32 -> the reference's float64 image, in flight
+        host["mask"].copy_(mask, non_blocking=True)
+        rgb_np = rgb.cpu().numpy()                                        # synchronises: the two copies above are done
+        pred_img = host["img"].numpy().copy()
+        mask_np = host["mask"].numpy().copy()
         t4 = time.time()
-        return {"rgb_map": rgb.cpu().numpy(), "pred_img": pred_img, "mask_at_box": mask_np.reshape(-1),
+        return {"rgb_map": rgb_np, "pred_img": pred_img, "mask_at_box": mask_np.reshape(-1),
                 # this path's own phases, plus the reference's ten keys (demo_render.py:97-357) so that consumers indexing them
                 # keep working: its per-frame phases collapse into `sp_encode`, its sigma / rgb passes into `sigma_f`
                 "time_slots": {"frame": t1 - t0, "ray_select": t2 - t1, "render": t3 - t2, "bc_render": t4 - t3,

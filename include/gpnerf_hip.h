@@ -129,8 +129,10 @@ int gpnerf_pack_head_split(const GpnerfHeadParams* params_host, float* blob_host
  * and raw2outputs :75-107, rgb_in_map :147.
  *   rays: device [N][8] = origin(3), direction(3, un-normalised), near, far (BaseRender.py:250)
  *   term_eps: transmittance threshold, read only with GPNERF_FLAG_EARLY_TERM
- *   ray_order: optional device [N] permutation of 0..N-1 (NULL = identity).  Launch slot i renders ray
- *     ray_order[i]; inputs are read and outputs written at the ray's own index, so results do not depend on it.
+ *   ray_order: optional device [N] list of distinct row indices (NULL = identity): launch slot i renders the ray in row
+ *     ray_order[i] of `rays`; inputs are read and outputs written at that row, so results do not depend on the order.  In the
+ *     plain case it is a permutation of 0..N-1; it may also pick N rows out of larger `rays` / output arrays (the progressive
+ *     renderer passes every pixel's ray and the list of selected pixels: rows not listed are neither read nor written).
  *     It only decides which 32 rays share a wavefront and which 256 share a workgroup: pass image patches
  *     (e.g. 32x8 pixels per workgroup) so neighbouring rays hit the same cache lines.
  *   workspace: optional device scratch of gpnerf_render_workspace_bytes() bytes (NULL = none).  With it the launch balances
@@ -211,10 +213,13 @@ int gpnerf_select_pixels(const float* occ, int32_t D, int32_t H, int32_t W, floa
  * pixel_world = (pixel_camera - T) @ R, rays_o = (-R^T) @ T, with every length-3 product accumulated as torch's CPU `@` does
  * (fused multiply-adds over k = 0,1,2), the box used as given (no +-0.01), directions not clamped, distances by torch.norm's
  * formula, and under neg_ray the second distance negated.  Kinv: host 3x3 (batch['target_K_inv']); pose: host 3x4 row-major
- * [R|T] (batch['target_pose']); bounds: host [2][3].  pixel_sel: optional device [H*W] mask of the pixels to consider
+ * [R|T] (batch['target_pose']); the box: bounds, host [2][3], or -- when world_minmax_dev is not NULL -- what
+ * gpnerf_select_pixels left on the device, decoded and z-padded by 0.05 (demo_render.py:168-175) inside the kernel, so the two
+ * launches need no host round trip between them.  pixel_sel: optional device [H*W] mask of the pixels to consider
  * (others get hit = 0).  Bit-exact against the reference's CPU run (tests/golden/demo_*.npz). */
-int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* pose, const float* bounds, int32_t neg_ray,
-                          const uint8_t* pixel_sel, float* rays, uint8_t* hit, void* stream);
+int gpnerf_make_rays_demo(int32_t H, int32_t W, const float* Kinv, const float* pose, const float* bounds,
+                          const int32_t* world_minmax_dev, int32_t neg_ray, const uint8_t* pixel_sel, float* rays, uint8_t* hit,
+                          void* stream);
 
 /* ---- per-frame sparse convolution pyramid (gpnerf_volume.hip), replacing the external spconv v1.2.1 calls of
  * libs/nerfheads/networks/SparseConvNet.py:22-111 (SubMConv3d / SparseConv3d + BatchNorm1d + ReLU, .dense()).
