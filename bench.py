@@ -216,10 +216,12 @@ def main():
         value = flow.rays_per_step * args.steps / dt
         flops_per_launch = float(flow.n_local) * S * FLOP_PER_SAMPLE
         evaluated = None
+        alive_after = None
         if args.early_term or args.occ_cull:
             # the units a launch processes are the samples it evaluates: terminated / culled samples are not work done
             done = fm.render_fused(wl.frame, flow.rays, S, want=("samples_done",), ray_order=flow.order, **kw)["samples_done"]
             evaluated = float(done.float().mean()) / S
+            alive_after = {str(k): float((done > k).float().mean()) for k in range(32, S, 32)}
             flops_per_launch *= evaluated
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         cfg_no = 2 if args.early_term else (3 if (args.size == 1024 and world > 1) else 1)
@@ -253,7 +255,7 @@ def main():
             line["roofline"]["note"] = ("flop_per_launch counts the samples the launch evaluated (32-ray tiles stop once every ray has T < term_eps / "
                                         "skip steps whose 32 samples are all unoccupied), not the S per ray the reference would")
         if args.early_term:
-            line["early_term"] = {"samples_evaluated_frac": evaluated,
+            line["early_term"] = {"samples_evaluated_frac": evaluated, "tiles_alive_after_samples": alive_after,
                                   "note": "wave-level scan: a 32-ray tile stops once every ray has T < term_eps"}
         if world == 1 and not args.no_extras:
             line["beside_headline"] = beside_headline(args, fm, wl, kw, flow)
