@@ -679,14 +679,14 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     float* part;
     int dynamic;              // 1: persistent workgroups pulling tiles from `queue`
     unsigned* queue;          // 8 counters (one per XCD), zero at launch
-    // chained sample segments (early termination): this launch walks samples [k_lo, k_hi) of the tiles in `list_in` (nullptr:
-    // every tile), resuming each ray from the 16 floats the previous segment left in `part`, and appends the tiles that are
-    // neither finished nor opaque to `list_out` for the next launch
-    int chain, k_lo, k_hi, wave_cap;
-    const int* list_in;
-    const int* count_in;
-    int* list_out;
-    int* count_out;
+    // chained sample segments (early termination): a work item is `chain` samples of one tile.  A tile that is neither
+    // finished nor opaque at the end of an item parks 16 floats per ray in `part` and is appended to the FIFO of the XCD that
+    // rendered it (render_fused_kernel); chain = 0: a work item is the whole ray.
+    int chain, wave_cap;
+    int chunk;                // tiles per chunk of the XCD queues (queue_tile())
+    unsigned* ctl;            // FIFO heads [0..8), FIFO tails [8..16), tiles finished [16]; zero at launch
+    unsigned* lists;          // [8][list_cap] FIFO entries: (tile + 1) | segment << 28, zero = not written yet
+    long list_cap;
 };
 
 // bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
@@ -695,6 +695,17 @@ DEV int xcd_remap(int bid, int nb) {
     const int q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+
+// The tile queue of XCD x holds the tiles of chunks x, x + 8, x + 16 ... (`chunk` consecutive tiles each): neighbouring tiles
+// share an L2, and every XCD gets a sample of the whole frame (with one contiguous run per XCD, an XCD whose eighth of the
+// image terminates late or culls little finishes last: +-14 % of work per eighth on the early-termination bench frame).
+DEV long queue_len(long n_tiles, int chunk, int x) {
+    const long nc = (n_tiles + chunk - 1) / chunk;               // chunks in all; only the last one may be short
+    const long mine = (nc - x + 7) >> 3;
+    const bool has_last = nc > 0 && ((nc - 1) & 7) == x;
+    return mine * chunk - (has_last ? nc * chunk - n_tiles : 0);
+}
+DEV long queue_tile(int chunk, int x, unsigned t) { return ((long)(t / (unsigned)chunk) * 8 + x) * chunk + t % (unsigned)chunk; }
 
 // torch.linspace(0,1,S)[k] as the CPU kernel evaluates it (one rounding per element; see oracle)
 DEV float linspace01(int k, int S, float step) {
@@ -731,6 +742,24 @@ DEV void write_z_vals(float* __restrict__ z_vals, const int lane, const int ray_
     }
 }
 
+// Device-scope (sc1) accesses for data that passes between waves of different CUs within a launch: they are performed at
+// the L2 / the memory side rather than in the CU's vector L1, which is neither invalidated nor shared between CUs.
+DEV unsigned agent_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void agent_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV float agent_loadf(const float* p) { return __builtin_bit_cast(float, agent_load(reinterpret_cast<const unsigned*>(p))); }
+DEV void agent_storef(float* p, float v) { agent_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v)); }
+// one lane performs the access, the wave gets the value
+DEV unsigned wave_load(const unsigned* p, int lane) {
+    unsigned v = 0;
+    if (lane == 0) v = agent_load(p);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
+    unsigned v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(p, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 // Launched with 1..8 waves per workgroup (blockDim.x = 64 * waves): one workgroup per CU either way (LDS), so the
 // host picks the width that balances the grid over the CUs (choose_geometry()).
 #ifndef GPNERF_MAX_WAVES
@@ -738,8 +767,9 @@ DEV void write_z_vals(float* __restrict__ z_vals, const int lane, const int ray_
 #endif
 // One work unit = (32-ray tile, sample segment) rendered by one wavefront: with split > 1 the samples of a tile are divided
 // between `split` waves, whose partial composites are merged by combine_segments_kernel (finer load balance for small frames).
-template <bool SPLIT>
-DEV void render_tile(float* lds, const int lane, const long tile, const int seg) {
+// Returns true when the tile goes on in a later work item (chained segments only).
+template <bool SPLIT, bool CHAIN>
+DEV bool render_tile(float* lds, const int lane, const long tile, const int seg) {
     // Everything the sample loop reads from the arguments is re-read from the kernarg segment (scalar loads, scalar
     // cache) at the top of every iteration through `kp`, a pointer the optimiser cannot see through.  Held in SGPRs
     // across the loop instead, the ~130 argument dwords spill to VGPR lanes and come back as v_readlane_b32 -- VALU
@@ -758,7 +788,7 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
 
     const int n = lane & 31, half = lane >> 5;
     const long ray0 = tile * RAYS_PER_WAVE;
-    if (ray0 >= n_rays) return;
+    if (ray0 >= n_rays) return false;
     const bool active = (ray0 + n) < n_rays;
     const long slot = active ? ray0 + n : n_rays - 1;
     const int ray = k0->out.order ? k0->out.order[slot] : (int)slot;
@@ -781,19 +811,18 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
 
     Stamps st;
     st.start();
-    const int chain = k0->chain;
-    const int k_end = chain ? min(k0->k_hi, S) : (int)(((long)S * (seg + 1)) / split);
-    int k = chain ? k0->k_lo : (int)(((long)S * seg) / split);
+    const int chain = CHAIN ? k0->chain : 0;        // the chained form is its own instantiation: the plain sample loop stays as it was
+    const int k_end = chain ? min((seg + 1) * chain, S) : (int)(((long)S * (seg + 1)) / split);
+    int k = chain ? seg * chain : (int)(((long)S * seg) / split);
     const int k_begin = k;
-    if (chain && k > 0) {       // resume: what the previous segment of this ray left behind (same 16-float record as a split segment)
-        const f32x4* p = reinterpret_cast<const f32x4*>(k0->part + (size_t)slot * 16);
-        const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
-        c_r = a[0]; c_g = a[1]; c_b = a[2]; depth = a[3];
-        acc = b[0]; T = b[1]; rin[0] = b[3];
-        const int packed = (int)b[2];
+    if (CHAIN && k > 0) {       // resume: what the previous segment of this ray left behind (the 16 floats of a split segment)
+        const float* p = k0->part + (size_t)slot * 16;
+        c_r = agent_loadf(p + 0); c_g = agent_loadf(p + 1); c_b = agent_loadf(p + 2); depth = agent_loadf(p + 3);
+        acc = agent_loadf(p + 4); T = agent_loadf(p + 5);
+        const int packed = (int)agent_loadf(p + 6);
         n_two = packed & 4095; n_done = packed >> 12;
-        rin[1] = c[0]; rin[2] = c[1]; rin[3] = c[2]; rin[4] = c[3];
-        rin[5] = d[0]; rin[6] = d[1]; rin[7] = d[2]; rin[8] = d[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rin[i] = agent_loadf(p + 7 + i);
     }
     for (; k < k_end; ++k) {
         kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -919,23 +948,19 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
     const __attribute__((address_space(4))) OutK& out = kp->out;
     float* const part = kp->part;
     // chained segments: the tile goes on in the next launch unless it has walked all S samples or every ray of it is opaque
-    const bool goes_on = chain && k_end < S && !(early && __all(T < term_eps));
+    const bool goes_on = CHAIN && k_end < S && !__all(T < term_eps);
     if (out.z_vals)
         write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_rays - ray0), S, step, k_begin,
-                     (chain && !goes_on) ? S : k_end);
-    if (goes_on) {
+                     (CHAIN && !goes_on) ? S : k_end);
+    if (CHAIN && goes_on) {
         if (writer) {
             float* p = part + (size_t)slot * 16;
-            f32x4 a, b, c, d;
-            a[0] = c_r; a[1] = c_g; a[2] = c_b; a[3] = depth;
-            b[0] = acc; b[1] = T; b[2] = (float)(n_two + 4096 * n_done); b[3] = rin[0];
-            c[0] = rin[1]; c[1] = rin[2]; c[2] = rin[3]; c[3] = rin[4];
-            d[0] = rin[5]; d[1] = rin[6]; d[2] = rin[7]; d[3] = rin[8];
-            reinterpret_cast<f32x4*>(p)[0] = a; reinterpret_cast<f32x4*>(p)[1] = b;
-            reinterpret_cast<f32x4*>(p)[2] = c; reinterpret_cast<f32x4*>(p)[3] = d;
+            agent_storef(p + 0, c_r); agent_storef(p + 1, c_g); agent_storef(p + 2, c_b); agent_storef(p + 3, depth);
+            agent_storef(p + 4, acc); agent_storef(p + 5, T); agent_storef(p + 6, (float)(n_two + 4096 * n_done));
+#pragma unroll
+            for (int i = 0; i < 9; ++i) agent_storef(p + 7 + i, rin[i]);
         }
-        if (lane == 0) kp->list_out[atomicAdd(kp->count_out, 1)] = (int)tile;
-        return;
+        return true;
     }
     if (writer && split > 1) {
         // partial composite of this segment: rgb, depth, acc, segment transmittance, rgb_in, #samples with >1 valid view
@@ -947,7 +972,7 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
         d[0] = rin[5]; d[1] = rin[6]; d[2] = rin[7]; d[3] = rin[8];
         reinterpret_cast<f32x4*>(p)[0] = a; reinterpret_cast<f32x4*>(p)[1] = b;
         reinterpret_cast<f32x4*>(p)[2] = c; reinterpret_cast<f32x4*>(p)[3] = d;
-        return;
+        return false;
     }
     if (writer) {
         // samples skipped by early termination carry weight 0
@@ -966,6 +991,7 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
         if (out.ray_mask) out.ray_mask[ray] = (uint8_t)(n_two > 8);
         if (out.samples_done) out.samples_done[ray] = n_done;
     }
+    return false;
 }
 
 // Workgroups are persistent when the launch is `dynamic`: the head image is staged into LDS once, then every wavefront
@@ -975,7 +1001,7 @@ DEV void render_tile(float* lds, const int lane, const long tile, const int seg)
 // 8-wave workgroup resident per CU a static grid holds the CU until its slowest tile is done -- the queue hands the next
 // tile to whichever wave is free.  Static launches (one unit per wave, XCD-aware remap) remain for frames smaller than
 // one round and for the sample-split geometry.
-template <bool SPLIT>
+template <bool SPLIT, bool CHAIN>
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const KArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -986,39 +1012,78 @@ render_fused_kernel(const KArgs ka) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int qx = blockIdx.x & 7;                    // workgroups are dealt to the XCDs round-robin
-    for (int dry = 0; dry < 8;) {
+    const int home = blockIdx.x & 7;            // workgroups are dealt to the XCDs round-robin
+    int qx = home, dry = 0;
+    for (;;) {
         typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
         kargs_ptr kq = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kq));            // re-read per tile rather than held across render_tile (see there)
-        long tile;
+        long tile = 0;
         int seg = 0;
-        if (kq->dynamic) {
-            // the work list: every tile of the frame, or the tiles the previous chained segment left alive
-            const long n_tiles = kq->list_in ? (long)*kq->count_in : (kq->n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
-            // fewer tiles than waves: deal them evenly, so that every CU runs the same few waves (each then steps faster) rather
-            // than the first workgroups to arrive running eight and the rest none
-            const long share = kq->wave_cap ? (long)kq->wave_cap : (n_tiles + gridDim.x - 1) / gridDim.x;
-            if (wave >= share) return;
-            const long q = n_tiles >> 3, r = n_tiles & 7;
-            unsigned t = 0;
-            if (lane == 0) t = atomicAdd(kq->queue + qx, 1u);
-            t = __builtin_amdgcn_readfirstlane(t);
-            const long start = qx < r ? qx * (q + 1) : r * (q + 1) + (qx - r) * q;
-            const long len = q + (qx < r ? 1 : 0);
-            if ((long)t >= len) {               // this XCD's queue is dry: move on to the next one
-                qx = (qx + 1) & 7;
-                ++dry;
-                continue;
-            }
-            tile = kq->list_in ? (long)kq->list_in[start + t] : start + t;
-        } else {                                // static launch: exactly one unit per wave
+        unsigned* const ctl = CHAIN ? kq->ctl : nullptr;
+        if (!kq->dynamic) {                     // static launch: exactly one unit per wave
+            if (dry) return;
             const long unit = (long)xcd_remap(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
             tile = unit / kq->split;
             seg = (int)(unit % kq->split);
             dry = 8;
+        } else if (dry < 8) {
+            // fresh tiles: every tile of the frame, one contiguous run per XCD
+            const long n_tiles = (kq->n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+            // fewer tiles than waves: deal them evenly, so that every CU runs the same few waves (each then steps faster) rather
+            // than the first workgroups to arrive running eight and the rest none
+            const long share = kq->wave_cap ? (long)kq->wave_cap : (n_tiles + gridDim.x - 1) / gridDim.x;
+            if (wave >= share) return;
+            const unsigned t = wave_add(kq->queue + qx, 1u, lane);
+            if ((long)t >= queue_len(n_tiles, kq->chunk, qx)) {     // this XCD's queue is dry: move on to the next one
+                qx = (qx + 1) & 7;
+                if (++dry == 8 && !CHAIN) return;
+                continue;
+            }
+            tile = queue_tile(kq->chunk, qx, t);
+        } else if constexpr (CHAIN) {
+            // tiles that go on (chained items): eight FIFOs, one per XCD; a wave appends to its own XCD's and takes from it
+            // first (the tile's volume neighbourhood is in that L2), from the others' when it is empty.  ctl[16] counts the
+            // tiles that are finished or opaque: once it reaches the number of tiles nothing can arrive any more.
+            const long n_tiles = (kq->n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+            const long left = n_tiles - (long)wave_load(ctl + 16, lane);
+            if (left <= 0) return;
+            if (left <= (long)wave * gridDim.x) {                   // few tiles left: the low waves of every CU take them (as above)
+                __builtin_amdgcn_s_sleep(127);
+                continue;
+            }
+            const unsigned v = lane < 16 ? agent_load(ctl + lane) : 0u;         // heads in lanes 0..7, tails in lanes 8..15
+            const unsigned vt = __shfl_down(v, 8);
+            unsigned has = (unsigned)__ballot(lane < 8 && (int)(vt - v) > 0) & 0xffu;
+            if (!has) {
+                __builtin_amdgcn_s_sleep(64);
+                continue;
+            }
+            has = ((has | (has << 8)) >> home) & 0xffu;             // rotate: bit i = FIFO (home + i) & 7
+            const int x = (home + __builtin_ctz(has)) & 7;
+            const unsigned h = wave_add(ctl + x, 1u, lane);
+            const unsigned* const entry = kq->lists + (size_t)x * kq->list_cap + h;
+            unsigned e;
+            while ((e = wave_load(entry, lane)) == 0) {             // ticket h: wait for whoever appends it
+                if ((long)wave_load(ctl + 16, lane) >= n_tiles) return;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            tile = (long)(e & 0x0fffffffu) - 1;
+            seg = (int)(e >> 28);
         }
-        render_tile<SPLIT>(lds, lane, tile, seg);
+        const bool goes_on = render_tile<SPLIT, CHAIN>(lds, lane, tile, seg);
+        if constexpr (CHAIN) {
+            kargs_ptr kr = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kr));
+            unsigned* const c2 = kr->ctl;
+            if (goes_on) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tile's parked state has left the CU
+                const unsigned t = wave_add(c2 + 8 + home, 1u, lane);
+                if (lane == 0) agent_store(kr->lists + (size_t)home * kr->list_cap + t, (unsigned)(tile + 1) | ((unsigned)(seg + 1) << 28));
+            } else {
+                wave_add(c2 + 16, 1u, lane);                        // finished
+            }
+        }
     }
 }
 
@@ -1537,16 +1602,25 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
 // rounds x step time x samples per unit.  GPNERF_WAVES / GPNERF_SPLIT override (diagnostics).
 constexpr int GPNERF_MAX_SPLIT = 8;     // waves that may share one tile's samples
 constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue counters (one per XCD), padded
-// Early termination runs the samples in chained segments of CHAIN_SEG (one launch per segment, see gpnerf_render_fused):
-// control block (per segment 8 queue counters + 1 list length), the lists of tiles still alive, 16 floats of state per ray.
+// Early termination renders a tile in chained work items of chain_len() samples (see gpnerf_render_fused); the workspace then
+// holds the control block (QUEUE_BYTES), eight FIFOs of list_cap entries, and 16 floats of parked state per ray.
 constexpr int CHAIN_SEG = 32;
+constexpr int CHAIN_MAX_ITEMS = 16;     // the item index travels in 4 bits of a FIFO entry
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-size_t chain_ctrl_bytes(int n_seg) { return align256((size_t)n_seg * 9 * sizeof(int)); }
-size_t chain_bytes(int64_t n_rays, int S) {
-    const int n_seg = (S + CHAIN_SEG - 1) / CHAIN_SEG;
-    if (n_seg < 2 || S > 4095) return 0;
+int chain_len(int S) {
+    static int f_seg = -1;
+    if (f_seg < 0) { const char* e = getenv("GPNERF_CHAIN_SEG"); f_seg = e ? atoi(e) : CHAIN_SEG; }
+    const int least = (S + CHAIN_MAX_ITEMS - 1) / CHAIN_MAX_ITEMS;
+    return f_seg > least ? f_seg : least;
+}
+size_t chain_list_cap(int64_t n_rays, int S) {
+    const int len = chain_len(S), items = (S + len - 1) / len;
     const size_t tiles = (size_t)((n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE);
-    return chain_ctrl_bytes(n_seg) + align256((size_t)n_seg * tiles * sizeof(int)) + (size_t)n_rays * 16 * sizeof(float);
+    return tiles * (size_t)(items - 1);
+}
+size_t chain_bytes(int64_t n_rays, int S) {
+    if (S <= chain_len(S) || S > 4095 || n_rays > ((int64_t)1 << 32)) return 0;
+    return QUEUE_BYTES + align256(8 * chain_list_cap(n_rays, S) * sizeof(unsigned)) + (size_t)n_rays * 16 * sizeof(float);
 }
 struct Geometry { int waves, split; };
 
@@ -1597,9 +1671,13 @@ int device_ready(int* cus) {
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) {
             d.cus = prop.multiProcessorCount;
             const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS, lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
-            d.ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<false>),
+            d.ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true>),
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split) == hipSuccess &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
@@ -1832,44 +1910,40 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     ka.fr = k; ka.rays = rays; ka.n_rays = (long)n_rays; ka.S = (int)n_samples; ka.flags = (unsigned)flags; ka.term_eps = term_eps;
     ka.out = ok; ka.split = g.split; ka.part = seg_part;
     ka.dynamic = dynamic ? 1 : 0; ka.queue = static_cast<unsigned*>(workspace);
-    // Early termination: the samples are walked in segments of CHAIN_SEG, one persistent-queue launch per segment.  A tile that
-    // is not opaque at the end of a segment parks 16 floats per ray and is queued for the next launch, so no work unit is
-    // longer than CHAIN_SEG samples and every launch is balanced over the tiles still alive -- one launch over the whole ray
-    // would leave the last waves walking their longest tiles alone (16.6 -> 12.x ms at 512x512x128).  Bit-identical results.
+    // Early termination: a work item is chain_len() samples of a tile rather than the whole ray.  A tile that is not opaque at
+    // the end of an item parks 16 floats per ray and queues up again behind the others, so no item is longer than that and the
+    // launch drains within one item's time -- with whole rays as items the last waves walk their longest tiles alone
+    // (512x512x128: 16.6 ms whole rays, 15.2 ms one launch per segment, 1x.x ms this).  Bit-identical results.
     static int f_cap = -1;
     if (f_cap < 0) { const char* e = getenv("GPNERF_WAVE_CAP"); f_cap = e ? atoi(e) : 0; }      // experiments: waves per CU that pull tiles
     ka.wave_cap = f_cap;
-    const size_t need_chain = (flags & GPNERF_FLAG_EARLY_TERM) && f_dynamic ? chain_bytes(n_rays, n_samples) : 0;
+    static int f_chunk = -1;
+    if (f_chunk < 0) { const char* e = getenv("GPNERF_QUEUE_CHUNK"); f_chunk = e ? atoi(e) : 64; }
+    ka.chunk = f_chunk > 0 ? f_chunk : (int)((tiles + 7) / 8);        // 0: one contiguous run per XCD
+    // (frames of less than one round of waves gain nothing from it, and every XCD's queue needs workgroups of its own)
+    const size_t need_chain = (flags & GPNERF_FLAG_EARLY_TERM) && f_dynamic && tiles >= (int64_t)n_cus * GPNERF_MAX_WAVES && n_cus >= 8
+                                  ? chain_bytes(n_rays, n_samples) : 0;
     if (need_chain && workspace && workspace_bytes >= need_chain) {
-        const int n_seg = (n_samples + CHAIN_SEG - 1) / CHAIN_SEG;
         char* const base = static_cast<char*>(workspace);
-        unsigned* const queues = reinterpret_cast<unsigned*>(base);                        // [n_seg][8]
-        int* const counts = reinterpret_cast<int*>(base) + (size_t)n_seg * 8;              // [n_seg]
-        int* const lists = reinterpret_cast<int*>(base + chain_ctrl_bytes(n_seg));         // [n_seg][tiles]
-        float* const state = reinterpret_cast<float*>(base + chain_ctrl_bytes(n_seg) + align256((size_t)n_seg * tiles * sizeof(int)));
-        if (hipMemsetAsync(base, 0, chain_ctrl_bytes(n_seg), S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
-        ka.split = 1; ka.part = state; ka.dynamic = 1; ka.chain = 1;
+        const size_t list_bytes = align256(8 * chain_list_cap(n_rays, n_samples) * sizeof(unsigned));
+        if (hipMemsetAsync(base, 0, QUEUE_BYTES + list_bytes, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+        ka.split = 1; ka.dynamic = 1; ka.chain = chain_len(n_samples);
+        ka.ctl = reinterpret_cast<unsigned*>(base) + 8;
+        ka.lists = reinterpret_cast<unsigned*>(base + QUEUE_BYTES);
+        ka.list_cap = (long)chain_list_cap(n_rays, n_samples);
+        ka.part = reinterpret_cast<float*>(base + QUEUE_BYTES + list_bytes);
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
         const unsigned grid = (unsigned)(wg < n_cus ? wg : n_cus);
-        for (int r = 0; r < n_seg; ++r) {
-            ka.k_lo = r * CHAIN_SEG; ka.k_hi = (r + 1) * CHAIN_SEG;
-            ka.queue = queues + (size_t)r * 8;
-            ka.list_in = r ? lists + (size_t)r * tiles : nullptr;
-            ka.count_in = r ? counts + r : nullptr;
-            ka.list_out = lists + (size_t)(r + 1 < n_seg ? r + 1 : r) * tiles;
-            ka.count_out = counts + (r + 1 < n_seg ? r + 1 : r);
-            if (split16)
-                hipLaunchKernelGGL(render_fused_kernel<true>, dim3(grid), dim3(GPNERF_MAX_WAVES * 64), lds_split, S_(stream), ka);
-            else
-                hipLaunchKernelGGL(render_fused_kernel<false>, dim3(grid), dim3(GPNERF_MAX_WAVES * 64), lds_bytes, S_(stream), ka);
-            if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
-        }
-        return GPNERF_OK;
+        if (split16)
+            hipLaunchKernelGGL((render_fused_kernel<true, true>), dim3(grid), dim3(GPNERF_MAX_WAVES * 64), lds_split, S_(stream), ka);
+        else
+            hipLaunchKernelGGL((render_fused_kernel<false, true>), dim3(grid), dim3(GPNERF_MAX_WAVES * 64), lds_bytes, S_(stream), ka);
+        return launch_status();
     }
     if (split16)
-        hipLaunchKernelGGL(render_fused_kernel<true>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
+        hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
     else
-        hipLaunchKernelGGL(render_fused_kernel<false>, dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
+        hipLaunchKernelGGL((render_fused_kernel<false, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),

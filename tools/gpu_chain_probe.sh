@@ -1,13 +1,9 @@
 #!/bin/bash
-# step time of the fused kernel against the number of waves per CU that pull tiles (GPNERF_WAVE_CAP), and the chained
-# early-termination frame (512x512x128)
 cd /root/repo
-ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],3))"; }
-for w in 1 2 3 4 5 6 7 8; do
-  GPNERF_WAVE_CAP=$w python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | tail -1 | ms "fp32 cap$w"
+ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3))"; }
+for c in 8 24 40 56 72 96 136; do
+GPNERF_QUEUE_CHUNK=$c GPNERF_CHAIN_SEG=16 timeout 120 python bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras 2>&1 | tail -1 | ms "ET128 item=16 chunk=$c"
 done
-for w in 2 4 6 8; do
-  GPNERF_WAVE_CAP=$w python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --split-f16 2>&1 | tail -1 | ms "split cap$w"
+for seg in 8 16 32; do
+GPNERF_QUEUE_CHUNK=24 GPNERF_CHAIN_SEG=$seg timeout 120 python bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras 2>&1 | tail -1 | ms "ET128 item=$seg chunk=24"
 done
-python bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras 2>&1 | tail -1 | ms "ET128 chain"
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>&1 | tail -1 | ms "headline"

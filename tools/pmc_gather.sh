@@ -22,7 +22,7 @@ TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum
 TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_VMEM_RD
 LIST
-python3 tools/pmc_summary.py $out "render_fused_kernel<false>" > /dev/null
+python3 tools/pmc_summary.py $out "render_fused_kernel<false," > /dev/null
 python3 - <<PY
 import json
 d=json.load(open("$out/summary.json"))
