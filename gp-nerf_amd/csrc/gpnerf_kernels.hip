@@ -70,9 +70,14 @@ DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }       
 DEV float elus(float xs) { return __builtin_amdgcn_fmed3f(xs, fmaf(__builtin_amdgcn_exp2f(xs), LOG2E, -LOG2E), 0.f); }
 // N accumulator registers at once, stage by stage: the v_exp_f32 results are not consumed back to back (a transcendental
 // feeding the next instruction costs a wait state) and the FMAs pair up as v_pk_fma_f32
-template <int N>
+#ifdef GPNERF_X_NOPIN_S
+constexpr bool SPIN = false;
+#else
+constexpr bool SPIN = true;
+#endif
+template <int N, bool PIN = true>
 DEV void elus_n(f32x16& a, float* out) {
-    asm volatile("" : "+v"(a));          // not before the MFMA groups issued so far (see the note at the end)
+    if constexpr (PIN) asm volatile("" : "+v"(a));          // not before the MFMA groups issued so far (see the note at the end)
     float e[N];
 #pragma unroll
     for (int r = 0; r < N; ++r) e[r] = __builtin_amdgcn_exp2f(a[r]);
@@ -87,6 +92,7 @@ DEV void elus_n(f32x16& a, float* out) {
     // instructions between the next layer's MFMAs, and every MFMA -> VALU -> MFMA switch inside one wave idles the matrix
     // pipe for ~20 cycles (tools/micro/mfma_chains.hip).  One burst per layer, then an uninterrupted MFMA run.
     static_assert(N == 8 || N == 16, "");
+    if constexpr (!PIN) return;
     asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]), "+v"(out[4]), "+v"(out[5]), "+v"(out[6]), "+v"(out[7]));
     if constexpr (N == 16)
         asm volatile("" : "+v"(out[8]), "+v"(out[9]), "+v"(out[10]), "+v"(out[11]), "+v"(out[12]), "+v"(out[13]), "+v"(out[14]), "+v"(out[15]));
@@ -330,7 +336,7 @@ DEV Frag make_frag(const float* v) {
         H[p] = w;
         Lo[p] = lo_pair(w, v[2 * p], v[2 * p + 1]);
     }
-    asm volatile("" : "+v"(H), "+v"(Lo));      // complete before the MFMA run that follows (no VALU between MFMAs)
+    if constexpr (SPIN) asm volatile("" : "+v"(H), "+v"(Lo));      // complete before the MFMA run that follows (no VALU between MFMAs)
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
     f.lo = __builtin_bit_cast(h8, Lo);
@@ -388,7 +394,7 @@ DEV void mfma_steps(const unsigned* lw, int m, int s0, int lane, const Frag* b, 
 // ELU of an accumulator tile -> its two B-operand k-steps (and optionally the fp32 values)
 DEV void tile_frags(f32x16& a, Frag* out2, float* keep = nullptr, float scale = 1.f) {
     float t[16];
-    elus_n<16>(a, t);
+    elus_n<16, SPIN>(a, t);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { if (keep) keep[r] = t[r]; t[r] *= scale; }
     out2[0] = make_frag(t);
@@ -409,7 +415,7 @@ DEV void geo_eval_s(const unsigned* __restrict__ lw, int lane, const float (&fv)
 }
 
 DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const float (&x)[NV][18], float nvalid,
-                    float& sigma, float (&rgb)[3]) {
+                    float& sigma, float (&rgb)[3], Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
     const float* lf = reinterpret_cast<const float*>(lw);
@@ -451,6 +457,7 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
         s = fmaxf(s, 0.f);
         sigma = (nvalid < 1.f) ? 0.f : s;
     }
+    STAMP(st, 3);
     // colour branch (trainhead.py:85-100,131,139-143)
     f32x16 s0 = bias_tile_s<gpl::BS>(lw, 0, half), s1 = bias_tile_s<gpl::BS>(lw, 1, half);
     mfma_steps<gpl::BS, 6>(lw, 0, 0, lane, mvf, s0);
@@ -479,12 +486,13 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
         f32x16 t2 = bias_tile_s<gpl::V2>(lw, 0, half);
         mfma_steps<gpl::V2, 2>(lw, 0, 0, lane, u1, t2);
         float y[16];
-        elus_n<16>(t2, y);
+        elus_n<16, SPIN>(t2, y);
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[r] += xb[r];
         yf[2 * v] = make_frag(y);
         yf[2 * v + 1] = make_frag(y + 8);
     }
+    STAMP(st, 4);
     {
         f32x16 c1 = bias_tile_s<gpl::R1>(lw, 0, half);
         mfma_steps<gpl::R1, 6>(lw, 0, 0, lane, yf, c1);
@@ -504,6 +512,7 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
             rgb[o] = 1.f / (1.f + fast_exp(-s));
         }
     }
+    STAMP(st, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -540,6 +549,9 @@ DEV Axis axis_taps(float g, int size) {
 // the base from SGPRs plus a 32-bit VGPR offset, so no 64-bit address arithmetic runs on the VALU.
 DEV unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
 DEV const float* at_byte(const float* base, unsigned byte_off) {
+#ifdef GPNERF_X_SAMELINE       // diagnostic only (wrong results): every lane of a load reads the first lane's line
+    byte_off = ((unsigned)__builtin_amdgcn_readfirstlane((int)byte_off) & ~127u) | (byte_off & 127u);
+#endif
     return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
@@ -683,6 +695,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     // finished nor opaque at the end of an item parks 16 floats per ray in `part` and is appended to the FIFO of the XCD that
     // rendered it (render_fused_kernel); chain = 0: a work item is the whole ray.
     int chain, wave_cap;
+    int stagger;              // experiment: waves 4..7 of a workgroup start this many x 64 cycles late
     int chunk;                // tiles per chunk of the XCD queues (queue_tile())
     unsigned* ctl;            // FIFO heads [0..8), FIFO tails [8..16), tiles finished [16]; zero at launch
     unsigned* lists;          // [8][list_cap] FIFO entries: (tile + 1) | segment << 28, zero = not written yet
@@ -890,7 +903,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
 
         STAMP(st, 2);
         float sigma, rgb[3];
-        if constexpr (SPLIT) mlp_eval_s(lw, lane, sff, x, nvalid, sigma, rgb);
+        if constexpr (SPLIT) mlp_eval_s(lw, lane, sff, x, nvalid, sigma, rgb, st);
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
         if (cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
@@ -1014,6 +1027,8 @@ render_fused_kernel(const KArgs ka) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int home = blockIdx.x & 7;            // workgroups are dealt to the XCDs round-robin
     int qx = home, dry = 0;
+    if (ka.stagger && wave >= 4)
+        for (int i = 0; i < ka.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     for (;;) {
         typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
         kargs_ptr kq = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1917,6 +1932,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     static int f_cap = -1;
     if (f_cap < 0) { const char* e = getenv("GPNERF_WAVE_CAP"); f_cap = e ? atoi(e) : 0; }      // experiments: waves per CU that pull tiles
     ka.wave_cap = f_cap;
+    static int f_stagger = -1;
+    if (f_stagger < 0) { const char* e = getenv("GPNERF_STAGGER"); f_stagger = e ? atoi(e) : 0; }
+    ka.stagger = f_stagger;
     static int f_chunk = -1;
     if (f_chunk < 0) { const char* e = getenv("GPNERF_QUEUE_CHUNK"); f_chunk = e ? atoi(e) : 64; }
     ka.chunk = f_chunk > 0 ? f_chunk : (int)((tiles + 7) / 8);        // 0: one contiguous run per XCD

@@ -74,13 +74,16 @@ class Frame:
     re-laid out channels-last on the device.  Built once per target view."""
 
     def __init__(self, src_imgs, featmaps, volumes, src_Ks, src_poses, Rh, Th, bounds_min, voxel_size, out_sh,
-                 head_blob):
+                 head_blob, consts=None):
         """
         src_imgs   [V,3,H,W] in [-1,1] (batch['src_imgs'][0]); de-normalised here (BaseRender.py:231)
         featmaps   [V,32,h,w]           encoder output (BaseRender.py:222)
         volumes    4 x [1,32,D,H,W] or [32,D,H,W]   dense levels (SparseConvNet.py:111)
         src_Ks [V,3,3], src_poses [V,3,4], Rh [3,3], Th [1,3] or [3], bounds_min [3] (xyz), voxel_size [3], out_sh [3] (dhw)
         head_blob  device tensor from pack_head()
+        consts     optional: what fetch_host(src_Ks, src_poses, Rh, Th, bounds_min, voxel_size, out_sh) returned earlier, so that
+                   building the frame does not synchronise with the device (Renderer.render fetches them before it enqueues
+                   the encoder, while the queue is still empty)
         """
         lib = L.lib()
         dev = src_imgs.device
@@ -113,7 +116,8 @@ class Frame:
         f.featmaps, f.feat_h, f.feat_w = self.featmaps.data_ptr(), fh, fw
         f.imgs, f.img_h, f.img_w = self.imgs.data_ptr(), H, W
         # K4 @ P4 in fp32, as train_intrinsics.bmm(train_poses) does (BaseRender.py:233-247,314)
-        Ks_h, poses_h, Rh_h, Th_h, bmin_h, vox_h, osh_h = fetch_host(src_Ks, src_poses, Rh, Th, bounds_min, voxel_size, out_sh)
+        Ks_h, poses_h, Rh_h, Th_h, bmin_h, vox_h, osh_h = consts if consts is not None else fetch_host(src_Ks, src_poses, Rh, Th, bounds_min,
+                                                                                                          voxel_size, out_sh)
         K4 = torch.eye(4, dtype=torch.float32).repeat(V, 1, 1)
         K4[:, :3, :3] = torch.from_numpy(Ks_h.astype(np.float32)).reshape(V, 3, 3)
         P4 = torch.eye(4, dtype=torch.float32).repeat(V, 1, 1)
@@ -192,11 +196,17 @@ class Frame:
         self.c = f
         return self
 
+    @staticmethod
+    def consts_of_batch(batch, voxel_size):
+        """The frame's small constants on the host, ONE device-to-host copy: Frame(..., consts=this)."""
+        return fetch_host(batch["src_Ks"][0], batch["src_poses"][0], batch["Rh"][0], batch["Th"][0], batch["bounds"][0, 0], voxel_size,
+                          batch["out_sh"][0])
+
     @classmethod
-    def from_batch(cls, batch, featmaps, volumes, voxel_size, head_blob):
+    def from_batch(cls, batch, featmaps, volumes, voxel_size, head_blob, consts=None):
         """batch: the reference's batch dict (leading dim 1) with device tensors."""
         return cls(batch["src_imgs"][0], featmaps, volumes, batch["src_Ks"][0], batch["src_poses"][0], batch["Rh"][0],
-                   batch["Th"][0], batch["bounds"][0, 0], voxel_size, batch["out_sh"][0], head_blob)
+                   batch["Th"][0], batch["bounds"][0, 0], voxel_size, batch["out_sh"][0], head_blob, consts=consts)
 
 
 def patch_order(mask_at_box, H, W, patch_w=32, patch_h=8):

@@ -72,36 +72,40 @@ class Renderer(nn.Module):
         featmaps = batch["featmaps"] if "featmaps" in batch else P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0))
         return featmaps[0] if featmaps.dim() == 5 else featmaps
 
-    def prepare_sp_input(self, batch):
-        """BaseRender.py:187-209 (the fields the volume builder reads)."""
+    def prepare_sp_input(self, batch, out_sh=None):
+        """BaseRender.py:187-209 (the fields the volume builder reads).  out_sh: the host copy of max(batch['out_sh'], 0) when the
+        caller already has it (the `.tolist()` below is a device synchronisation)."""
         sh = batch["coord"].shape
-        idx = torch.cat([torch.full([sh[1]], i) for i in range(sh[0])]).to(batch["coord"])
+        idx = torch.arange(sh[0], device=batch["coord"].device, dtype=batch["coord"].dtype).repeat_interleave(sh[1])
         coord = torch.cat([idx[:, None], batch["coord"].view(-1, sh[-1])], dim=1)
-        out_sh, _ = torch.max(batch["out_sh"], dim=0)
+        if out_sh is None:
+            out_sh = torch.max(batch["out_sh"], dim=0)[0].tolist()
         sp = {"feature": batch["feature"].view(-1, batch["feature"].shape[-1]), "coord": coord,
-              "out_sh": out_sh.tolist(), "batch_size": sh[0], "Rh": batch["Rh"], "R": batch.get("R", batch["Rh"]),
+              "out_sh": [int(v) for v in out_sh], "batch_size": sh[0], "Rh": batch["Rh"], "R": batch.get("R", batch["Rh"]),
               "src_imgs": batch["src_imgs"]}
         if "volumes" in batch:
             sp["volumes"] = batch["volumes"]
         return sp
 
-    def build_frame(self, batch, featmaps=None):
-        """Per-frame work after the encoder: volume pyramid, channels-last re-layout, weight image."""
+    def build_frame(self, batch, featmaps=None, consts=None):
+        """Per-frame work after the encoder: volume pyramid, channels-last re-layout, weight image.  consts: Frame.consts_of_batch()
+        fetched earlier; with it nothing below synchronises with the device (a batch of one frame: out_sh[0] is the maximum)."""
         dev = batch["src_imgs"].device
         if featmaps is None:
             featmaps = self.encode(batch)
         blob = self.nerfhead.head_blob(dev)
         if "volumes" in batch:
-            return F_.Frame.from_batch(batch, featmaps, batch["volumes"], self.voxel_size, blob)
+            return F_.Frame.from_batch(batch, featmaps, batch["volumes"], self.voxel_size, blob, consts=consts)
         # No pre-built pyramid: gather the SMPL vertices' per-view features with the image half of the frame
         # (BaseRender.py:128-131,344-347), run the per-frame volume builder (trainhead.py:48-56), then attach it.
         placeholder = [torch.zeros((1, L.CH, 1, 1, 1), device=dev) for _ in range(L.LEVELS)]
-        frame = F_.Frame.from_batch(batch, featmaps, placeholder, self.voxel_size, blob)
+        frame = F_.Frame.from_batch(batch, featmaps, placeholder, self.voxel_size, blob, consts=consts)
         xyz = batch["feature"][..., :3].float()
         smpl_xyz = torch.bmm(xyz, batch["Rh"].float().transpose(1, 2)) + batch["Th"].float()
         feat, _ = F_.project_gather(frame, smpl_xyz[0], neg_ray=False)
         smpl_feat = feat[:, :, 3:].unsqueeze(0)                     # [1,6890,V,32]
-        volumes = self.nerfhead.sigmahead.build_volumes(self.prepare_sp_input(batch), smpl_feat)
+        out_sh = consts[6].ravel() if (consts is not None and batch["out_sh"].shape[0] == 1) else None
+        volumes = self.nerfhead.sigmahead.build_volumes(self.prepare_sp_input(batch, out_sh), smpl_feat)
         frame._set_volumes(frame.c, volumes, frame._keep)
         return frame
 
@@ -187,10 +191,12 @@ class Renderer(nn.Module):
         dev = batch["ray_o"].device
         torch.cuda.synchronize(dev)
         te = time.time()
-        featmaps = self.encode(batch)
-        torch.cuda.synchronize(dev)
-        t0 = time.time()
-        frame = self.build_frame(batch, featmaps)
+        # Everything that needs the host to wait for the device happens HERE, while the queue is empty: the frame's small
+        # constants in one copy, and the patch order (its boolean index is a synchronisation).  From the encoder's first launch
+        # to the end of the per-ray kernel the host only enqueues, so it runs ahead of the device and the ~180 launches of a
+        # frame go back to back (with a synchronisation after the encoder and five more in the frame build the device idled
+        # 1.4 ms of an 18.4 ms call).
+        consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
         rays = torch.cat([batch["ray_o"], batch["ray_d"], batch["near"].unsqueeze(-1), batch["far"].unsqueeze(-1)], dim=-1)[0]
         neg = self._neg_ray(batch)
         n = rays.shape[0]
@@ -206,6 +212,12 @@ class Renderer(nn.Module):
                 order = F_.patch_order_device(m.bool(), Hs, Ws, patch_w=32, patch_h=8)
                 if order.numel() != n:
                     order = None
+        # the encoder's time comes from two events on the stream instead of two host synchronisations around it
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        featmaps = self.encode(batch)
+        ev1.record()
+        frame = self.build_frame(batch, featmaps, consts)
 
         def fn(r):
             return F_.render_fused(frame, r, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
@@ -218,8 +230,12 @@ class Renderer(nn.Module):
         o = P_.render_sharded(fn, rays, keys=keys)
         torch.cuda.synchronize(dev)
         t2 = time.time()
+        # etime = the encoder alone, rtime = everything else of the call (demo_render.py:441-446,494-497 keeps these two clocks;
+        # BaseTrainer.py:276 sums rtime): the encoder's share is its device time between the two events
+        etime = ev0.elapsed_time(ev1) * 1e-3
+        rtime = max(0.0, (t2 - te) - etime)
         if keys is P_.PIXEL_KEYS:
-            return {"rgb_map": o["rgb_map"].view(1, n, 3), "depth_map": o["depth_map"].view(1, n, 1), "etime": t0 - te, "rtime": t2 - t0}
+            return {"rgb_map": o["rgb_map"].view(1, n, 3), "depth_map": o["depth_map"].view(1, n, 1), "etime": etime, "rtime": rtime}
         return {
             "rgb_map": o["rgb_map"].view(1, n, 3), "disp_map": o["disp_map"].view(1, n, 1),
             "acc_map": o["acc_map"].view(1, n, 1), "depth_map": o["depth_map"].view(1, n, 1),
@@ -227,7 +243,7 @@ class Renderer(nn.Module):
             "rgb_in_map": o["rgb_in_map"].view(1, n, 9),
             # BaseRender.render returns neither; the evaluation loop reads ret["rtime"] (BaseTrainer.py:276), which only the
             # demo renderer provides: encoder time and everything after it, each on its own clock (demo_render.py:441-446,494-497)
-            "etime": t0 - te, "rtime": t2 - t0,
+            "etime": etime, "rtime": rtime,
         }
 
 
