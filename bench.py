@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--split-f16", action="store_true",
                     help="dense layers on f16 MFMA with fp32 operands split into hi+lo (GPNERF_FLAG_SPLIT_F16)")
+    ap.add_argument("--no-guard", action="store_true", help="with --split-f16: without the range guard (GPNERF_FLAG_SPLIT_GUARD)")
     ap.add_argument("--occ-cull", action="store_true",
                     help="progressive sample culling (demo_render.py semantics) on a sparse synthetic pyramid")
     ap.add_argument("--occupancy", type=float, default=None, help="fraction of coarse volume blocks that are occupied")
@@ -136,7 +137,8 @@ def main():
     S = wl.S
     want = API_OUTPUTS if args.outputs == "api" else ()
     strong = world > 1 and args.scaling == "strong"
-    kw = dict(early_term=args.early_term, term_eps=args.term_eps, occ_cull=args.occ_cull, split_f16=args.split_f16)
+    kw = dict(early_term=args.early_term, term_eps=args.term_eps, occ_cull=args.occ_cull, split_f16=args.split_f16,
+              guard=False if args.no_guard else None)
 
     class Flow:
         """The timed step for one workload: single-GPU frame, strong-scaling share + gather, or weak-scaling band + gather."""
@@ -246,7 +248,7 @@ def main():
                        "ray_order": args.ray_order, "outputs": "rgb+depth (the all-gather payload)" if strong else
                        ("rgb,depth,acc,disp,weights,z_vals,rgb_in (Renderer.render's dict)" if args.outputs == "api" else "rgb,depth,acc,disp"),
                        "early_term": bool(args.early_term), "term_eps": args.term_eps if args.early_term else None, "sigma_bias": sigma_bias,
-                       "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "vol_occupancy": args.occupancy,
+                       "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "split_guard": bool(args.split_f16 and not args.no_guard), "vol_occupancy": args.occupancy,
                        "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -286,7 +288,9 @@ def beside_headline(args, fm, wl, kw, flow):
     res = {}
     head_ms = None
     for name, want, order, extra in (("api_outputs_patch_order", API_OUTPUTS, wl.patch, {}), ("light_outputs_patch_order", (), wl.patch, {}),
-                                     ("api_outputs_raster_order", API_OUTPUTS, None, {}), ("split_f16_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True})):
+                                     ("api_outputs_raster_order", API_OUTPUTS, None, {}),
+                                     ("split_f16_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True}),
+                                     ("split_f16_unguarded_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True, "guard": False})):
         k2 = dict(kw)
         k2.update(extra)
         ms, o = time_launches(lambda: fm.render_fused(wl.frame, wl.rays, S, want=want, ray_order=order, **k2), st, wu)
@@ -296,7 +300,9 @@ def beside_headline(args, fm, wl, kw, flow):
         if extra:
             res[name]["max_abs_vs_f32_form"] = {"rgb": float((o["rgb_map"] - head_out["rgb_map"]).abs().max()),
                                                 "depth": float((o["depth_map"] - head_out["depth_map"]).abs().max())}
-            res[name]["note"] = "dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation"
+            res[name]["note"] = ("dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation; " +
+                                 ("no range check (operands must stay below 65504)" if extra.get("guard") is False else
+                                  "range guard on: tiles with an operand at the f16 range are rendered again in the fp32 form"))
     try:
         res["renderer_api"] = renderer_api_wall(args, wl)
     except Exception as e:                       # the API timing must never take the headline down with it

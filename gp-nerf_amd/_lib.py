@@ -64,6 +64,7 @@ FLAG_EARLY_TERM = 2
 FLAG_OCC_CULL = 4
 FLAG_SPLIT_F16 = 8
 FLAG_FLIP_SAMPLES = 16
+FLAG_SPLIT_GUARD = 32
 
 # every symbol include/gpnerf_hip.h declares: (restype, argtypes)
 SYMBOLS = {
@@ -74,6 +75,7 @@ SYMBOLS = {
     "gpnerf_render_fused": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float,
                                       C.c_void_p, C.POINTER(GpnerfOutputs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpnerf_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "gpnerf_render_guard_bytes": (C.c_size_t, [C.c_int64]),
     "gpnerf_sample_points": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "gpnerf_sample_volume": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

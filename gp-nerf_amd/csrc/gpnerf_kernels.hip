@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/gpnerf_hip.h"
 #include "head_layout.h"
@@ -327,8 +328,38 @@ DEV unsigned lo_pair(unsigned w, float x0, float x1) {
     return r;
 }
 
+// Range guard of the split form (GPNERF_FLAG_SPLIT_GUARD): every value that becomes an MFMA operand passes through guard_n().
+// It costs one v_max3_f32 per two values into a short-lived maximum, one compare and one LDS store per group; nothing lives
+// across the sample loop: a lane that sees a value at or beyond the f16 range (or a NaN) writes to its wave's LDS slot (indexed
+// by the hardware wave slot, HW_ID[5:0]), the others to a dummy word; render_tile() reads the slot back at the end of the tile.  A flagged tile is rendered again by
+// the fp32 form (gpnerf_render_fused).
+struct NoGuard {};
+struct Guard {};
+constexpr float F16_RANGE = 65504.f;
+constexpr int GUARD_LDS_SLOTS = 64;            // followed by as many dummy words
+extern __shared__ __attribute__((aligned(16))) float g_dyn_lds[];       // the kernel's dynamic LDS (same base as its `lds`)
+DEV unsigned wave_slot() {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 6)" : "=s"(id));
+    return id;
+}
+DEV unsigned* guard_slot() { return reinterpret_cast<unsigned*>(g_dyn_lds) + gph::BLOB_WORDS + wave_slot(); }
+template <int N> DEV void guard_n(NoGuard&, const float*) {}
+template <int N> DEV void guard_n(Guard&, const float* v) {
+    static_assert(N % 2 == 0, "");
+    float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+    for (int i = 2; i < N; i += 2) m = fmaxf(fmaxf(m, fabsf(v[i])), fabsf(v[i + 1]));
+    // Branch-free on purpose: lanes in range write a dummy word.  A branch here would split the layer chain into basic blocks,
+    // and with one in the chain the kernel's results came out 2e-5 off and different from run to run (measured): the wait
+    // states the compiler puts between an MFMA and the instructions that read its result are not kept across the boundary.
+    unsigned* const sl = guard_slot();
+    (m < F16_RANGE ? sl + GUARD_LDS_SLOTS : sl)[0] = 1u;
+}
+
 // x = hi + lo with hi = f16(x) toward zero (never overflows to inf), lo = f16(x - hi): ~22 significant bits
-DEV Frag make_frag(const float* v) {
+template <class G>
+DEV Frag make_frag(const float* v, G& g) {
     u32x4 H, Lo;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -343,7 +374,8 @@ DEV Frag make_frag(const float* v) {
     return f;
 }
 
-DEV Frag make_frag2(float a, float b) {                    // the rgb k-step: two live slots, six zero pads
+template <class G>
+DEV Frag make_frag2(float a, float b, G& g) {              // the rgb k-step: two live slots, six zero pads
     const unsigned w = pk_rtz(a, b);
     u32x4 H = {w, 0u, 0u, 0u}, Lo = {lo_pair(w, a, b), 0u, 0u, 0u};
     Frag f;
@@ -392,29 +424,34 @@ DEV void mfma_steps(const unsigned* lw, int m, int s0, int lane, const Frag* b, 
 }
 
 // ELU of an accumulator tile -> its two B-operand k-steps (and optionally the fp32 values)
-DEV void tile_frags(f32x16& a, Frag* out2, float* keep = nullptr, float scale = 1.f) {
+template <class G>
+DEV void tile_frags(G& g, f32x16& a, Frag* out2, float* keep = nullptr) {
     float t[16];
     elus_n<16, SPIN>(a, t);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { if (keep) keep[r] = t[r]; t[r] *= scale; }
-    out2[0] = make_frag(t);
-    out2[1] = make_frag(t + 8);
+    for (int r = 0; r < 16; ++r) { if (keep) keep[r] = t[r]; }
+    guard_n<16>(g, t);
+    out2[0] = make_frag(t, g);
+    out2[1] = make_frag(t + 8, g);
 }
 
-DEV void geo_eval_s(const unsigned* __restrict__ lw, int lane, const float (&fv)[64], Frag (&sff)[4]) {
+template <class G>
+DEV void geo_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const float (&fv)[64], Frag (&sff)[4]) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
     Frag in[8];
+    guard_n<64>(g, fv);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) in[s] = make_frag(fv + 8 * s);
+    for (int s = 0; s < 8; ++s) in[s] = make_frag(fv + 8 * s, g);
     f32x16 g0 = bias_tile_s<gpl::GEO>(lw, 0, half), g1 = bias_tile_s<gpl::GEO>(lw, 1, half);
     mfma_steps<gpl::GEO, 8>(lw, 0, 0, lane, in, g0);
     mfma_steps<gpl::GEO, 8>(lw, 1, 0, lane, in, g1);
-    tile_frags(g0, sff);
-    tile_frags(g1, sff + 2);
+    tile_frags(g, g0, sff);
+    tile_frags(g, g1, sff + 2);
 }
 
-DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const float (&x)[NV][18], float nvalid,
+template <class G>
+DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const float (&x)[NV][18], float nvalid,
                     float& sigma, float (&rgb)[3], Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
@@ -430,8 +467,9 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
             mv[t] = m;
             mv[18 + t] = ((a * a + b * b) + c * c) * (1.f / 3.f);
         }
-        mvf[0] = make_frag(mv); mvf[1] = make_frag(mv + 8); mvf[2] = make_frag2(mv[16], mv[17]);
-        mvf[3] = make_frag(mv + 18); mvf[4] = make_frag(mv + 26); mvf[5] = make_frag2(mv[34], mv[35]);
+        guard_n<36>(g, mv);
+        mvf[0] = make_frag(mv, g); mvf[1] = make_frag(mv + 8, g); mvf[2] = make_frag2(mv[16], mv[17], g);
+        mvf[3] = make_frag(mv + 18, g); mvf[4] = make_frag(mv + 26, g); mvf[5] = make_frag2(mv[34], mv[35], g);
     }
     // density branch (trainhead.py:102-110,133-137)
     {
@@ -441,12 +479,12 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
         mfma_steps<gpl::D1, 4>(lw, 1, 0, lane, sff, a1);
         mfma_steps<gpl::D1, 6>(lw, 1, 4, lane, mvf, a1);
         Frag h1[4];
-        tile_frags(a0, h1);
-        tile_frags(a1, h1 + 2);
+        tile_frags(g, a0, h1);
+        tile_frags(g, a1, h1 + 2);
         f32x16 a2 = bias_tile_s<gpl::D2>(lw, 0, half);
         mfma_steps<gpl::D2, 4>(lw, 0, 0, lane, h1, a2);
         Frag h2[2];
-        tile_frags(a2, h2);
+        tile_frags(g, a2, h2);
         f32x16 a3 = bias_tile_s<gpl::D3>(lw, 0, half);
         mfma_steps<gpl::D3, 2>(lw, 0, 0, lane, h2, a3);
         const float* w4 = lf + gph::D4_W + half * 8;
@@ -467,37 +505,39 @@ DEV void mlp_eval_s(const unsigned* __restrict__ lw, int lane, const Frag (&sff)
     for (int v = 0; v < NV; ++v) {
         asm volatile("" : "+v"(lane));
         Frag xf[3];
-        xf[0] = make_frag(x[v]); xf[1] = make_frag(x[v] + 8); xf[2] = make_frag2(x[v][16], x[v][17]);
+        guard_n<18>(g, x[v]);
+        xf[0] = make_frag(x[v], g); xf[1] = make_frag(x[v] + 8, g); xf[2] = make_frag2(x[v][16], x[v][17], g);
         f32x16 a0 = s0, a1 = s1;
         mfma_steps<gpl::BV, 3>(lw, 0, 0, lane, xf, a0);
         mfma_steps<gpl::BV, 3>(lw, 1, 0, lane, xf, a1);
         Frag h1[4];
-        tile_frags(a0, h1);
-        tile_frags(a1, h1 + 2);
+        tile_frags(g, a0, h1);
+        tile_frags(g, a1, h1 + 2);
         f32x16 a2 = bias_tile_s<gpl::B2>(lw, 0, half);
         mfma_steps<gpl::B2, 4>(lw, 0, 0, lane, h1, a2);
         float xb[16];
         Frag xs[2];
-        tile_frags(a2, xs, xb);                               // x * 1.0 / num_views rides on vis_fc.0's packed weights
+        tile_frags(g, a2, xs, xb);                            // x * 1.0 / num_views rides on vis_fc.0's packed weights
         f32x16 t1 = bias_tile_s<gpl::V1>(lw, 0, half);
         mfma_steps<gpl::V1, 2>(lw, 0, 0, lane, xs, t1);
         Frag u1[2];
-        tile_frags(t1, u1);
+        tile_frags(g, t1, u1);
         f32x16 t2 = bias_tile_s<gpl::V2>(lw, 0, half);
         mfma_steps<gpl::V2, 2>(lw, 0, 0, lane, u1, t2);
         float y[16];
         elus_n<16, SPIN>(t2, y);
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[r] += xb[r];
-        yf[2 * v] = make_frag(y);
-        yf[2 * v + 1] = make_frag(y + 8);
+        guard_n<16>(g, y);
+        yf[2 * v] = make_frag(y, g);
+        yf[2 * v + 1] = make_frag(y + 8, g);
     }
     STAMP(st, 4);
     {
         f32x16 c1 = bias_tile_s<gpl::R1>(lw, 0, half);
         mfma_steps<gpl::R1, 6>(lw, 0, 0, lane, yf, c1);
         Frag h1[2];
-        tile_frags(c1, h1);
+        tile_frags(g, c1, h1);
         f32x16 c2 = bias_tile_s<gpl::R2>(lw, 0, half);
         mfma_steps<gpl::R2, 2>(lw, 0, 0, lane, h1, c2);
         float e[8];
@@ -700,7 +740,14 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     unsigned* ctl;            // FIFO heads [0..8), FIFO tails [8..16), tiles finished [16]; zero at launch
     unsigned* lists;          // [8][list_cap] FIFO entries: (tile + 1) | segment << 28, zero = not written yet
     long list_cap;
+    // range guard of the split form: guard[0] = number of flagged tiles, guard[64 + tile] = 1 when an MFMA operand of the tile
+    // reached the f16 range; the fix-up launch (FORM_F32_FIXUP) renders exactly the flagged tiles again in the fp32 form
+    unsigned* guard;
 };
+
+// the forms of the fused kernel
+constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3;
+constexpr int GUARD_HEADER_WORDS = 64;
 
 // bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
 // contiguous run of tiles so neighbouring ray tiles hit the same L2 (speed only, never correctness)
@@ -781,8 +828,11 @@ DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
 // One work unit = (32-ray tile, sample segment) rendered by one wavefront: with split > 1 the samples of a tile are divided
 // between `split` waves, whose partial composites are merged by combine_segments_kernel (finer load balance for small frames).
 // Returns true when the tile goes on in a later work item (chained segments only).
-template <bool SPLIT, bool CHAIN>
+template <int FORM, bool CHAIN>
 DEV bool render_tile(float* lds, const int lane, const long tile, const int seg) {
+    constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
+    // tag: the split form's helpers check their operands' range (FORM_SPLIT_GUARD) or do not
+    typename std::conditional<FORM == FORM_SPLIT_GUARD, Guard, NoGuard>::type gmax{};
     // Everything the sample loop reads from the arguments is re-read from the kernarg segment (scalar loads, scalar
     // cache) at the top of every iteration through `kp`, a pointer the optimiser cannot see through.  Held in SGPRs
     // across the loop instead, the ~130 argument dwords spill to VGPR lanes and come back as v_readlane_b32 -- VALU
@@ -881,7 +931,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
         STAMP(st, 0);
         float sf[32];
         Frag sff[4];
-        if constexpr (SPLIT) geo_eval_s(lw, lane, fv, sff);
+        if constexpr (SPLIT) geo_eval_s(gmax, lw, lane, fv, sff);
         else geo_eval(lds, lane, fv, sf);
         STAMP(st, 1);
 
@@ -903,7 +953,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
 
         STAMP(st, 2);
         float sigma, rgb[3];
-        if constexpr (SPLIT) mlp_eval_s(lw, lane, sff, x, nvalid, sigma, rgb, st);
+        if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
         if (cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
@@ -958,6 +1008,15 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
     st.flush(lane);
     kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
+    if constexpr (FORM == FORM_SPLIT_GUARD) {
+        // an operand at or beyond the f16 range (or a NaN): the hi/lo pair no longer carries the value, flag the tile
+        unsigned* const slot = guard_slot();
+        if (*slot) {                            // uniform: every lane reads the wave's slot
+            unsigned* const gd = kp->guard;
+            if (lane == 0 && atomicExch(gd + GUARD_HEADER_WORDS + tile, 1u) == 0u) atomicAdd(gd, 1u);
+            *slot = 0u;
+        }
+    }
     const __attribute__((address_space(4))) OutK& out = kp->out;
     float* const part = kp->part;
     // chained segments: the tile goes on in the next launch unless it has walked all S samples or every ray of it is opaque
@@ -1014,14 +1073,21 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
 // 8-wave workgroup resident per CU a static grid holds the CU until its slowest tile is done -- the queue hands the next
 // tile to whichever wave is free.  Static launches (one unit per wave, XCD-aware remap) remain for frames smaller than
 // one round and for the sample-split geometry.
-template <bool SPLIT, bool CHAIN>
+template <int FORM, bool CHAIN>
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const KArgs ka) {
+    constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if constexpr (FORM == FORM_F32_FIXUP) {
+        if (__hip_atomic_load(ka.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;     // nothing was flagged
+    }
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : ka.fr.head_blob);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         for (int i = threadIdx.x; i < (SPLIT ? gph::BLOB_WORDS : gpl::BLOB_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
+        if constexpr (FORM == FORM_SPLIT_GUARD) {
+            if (threadIdx.x < GUARD_LDS_SLOTS) reinterpret_cast<unsigned*>(lds)[gph::BLOB_WORDS + threadIdx.x] = 0u;
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1056,6 +1122,9 @@ render_fused_kernel(const KArgs ka) {
                 continue;
             }
             tile = queue_tile(kq->chunk, qx, t);
+            if constexpr (FORM == FORM_F32_FIXUP) {                 // only the tiles the split form flagged
+                if (wave_load(kq->guard + GUARD_HEADER_WORDS + tile, lane) == 0u) continue;
+            }
         } else if constexpr (CHAIN) {
             // tiles that go on (chained items): eight FIFOs, one per XCD; a wave appends to its own XCD's and takes from it
             // first (the tile's volume neighbourhood is in that L2), from the others' when it is empty.  ctl[16] counts the
@@ -1086,7 +1155,7 @@ render_fused_kernel(const KArgs ka) {
             tile = (long)(e & 0x0fffffffu) - 1;
             seg = (int)(e >> 28);
         }
-        const bool goes_on = render_tile<SPLIT, CHAIN>(lds, lane, tile, seg);
+        const bool goes_on = render_tile<FORM == FORM_F32_FIXUP ? FORM_F32 : FORM, CHAIN>(lds, lane, tile, seg);
         if constexpr (CHAIN) {
             kargs_ptr kr = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kr));
@@ -1633,6 +1702,10 @@ size_t chain_list_cap(int64_t n_rays, int S) {
     const size_t tiles = (size_t)((n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE);
     return tiles * (size_t)(items - 1);
 }
+// range guard of the split form: header (flag count, the fix-up launch's queue counters) + one word per tile, at the workspace's end
+size_t guard_bytes(int64_t n_rays) {
+    return align256((GUARD_HEADER_WORDS + (size_t)((n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE)) * sizeof(unsigned));
+}
 size_t chain_bytes(int64_t n_rays, int S) {
     if (S <= chain_len(S) || S > 4095 || n_rays > ((int64_t)1 << 32)) return 0;
     return QUEUE_BYTES + align256(8 * chain_list_cap(n_rays, S) * sizeof(unsigned)) + (size_t)n_rays * 16 * sizeof(float);
@@ -1686,14 +1759,16 @@ int device_ready(int* cus) {
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) {
             d.cus = prop.multiProcessorCount;
             const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS, lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
-            d.ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<false, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<false, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&render_fused_kernel<true, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split) == hipSuccess &&
+            auto lds_ok = [](const void* fn, size_t bytes) {
+                return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+            };
+            d.ok = lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, false>), lds_split) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, true>), lds_split) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT_GUARD, false>), lds_split + GUARD_LDS_SLOTS * 8) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT_GUARD, true>), lds_split + GUARD_LDS_SLOTS * 8) &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES, 1>),
@@ -1901,6 +1976,18 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
     const bool split16 = (flags & GPNERF_FLAG_SPLIT_F16) != 0;
     if (split16 && !f->head_blob_split) return GPNERF_E_ARG;
+    // GPNERF_FLAG_SPLIT_GUARD: the split form records the tiles in which an MFMA operand reached the f16 range, and a second
+    // launch renders exactly those again in the fp32 form (it returns at once when there are none).  The flags live in the
+    // last guard_bytes() of the workspace.
+    const bool guard = split16 && (flags & GPNERF_FLAG_SPLIT_GUARD) != 0;
+    unsigned* guard_words = nullptr;
+    if (guard) {
+        const size_t gb = guard_bytes(n_rays);
+        if (!workspace || workspace_bytes < QUEUE_BYTES + gb) return GPNERF_E_ARG;
+        workspace_bytes = (workspace_bytes - gb) & ~(size_t)255;
+        guard_words = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + workspace_bytes);
+        if (hipMemsetAsync(guard_words, 0, gb, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+    }
     const size_t lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
     int n_cus = 0;
     if (device_ready(&n_cus) != GPNERF_OK) return GPNERF_E_DEVICE;
@@ -1925,6 +2012,21 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     ka.fr = k; ka.rays = rays; ka.n_rays = (long)n_rays; ka.S = (int)n_samples; ka.flags = (unsigned)flags; ka.term_eps = term_eps;
     ka.out = ok; ka.split = g.split; ka.part = seg_part;
     ka.dynamic = dynamic ? 1 : 0; ka.queue = static_cast<unsigned*>(workspace);
+    ka.guard = guard_words;
+    const dim3 full_block(GPNERF_MAX_WAVES * 64);
+    // the fp32 form over the tiles the guarded split form flagged: persistent workgroups on a queue of their own
+    auto fixup = [&]() -> int {
+        if (!guard) return launch_status();
+        if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
+        KArgs kf = ka;
+        kf.flags = (unsigned)flags & ~(GPNERF_FLAG_SPLIT_F16 | GPNERF_FLAG_SPLIT_GUARD);
+        kf.split = 1; kf.part = nullptr; kf.dynamic = 1; kf.queue = guard_words + 8; kf.wave_cap = 0;
+        kf.chain = 0; kf.ctl = nullptr; kf.lists = nullptr;
+        const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
+        hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FIXUP, false>), dim3((unsigned)(wg < n_cus ? wg : n_cus)), full_block, lds_bytes,
+                           S_(stream), kf);
+        return launch_status();
+    };
     // Early termination: a work item is chain_len() samples of a tile rather than the whole ray.  A tile that is not opaque at
     // the end of an item parks 16 floats per ray and queues up again behind the others, so no item is longer than that and the
     // launch drains within one item's time -- with whole rays as items the last waves walk their longest tiles alone
@@ -1952,22 +2054,26 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         ka.part = reinterpret_cast<float*>(base + QUEUE_BYTES + list_bytes);
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
         const unsigned grid = (unsigned)(wg < n_cus ? wg : n_cus);
-        if (split16)
-            hipLaunchKernelGGL((render_fused_kernel<true, true>), dim3(grid), dim3(GPNERF_MAX_WAVES * 64), lds_split, S_(stream), ka);
+        if (guard)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3(grid), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
+        else if (split16)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3(grid), full_block, lds_split, S_(stream), ka);
         else
-            hipLaunchKernelGGL((render_fused_kernel<false, true>), dim3(grid), dim3(GPNERF_MAX_WAVES * 64), lds_bytes, S_(stream), ka);
-        return launch_status();
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
+        return fixup();
     }
-    if (split16)
-        hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
+    if (guard)
+        hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
+    else if (split16)
+        hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
     else
-        hipLaunchKernelGGL((render_fused_kernel<false, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
+        hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),
                            (const float*)seg_part, (long)n_rays, (int)n_samples, g.split, ok);
     }
-    return launch_status();
+    return fixup();
 }
 
 size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples) {
@@ -1976,8 +2082,10 @@ size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples) {
     // sample segments per ray, 16 floats each; or what the chained segments of an early-terminating launch need
     const size_t plain = QUEUE_BYTES + (n_rays <= 131072 ? (size_t)n_rays * GPNERF_MAX_SPLIT * 16 * sizeof(float) : 0);
     const size_t chain = chain_bytes(n_rays, n_samples);
-    return plain > chain ? plain : chain;
+    return align256(plain > chain ? plain : chain) + guard_bytes(n_rays);      // + the split form's range-guard flags
 }
+
+size_t gpnerf_render_guard_bytes(int64_t n_rays) { return n_rays > 0 ? guard_bytes(n_rays) : 0; }
 
 int gpnerf_sample_points(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, float* pts,
                          float* z_vals, float* grid, void* stream) {

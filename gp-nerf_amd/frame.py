@@ -239,7 +239,7 @@ def patch_order_device(mask, H, W, patch_w=4, patch_h=8):
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
-                 split_f16=False, flip=None, subset=False):
+                 split_f16=False, flip=None, subset=False, guard=None):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); defaults to neg_ray for the dense renderer
     (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
@@ -248,6 +248,9 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     load_balance: lend the kernel a workspace: large frames run persistent workgroups on a tile queue, small frames split a
     tile's samples over several wavefronts.
     split_f16: dense layers on f16 MFMA with fp32 operands split into hi + lo (GPNERF_FLAG_SPLIT_F16).
+    guard: with split_f16, check every MFMA operand against the f16 range and render the tiles that reach it again in the fp32
+    form (GPNERF_FLAG_SPLIT_GUARD; default on whenever the kernel has a workspace).  want=("guard_tiles",) returns how many
+    32-ray tiles that were (int32 tensor [1]).
     subset: ray_order lists the rows of `rays` to render (any number of distinct rows); outputs keep rays' row count, rows
     that are not listed come back zero."""
     lib = L.lib()
@@ -292,6 +295,12 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         if not frame.c.head_blob_split:
             raise L.GpnerfError("split_f16 needs the f16 hi/lo head image (build the frame from pack_head()'s tensor)")
         flags |= L.FLAG_SPLIT_F16
+        if guard is None:
+            guard = bool(load_balance)
+        if guard:
+            if not load_balance:
+                raise L.GpnerfError("the split form's range guard keeps its flags in the workspace (load_balance=True)")
+            flags |= L.FLAG_SPLIT_GUARD
     if occ_cull:
         if not frame.c.occ:
             frame.build_occupancy()
@@ -308,6 +317,13 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), n_launch, S, flags, float(term_eps),
                                     ray_order.data_ptr() if ray_order is not None else None, C.byref(o),
                                     ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(dev)), "gpnerf_render_fused")
+    if "guard_tiles" in want:
+        # the flag count is the first word of the guard block, which is the tail of the workspace (include/gpnerf_hip.h)
+        if flags & L.FLAG_SPLIT_GUARD:
+            off = ((ws_bytes - int(lib.gpnerf_render_guard_bytes(n_launch))) // 256) * 256
+            res["guard_tiles"] = ws[off:off + 4].view(torch.int32).clone()
+        else:
+            res["guard_tiles"] = torch.zeros((1,), device=dev, dtype=torch.int32)
     return res
 
 

@@ -46,7 +46,13 @@ extern "C" {
 #define GPNERF_FLAG_EARLY_TERM 2u  /* stop a 32-ray wave tile once every ray has T < term_eps (not in the reference) */
 #define GPNERF_FLAG_SPLIT_F16 8u   /* dense layers on f16 MFMA with every fp32 operand split into f16 hi + lo (three MFMAs per
                                       k-step, f32 accumulation): ~fp32 accuracy (1e-6 on rgb), 3/16 of the fp32 MFMA cost.
-                                      Needs frame->head_blob_split; operands must stay below the f16 range (65504) */
+                                      Needs frame->head_blob_split; operands must stay below the f16 range (65504):
+                                      GPNERF_FLAG_SPLIT_GUARD checks it */
+#define GPNERF_FLAG_SPLIT_GUARD 32u /* with GPNERF_FLAG_SPLIT_F16: track the largest magnitude that becomes an MFMA operand in every
+                                      32-ray tile (raw features, cross-view mean / variance, every activation); tiles in which it
+                                      reaches the f16 range are rendered again by the fp32 form in a second launch of the same
+                                      call, so the result never depends on the range of the data.  Needs the workspace
+                                      (gpnerf_render_workspace_bytes) and frame->head_blob */
 #define GPNERF_FLAG_OCC_CULL 4u    /* the progressive renderer's per-sample rules (libs/renders/demo_render.py): grid coordinates
                                       with its literal voxel size 0.005 instead of frame->voxel (:87-95), a sample is evaluated
                                       only where the occupancy volume (frame->occ) interpolates to > 0 (:270-283), culled
@@ -146,6 +152,9 @@ int gpnerf_render_fused(const GpnerfFrame* frame, const float* rays, int64_t n_r
                         void* workspace, size_t workspace_bytes, void* stream);
 /* Bytes of workspace gpnerf_render_fused can use for this launch (0: it would not split). */
 size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples);
+/* GPNERF_FLAG_SPLIT_GUARD keeps its state in the last gpnerf_render_guard_bytes(n_rays) bytes of the workspace (start rounded down
+ * to 256): word 0 = number of flagged tiles once the stream has passed the call, words 64.. = one flag per 32-ray tile. */
+size_t gpnerf_render_guard_bytes(int64_t n_rays);
 
 /* Stage entry points (the same device code as the fused kernel, one reference function per launch).
  *

@@ -80,3 +80,17 @@ def test_encoder_on_gpu_feeds_frame_without_relayout(name):
     ref = fm.Frame(dev(sc["src_imgs"][0]), out.contiguous(), [dev(v) for v in sc["volumes"]], dev(sc["src_Ks"][0]),
                    dev(sc["src_poses"][0]), sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0], blob)
     assert torch.equal(fr.featmaps, ref.featmaps)
+
+
+@pytest.mark.gpu
+def test_encoder_is_bit_deterministic_at_full_size():
+    """Three forwards of a 3x512x512 frame give the same bits (every reduction of the kernels has a fixed order, and no result
+    may depend on how the wavefronts of a CU interleave): a timing-dependent difference would mean an MFMA result is being read
+    before it is complete."""
+    net, _ = _net(3)
+    net = net.to("cuda:0")
+    imgs = torch.from_numpy(syn.make_encoder_images(512, 512, 3)).to("cuda:0")
+    with torch.no_grad():
+        outs = [net(imgs).clone() for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert bool(torch.isfinite(outs[0]).all())

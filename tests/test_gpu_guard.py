@@ -1,0 +1,127 @@
+"""GPU: the range guard of the split-precision form (GPNERF_FLAG_SPLIT_GUARD) and the edge cases of the early-termination
+work queue (chained 32-sample items that re-queue inside one launch).
+
+The split form writes every fp32 MFMA operand as an f16 hi + lo pair, which only carries the value below the f16 range
+(65504).  The guard flags the 32-ray tiles in which an operand reaches that range and renders them again in the fp32 form:
+the result must not depend on the range of the data."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def fm():
+    return importlib.import_module("gp-nerf_amd.frame")
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def build_frame(fm, sc):
+    return fm.Frame(to_dev(sc["src_imgs"][0]), to_dev(sc["featmaps"]), [to_dev(v) for v in sc["volumes"]], to_dev(sc["src_Ks"][0]),
+                    to_dev(sc["src_poses"][0]), sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0],
+                    fm.pack_head(sc["head"], torch.device("cuda:0")))
+
+
+def rays_of(sc):
+    return to_dev(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32))
+
+
+WANT = ("weights", "z_vals", "rgb_in", "ray_mask", "guard_tiles")
+KEYS = ("rgb_map", "depth_map", "acc_map", "weights", "rgb_in_map")
+
+
+def overflow_scene(syn, size, seed, what):
+    """A scene whose MFMA operands leave the f16 range in part of the image: huge source-view features (raw inputs and the
+    cross-view variance overflow) or a huge volume level (the sigma-feature layer's inputs and its activations overflow)."""
+    sc = syn.make_scene(H=size, W=size, seed=seed, fill="full", pose="identity")
+    sc = dict(sc)
+    if what == "featmaps":
+        f = sc["featmaps"].copy()
+        f[:, :, : f.shape[2] // 3] *= 3.0e5
+        sc["featmaps"] = f
+    else:
+        v = [a.copy() for a in sc["volumes"]]
+        v[1][..., : v[1].shape[-2] // 3, : v[1].shape[-1] // 3] *= 2.0e5
+        sc["volumes"] = v
+    return sc
+
+
+@pytest.mark.parametrize("what", ["featmaps", "volume"])
+@pytest.mark.parametrize("size,S,early", [(64, 32, False), (200, 48, False), (512, 64, False), (512, 128, True)])
+def test_guarded_split_form_does_not_depend_on_the_range_of_the_data(what, size, S, early, fm, syn):
+    sc = overflow_scene(syn, size, 5, what)
+    fr, rays = build_frame(fm, sc), rays_of(sc)
+    kw = dict(early_term=early, term_eps=1e-5)
+    ref = fm.render_fused(fr, rays, S, want=WANT, **kw)                                    # the fp32 form
+    bad = fm.render_fused(fr, rays, S, want=WANT, split_f16=True, guard=False, **kw)
+    got = fm.render_fused(fr, rays, S, want=WANT, split_f16=True, **kw)                    # guard on by default
+    n_tiles = (rays.shape[0] + 31) // 32
+    flagged = int(got["guard_tiles"])
+    assert 0 < flagged <= n_tiles and (flagged < n_tiles or size < 200), (flagged, n_tiles)
+    assert int(ref["guard_tiles"]) == 0 and int(bad["guard_tiles"]) == 0
+    # without the guard the split form is simply wrong on this data ...
+    assert float((bad["rgb_map"] - ref["rgb_map"]).abs().max()) > 1e-2
+    # ... with it, every map is the fp32 form's to the usual bound
+    for k in KEYS:
+        assert float((got[k] - ref[k]).abs().max()) < TOL, k
+    assert torch.equal(got["z_vals"], ref["z_vals"]) and torch.equal(got["ray_mask"], ref["ray_mask"])
+    # and the flagged tiles ARE the fp32 form's, bit for bit: the fix-up launch runs the same code on the same 32 rays, one
+    # wavefront per whole ray (load_balance=False keeps the reference launch from splitting a small frame's samples over
+    # several wavefronts, which re-associates the composite); termination is tile-granular in both
+    whole = fm.render_fused(fr, rays, S, load_balance=False, **kw)
+    diff = (got["rgb_map"] != whole["rgb_map"]).any(1)
+    pad = torch.zeros(n_tiles * 32, dtype=torch.bool, device=diff.device)
+    pad[: diff.numel()] = diff
+    assert int((~pad.view(n_tiles, 32).any(1)).sum()) >= flagged
+
+
+def test_guard_is_silent_and_free_of_side_effects_on_ordinary_data(fm, syn):
+    sc = syn.make_scene(H=96, W=96, seed=2, fill="full", pose="random")
+    fr, rays = build_frame(fm, sc), rays_of(sc)
+    a = fm.render_fused(fr, rays, 40, want=WANT, split_f16=True, guard=False)
+    b = fm.render_fused(fr, rays, 40, want=WANT, split_f16=True, guard=True)
+    assert int(b["guard_tiles"]) == 0
+    for k in KEYS:
+        assert float((a[k] - b[k]).abs().max()) < 1e-6, k
+
+
+def test_guard_needs_the_workspace(fm, syn):
+    sc = syn.make_scene(H=16, W=16, seed=1, fill="full", pose="identity")
+    fr, rays = build_frame(fm, sc), rays_of(sc)
+    L = importlib.import_module("gp-nerf_amd._lib")
+    with pytest.raises(L.GpnerfError):
+        fm.render_fused(fr, rays, 8, split_f16=True, guard=True, load_balance=False)
+    fm.render_fused(fr, rays, 8, split_f16=True, load_balance=False)          # default: no workspace, no guard
+
+
+@pytest.mark.parametrize("split_f16", [False, True])
+@pytest.mark.parametrize("n_rays,S", [(65536 + 17, 80), (70001, 33), (131072 + 31, 64), (65536, 4000)])
+def test_early_termination_queue_on_ragged_sizes(n_rays, S, split_f16, fm, syn):
+    """Frames of at least one full round of wavefronts walk their samples in chained 32-sample work items that re-queue inside
+    the launch; ragged tile counts, sample counts that are not a multiple of the item length, and more than 16 items' worth of
+    samples must give the whole-ray launch's pixels bit for bit (same kernel arithmetic, same tile-granular stop rule)."""
+    if S > 1000:
+        n_rays, size = 65536, 64
+    else:
+        size = 96
+    sc = syn.make_scene(H=size, W=size, seed=4, fill="full", pose="identity", sigma_bias=1.0)
+    fr = build_frame(fm, sc)
+    base = rays_of(sc)
+    rays = base[torch.arange(n_rays, device=base.device) % base.shape[0]].contiguous()
+    want = ("weights", "z_vals", "rgb_in", "ray_mask", "samples_done")
+    kw = dict(early_term=True, term_eps=1e-5, want=want, split_f16=split_f16, guard=False)
+    chained = fm.render_fused(fr, rays, S, **kw)
+    # the same rays in launches too small for the chained form (< one round of wavefronts), cut on tile boundaries
+    parts = [fm.render_fused(fr, rays[a:a + 32768], S, **kw) for a in range(0, n_rays, 32768)]
+    for k in ("rgb_map", "depth_map", "acc_map", "disp_map", "weights", "z_vals", "rgb_in_map", "ray_mask", "samples_done"):
+        whole = torch.cat([p[k] for p in parts])
+        assert torch.equal(chained[k], whole), k
+    done = chained["samples_done"]
+    assert int(done.min()) >= 1 and int(done.max()) <= S and float(done.float().mean()) < 0.9 * S
