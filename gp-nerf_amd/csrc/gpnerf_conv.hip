@@ -17,6 +17,7 @@
 //   a wave owns 2 x 32 output pixels x COT x 32 output channels (weights read from LDS are used for both pixel tiles).
 // Reflection padding is index arithmetic (no padded copy of the input, no pad launches).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/gpnerf_hip.h"
@@ -582,7 +583,12 @@ int launch_conv(const ConvArgs& a, int N, void* stream) {
 
 int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     const int tiles = ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
-    const int cot = (a.CT % 2 == 0) ? 2 : 1;
+    // two output tiles per workgroup reuse the staged patch twice; layers whose grid would not give every CU a workgroup that
+    // way (the 256-channel layers at 1/8 resolution: 48 workgroups) take one tile each instead
+    static int f_cot = -1;
+    if (f_cot < 0) { const char* e = getenv("GPNERF_CONV_COT"); f_cot = e ? atoi(e) : 0; }
+    int cot = (a.CT % 2 == 0) ? 2 : 1;
+    if (f_cot == 1 || (f_cot == 0 && cot == 2 && (long)tiles * N * (a.CT / 2) < 192)) cot = 1;
     const size_t lds = 2 * (size_t)PATCH_BYTES + 2 * (size_t)9 * cot * STEP_BYTES;
     const void* fn = cot == 2 ? reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<2>) : reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<1>);
     // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch

@@ -71,11 +71,10 @@ DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }       
 DEV float elus(float xs) { return __builtin_amdgcn_fmed3f(xs, fmaf(__builtin_amdgcn_exp2f(xs), LOG2E, -LOG2E), 0.f); }
 // N accumulator registers at once, stage by stage: the v_exp_f32 results are not consumed back to back (a transcendental
 // feeding the next instruction costs a wait state) and the FMAs pair up as v_pk_fma_f32
-#ifdef GPNERF_X_NOPIN_S
+// The split form leaves the ordering pins off: its f16 MFMAs hold the vector issue port for 8 of their 32 cycles, so what
+// the scheduler threads between them is (mostly) hidden -- measured 7.32 -> 7.17 ms on the headline frame; the fp32 form
+// (PIN = true) loses time the same way, its MFMAs run on the vector ALUs.
 constexpr bool SPIN = false;
-#else
-constexpr bool SPIN = true;
-#endif
 template <int N, bool PIN = true>
 DEV void elus_n(f32x16& a, float* out) {
     if constexpr (PIN) asm volatile("" : "+v"(a));          // not before the MFMA groups issued so far (see the note at the end)
