@@ -1687,7 +1687,7 @@ constexpr int GPNERF_MAX_SPLIT = 8;     // waves that may share one tile's sampl
 constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue counters (one per XCD), padded
 // Early termination renders a tile in chained work items of chain_len() samples (see gpnerf_render_fused); the workspace then
 // holds the control block (QUEUE_BYTES), eight FIFOs of list_cap entries, and 16 floats of parked state per ray.
-constexpr int CHAIN_SEG = 32;
+constexpr int CHAIN_SEG = 16;
 constexpr int CHAIN_MAX_ITEMS = 16;     // the item index travels in 4 bits of a FIFO entry
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 int chain_len(int S) {

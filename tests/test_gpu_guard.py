@@ -1,5 +1,5 @@
 """GPU: the range guard of the split-precision form (GPNERF_FLAG_SPLIT_GUARD) and the edge cases of the early-termination
-work queue (chained 32-sample items that re-queue inside one launch).
+work queue (chained 16-sample items that re-queue inside one launch).
 
 The split form writes every fp32 MFMA operand as an f16 hi + lo pair, which only carries the value below the f16 range
 (65504).  The guard flags the 32-ray tiles in which an operand reaches that range and renders them again in the fp32 form:
@@ -104,7 +104,7 @@ def test_guard_needs_the_workspace(fm, syn):
 @pytest.mark.parametrize("split_f16", [False, True])
 @pytest.mark.parametrize("n_rays,S", [(65536 + 17, 80), (70001, 33), (131072 + 31, 64), (65536, 4000)])
 def test_early_termination_queue_on_ragged_sizes(n_rays, S, split_f16, fm, syn):
-    """Frames of at least one full round of wavefronts walk their samples in chained 32-sample work items that re-queue inside
+    """Frames of at least one full round of wavefronts walk their samples in chained 16-sample work items that re-queue inside
     the launch; ragged tile counts, sample counts that are not a multiple of the item length, and more than 16 items' worth of
     samples must give the whole-ray launch's pixels bit for bit (same kernel arithmetic, same tile-granular stop rule)."""
     if S > 1000:
