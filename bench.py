@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 FLOP_PER_SAMPLE = 110848           # 2*MAC of the reference's dense layers, V=3, C=32
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_F16_MFMA_TFLOPS = 2500.0      # dense f16 MFMA peak (the split-precision form's matrix instructions)
 API_OUTPUTS = ("weights", "z_vals", "rgb_in")      # + rgb, depth, acc, disp (always written) = Renderer.render's dict
 
 
@@ -238,6 +239,7 @@ def main():
         else:
             parallelism = f"weak: every one of {world} GPUs renders its own frame-sized band, all-gather of rgb+depth"
         traffic, traffic_src = measured_traffic(args, world)
+        peak = PEAK_F16_MFMA_TFLOPS if args.split_f16 else PEAK_F32_MFMA_TFLOPS
         line = {
             "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step,
@@ -250,11 +252,15 @@ def main():
                        "early_term": bool(args.early_term), "term_eps": args.term_eps if args.early_term else None, "sigma_bias": sigma_bias,
                        "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "split_guard": bool(args.split_f16 and not args.no_guard), "vol_occupancy": args.occupancy,
                        "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_per_launch},
         }
         line.update(extras)
+        if args.split_f16:
+            line["dtype"] = "f32 operands as f16 hi+lo pairs on v_mfma_f32_32x32x16_f16, f32 accumulation"
+            line["roofline"]["split_note"] = ("peak = dense f16 MFMA; the form issues 3 MFMAs per 16-deep k-step (3x the algorithmic FLOPs) and is "
+                                              "bound by vector-ALU issue, not by the matrix pipe (30 % busy: profiles/r02/b_pmc_summary_split_guarded.json)")
         if evaluated is not None:
             line["roofline"]["samples_evaluated_frac"] = evaluated
             line["roofline"]["note"] = ("flop_per_launch counts the samples the launch evaluated (32-ray tiles stop once every ray has T < term_eps / "
