@@ -125,3 +125,28 @@ def test_early_termination_queue_on_ragged_sizes(n_rays, S, split_f16, fm, syn):
         assert torch.equal(chained[k], whole), k
     done = chained["samples_done"]
     assert int(done.min()) >= 1 and int(done.max()) <= S and float(done.float().mean()) < 0.9 * S
+
+
+@pytest.mark.parametrize("sigma_bias", [-20.0, 12.0])
+def test_early_termination_queue_when_nothing_or_everything_terminates(sigma_bias, fm, syn):
+    """The two ends of the work queue: a density that never makes a ray opaque (every tile walks all its items: the FIFOs carry
+    tiles x (items - 1) entries, and the result is the unterminated launch's, bit for bit), and one that makes every ray opaque
+    within the first item (nothing is ever queued twice)."""
+    S = 96
+    sc = syn.make_scene(H=96, W=96, seed=6, fill="full", pose="identity", sigma_bias=sigma_bias)
+    fr = build_frame(fm, sc)
+    base = rays_of(sc)
+    n_rays = 65536 + 96
+    rays = base[torch.arange(n_rays, device=base.device) % base.shape[0]].contiguous()
+    want = ("weights", "z_vals", "rgb_in", "samples_done")
+    chained = fm.render_fused(fr, rays, S, early_term=True, term_eps=1e-5, want=want)
+    plain = fm.render_fused(fr, rays, S, early_term=False, want=want)
+    done = chained["samples_done"]
+    if sigma_bias < 0.0:
+        assert int(done.min()) == S
+        for k in ("rgb_map", "depth_map", "acc_map", "disp_map", "weights", "z_vals", "rgb_in_map"):
+            assert torch.equal(chained[k].view(torch.int32), plain[k].view(torch.int32)), k      # bit patterns: disp is NaN where acc = 0
+    else:
+        assert int(done.max()) <= 16
+        for k in ("rgb_map", "depth_map", "acc_map"):
+            assert float((chained[k] - plain[k]).abs().max()) < 1e-4, k
