@@ -103,26 +103,34 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict_
 #pragma unroll
         for (int g = 0; g < 4; ++g) b[g] = (g < ng && j >= 0) ? *reinterpret_cast<const f32x4v*>(x + 4 * g) : zero4;
     };
-    f32x4v cur[4], nxt[4];
-    load_tap(0, cur);
+    // The neighbour rows and the packed weights come from L2 (a round trip each) and a tap's 4 * ng MFMAs take ~0.4 us: with the
+    // weights loaded right before their MFMAs and only the next tap's rows in flight the wave spent its time waiting (46 us per
+    // launch); DEPTH taps ahead, weights included, it does not.  The MFMA chain
+    // is branch-free on purpose (absent neighbours contribute zeros): a branch between two MFMAs of one accumulator chain is
+    // what broke the split-precision form's first range guard.
+    constexpr int DEPTH = 4;
+    f32x4v buf[DEPTH][4], wbuf[DEPTH][4];                       // a tap's neighbour channels and its packed weights (L2-resident)
+    auto load_w = [&](int k, f32x4v (&a)[4]) {
+        const float* wk = Wp + ((size_t)k * ng * 64 + lane) * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a[g] = g < ng ? *reinterpret_cast<const f32x4v*>(wk + (size_t)g * 256) : zero4;
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1; ++k) { load_tap(k, buf[k]); load_w(k, wbuf[k]); }
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
-        if (k + 1 < KV) load_tap(k + 1, nxt);
-        if (__any(nbr[k] >= 0)) {                               // some site of the tile has this neighbour
-            const float* wk = Wp + ((size_t)k * ng * 64 + lane) * 4;
+        if (k + DEPTH - 1 < KV) { load_tap(k + DEPTH - 1, buf[(k + DEPTH - 1) % DEPTH]); load_w(k + DEPTH - 1, wbuf[(k + DEPTH - 1) % DEPTH]); }
+        const f32x4v(&cur)[4] = buf[k % DEPTH];
+        const f32x4v(&wa)[4] = wbuf[k % DEPTH];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < ng) {
-                    const f32x4v a = *reinterpret_cast<const f32x4v*>(wk + (size_t)g * 256);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], cur[g][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], cur[g][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], cur[g][2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], cur[g][3], acc, 0, 0, 0);
-                }
+        for (int g = 0; g < 4; ++g) {
+            if (g < ng) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g][0], cur[g][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g][1], cur[g][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g][2], cur[g][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[g][3], cur[g][3], acc, 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) cur[g] = nxt[g];
     }
     if (!valid) return;
 #pragma unroll
@@ -139,6 +147,9 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict_
 // addition does not commute with that): count_duplicates_kernel counts, per indexed row, how many other rows share its voxel;
 // merge_duplicates_kernel gives every row that has company one wavefront, which scans the row list in ascending order and
 // adds the matching rows' features onto its own, lowest row index first.
+// scratch: count[m], then DUP_SLOTS row slots per owner: a row that shares an owner's voxel leaves its index in the owner's
+// next free slot, so the owner finds its company without scanning the row list (owners with more company than slots still scan)
+constexpr int DUP_SLOTS = 8;
 __global__ void count_duplicates_kernel(const int32_t* __restrict__ coords, const int32_t* __restrict__ grid, const int m,
                                         const Dims s, int32_t* __restrict__ count) {
     const int site = blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,7 +157,10 @@ __global__ void count_duplicates_kernel(const int32_t* __restrict__ coords, cons
     const int d = coords[3 * site], h = coords[3 * site + 1], w = coords[3 * site + 2];
     if (d < 0 || d >= s.d || h < 0 || h >= s.h || w < 0 || w >= s.w) return;
     const int owner = grid[cell_of(s, d, h, w)];
-    if (owner != site) atomicAdd(count + owner, 1);
+    if (owner != site) {
+        const int slot = atomicAdd(count + owner, 1);
+        if (slot < DUP_SLOTS) count[m + owner * DUP_SLOTS + slot] = site;
+    }
 }
 
 __global__ void merge_duplicates_kernel(float* __restrict__ feat, const int c, const int32_t* __restrict__ coords,
@@ -158,6 +172,24 @@ __global__ void merge_duplicates_kernel(float* __restrict__ feat, const int c, c
     const int want = count[site];
     if (want == 0) return;
     float acc = lane < c ? feat[(size_t)site * c + lane] : 0.f;
+    if (want <= DUP_SLOTS) {
+        // the slots were filled in arrival order: add the rows lowest index first all the same (a fixed order of additions)
+        int r[DUP_SLOTS];
+#pragma unroll
+        for (int k = 0; k < DUP_SLOTS; ++k) r[k] = k < want ? count[m + site * DUP_SLOTS + k] : 0x7fffffff;
+#pragma unroll
+        for (int a = 0; a < DUP_SLOTS - 1; ++a)
+#pragma unroll
+            for (int b = 0; b < DUP_SLOTS - 1 - a; ++b) {
+                const int lo = min(r[b], r[b + 1]), hi = max(r[b], r[b + 1]);
+                r[b] = lo; r[b + 1] = hi;
+            }
+#pragma unroll
+        for (int k = 0; k < DUP_SLOTS; ++k)
+            if (k < want && lane < c) acc += feat[(size_t)r[k] * c + lane];      // rows that are added are never owners: nobody writes them
+        if (lane < c) feat[(size_t)site * c + lane] = acc;
+        return;
+    }
     int found = 0;
     for (int base = 0; base < m && found < want; base += 64) {
         const int j = base + lane;
@@ -170,7 +202,7 @@ __global__ void merge_duplicates_kernel(float* __restrict__ feat, const int c, c
         found += __popcll(mask);
         while (mask) {
             const int j0 = base + __ffsll((long long)mask) - 1;
-            if (lane < c) acc += feat[(size_t)j0 * c + lane];      // rows that are added are never owners: nobody writes them
+            if (lane < c) acc += feat[(size_t)j0 * c + lane];
             mask &= mask - 1;
         }
     }
@@ -197,24 +229,51 @@ __global__ void mark_kernel(const int32_t* __restrict__ coords, const int* __res
     }
 }
 
-// step 2: give every marked site a row (order is arbitrary; nothing downstream depends on it)
-__global__ void assign_kernel(const Dims s, int32_t* __restrict__ grid, int* __restrict__ counter, const int cap,
-                              int32_t* __restrict__ coords) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool marked = i < (long)s.d * s.h * s.w && grid[i] == -2;
-    // one atomic per wavefront, not per site: same-address atomics serialise at ~10 ns each (a few thousand sites: 38 us)
-    const unsigned long long m = __ballot(marked);
-    if (!m) return;
-    int base = 0;
-    if ((threadIdx.x & 63) == __builtin_ctzll(m)) base = atomicAdd(counter, __builtin_popcountll(m));
-    base = __shfl(base, __builtin_ctzll(m));
-    if (!marked) return;
-    const int row = base + __builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-    if (row >= cap) { grid[i] = -1; return; }
-    grid[i] = row;
-    coords[3 * row + 0] = (int)(i / ((long)s.h * s.w));
-    coords[3 * row + 1] = (int)((i / s.w) % s.h);
-    coords[3 * row + 2] = (int)(i % s.w);
+// step 2: give every marked site a row (order is arbitrary; nothing downstream depends on it).  A workgroup takes
+// ASSIGN_PER x 256 consecutive cells, ranks its marked cells with a wave scan + four LDS words, and claims their rows with ONE
+// atomic: the marked cells are a thin shell (a wavefront holds one or two), so an atomic per site -- or per wavefront -- is
+// ~10 k same-address atomics at ~10 ns each (115 us at the finest level); this is a few hundred.
+constexpr int ASSIGN_PER = 16;
+__global__ void __launch_bounds__(256) assign_kernel(const Dims s, int32_t* __restrict__ grid, int* __restrict__ counter, const int cap,
+                                                      int32_t* __restrict__ coords) {
+    __shared__ int wave_total[4];
+    __shared__ int block_base;
+    const long cells = (long)s.d * s.h * s.w;
+    const long b0 = (long)blockIdx.x * (256 * ASSIGN_PER);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < ASSIGN_PER; ++j) {
+        const long i = b0 + j * 256 + threadIdx.x;
+        if (i < cells && grid[i] == -2) mask |= 1u << j;
+    }
+    const int cnt = __popc(mask);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        block_base = total ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    int row = block_base + incl - cnt;
+    for (int w = 0; w < wave; ++w) row += wave_total[w];
+    while (mask) {
+        const int j = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const long i = b0 + j * 256 + threadIdx.x;
+        if (row >= cap) { grid[i] = -1; ++row; continue; }
+        grid[i] = row;
+        coords[3 * row + 0] = (int)(i / ((long)s.h * s.w));
+        coords[3 * row + 1] = (int)((i / s.w) % s.h);
+        coords[3 * row + 2] = (int)(i % s.w);
+        ++row;
+    }
 }
 
 // .dense() in the render kernel's channels-last layout; the volume is zero-filled by the caller side of this file
@@ -371,7 +430,7 @@ int gpnerf_sparse_down_sites(const int32_t* in_coords, const int32_t* m_in_dev, 
     if (m_in_cap == 0) return GPNERF_OK;
     hipLaunchKernelGGL(mark_kernel, dim3((m_in_cap + 255) / 256), dim3(256), 0, S_(stream), in_coords, (const int*)m_in_dev,
                        (int)m_in_cap, s, out_grid);
-    hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, S_(stream), s, out_grid, (int*)m_out_dev,
+    hipLaunchKernelGGL(assign_kernel, dim3((unsigned)((cells + 256 * ASSIGN_PER - 1) / (256 * ASSIGN_PER))), dim3(256), 0, S_(stream), s, out_grid, (int*)m_out_dev,
                        (int)m_out_cap, out_coords);
     return status();
 }
@@ -381,7 +440,7 @@ int gpnerf_sparse_merge_duplicates(float* feat, int32_t channels, const int32_t*
     if (!feat || !coords || !grid || !scratch || bad(dims) || channels < 1 || channels > 32 || m < 0) return GPNERF_E_ARG;
     if (m == 0) return GPNERF_OK;
     const Dims s{dims[0], dims[1], dims[2]};
-    if (hipMemsetAsync(scratch, 0, sizeof(int32_t) * (size_t)m, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+    if (hipMemsetAsync(scratch, 0, sizeof(int32_t) * (size_t)m, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;     // the counts
     hipLaunchKernelGGL(count_duplicates_kernel, dim3((m + 255) / 256), dim3(256), 0, S_(stream), coords, grid, (int)m, s, scratch);
     hipLaunchKernelGGL(merge_duplicates_kernel, dim3((m + 3) / 4), dim3(256), 0, S_(stream), feat, (int)channels, coords, grid,
                        (int)m, s, (const int32_t*)scratch);

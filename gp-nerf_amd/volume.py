@@ -192,7 +192,7 @@ class SparseConvNet(nn.Module):
             dc = self.net[0]                                            # double_conv at full resolution
             x = conv(False, dc[0], dc[1], x, grid, dims, coords, m_dev, m_cap)
             x = conv(False, dc[3], dc[4], x, grid, dims, coords, m_dev, m_cap)
-            dup = torch.empty((m_cap,), device=dev, dtype=torch.int32)
+            dup = torch.empty((9 * m_cap,), device=dev, dtype=torch.int32)       # a count + eight row slots per row
             L.check(lib.gpnerf_sparse_merge_duplicates(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_cap,
                                                        I3(*dims), dup.data_ptr(), st), "gpnerf_sparse_merge_duplicates")
             levels = []

@@ -256,7 +256,8 @@ int gpnerf_sparse_conv3_mfma(int32_t strided, const float* in, int32_t cin, cons
                              int32_t cout, const float* bn_scale, const float* bn_shift, float* out, void* stream);
 /* Before the first strided conv: feat[owner] += feat[i] for every row i whose voxel is indexed by another row (two
  * vertices rounded into one voxel).  spconv's strided rulebook takes every input row; its submanifold lookups one.
- * The rows of a voxel are added in ascending row order (deterministic); scratch: device int32[m], overwritten. */
+ * The rows of a voxel are added in ascending row order (deterministic); scratch: device int32[9 * m], overwritten (a count
+ * and eight row slots per row). */
 int gpnerf_sparse_merge_duplicates(float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, int32_t m,
                                    const int32_t* dims, int32_t* scratch, void* stream);
 /* Active sites of the next (half-resolution) level: out_grid / out_coords / m_out_dev from the finer level's coords. */
