@@ -66,8 +66,15 @@ def parse():
     ap.add_argument("--occupancy", type=float, default=None, help="fraction of coarse volume blocks that are occupied")
     ap.add_argument("--ray-order", default="patch", choices=["patch", "raster"],
                     help="patch: 32x8-pixel workgroup tiles (what Renderer.render passes as ray_order); raster: the list as given")
-    ap.add_argument("--patch", default="32x8", help="WxH of the patches of --ray-order patch")
-    return ap.parse_args()
+    ap.add_argument("--patch", default=None,
+                    help="WxH of the patches of --ray-order patch: one patch row of W pixels per wavefront when W >= 32, a whole WxH = 32 "
+                         "pixel block per wavefront otherwise.  Default 32x8 (Renderer.render's dense order), 8x4 with --early-term and "
+                         "4x8 with --occ-cull: the rays of a compact block terminate / are culled together far more often than those "
+                         "of a 32-pixel row")
+    args = ap.parse_args()
+    if args.patch is None:
+        args.patch = "8x4" if args.early_term else ("4x8" if args.occ_cull else "32x8")
+    return args
 
 
 class Workload:
@@ -247,7 +254,7 @@ def main():
             "config": {"workload": f"{wl.H}x{wl.W} frame, {S} samples/ray, fused HIP render kernel, synthetic SMPL bound + random "
                                    f"feature volume (BASELINE.json configs[{cfg_no}])",
                        "rays_per_gpu": int(flow.n_local), "rays_total": int(flow.rays_per_step), "samples_per_ray": S, "fill": args.fill,
-                       "ray_order": args.ray_order, "outputs": "rgb+depth (the all-gather payload)" if strong else
+                       "ray_order": args.ray_order, "patch": args.patch if args.ray_order == "patch" else None, "outputs": "rgb+depth (the all-gather payload)" if strong else
                        ("rgb,depth,acc,disp,weights,z_vals,rgb_in (Renderer.render's dict)" if args.outputs == "api" else "rgb,depth,acc,disp"),
                        "early_term": bool(args.early_term), "term_eps": args.term_eps if args.early_term else None, "sigma_bias": sigma_bias,
                        "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "split_guard": bool(args.split_f16 and not args.no_guard), "vol_occupancy": args.occupancy,

@@ -730,15 +730,16 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     float* part;
     int dynamic;              // 1: persistent workgroups pulling tiles from `queue`
     unsigned* queue;          // 8 counters (one per XCD), zero at launch
-    // chained sample segments (early termination): a work item is `chain` samples of one tile.  A tile that is neither
-    // finished nor opaque at the end of an item parks 16 floats per ray in `part` and is appended to the FIFO of the XCD that
-    // rendered it (render_fused_kernel); chain = 0: a work item is the whole ray.
-    int chain, wave_cap;
+    // chained sample segments (early termination, render_fused_kernel<., true>): this launch walks samples
+    // [seg * chain, (seg + 1) * chain) of the rays listed in `list_in` (nullptr: every ray, segment 0), 32 list entries per
+    // wavefront, and appends the rays that are neither finished nor opaque to `list_out` for the next launch
+    int chain, seg, wave_cap;
     int stagger;              // experiment: waves 4..7 of a workgroup start this many x 64 cycles late
     int chunk;                // tiles per chunk of the XCD queues (queue_tile())
-    unsigned* ctl;            // FIFO heads [0..8), FIFO tails [8..16), tiles finished [16]; zero at launch
-    unsigned* lists;          // [8][list_cap] FIFO entries: (tile + 1) | segment << 28, zero = not written yet
-    long list_cap;
+    const int* list_in;
+    const unsigned* count_in;
+    int* list_out;
+    unsigned* count_out;
     // range guard of the split form: guard[0] = number of flagged tiles, guard[64 + tile] = 1 when an MFMA operand of the tile
     // reached the f16 range; the fix-up launch (FORM_F32_FIXUP) renders exactly the flagged tiles again in the fp32 form
     unsigned* guard;
@@ -824,6 +825,10 @@ DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
 #ifndef GPNERF_MAX_WAVES
 #define GPNERF_MAX_WAVES 8
 #endif
+// number of launch slots a chained launch renders: the previous segment's survivors, or every ray (segment 0)
+typedef const __attribute__((address_space(4))) KArgs* kargs_cptr;
+DEV long chain_items(kargs_cptr k) { return k->list_in ? (long)*k->count_in : k->n_rays; }
+
 // One work unit = (32-ray tile, sample segment) rendered by one wavefront: with split > 1 the samples of a tile are divided
 // between `split` waves, whose partial composites are merged by combine_segments_kernel (finer load balance for small frames).
 // Returns true when the tile goes on in a later work item (chained segments only).
@@ -850,9 +855,13 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
 
     const int n = lane & 31, half = lane >> 5;
     const long ray0 = tile * RAYS_PER_WAVE;
-    if (ray0 >= n_rays) return false;
-    const bool active = (ray0 + n) < n_rays;
-    const long slot = active ? ray0 + n : n_rays - 1;
+    // the chained form renders the launch slots listed in list_in (the rays the previous segment left alive, in no particular
+    // order), 32 list entries per wavefront; everything else renders 32 consecutive slots
+    const long n_items = CHAIN ? chain_items(k0) : n_rays;
+    if (ray0 >= n_items) return false;
+    const bool active = (ray0 + n) < n_items;
+    long slot = active ? ray0 + n : n_items - 1;
+    if constexpr (CHAIN) { if (k0->list_in) slot = k0->list_in[slot]; }
     const int ray = k0->out.order ? k0->out.order[slot] : (int)slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;             // Projector front test
     const bool flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;       // raw2outputs(neg=True)
@@ -874,17 +883,18 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
     Stamps st;
     st.start();
     const int chain = CHAIN ? k0->chain : 0;        // the chained form is its own instantiation: the plain sample loop stays as it was
-    const int k_end = chain ? min((seg + 1) * chain, S) : (int)(((long)S * (seg + 1)) / split);
-    int k = chain ? seg * chain : (int)(((long)S * seg) / split);
+    const int k_end = CHAIN ? min((seg + 1) * chain, S) : (int)(((long)S * (seg + 1)) / split);
+    int k = CHAIN ? seg * chain : (int)(((long)S * seg) / split);
     const int k_begin = k;
     if (CHAIN && k > 0) {       // resume: what the previous segment of this ray left behind (the 16 floats of a split segment)
-        const float* p = k0->part + (size_t)slot * 16;
-        c_r = agent_loadf(p + 0); c_g = agent_loadf(p + 1); c_b = agent_loadf(p + 2); depth = agent_loadf(p + 3);
-        acc = agent_loadf(p + 4); T = agent_loadf(p + 5);
-        const int packed = (int)agent_loadf(p + 6);
+        const f32x4* p = reinterpret_cast<const f32x4*>(k0->part + (size_t)slot * 16);
+        const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+        c_r = a[0]; c_g = a[1]; c_b = a[2]; depth = a[3];
+        acc = b[0]; T = b[1]; rin[0] = b[3];
+        const int packed = (int)b[2];
         n_two = packed & 4095; n_done = packed >> 12;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) rin[i] = agent_loadf(p + 7 + i);
+        rin[1] = c[0]; rin[2] = c[1]; rin[3] = c[2]; rin[4] = c[3];
+        rin[5] = d[0]; rin[6] = d[1]; rin[7] = d[2]; rin[8] = d[3];
     }
     for (; k < k_end; ++k) {
         kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -917,7 +927,10 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
             }
         }
 
-        ++n_done;
+        // chained form: a ray that is opaque stops HERE, whatever the other rays of its wavefront do (its result is a function
+        // of the ray alone, so it does not matter which rays are packed together); the plain form stops a tile as a whole
+        const bool dead = CHAIN && T < term_eps;
+        n_done += dead ? 0 : 1;
         // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
         float fv[64];
 #pragma unroll
@@ -948,7 +961,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
             vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
             nvalid += s.valid;
         }
-        if (nvalid > 1.f && keep) ++n_two;              // pixel_mask (:139); culled samples never count
+        if (nvalid > 1.f && keep && !dead) ++n_two;     // pixel_mask (:139); culled samples never count
 
         STAMP(st, 2);
         float sigma, rgb[3];
@@ -986,8 +999,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
 
         // raw2outputs (:90-104): alpha = 1 - exp(-sigma); T = cumprod(1 - alpha + 1e-10) exclusive
         const float alpha = 1.f - fast_exp(-sigma);
-        const float wgt = alpha * T;
-        T = T * ((1.f - alpha) + 1e-10f);
+        const float wgt = dead ? 0.f : alpha * T;
+        T = dead ? T : T * ((1.f - alpha) + 1e-10f);
         c_r = fmaf(wgt, rgb[0], c_r); c_g = fmaf(wgt, rgb[1], c_g); c_b = fmaf(wgt, rgb[2], c_b);
         depth = fmaf(wgt, zk, depth);
         acc += wgt;
@@ -1009,29 +1022,45 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
     asm volatile("" : "+s"(kp));
     if constexpr (FORM == FORM_SPLIT_GUARD) {
         // an operand at or beyond the f16 range (or a NaN): the hi/lo pair no longer carries the value, flag the tile
-        unsigned* const slot = guard_slot();
-        if (*slot) {                            // uniform: every lane reads the wave's slot
+        unsigned* const gs = guard_slot();
+        if (*gs) {                              // uniform: every lane reads the wave's slot
             unsigned* const gd = kp->guard;
-            if (lane == 0 && atomicExch(gd + GUARD_HEADER_WORDS + tile, 1u) == 0u) atomicAdd(gd, 1u);
-            *slot = 0u;
+            // the fix-up launch re-renders 32 consecutive launch slots at a time: flag the tile of every ray of this wavefront
+            // (the chained form packs rays of many tiles together)
+            const bool mine = CHAIN ? writer : lane == 0;
+            if (mine && atomicExch(gd + GUARD_HEADER_WORDS + (CHAIN ? slot / RAYS_PER_WAVE : tile), 1u) == 0u) atomicAdd(gd, 1u);
+            *gs = 0u;
         }
     }
     const __attribute__((address_space(4))) OutK& out = kp->out;
     float* const part = kp->part;
-    // chained segments: the tile goes on in the next launch unless it has walked all S samples or every ray of it is opaque
-    const bool goes_on = CHAIN && k_end < S && !__all(T < term_eps);
-    if (out.z_vals)
-        write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_rays - ray0), S, step, k_begin,
-                     (CHAIN && !goes_on) ? S : k_end);
-    if (CHAIN && goes_on) {
-        if (writer) {
-            float* p = part + (size_t)slot * 16;
-            agent_storef(p + 0, c_r); agent_storef(p + 1, c_g); agent_storef(p + 2, c_b); agent_storef(p + 3, depth);
-            agent_storef(p + 4, acc); agent_storef(p + 5, T); agent_storef(p + 6, (float)(n_two + 4096 * n_done));
-#pragma unroll
-            for (int i = 0; i < 9; ++i) agent_storef(p + 7 + i, rin[i]);
+    if constexpr (CHAIN) {
+        // z_vals is a function of (near, far, k): segment 0 writes every row completely
+        if (out.z_vals && seg == 0)
+            write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_items - ray0), S, step, 0, S);
+        // a ray goes on in the next launch unless it has walked all S samples or is opaque; the survivors of the wavefront
+        // take consecutive places in list_out (one atomic per wavefront) and park their 16 floats of state
+        const bool goes_on = writer && k_end < S && !(T < term_eps);
+        const unsigned long long alive = __ballot(goes_on);
+        if (alive) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(kp->count_out, (unsigned)__popcll(alive));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (goes_on) {
+                kp->list_out[base + __popcll(alive & ((1ull << lane) - 1ull))] = (int)slot;
+                f32x4* p = reinterpret_cast<f32x4*>(part + (size_t)slot * 16);
+                f32x4 a, b, c, d;
+                a[0] = c_r; a[1] = c_g; a[2] = c_b; a[3] = depth;
+                b[0] = acc; b[1] = T; b[2] = (float)(n_two + 4096 * n_done); b[3] = rin[0];
+                c[0] = rin[1]; c[1] = rin[2]; c[2] = rin[3]; c[3] = rin[4];
+                d[0] = rin[5]; d[1] = rin[6]; d[2] = rin[7]; d[3] = rin[8];
+                p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+            }
         }
-        return true;
+        if (goes_on || !writer) return false;
+    } else {
+        if (out.z_vals)
+            write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_rays - ray0), S, step, k_begin, k_end);
     }
     if (writer && split > 1) {
         // partial composite of this segment: rgb, depth, acc, segment transmittance, rgb_in, #samples with >1 valid view
@@ -1080,6 +1109,9 @@ render_fused_kernel(const KArgs ka) {
     if constexpr (FORM == FORM_F32_FIXUP) {
         if (__hip_atomic_load(ka.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;     // nothing was flagged
     }
+    if constexpr (CHAIN) {
+        if (ka.list_in && *ka.count_in == 0u) return;               // no ray is left for this segment
+    }
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : ka.fr.head_blob);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
@@ -1100,7 +1132,6 @@ render_fused_kernel(const KArgs ka) {
         asm volatile("" : "+s"(kq));            // re-read per tile rather than held across render_tile (see there)
         long tile = 0;
         int seg = 0;
-        unsigned* const ctl = CHAIN ? kq->ctl : nullptr;
         if (!kq->dynamic) {                     // static launch: exactly one unit per wave
             if (dry) return;
             const long unit = (long)xcd_remap(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
@@ -1108,8 +1139,8 @@ render_fused_kernel(const KArgs ka) {
             seg = (int)(unit % kq->split);
             dry = 8;
         } else if (dry < 8) {
-            // fresh tiles: every tile of the frame, one contiguous run per XCD
-            const long n_tiles = (kq->n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+            // every tile of the launch (32 consecutive slots, or 32 consecutive entries of the chained form's ray list)
+            const long n_tiles = ((CHAIN ? chain_items(kq) : kq->n_rays) + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
             // fewer tiles than waves: deal them evenly, so that every CU runs the same few waves (each then steps faster) rather
             // than the first workgroups to arrive running eight and the rest none
             const long share = kq->wave_cap ? (long)kq->wave_cap : (n_tiles + gridDim.x - 1) / gridDim.x;
@@ -1117,56 +1148,16 @@ render_fused_kernel(const KArgs ka) {
             const unsigned t = wave_add(kq->queue + qx, 1u, lane);
             if ((long)t >= queue_len(n_tiles, kq->chunk, qx)) {     // this XCD's queue is dry: move on to the next one
                 qx = (qx + 1) & 7;
-                if (++dry == 8 && !CHAIN) return;
+                if (++dry == 8) return;
                 continue;
             }
             tile = queue_tile(kq->chunk, qx, t);
+            if constexpr (CHAIN) seg = kq->seg;
             if constexpr (FORM == FORM_F32_FIXUP) {                 // only the tiles the split form flagged
                 if (wave_load(kq->guard + GUARD_HEADER_WORDS + tile, lane) == 0u) continue;
             }
-        } else if constexpr (CHAIN) {
-            // tiles that go on (chained items): eight FIFOs, one per XCD; a wave appends to its own XCD's and takes from it
-            // first (the tile's volume neighbourhood is in that L2), from the others' when it is empty.  ctl[16] counts the
-            // tiles that are finished or opaque: once it reaches the number of tiles nothing can arrive any more.
-            const long n_tiles = (kq->n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
-            const long left = n_tiles - (long)wave_load(ctl + 16, lane);
-            if (left <= 0) return;
-            if (left <= (long)wave * gridDim.x) {                   // few tiles left: the low waves of every CU take them (as above)
-                __builtin_amdgcn_s_sleep(127);
-                continue;
-            }
-            const unsigned v = lane < 16 ? agent_load(ctl + lane) : 0u;         // heads in lanes 0..7, tails in lanes 8..15
-            const unsigned vt = __shfl_down(v, 8);
-            unsigned has = (unsigned)__ballot(lane < 8 && (int)(vt - v) > 0) & 0xffu;
-            if (!has) {
-                __builtin_amdgcn_s_sleep(64);
-                continue;
-            }
-            has = ((has | (has << 8)) >> home) & 0xffu;             // rotate: bit i = FIFO (home + i) & 7
-            const int x = (home + __builtin_ctz(has)) & 7;
-            const unsigned h = wave_add(ctl + x, 1u, lane);
-            const unsigned* const entry = kq->lists + (size_t)x * kq->list_cap + h;
-            unsigned e;
-            while ((e = wave_load(entry, lane)) == 0) {             // ticket h: wait for whoever appends it
-                if ((long)wave_load(ctl + 16, lane) >= n_tiles) return;
-                __builtin_amdgcn_s_sleep(64);
-            }
-            tile = (long)(e & 0x0fffffffu) - 1;
-            seg = (int)(e >> 28);
         }
-        const bool goes_on = render_tile<FORM == FORM_F32_FIXUP ? FORM_F32 : FORM, CHAIN>(lds, lane, tile, seg);
-        if constexpr (CHAIN) {
-            kargs_ptr kr = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(kr));
-            unsigned* const c2 = kr->ctl;
-            if (goes_on) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tile's parked state has left the CU
-                const unsigned t = wave_add(c2 + 8 + home, 1u, lane);
-                if (lane == 0) agent_store(kr->lists + (size_t)home * kr->list_cap + t, (unsigned)(tile + 1) | ((unsigned)(seg + 1) << 28));
-            } else {
-                wave_add(c2 + 16, 1u, lane);                        // finished
-            }
-        }
+        render_tile<FORM == FORM_F32_FIXUP ? FORM_F32 : FORM, CHAIN>(lds, lane, tile, seg);
     }
 }
 
@@ -1685,29 +1676,27 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
 // rounds x step time x samples per unit.  GPNERF_WAVES / GPNERF_SPLIT override (diagnostics).
 constexpr int GPNERF_MAX_SPLIT = 8;     // waves that may share one tile's samples
 constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue counters (one per XCD), padded
-// Early termination renders a tile in chained work items of chain_len() samples (see gpnerf_render_fused); the workspace then
-// holds the control block (QUEUE_BYTES), eight FIFOs of list_cap entries, and 16 floats of parked state per ray.
+// Early termination walks the samples in segments of chain_len(), one launch per segment over the rays still alive (see
+// gpnerf_render_fused); the workspace then holds a control block (per segment: 8 queue counters + the length of its output
+// list), two ray lists (written and read alternately) and 16 floats of parked state per ray.
 constexpr int CHAIN_SEG = 16;
-constexpr int CHAIN_MAX_ITEMS = 16;     // the item index travels in 4 bits of a FIFO entry
+constexpr int CHAIN_MAX_SEGS = 64;
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 int chain_len(int S) {
     static int f_seg = -1;
     if (f_seg < 0) { const char* e = getenv("GPNERF_CHAIN_SEG"); f_seg = e ? atoi(e) : CHAIN_SEG; }
-    const int least = (S + CHAIN_MAX_ITEMS - 1) / CHAIN_MAX_ITEMS;
+    const int least = (S + CHAIN_MAX_SEGS - 1) / CHAIN_MAX_SEGS;
     return f_seg > least ? f_seg : least;
 }
-size_t chain_list_cap(int64_t n_rays, int S) {
-    const int len = chain_len(S), items = (S + len - 1) / len;
-    const size_t tiles = (size_t)((n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE);
-    return tiles * (size_t)(items - 1);
-}
+int chain_segs(int S) { const int len = chain_len(S); return (S + len - 1) / len; }
+size_t chain_ctrl_bytes(int n_seg) { return align256((size_t)n_seg * 9 * sizeof(unsigned)); }
 // range guard of the split form: header (flag count, the fix-up launch's queue counters) + one word per tile, at the workspace's end
 size_t guard_bytes(int64_t n_rays) {
     return align256((GUARD_HEADER_WORDS + (size_t)((n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE)) * sizeof(unsigned));
 }
 size_t chain_bytes(int64_t n_rays, int S) {
-    if (S <= chain_len(S) || S > 4095 || n_rays > ((int64_t)1 << 32)) return 0;
-    return QUEUE_BYTES + align256(8 * chain_list_cap(n_rays, S) * sizeof(unsigned)) + (size_t)n_rays * 16 * sizeof(float);
+    if (chain_segs(S) < 2 || n_rays >= ((int64_t)1 << 31)) return 0;
+    return chain_ctrl_bytes(chain_segs(S)) + 2 * align256((size_t)n_rays * sizeof(int)) + (size_t)n_rays * 16 * sizeof(float);
 }
 struct Geometry { int waves, split; };
 
@@ -2020,16 +2009,12 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         KArgs kf = ka;
         kf.flags = (unsigned)flags & ~(GPNERF_FLAG_SPLIT_F16 | GPNERF_FLAG_SPLIT_GUARD);
         kf.split = 1; kf.part = nullptr; kf.dynamic = 1; kf.queue = guard_words + 8; kf.wave_cap = 0;
-        kf.chain = 0; kf.ctl = nullptr; kf.lists = nullptr;
+        kf.chain = 0; kf.seg = 0; kf.list_in = nullptr; kf.count_in = nullptr; kf.list_out = nullptr; kf.count_out = nullptr;
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
         hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FIXUP, false>), dim3((unsigned)(wg < n_cus ? wg : n_cus)), full_block, lds_bytes,
                            S_(stream), kf);
         return launch_status();
     };
-    // Early termination: a work item is chain_len() samples of a tile rather than the whole ray.  A tile that is not opaque at
-    // the end of an item parks 16 floats per ray and queues up again behind the others, so no item is longer than that and the
-    // launch drains within one item's time -- with whole rays as items the last waves walk their longest tiles alone
-    // (512x512x128: 16.6 ms whole rays, 15.2 ms one launch per segment, 1x.x ms this).  Bit-identical results.
     static int f_cap = -1;
     if (f_cap < 0) { const char* e = getenv("GPNERF_WAVE_CAP"); f_cap = e ? atoi(e) : 0; }      // experiments: waves per CU that pull tiles
     ka.wave_cap = f_cap;
@@ -2039,26 +2024,40 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     static int f_chunk = -1;
     if (f_chunk < 0) { const char* e = getenv("GPNERF_QUEUE_CHUNK"); f_chunk = e ? atoi(e) : 64; }
     ka.chunk = f_chunk > 0 ? f_chunk : (int)((tiles + 7) / 8);        // 0: one contiguous run per XCD
+    // Early termination on frames of at least one round of wavefronts: the samples are walked in segments of chain_len(), one
+    // persistent-queue launch per segment.  A ray that is opaque stops (per ray, not per tile); the rays that go on park 16
+    // floats and are appended to the next launch's list, so every launch packs the survivors 32 to a wavefront again: on the
+    // bench frame a ray needs 20 % of its samples, a fixed 32-ray tile 35-43 % (until its last ray is opaque).  The launches
+    // are enqueued unconditionally -- one that finds its list empty returns before it stages anything.
     // (frames of less than one round of waves gain nothing from it, and every XCD's queue needs workgroups of its own)
     const size_t need_chain = (flags & GPNERF_FLAG_EARLY_TERM) && f_dynamic && tiles >= (int64_t)n_cus * GPNERF_MAX_WAVES && n_cus >= 8
                                   ? chain_bytes(n_rays, n_samples) : 0;
     if (need_chain && workspace && workspace_bytes >= need_chain) {
+        const int n_seg = chain_segs(n_samples);
         char* const base = static_cast<char*>(workspace);
-        const size_t list_bytes = align256(8 * chain_list_cap(n_rays, n_samples) * sizeof(unsigned));
-        if (hipMemsetAsync(base, 0, QUEUE_BYTES + list_bytes, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+        unsigned* const ctrl = reinterpret_cast<unsigned*>(base);                      // [n_seg][8] queue counters, then [n_seg] list lengths
+        const size_t list_bytes = align256((size_t)n_rays * sizeof(int));
+        int* const lists[2] = {reinterpret_cast<int*>(base + chain_ctrl_bytes(n_seg)), reinterpret_cast<int*>(base + chain_ctrl_bytes(n_seg) + list_bytes)};
+        if (hipMemsetAsync(base, 0, chain_ctrl_bytes(n_seg), S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
         ka.split = 1; ka.dynamic = 1; ka.chain = chain_len(n_samples);
-        ka.ctl = reinterpret_cast<unsigned*>(base) + 8;
-        ka.lists = reinterpret_cast<unsigned*>(base + QUEUE_BYTES);
-        ka.list_cap = (long)chain_list_cap(n_rays, n_samples);
-        ka.part = reinterpret_cast<float*>(base + QUEUE_BYTES + list_bytes);
+        ka.part = reinterpret_cast<float*>(base + chain_ctrl_bytes(n_seg) + 2 * list_bytes);
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
         const unsigned grid = (unsigned)(wg < n_cus ? wg : n_cus);
-        if (guard)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3(grid), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
-        else if (split16)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3(grid), full_block, lds_split, S_(stream), ka);
-        else
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
+        for (int sg = 0; sg < n_seg; ++sg) {
+            ka.seg = sg;
+            ka.queue = ctrl + 8 * sg;
+            ka.list_in = sg ? lists[(sg - 1) & 1] : nullptr;
+            ka.count_in = sg ? ctrl + 8 * n_seg + (sg - 1) : nullptr;
+            ka.list_out = lists[sg & 1];
+            ka.count_out = ctrl + 8 * n_seg + sg;
+            if (guard)
+                hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3(grid), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
+            else if (split16)
+                hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3(grid), full_block, lds_split, S_(stream), ka);
+            else
+                hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
+            if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
+        }
         return fixup();
     }
     if (guard)

@@ -209,7 +209,10 @@ class Renderer(nn.Module):
             Hs, Ws = batch["src_imgs"].shape[-2:]
             m = batch["mask_at_box"].reshape(-1)
             if m.numel() == Hs * Ws and m.is_cuda:
-                order = F_.patch_order_device(m.bool(), Hs, Ws, patch_w=32, patch_h=8)
+                # with early termination a wavefront's 32 rays are a compact 8x4-pixel block rather than a 32-pixel row: the rays of
+                # a block become opaque together far more often (bench frame: 43 % -> 35 % of the samples evaluated)
+                pw, ph = (8, 4) if self.early_term else (32, 8)
+                order = F_.patch_order_device(m.bool(), Hs, Ws, patch_w=pw, patch_h=ph)
                 if order.numel() != n:
                     order = None
         # the encoder's time comes from two events on the stream instead of two host synchronisations around it

@@ -68,18 +68,30 @@ def test_config3_512x512x128_early_termination_against_the_oracle(split_f16, fm,
     for j, i in enumerate(idx):
         assert ref["weights"][j, done[i]:].sum() <= eps * 1.01
     assert np.abs(cut["weights"][idx] - ref["weights"]).max() < 2e-5
-    # (3) invariants over all 262 144 rays; rays of one 32-ray tile stop together
+    # (3) invariants over all 262 144 rays; every ray stops on its own: after the first sample that takes ITS transmittance
+    # below the threshold (read off the unterminated launch's weights)
     check_invariants(cut, S)
-    assert (done.reshape(-1, 32) == done.reshape(-1, 32)[:, :1]).all()
-    # (4) same pixels from a shard of the rays: a tile stops when its 32 rays are opaque, so shards cut on tile boundaries
-    # (what parallel.py's bands are) reproduce the frame bit for bit, termination included; a ragged last tile holds
-    # fewer rays, may stop earlier, and stays within what termination is allowed to drop
-    full = fm.render_fused(fr, rays, S, early_term=True, term_eps=eps, split_f16=split_f16)
+    full_w = fm.render_fused(fr, rays, S, want=("weights",), split_f16=split_f16)["weights"].double()
+    T = torch.cat([torch.ones((full_w.shape[0], 1), dtype=torch.float64, device=full_w.device), 1.0 - torch.cumsum(full_w, 1)], 1)   # T[:, k] = after k samples
+    d = torch.from_numpy(done.astype(np.int64)).to(T.device)
+    noise = 5e-7                                    # 1 - sum of fp32 weights against the kernel's running product
+    t_stop = T.gather(1, d[:, None])[:, 0]          # transmittance after the samples the ray evaluated
+    t_prev = T.gather(1, (d - 1)[:, None])[:, 0]    # ... and one sample earlier: still at or above the threshold
+    assert bool(((t_stop < eps + noise) | (d == S)).all()) and bool((t_prev >= eps - noise).all())
+    assert frac < 0.3, f"per-ray termination evaluated {frac:.2f} of the samples"
+    # (4) a ray's result is a function of that ray alone, so any order of the rays gives the same bits per ray (the launch
+    # packs whichever rays are still alive 32 to a wavefront, segment after segment) ...
+    g = torch.Generator(device="cpu").manual_seed(1)
+    perm = torch.randperm(rays.shape[0], generator=g).to(rays.device)
+    full = fm.render_fused(fr, rays, S, early_term=True, term_eps=eps, split_f16=split_f16, want=("weights", "samples_done"))
+    shuf = fm.render_fused(fr, rays[perm].contiguous(), S, early_term=True, term_eps=eps, split_f16=split_f16, want=("weights", "samples_done"))
+    for k in ("rgb_map", "depth_map", "acc_map", "weights", "samples_done"):
+        assert torch.equal(shuf[k], full[k][perm]), k
+    # ... and a shard of the rays too small for the chained form (tile-granular termination: a tile goes on until its last ray
+    # is opaque) stays within what termination is allowed to drop
     for a, b in ((0, 4096), (32 * 4001, 32 * 4001 + 555), (262144 - 64, 262144)):
-        part = fm.render_fused(fr, rays[a:b], S, early_term=True, term_eps=eps, split_f16=split_f16)
-        whole = (b - a) // 32 * 32
+        part = fm.render_fused(fr, rays[a:b], S, early_term=True, term_eps=eps, split_f16=split_f16, want=("weights",))
         for k in ("rgb_map", "depth_map", "acc_map", "weights"):
-            assert torch.equal(part[k][:whole], full[k][a:a + whole]), (k, a, b)
             assert float((part[k] - full[k][a:b]).abs().max()) <= 5e-5, (k, a, b)
 
 
