@@ -270,11 +270,12 @@ def main():
                                               "bound by vector-ALU issue, not by the matrix pipe (30 % busy: profiles/r02/b_pmc_summary_split_guarded.json)")
         if evaluated is not None:
             line["roofline"]["samples_evaluated_frac"] = evaluated
-            line["roofline"]["note"] = ("flop_per_launch counts the samples the launch evaluated (32-ray tiles stop once every ray has T < term_eps / "
-                                        "skip steps whose 32 samples are all unoccupied), not the S per ray the reference would")
+            line["roofline"]["note"] = ("flop_per_launch counts the samples the launch evaluated (a ray stops once its T < term_eps / a wavefront skips "
+                                        "steps whose 32 samples are all unoccupied), not the S per ray the reference would")
         if args.early_term:
-            line["early_term"] = {"samples_evaluated_frac": evaluated, "tiles_alive_after_samples": alive_after,
-                                  "note": "wave-level scan: a 32-ray tile stops once every ray has T < term_eps"}
+            line["early_term"] = {"samples_evaluated_frac": evaluated, "rays_alive_after_samples": alive_after,
+                                  "note": "a ray stops once its T < term_eps; the launch walks the samples in 16-sample segments and re-packs the rays still alive "
+                                          "32 to a wavefront for every segment (frames smaller than one round of wavefronts: a 32-ray tile stops as a whole)"}
         if world == 1 and not args.no_extras:
             line["beside_headline"] = beside_headline(args, fm, wl, kw, flow)
         if world == 1 and not args.no_cpu_baseline:
