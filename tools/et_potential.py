@@ -18,3 +18,4 @@ stop = torch.where((T < eps).any(1), (T < eps).double().argmax(1) + 1, torch.ful
 for name, perm in (("32x1 rows (patch order 32x8)", order.long()), ("4x8 patches", torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], 512, 512, patch_w=4, patch_h=8)).to(dev).long())):
     s = stop[perm].view(-1, 32)
     print(f"{name}: per-ray mean {float(stop.mean()) / S:.3f} of S, per-tile (max over 32) mean {float(s.max(1)[0].mean()) / S:.3f}")
+np.save(os.path.join(ROOT, "gpurun_out", "stop_rays.npy"), stop.cpu().numpy().astype(np.int16))
