@@ -280,6 +280,10 @@ def main():
             line["beside_headline"] = beside_headline(args, fm, wl, kw, flow)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl.sc, wl.rays_h, S, args.cpu_seconds)
+            try:        # BASELINE.json configs[0] (the reference's own CPU-runnable case): the whole 64x64x32 crop on the same cores
+                line["cpu_baseline"]["config1_64x64x32"] = cpu_config1(args.seed)
+            except Exception as e:
+                line["cpu_baseline"]["config1_64x64x32"] = {"error": repr(e)[:200]}
             line["vs_cpu"] = value / line["cpu_baseline"]["value"]
         # sanity on the product's own output (not a parity check; tests/ do that)
         assert bool(torch.isfinite(out["rgb_map"]).all()), "non-finite rgb"
@@ -402,6 +406,22 @@ def cpu_baseline(sc, rays_h, S, target_s):
     return {"value": sample.shape[0] / dt, "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{sample.shape[0]} evenly spaced rays of the same frame x {S} samples, {dt:.1f} s on {threads} OpenMP threads "
                       f"(oracle/gpnerf_oracle.c)"}
+
+
+def cpu_config1(seed):
+    """BASELINE.json configs[0] on the CPU oracle: every ray of a 64x64 crop, 32 samples per ray, median of 3 runs after a warm-up."""
+    from oracle import oracle
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    sc = syn.make_scene(H=64, W=64, seed=seed, fill="full", pose="identity")
+    rays = np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32)
+    oracle.render(sc, 32, rays=rays, want_weights=False)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.render(sc, 32, rays=rays, want_weights=False)
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    return {"value": rays.shape[0] / dt, "unit": "rays/s", "ms_per_frame": dt * 1e3, "rays": int(rays.shape[0]), "cores": oracle.max_threads()}
 
 
 if __name__ == "__main__":
