@@ -802,12 +802,9 @@ DEV void write_z_vals(float* __restrict__ z_vals, const int lane, const int ray_
     }
 }
 
-// Device-scope (sc1) accesses for data that passes between waves of different CUs within a launch: they are performed at
-// the L2 / the memory side rather than in the CU's vector L1, which is neither invalidated nor shared between CUs.
+// Device-scope (sc1) accesses for the counters waves of different CUs share within a launch: they are performed at the L2 /
+// the memory side rather than in the CU's vector L1, which is neither invalidated nor shared between CUs.
 DEV unsigned agent_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV void agent_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV float agent_loadf(const float* p) { return __builtin_bit_cast(float, agent_load(reinterpret_cast<const unsigned*>(p))); }
-DEV void agent_storef(float* p, float v) { agent_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v)); }
 // one lane performs the access, the wave gets the value
 DEV unsigned wave_load(const unsigned* p, int lane) {
     unsigned v = 0;

@@ -43,7 +43,7 @@ class NeRFSigmaHead(nn.Module):
     def build_volumes(self, sp_input, smpl_feat_sampled):
         """Embedding -> attention over the V views -> sparse conv net -> 4 dense levels
         (trainhead.py:48-56, SparseConvNet.py:105-111).  Per frame, not per ray."""
-        code = self.c(torch.arange(0, self.n_smpl, device=smpl_feat_sampled.device))
+        code = self.c.weight                        # = self.c(arange(n_smpl)) (trainhead.py:48): every row, in order
         fused = self.xyzc_attn.fuse_vertices(code, smpl_feat_sampled.flatten(0, 1))          # HIP only: raises on CPU / in training
         return self.xyzc_net.dense_levels_hip(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
 

@@ -87,9 +87,31 @@ class Renderer(nn.Module):
             sp["volumes"] = batch["volumes"]
         return sp
 
-    def build_frame(self, batch, featmaps=None, consts=None):
+    def prepare_builder_inputs(self, batch, consts=None):
+        """What the volume builder needs that does not depend on the encoder: the sparse-conv input dict and the SMPL vertices in
+        world space (BaseRender.py:128-131).  Renderer.render enqueues this BEFORE the encoder, so that the host-bound little
+        launches run while the queue is empty and the encoder's ~110 launches are followed directly by the builder's."""
+        if "volumes" in batch:
+            return None
+        out_sh = consts[6].ravel() if (consts is not None and batch["out_sh"].shape[0] == 1) else None
+        xyz = batch["feature"][..., :3].float()
+        smpl_xyz = torch.bmm(xyz, batch["Rh"].float().transpose(1, 2)) + batch["Th"].float()
+        return self.prepare_sp_input(batch, out_sh), smpl_xyz
+
+    def _placeholder_volumes(self, dev):
+        """Four one-voxel channels-last levels: what a Frame carries until the builder's volumes are attached (cached per device)."""
+        cache = self.__dict__.setdefault("_placeholders", {})
+        if str(dev) not in cache:
+            vols = [torch.zeros((1, 1, 1, L.CH), device=dev) for _ in range(L.LEVELS)]
+            for v in vols:
+                v._gpnerf_ndhwc = True
+            cache[str(dev)] = vols
+        return cache[str(dev)]
+
+    def build_frame(self, batch, featmaps=None, consts=None, prepared=None):
         """Per-frame work after the encoder: volume pyramid, channels-last re-layout, weight image.  consts: Frame.consts_of_batch()
-        fetched earlier; with it nothing below synchronises with the device (a batch of one frame: out_sh[0] is the maximum)."""
+        fetched earlier; with it nothing below synchronises with the device (a batch of one frame: out_sh[0] is the maximum).
+        prepared: prepare_builder_inputs() done earlier."""
         dev = batch["src_imgs"].device
         if featmaps is None:
             featmaps = self.encode(batch)
@@ -98,14 +120,11 @@ class Renderer(nn.Module):
             return F_.Frame.from_batch(batch, featmaps, batch["volumes"], self.voxel_size, blob, consts=consts)
         # No pre-built pyramid: gather the SMPL vertices' per-view features with the image half of the frame
         # (BaseRender.py:128-131,344-347), run the per-frame volume builder (trainhead.py:48-56), then attach it.
-        placeholder = [torch.zeros((1, L.CH, 1, 1, 1), device=dev) for _ in range(L.LEVELS)]
-        frame = F_.Frame.from_batch(batch, featmaps, placeholder, self.voxel_size, blob, consts=consts)
-        xyz = batch["feature"][..., :3].float()
-        smpl_xyz = torch.bmm(xyz, batch["Rh"].float().transpose(1, 2)) + batch["Th"].float()
+        sp_input, smpl_xyz = prepared if prepared is not None else self.prepare_builder_inputs(batch, consts)
+        frame = F_.Frame.from_batch(batch, featmaps, self._placeholder_volumes(dev), self.voxel_size, blob, consts=consts)
         feat, _ = F_.project_gather(frame, smpl_xyz[0], neg_ray=False)
         smpl_feat = feat[:, :, 3:].unsqueeze(0)                     # [1,6890,V,32]
-        out_sh = consts[6].ravel() if (consts is not None and batch["out_sh"].shape[0] == 1) else None
-        volumes = self.nerfhead.sigmahead.build_volumes(self.prepare_sp_input(batch, out_sh), smpl_feat)
+        volumes = self.nerfhead.sigmahead.build_volumes(sp_input, smpl_feat)
         frame._set_volumes(frame.c, volumes, frame._keep)
         return frame
 
@@ -217,10 +236,12 @@ class Renderer(nn.Module):
                     order = None
         # the encoder's time comes from two events on the stream instead of two host synchronisations around it
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        prepared = self.prepare_builder_inputs(batch, consts)          # before the encoder: see there
+        blob = self.nerfhead.head_blob(dev)                            # (cached; packs on a parameter change)
         ev0.record()
         featmaps = self.encode(batch)
         ev1.record()
-        frame = self.build_frame(batch, featmaps, consts)
+        frame = self.build_frame(batch, featmaps, consts, prepared)
 
         def fn(r):
             return F_.render_fused(frame, r, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
