@@ -446,18 +446,19 @@ def project_gather(frame, pts, neg_ray=False):
 
 
 def select_rays(frame, target_K, target_pose, H, W, voxel_size, bounds_min, Rh, Th, neg_ray=False, threshold=0.1,
-                target_K_inv=None, compact=True):
+                target_K_inv=None, compact=True, host=None):
     """Progressive ray selection of the inference renderer (demo_render.py:166-247) on the device:
     occupied voxels -> marked pixels (gpnerf_select_pixels) -> rays with near/far (gpnerf_make_rays_demo).
     Returns (rays [n,8] in raster order of the kept pixels, mask_at_box [H*W] bool); with compact=False the rays of ALL H*W
-    pixels (rows of pixels that are not kept are unspecified) and the mask, without any host synchronisation."""
+    pixels (rows of pixels that are not kept are unspecified) and the mask, without any host synchronisation when `host` --
+    fetch_host(target_K, target_pose, voxel_size, bounds_min, Rh, Th[, target_K_inv]) done earlier -- is handed in."""
     lib = L.lib()
     if not frame.c.occ:
         frame.build_occupancy()
     occ = frame.occ
     dev = occ.device
     items = [target_K, target_pose, voxel_size, bounds_min, Rh, Th] + ([target_K_inv] if target_K_inv is not None else [])
-    host = [np.ascontiguousarray(a.astype(np.float32).ravel()) for a in fetch_host(*items)]
+    host = [np.ascontiguousarray(a.astype(np.float32).ravel()) for a in (host if host is not None else fetch_host(*items))]
     f32 = lambda a, n: a[:n]
     K, pose = f32(host[0], 9), f32(host[1], 12)
     vox, bmin, rh, th = f32(host[2], 3), f32(host[3], 3), f32(host[4], 9), f32(host[5], 3)

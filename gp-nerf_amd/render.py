@@ -157,21 +157,36 @@ class Renderer(nn.Module):
         H, W = batch["src_imgs"].shape[-2:]
         torch.cuda.synchronize(dev)
         te = time.time()
+        # as in render(): the small constants come over in ONE copy while the queue is empty, what does not depend on the encoder
+        # is enqueued before it, and the phases are timed with stream events -- the host waits for the device once, for the
+        # number of selected pixels (the reference synchronises around every phase, demo_render.py:97-357)
+        sel_items = [batch["target_K"][0], batch["target_pose"][0], self.voxel_size, batch["bounds"][0, 0], batch["Rh"][0], batch["Th"][0]]
+        if "target_K_inv" in batch:
+            sel_items.append(batch["target_K_inv"][0])
+        fetched = F_.fetch_host(batch["src_Ks"][0], batch["src_poses"][0], batch["Rh"][0], batch["Th"][0], batch["bounds"][0, 0],
+                                self.voxel_size, batch["out_sh"][0], *sel_items)
+        consts, sel_host = fetched[:7], fetched[7:]
+        prepared = self.prepare_builder_inputs(batch, consts)
+        self.nerfhead.head_blob(dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
         featmaps = self.encode(batch)
-        torch.cuda.synchronize(dev)
-        t0 = time.time()                                     # the reference restarts its clock here (demo_render.py:443-446)
-        frame = self.build_frame(batch, featmaps)
+        ev[1].record()                                       # the reference restarts its clock here (demo_render.py:443-446)
+        frame = self.build_frame(batch, featmaps, consts, prepared)
         frame.build_occupancy()
-        torch.cuda.synchronize(dev)
-        t1 = time.time()
+        ev[2].record()
         neg = self._neg_ray(batch)
         # every pixel's ray + the mask of the kept ones, no compaction and no host round trip (the box stays on the device)
         rays, mask = F_.select_rays(frame, batch["target_K"][0], batch["target_pose"][0], H, W, self.voxel_size,
                                     batch["bounds"][0, 0], batch["Rh"][0], batch["Th"][0], neg_ray=neg,
-                                    target_K_inv=batch["target_K_inv"][0] if "target_K_inv" in batch else None, compact=False)
+                                    target_K_inv=batch["target_K_inv"][0] if "target_K_inv" in batch else None, compact=False,
+                                    host=sel_host)
         idx = torch.nonzero(mask).squeeze(1)                 # kept pixels in raster order (the frame's one synchronisation)
+        ev[3].record()
         torch.cuda.synchronize(dev)
         t2 = time.time()
+        etime = ev[0].elapsed_time(ev[1]) * 1e-3
+        t_frame, t_select = ev[1].elapsed_time(ev[2]) * 1e-3, ev[2].elapsed_time(ev[3]) * 1e-3
         if idx.numel():
             # the kernel renders the listed rows of the H*W ray array, 4x8-pixel patches per wavefront (a compact tile is empty
             # or full together far more often: whole tile-steps are culled), and writes each pixel's colour at its own row:
@@ -194,12 +209,12 @@ class Renderer(nn.Module):
         return {"rgb_map": rgb_np, "pred_img": pred_img, "mask_at_box": mask_np.reshape(-1),
                 # this path's own phases, plus the reference's ten keys (demo_render.py:97-357) so that consumers indexing them
                 # keep working: its per-frame phases collapse into `sp_encode`, its sigma / rgb passes into `sigma_f`
-                "time_slots": {"frame": t1 - t0, "ray_select": t2 - t1, "render": t3 - t2, "bc_render": t4 - t3,
-                               "bc_time": t2 - t1, "sigma_c": 0.0, "bc_attn": 0.0, "sigma_attn": 0.0, "sp_encode": t1 - t0,
+                "time_slots": {"frame": t_frame, "ray_select": t_select, "render": t3 - t2, "bc_render": t4 - t3,
+                               "bc_time": t_select, "sigma_c": 0.0, "bc_attn": 0.0, "sigma_attn": 0.0, "sp_encode": t_frame,
                                "bf_sigma": 0.0, "sigma_f": t3 - t2, "bf_rgb": 0.0, "rgb_f": 0.0},
-                # etime = the encoder alone, rtime = everything after it, as demo_render.py:441-446,494-497 measures them
-                # (libs/trainers/BaseTrainer.py:276 sums rtime into the reported render time)
-                "etime": t0 - te, "rtime": t4 - t0}
+                # etime = the encoder alone (its device time), rtime = everything else of the call, as demo_render.py:441-446,494-497
+                # keeps its two clocks (libs/trainers/BaseTrainer.py:276 sums rtime into the reported render time)
+                "etime": etime, "rtime": max(0.0, (t4 - te) - etime)}
 
     # ---- the hot path ---------------------------------------------------------------------------------
     def render(self, batch):
