@@ -740,6 +740,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     const unsigned* count_in;
     int* list_out;
     unsigned* count_out;
+    long p_cap;               // chain_plan(): 32 x the wavefronts the launch's remainder units may spread over
     // range guard of the split form: guard[0] = number of flagged tiles, guard[64 + tile] = 1 when an MFMA operand of the tile
     // reached the f16 range; the fix-up launch (FORM_F32_FIXUP) renders exactly the flagged tiles again in the fp32 form
     unsigned* guard;
@@ -826,11 +827,39 @@ DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
 typedef const __attribute__((address_space(4))) KArgs* kargs_cptr;
 DEV long chain_items(kargs_cptr k) { return k->list_in ? (long)*k->count_in : k->n_rays; }
 
+// Work units of a chained launch over n list entries on `slots` wavefronts: whole rounds of 32-entry tiles at one sample per step
+// (throughput-bound), then the remainder -- the tiles of the last, partial round, or all of a level with few rays -- with as many
+// samples of a ray side by side (render_tile's P) as still leave every wavefront a unit: what is left when the queue runs dry
+// is bound by the latency of a tile's dependent steps, not by throughput.  Segment 0 and occupancy culling: one sample per step.
+struct ChainPlan { long bulk_tiles, rem_tiles; int rem_p; };
+DEV ChainPlan chain_plan(kargs_cptr k) {
+    const long n = chain_items(k), n32 = (n + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+    ChainPlan c;
+    c.bulk_tiles = n32; c.rem_tiles = 0; c.rem_p = 1;
+    if (k->seg == 0 || (k->flags & GPNERF_FLAG_OCC_CULL) || k->p_cap <= 0) return c;
+    const long slots = k->p_cap / RAYS_PER_WAVE;
+    c.bulk_tiles = (n32 / slots) * slots;
+    const long rem = n - c.bulk_tiles * RAYS_PER_WAVE;
+    if (rem <= 0) { c.bulk_tiles = n32; return c; }
+    int p = 1;
+    while (p < 8 && rem * (2 * p) <= k->p_cap) p *= 2;
+    c.rem_p = p;
+    c.rem_tiles = (rem * p + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+    return c;
+}
+
 // One work unit = (32-ray tile, sample segment) rendered by one wavefront: with split > 1 the samples of a tile are divided
 // between `split` waves, whose partial composites are merged by combine_segments_kernel (finer load balance for small frames).
 // Returns true when the tile goes on in a later work item (chained segments only).
-template <int FORM, bool CHAIN>
-DEV bool render_tile(float* lds, const int lane, const long tile, const int seg) {
+// P (chained form only): samples of one ray a wavefront evaluates per step.  A level with few rays left is bound by the latency
+// of its 16 dependent steps (~30 us each however few waves a CU runs), not by throughput: with P = 2, 4, 8 a wavefront renders
+// 32 / P rays, P consecutive samples of each side by side in P neighbouring lanes, and walks a segment in 16 / P steps.  Every
+// lane of a ray's group composites the group's P samples in order from values fetched across the lanes, so the ray's state is
+// replicated in the group and the arithmetic per ray -- and with it every output bit -- is the same as with P = 1.
+template <int FORM, bool CHAIN, int P = 1>
+DEV bool render_tile(float* lds, const int lane, const long tile, const int seg, const long entry_base = 0) {
+    static_assert(P == 1 || CHAIN, "several samples per step: chained form only");
+    constexpr int RAYS = RAYS_PER_WAVE / P;             // rays per wavefront
     constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
     // tag: the split form's helpers check their operands' range (FORM_SPLIT_GUARD) or do not
     typename std::conditional<FORM == FORM_SPLIT_GUARD, Guard, NoGuard>::type gmax{};
@@ -851,13 +880,14 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
     const unsigned* const lw = reinterpret_cast<const unsigned*>(lds);
 
     const int n = lane & 31, half = lane >> 5;
-    const long ray0 = tile * RAYS_PER_WAVE;
+    const int sub = n & (P - 1), rn = n / P;            // which of the step's P samples this lane evaluates, which ray of the wavefront
+    const long ray0 = entry_base + tile * RAYS;      // (entry_base: where the launch's remainder units start in the ray list)
     // the chained form renders the launch slots listed in list_in (the rays the previous segment left alive, in no particular
-    // order), 32 list entries per wavefront; everything else renders 32 consecutive slots
+    // order), 32 / P list entries per wavefront; everything else renders 32 consecutive slots
     const long n_items = CHAIN ? chain_items(k0) : n_rays;
     if (ray0 >= n_items) return false;
-    const bool active = (ray0 + n) < n_items;
-    long slot = active ? ray0 + n : n_items - 1;
+    const bool active = (ray0 + rn) < n_items;
+    long slot = active ? ray0 + rn : n_items - 1;
     if constexpr (CHAIN) { if (k0->list_in) slot = k0->list_in[slot]; }
     const int ray = k0->out.order ? k0->out.order[slot] : (int)slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;             // Projector front test
@@ -875,7 +905,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
     for (int i = 0; i < 9; ++i) rin[i] = 0.f;
     int n_two = 0, n_done = 0;
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
-    const bool writer = active && (half == 0);
+    const bool writer = active && (half == 0) && (sub == 0);
 
     Stamps st;
     st.start();
@@ -893,14 +923,17 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
         rin[1] = c[0]; rin[2] = c[1]; rin[3] = c[2]; rin[4] = c[3];
         rin[5] = d[0]; rin[6] = d[1]; rin[7] = d[2]; rin[8] = d[3];
     }
-    for (; k < k_end; ++k) {
+    for (; k < k_end; k += P) {
         kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         const __attribute__((address_space(4))) FrameK& fr = kp->fr;
         const __attribute__((address_space(4))) OutK& out = kp->out;
+        // this lane's sample of the step (P > 1: the group's lanes take consecutive samples; one past the segment's end idles)
+        const bool in_seg = P == 1 || k + sub < k_end;
+        const int kl = P == 1 ? k : min(k + sub, k_end - 1);
         // raw2outputs(neg=True) flips rgb and sigma along the ray but not z (BaseRender.py:86-88,101):
         // composite step k consumes the network output of sample S-1-k.
-        const int ks = flip ? (S - 1 - k) : k;
+        const int ks = flip ? (S - 1 - kl) : kl;
         // get_sampling_points (BaseRender.py:37-38,48), jitter off
         const float t = (S > 1) ? linspace01(ks, S, step) : 0.f;
         const float z = near * (1.f - t) + far * t;
@@ -916,7 +949,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
             keep = sample_occupancy(fr.occ, fr.vol_dhw[0][0], fr.vol_dhw[0][1], fr.vol_dhw[0][2], gx, gy, gz) > 0.f;
             if (!__any(keep)) {
                 if (writer) {
-                    if (out.weights) out.weights[(size_t)ray * S + k] = 0.f;
+                    if (out.weights) out.weights[(size_t)ray * S + kl] = 0.f;
                     if (out.raw) *reinterpret_cast<f32x4*>(out.raw + ((size_t)ray * S + ks) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 T = T * (1.f + 1e-10f);                 // cumprod(1 - alpha + 1e-10) with alpha = 0
@@ -926,8 +959,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
 
         // chained form: a ray that is opaque stops HERE, whatever the other rays of its wavefront do (its result is a function
         // of the ray alone, so it does not matter which rays are packed together); the plain form stops a tile as a whole
-        const bool dead = CHAIN && T < term_eps;
-        n_done += dead ? 0 : 1;
+        const bool dead = CHAIN && P == 1 && T < term_eps;     // (P > 1: decided sample by sample in the composite below)
+        if constexpr (P == 1) n_done += dead ? 0 : 1;
         // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
         float fv[64];
 #pragma unroll
@@ -958,7 +991,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
             vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
             nvalid += s.valid;
         }
-        if (nvalid > 1.f && keep && !dead) ++n_two;     // pixel_mask (:139); culled samples never count
+        const bool two_views = nvalid > 1.f && keep;    // pixel_mask (:139); culled samples never count
+        if constexpr (P == 1) { if (two_views && !dead) ++n_two; }
 
         STAMP(st, 2);
         float sigma, rgb[3];
@@ -969,7 +1003,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
         }
 
-        if (out.raw && writer) {
+        if (out.raw && active && half == 0 && in_seg) {
             f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
             *reinterpret_cast<f32x4*>(out.raw + ((size_t)ray * S + ks) * 4) = rw;
         }
@@ -978,7 +1012,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
         float irgb[NV][3];
         float zk = z;
         if (flip) {
-            const float tk = (S > 1) ? linspace01(k, S, step) : 0.f;
+            const float tk = (S > 1) ? linspace01(kl, S, step) : 0.f;
             zk = near * (1.f - tk) + far * tk;
             const float ax_ = ox + dx * zk, ay_ = oy + dy * zk, az_ = oz + dz * zk;
 #pragma unroll
@@ -996,23 +1030,50 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
 
         // raw2outputs (:90-104): alpha = 1 - exp(-sigma); T = cumprod(1 - alpha + 1e-10) exclusive
         const float alpha = 1.f - fast_exp(-sigma);
-        const float wgt = dead ? 0.f : alpha * T;
-        T = dead ? T : T * ((1.f - alpha) + 1e-10f);
-        c_r = fmaf(wgt, rgb[0], c_r); c_g = fmaf(wgt, rgb[1], c_g); c_b = fmaf(wgt, rgb[2], c_b);
-        depth = fmaf(wgt, zk, depth);
-        acc += wgt;
+        if constexpr (P == 1) {
+            const float wgt = dead ? 0.f : alpha * T;
+            T = dead ? T : T * ((1.f - alpha) + 1e-10f);
+            c_r = fmaf(wgt, rgb[0], c_r); c_g = fmaf(wgt, rgb[1], c_g); c_b = fmaf(wgt, rgb[2], c_b);
+            depth = fmaf(wgt, zk, depth);
+            acc += wgt;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            rin[3 * v + 0] = fmaf(wgt, irgb[v][0], rin[3 * v + 0]);
-            rin[3 * v + 1] = fmaf(wgt, irgb[v][1], rin[3 * v + 1]);
-            rin[3 * v + 2] = fmaf(wgt, irgb[v][2], rin[3 * v + 2]);
-        }
-        if (writer) {
-            if (out.weights) out.weights[(size_t)ray * S + k] = wgt;
+            for (int v = 0; v < NV; ++v) {
+                rin[3 * v + 0] = fmaf(wgt, irgb[v][0], rin[3 * v + 0]);
+                rin[3 * v + 1] = fmaf(wgt, irgb[v][1], rin[3 * v + 1]);
+                rin[3 * v + 2] = fmaf(wgt, irgb[v][2], rin[3 * v + 2]);
+            }
+            if (writer) {
+                if (out.weights) out.weights[(size_t)ray * S + k] = wgt;
+            }
+        } else {
+            // the group's P samples in order, in every lane of the group alike: sample j's values come from lane (group base + j)
+            float my_wgt = 0.f;
+            const int base_lane = lane & ~(P - 1);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int src = base_lane + j;
+                const float a_j = __shfl(alpha, src);
+                const bool live = __shfl((int)(in_seg ? 1 : 0), src) != 0 && !(T < term_eps);     // this ray stops when ITS T is below the threshold
+                const float wgt = live ? a_j * T : 0.f;
+                T = live ? T * ((1.f - a_j) + 1e-10f) : T;
+                c_r = fmaf(wgt, __shfl(rgb[0], src), c_r); c_g = fmaf(wgt, __shfl(rgb[1], src), c_g); c_b = fmaf(wgt, __shfl(rgb[2], src), c_b);
+                depth = fmaf(wgt, __shfl(zk, src), depth);
+                acc += wgt;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    rin[3 * v + 0] = fmaf(wgt, __shfl(irgb[v][0], src), rin[3 * v + 0]);
+                    rin[3 * v + 1] = fmaf(wgt, __shfl(irgb[v][1], src), rin[3 * v + 1]);
+                    rin[3 * v + 2] = fmaf(wgt, __shfl(irgb[v][2], src), rin[3 * v + 2]);
+                }
+                n_done += live ? 1 : 0;
+                n_two += (live && __shfl((int)(two_views ? 1 : 0), src) != 0) ? 1 : 0;
+                if (j == sub) my_wgt = wgt;
+            }
+            if (active && half == 0 && in_seg && out.weights) out.weights[(size_t)ray * S + kl] = my_wgt;
         }
         STAMP(st, 6);
         // wavefront-level early termination (not in the reference): every ray of the tile is opaque
-        if (early && __all(T < term_eps)) { ++k; break; }
+        if (early && __all(T < term_eps)) { k += P; break; }
     }
     st.flush(lane);
     kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1033,8 +1094,10 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
     float* const part = kp->part;
     if constexpr (CHAIN) {
         // z_vals is a function of (near, far, k): segment 0 writes every row completely
-        if (out.z_vals && seg == 0)
-            write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_items - ray0), S, step, 0, S);
+        if constexpr (P == 1) {                 // (segment 0 always runs with one sample per step)
+            if (out.z_vals && seg == 0)
+                write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_items - ray0), S, step, 0, S);
+        }
         // a ray goes on in the next launch unless it has walked all S samples or is opaque; the survivors of the wavefront
         // take consecutive places in list_out (one atomic per wavefront) and park their 16 floats of state
         const bool goes_on = writer && k_end < S && !(T < term_eps);
@@ -1072,8 +1135,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg)
         return false;
     }
     if (writer) {
-        // samples skipped by early termination carry weight 0
-        for (; k < S; ++k) {
+        // samples skipped by early termination carry weight 0 (the loop has written this segment's up to where it stopped)
+        for (k = min(k, k_end); k < S; ++k) {
             if (out.weights) out.weights[(size_t)ray * S + k] = 0.f;
         }
         out.rgb[(size_t)ray * 3 + 0] = c_r; out.rgb[(size_t)ray * 3 + 1] = c_g; out.rgb[(size_t)ray * 3 + 2] = c_b;
@@ -1121,6 +1184,8 @@ render_fused_kernel(const KArgs ka) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int home = blockIdx.x & 7;            // workgroups are dealt to the XCDs round-robin
     int qx = home, dry = 0;
+    int samples_per_step = 1;                   // chained form: render_tile's P and list offset of the current unit
+    long entry_base = 0;
     if (ka.stagger && wave >= 4)
         for (int i = 0; i < ka.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     for (;;) {
@@ -1136,8 +1201,10 @@ render_fused_kernel(const KArgs ka) {
             seg = (int)(unit % kq->split);
             dry = 8;
         } else if (dry < 8) {
-            // every tile of the launch (32 consecutive slots, or 32 consecutive entries of the chained form's ray list)
-            const long n_tiles = ((CHAIN ? chain_items(kq) : kq->n_rays) + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+            // every tile of the launch (32 consecutive slots; chained form: the units of chain_plan())
+            long n_tiles = (kq->n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
+            ChainPlan plan;
+            if constexpr (CHAIN) { plan = chain_plan(kq); n_tiles = plan.bulk_tiles + plan.rem_tiles; }
             // fewer tiles than waves: deal them evenly, so that every CU runs the same few waves (each then steps faster) rather
             // than the first workgroups to arrive running eight and the rest none
             const long share = kq->wave_cap ? (long)kq->wave_cap : (n_tiles + gridDim.x - 1) / gridDim.x;
@@ -1149,12 +1216,24 @@ render_fused_kernel(const KArgs ka) {
                 continue;
             }
             tile = queue_tile(kq->chunk, qx, t);
-            if constexpr (CHAIN) seg = kq->seg;
+            if constexpr (CHAIN) {
+                seg = kq->seg;
+                samples_per_step = 1; entry_base = 0;
+                if (tile >= plan.bulk_tiles) { samples_per_step = plan.rem_p; entry_base = plan.bulk_tiles * RAYS_PER_WAVE; tile -= plan.bulk_tiles; }
+            }
             if constexpr (FORM == FORM_F32_FIXUP) {                 // only the tiles the split form flagged
                 if (wave_load(kq->guard + GUARD_HEADER_WORDS + tile, lane) == 0u) continue;
             }
         }
-        render_tile<FORM == FORM_F32_FIXUP ? FORM_F32 : FORM, CHAIN>(lds, lane, tile, seg);
+        constexpr int F = FORM == FORM_F32_FIXUP ? FORM_F32 : FORM;
+        if constexpr (CHAIN) {
+            if (samples_per_step == 8) render_tile<F, true, 8>(lds, lane, tile, seg, entry_base);
+            else if (samples_per_step == 4) render_tile<F, true, 4>(lds, lane, tile, seg, entry_base);
+            else if (samples_per_step == 2) render_tile<F, true, 2>(lds, lane, tile, seg, entry_base);
+            else render_tile<F, true, 1>(lds, lane, tile, seg, entry_base);
+        } else {
+            render_tile<F, false>(lds, lane, tile, seg);
+        }
     }
 }
 
@@ -2040,6 +2119,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         ka.part = reinterpret_cast<float*>(base + chain_ctrl_bytes(n_seg) + 2 * list_bytes);
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
         const unsigned grid = (unsigned)(wg < n_cus ? wg : n_cus);
+        static float f_fill = -1.f;
+        if (f_fill < 0.f) { const char* e = getenv("GPNERF_CHAIN_PFILL"); f_fill = e ? (float)atof(e) : 1.f; }
+        ka.p_cap = (long)((double)grid * GPNERF_MAX_WAVES * RAYS_PER_WAVE * f_fill);
         for (int sg = 0; sg < n_seg; ++sg) {
             ka.seg = sg;
             ka.queue = ctrl + 8 * sg;
