@@ -741,6 +741,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     int* list_out;
     unsigned* count_out;
     long p_cap;               // chain_plan(): 32 x the wavefronts the launch's remainder units may spread over
+    long first_slot, first_items;   // segment 0 (no list) renders launch slots [first_slot, first_slot + first_items)
     // range guard of the split form: guard[0] = number of flagged tiles, guard[64 + tile] = 1 when an MFMA operand of the tile
     // reached the f16 range; the fix-up launch (FORM_F32_FIXUP) renders exactly the flagged tiles again in the fp32 form
     unsigned* guard;
@@ -790,12 +791,13 @@ DEV void grid_coords(const FR& fr, float px, float py, float pz, float& gx, floa
 // its own 64-byte write request (measured: 2 GB of requests per 512x512x64 frame for the 134 MB of weights + z_vals).
 // z_vals is a function of (near, far, k) alone, so it is written after the sample loop instead, the whole wave walking one
 // ray's row: z_vals[ray][k] for k in [k_from, k_to), 64 consecutive samples per store instruction.
+// lane_stride: ray rr of the wavefront sits in lane rr * lane_stride (render_tile's P)
 DEV void write_z_vals(float* __restrict__ z_vals, const int lane, const int ray_lo, const float near, const float far,
-                      const int n_active, const int S, const float step, const int k_from, const int k_to) {
+                      const int n_active, const int S, const float step, const int k_from, const int k_to, const int lane_stride = 1) {
     for (int rr = 0; rr < n_active; ++rr) {
-        const int rid = __builtin_amdgcn_readlane(ray_lo, rr);
-        const float nr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, near), rr));
-        const float fr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, far), rr));
+        const int rid = __builtin_amdgcn_readlane(ray_lo, rr * lane_stride);
+        const float nr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, near), rr * lane_stride));
+        const float fr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, far), rr * lane_stride));
         for (int kk = k_from + lane; kk < k_to; kk += 64) {
             const float tk = (S > 1) ? linspace01(kk, S, step) : 0.f;
             z_vals[(size_t)rid * S + kk] = nr * (1.f - tk) + fr * tk;
@@ -825,18 +827,18 @@ DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
 #endif
 // number of launch slots a chained launch renders: the previous segment's survivors, or every ray (segment 0)
 typedef const __attribute__((address_space(4))) KArgs* kargs_cptr;
-DEV long chain_items(kargs_cptr k) { return k->list_in ? (long)*k->count_in : k->n_rays; }
+DEV long chain_items(kargs_cptr k) { return k->list_in ? (long)*k->count_in : k->first_items; }
 
 // Work units of a chained launch over n list entries on `slots` wavefronts: whole rounds of 32-entry tiles at one sample per step
 // (throughput-bound), then the remainder -- the tiles of the last, partial round, or all of a level with few rays -- with as many
 // samples of a ray side by side (render_tile's P) as still leave every wavefront a unit: what is left when the queue runs dry
-// is bound by the latency of a tile's dependent steps, not by throughput.  Segment 0 and occupancy culling: one sample per step.
+// is bound by the latency of a tile's dependent steps, not by throughput.  Under occupancy culling: one sample per step.
 struct ChainPlan { long bulk_tiles, rem_tiles; int rem_p; };
 DEV ChainPlan chain_plan(kargs_cptr k) {
     const long n = chain_items(k), n32 = (n + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     ChainPlan c;
     c.bulk_tiles = n32; c.rem_tiles = 0; c.rem_p = 1;
-    if (k->seg == 0 || (k->flags & GPNERF_FLAG_OCC_CULL) || k->p_cap <= 0) return c;
+    if ((k->flags & GPNERF_FLAG_OCC_CULL) || k->p_cap <= 0) return c;
     const long slots = k->p_cap / RAYS_PER_WAVE;
     c.bulk_tiles = (n32 / slots) * slots;
     const long rem = n - c.bulk_tiles * RAYS_PER_WAVE;
@@ -888,7 +890,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     if (ray0 >= n_items) return false;
     const bool active = (ray0 + rn) < n_items;
     long slot = active ? ray0 + rn : n_items - 1;
-    if constexpr (CHAIN) { if (k0->list_in) slot = k0->list_in[slot]; }
+    if constexpr (CHAIN) slot = k0->list_in ? (long)k0->list_in[slot] : k0->first_slot + slot;
     const int ray = k0->out.order ? k0->out.order[slot] : (int)slot;
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;             // Projector front test
     const bool flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;       // raw2outputs(neg=True)
@@ -1094,10 +1096,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     float* const part = kp->part;
     if constexpr (CHAIN) {
         // z_vals is a function of (near, far, k): segment 0 writes every row completely
-        if constexpr (P == 1) {                 // (segment 0 always runs with one sample per step)
-            if (out.z_vals && seg == 0)
-                write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS_PER_WAVE, n_items - ray0), S, step, 0, S);
-        }
+        if (out.z_vals && seg == 0)
+            write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS, n_items - ray0), S, step, 0, S, P);
         // a ray goes on in the next launch unless it has walked all S samples or is opaque; the survivors of the wavefront
         // take consecutive places in list_out (one atomic per wavefront) and park their 16 floats of state
         const bool goes_on = writer && k_end < S && !(T < term_eps);
@@ -2060,7 +2060,15 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const size_t seg_bytes = workspace && workspace_bytes > QUEUE_BYTES ? workspace_bytes - QUEUE_BYTES : 0;
     float* const seg_part = seg_bytes ? reinterpret_cast<float*>(static_cast<char*>(workspace) + QUEUE_BYTES) : nullptr;
     const bool may_split = seg_bytes && !(flags & GPNERF_FLAG_EARLY_TERM) && !out->samples_done;
-    const Geometry g = choose_geometry(tiles, n_samples, may_split, seg_bytes, n_rays, n_cus);
+    Geometry g = choose_geometry(tiles, n_samples, may_split, seg_bytes, n_rays, n_cus);
+    // whole rounds of full workgroups + a remainder launch (below) when the frame is that shape
+    static int f_rem = -1;
+    if (f_rem < 0) { const char* e = getenv("GPNERF_REMAINDER"); f_rem = e ? atoi(e) : 1; }
+    const int64_t slots = (int64_t)n_cus * GPNERF_MAX_WAVES;
+    const int64_t rem_tiles = tiles % slots;
+    const bool remainder = f_rem && workspace && workspace_bytes >= QUEUE_BYTES && !(flags & (GPNERF_FLAG_EARLY_TERM | GPNERF_FLAG_OCC_CULL)) &&
+                           n_cus >= 8 && tiles > slots && rem_tiles > 0 && rem_tiles * 8 <= slots && n_samples >= 8 && !getenv("GPNERF_WAVES");
+    if (remainder) { g.waves = GPNERF_MAX_WAVES; g.split = 1; }
     int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
     // more than one round of workgroups and nothing split: persistent workgroups + tile queue (see render_fused_kernel)
     static int f_dynamic = -1;
@@ -2070,6 +2078,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         if (hipMemsetAsync(workspace, 0, QUEUE_BYTES, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
         blocks = n_cus;
     }
+    const bool do_remainder = remainder && dynamic;
     const OutK ok = to_outk(out, ray_order);
     KArgs ka;
     memset(&ka, 0, sizeof(ka));
@@ -2122,6 +2131,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         static float f_fill = -1.f;
         if (f_fill < 0.f) { const char* e = getenv("GPNERF_CHAIN_PFILL"); f_fill = e ? (float)atof(e) : 1.f; }
         ka.p_cap = (long)((double)grid * GPNERF_MAX_WAVES * RAYS_PER_WAVE * f_fill);
+        ka.first_slot = 0; ka.first_items = (long)n_rays;
         for (int sg = 0; sg < n_seg; ++sg) {
             ka.seg = sg;
             ka.queue = ctrl + 8 * sg;
@@ -2139,12 +2149,37 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         }
         return fixup();
     }
+    // A frame of q whole rounds of wavefronts plus a FEW tiles (at most an eighth of a round) ends with those few running alone,
+    // S dependent steps at one wave per CU.  The persistent launch then takes the whole rounds, and the remainder goes to the
+    // segmented form's kernel as ONE segment of all S samples: its work units put 8 samples of a ray side by side (render_tile's
+    // P), S / 8 steps each, with the plain form's arithmetic per ray (term_eps = 0: nothing is ever frozen).  Bit-identical
+    // results; 576x576x64: 18.8 -> 18.0 ms.  (A larger remainder is better left to the queue: CUs with few waves step faster.)
+    if (do_remainder) ka.n_rays = (long)((tiles - rem_tiles) * RAYS_PER_WAVE);
     if (guard)
         hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
     else if (split16)
         hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
     else
         hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
+    if (do_remainder) {
+        if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
+        KArgs kr = ka;
+        kr.n_rays = (long)n_rays;
+        kr.queue = static_cast<unsigned*>(workspace) + 8;             // the second set of queue counters of the QUEUE_BYTES block
+        kr.chain = (int)n_samples; kr.seg = 0; kr.term_eps = 0.f;
+        kr.first_slot = ka.n_rays; kr.first_items = (long)n_rays - ka.n_rays;
+        kr.list_in = nullptr; kr.count_in = nullptr;
+        kr.list_out = reinterpret_cast<int*>(static_cast<unsigned*>(workspace) + 32);        // never written: nothing goes on after segment 0 of 1
+        kr.count_out = static_cast<unsigned*>(workspace) + 16;
+        kr.part = nullptr;
+        kr.p_cap = (long)(slots * RAYS_PER_WAVE);
+        if (guard)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3((unsigned)n_cus), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), kr);
+        else if (split16)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3((unsigned)n_cus), full_block, lds_split, S_(stream), kr);
+        else
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
+    }
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),

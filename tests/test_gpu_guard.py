@@ -159,3 +159,26 @@ def test_early_termination_in_segments_when_nothing_or_everything_terminates(sig
         assert int(done.max()) <= 16
         for k in ("rgb_map", "depth_map", "acc_map"):
             assert float((chained[k] - plain[k]).abs().max()) < 1e-4, k
+
+
+@pytest.mark.parametrize("split_f16", [False, True])
+@pytest.mark.parametrize("n_rays,S", [(65536 + 7, 24), (65536 + 255 * 32 + 1, 64), (65536 + 1000 * 32, 33), (2 * 65536 + 40 * 32 + 31, 16)])   # the first and the last take the remainder launch
+def test_a_frames_last_partial_round_runs_several_samples_per_step(n_rays, S, split_f16, fm, syn):
+    """A frame of whole rounds of wavefronts plus a few tiles: the few go to the segmented form's kernel as one segment of all S
+    samples, 2 / 4 / 8 samples of a ray side by side.  Same bits as the launch without a workspace (one wavefront per tile, every
+    sample in turn), for every output."""
+    sc = syn.make_scene(H=64, W=64, seed=9, fill="full", pose="random")
+    fr = build_frame(fm, sc)
+    base = rays_of(sc)
+    rays = base[torch.arange(n_rays, device=base.device) % base.shape[0]].contiguous()
+    want = ("weights", "z_vals", "rgb_in", "ray_mask", "raw", "samples_done")
+    a = fm.render_fused(fr, rays, S, want=want, split_f16=split_f16, guard=False)
+    b = fm.render_fused(fr, rays, S, want=want, split_f16=split_f16, guard=False, load_balance=False)
+    for k in a:
+        x, y = a[k], b[k]
+        if x.dtype == torch.float32:
+            x, y = x.view(torch.int32), y.view(torch.int32)
+        assert torch.equal(x, y), k
+    g = fm.render_fused(fr, rays, S, want=want + ("guard_tiles",), split_f16=split_f16, guard=True) if split_f16 else None
+    if g is not None:
+        assert int(g["guard_tiles"]) == 0 and torch.equal(g["rgb_map"], a["rgb_map"])
