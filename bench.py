@@ -232,9 +232,6 @@ def main():
             done = fm.render_fused(wl.frame, flow.rays, S, want=("samples_done",), ray_order=flow.order, **kw)["samples_done"]
             evaluated = float(done.float().mean()) / S
             alive_after = {str(k): float((done > k).float().mean()) for k in range(32, S, 32)}
-            if os.environ.get("GPNERF_DUMP_DONE"):      # per-tile item lengths, for tools/sim_tile_queue.py
-                import numpy as _np
-                _np.save(os.environ["GPNERF_DUMP_DONE"], done.view(-1, 32)[:, 0].cpu().numpy().astype(_np.int16))
             flops_per_launch *= evaluated
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         cfg_no = 2 if args.early_term else (3 if (args.size == 1024 and world > 1) else 1)
