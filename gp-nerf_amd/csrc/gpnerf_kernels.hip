@@ -349,9 +349,9 @@ template <int N> DEV void guard_n(Guard&, const float* v) {
     float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
 #pragma unroll
     for (int i = 2; i < N; i += 2) m = fmaxf(fmaxf(m, fabsf(v[i])), fabsf(v[i + 1]));
-    // Branch-free on purpose: lanes in range write a dummy word.  A branch here would split the layer chain into basic blocks,
-    // and with one in the chain the kernel's results came out 2e-5 off and different from run to run (measured): the wait
-    // states the compiler puts between an MFMA and the instructions that read its result are not kept across the boundary.
+    // Branch-free on purpose: lanes in range write a dummy word.  With `if (__any(...))` here -- a branch in the middle of the
+    // layer chain, never taken -- this kernel's results came out 2e-5 off and different from run to run (measured; a minimal
+    // kernel does not reproduce it, tools/micro/mfma_branch_hazard.hip, so the cause is not established).
     unsigned* const sl = guard_slot();
     (m < F16_RANGE ? sl + GUARD_LDS_SLOTS : sl)[0] = 1u;
 }

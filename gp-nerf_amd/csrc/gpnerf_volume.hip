@@ -106,8 +106,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict_
     // The neighbour rows and the packed weights come from L2 (a round trip each) and a tap's 4 * ng MFMAs take ~0.4 us: with the
     // weights loaded right before their MFMAs and only the next tap's rows in flight the wave spent its time waiting (46 us per
     // launch); DEPTH taps ahead, weights included, it does not.  The MFMA chain
-    // is branch-free on purpose (absent neighbours contribute zeros): a branch between two MFMAs of one accumulator chain is
-    // what broke the split-precision form's first range guard.
+    // is branch-free (absent neighbours contribute zeros): once the weights are prefetched the kernel is not bound by the MFMAs
+    // it could skip, and a never-taken branch inside an MFMA chain is what once broke the fused kernel.
     constexpr int DEPTH = 4;
     f32x4v buf[DEPTH][4], wbuf[DEPTH][4];                       // a tap's neighbour channels and its packed weights (L2-resident)
     auto load_w = [&](int k, f32x4v (&a)[4]) {
