@@ -67,6 +67,11 @@ typedef struct {
     float *st_rgb_feat; /* [N,S,V,35] */
     float *st_mask;     /* [N,S,V] */
     float *st_raw;      /* [N,S,4] */
+    /* build-side early termination (NOT in the reference; GPNERF_FLAG_EARLY_TERM in its per-ray form): with term_eps > 0 a ray
+     * stops accumulating at the first sample at whose start its transmittance is below term_eps (weight 0 from there on);
+     * samples_done [N] or NULL = the samples it evaluated; ray_mask then counts evaluated samples only */
+    int32_t *samples_done;
+    float term_eps;
 } OracleOut;
 
 static inline float elu(float x) { return x > 0.f ? x : expm1f(x); } /* nn.ELU(alpha=1) */
@@ -194,12 +199,13 @@ static void head_forward(const OracleFrame *f, const float *vol_feat /*128*/, co
  *                     are outputs of that file's Renderer.render (tests/golden/make_golden.py run_demo_case).
  *                     ray_mask (which that renderer does not return) counts kept samples only. */
 static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near far*/, int S, int flags,
-                           int64_t r, OracleOut *o, float *scratch /* S*(4+9+1) */) {
+                           int64_t r, OracleOut *o, float *scratch /* S*(4+9+1+1) */) {
     const int neg_ray = flags & 1, flip = (flags & 2) != 0, cull = (flags & 4) && f->occ;
     float *raw = scratch;            /* [S][4] */
     float *rin = scratch + 4 * S;    /* [S][9] */
     float *zv = scratch + 13 * S;    /* [S] */
-    int n_two = 0;
+    float *two = scratch + 14 * S;   /* [S] 1 where the sample has more than one valid view (pixel_mask :139) */
+    int n_two = 0, n_done = 0;
     const float near = ray[6], far = ray[7];
     for (int k = 0; k < S; ++k) {
         /* get_sampling_points :37-38,48.  torch.linspace(0,1,S) on CPU evaluates, per element,
@@ -255,7 +261,7 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
             grid_sample3d(f->occ, 1, f->vol_dhw[0][0], f->vol_dhw[0][1], f->vol_dhw[0][2], g[0], g[1], g[2], &occv);
             kept = occv > 0.f;
         }
-        if (kept && mask[0] + mask[1] + mask[2] > 1.f) ++n_two;     /* pixel_mask :139 */
+        two[k] = (kept && mask[0] + mask[1] + mask[2] > 1.f) ? 1.f : 0.f;     /* pixel_mask :139 */
         head_forward(f, vf, x, mask, raw + 4 * k, rin + 9 * k);
         if (cull) {
             if (!kept) raw[4 * k + 3] = 0.f;
@@ -268,8 +274,13 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
     for (int k = 0; k < S; ++k) {
         int src = flip ? (S - 1 - k) : k;              /* torch.flip of rgb and sigma only :86-88 */
         float alpha = 1.f - expf(-raw[4 * src + 3]);
-        float w = alpha * T;
-        T = T * (1.f - alpha + 1e-10f);
+        const int dead = o->term_eps > 0.f && T < o->term_eps;     /* build-side early termination, see OracleOut */
+        float w = dead ? 0.f : alpha * T;
+        if (!dead) {
+            T = T * (1.f - alpha + 1e-10f);
+            ++n_done;
+            n_two += two[src] != 0.f;
+        }
         for (int c = 0; c < 3; ++c) rgb[c] += w * raw[4 * src + c];
         depth += w * zv[k];
         acc += w;
@@ -287,6 +298,7 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
     }
     if (o->rgb_in) memcpy(o->rgb_in + 9 * r, rgbin, sizeof(rgbin));
     if (o->ray_mask) o->ray_mask[r] = (uint8_t)(n_two > 8);
+    if (o->samples_done) o->samples_done[r] = n_done;
 }
 
 /* rays: [N][8] = o(3) d(3) near far  (BaseRender.py:250).  Returns 0. */
@@ -296,7 +308,7 @@ int oracle_render(const OracleFrame *f, const float *rays, int64_t N, int S, int
 #endif
 #pragma omp parallel
     {
-        float *scratch = (float *)malloc(sizeof(float) * 14 * (size_t)S);
+        float *scratch = (float *)malloc(sizeof(float) * 15 * (size_t)S);
 #pragma omp for schedule(dynamic, 16)
         for (int64_t r = 0; r < N; ++r) render_one_ray(f, rays + 8 * r, S, flags, r, out, scratch);
         free(scratch);

@@ -34,6 +34,7 @@ class OracleOut(C.Structure):
         ("rgb", FP), ("depth", FP), ("acc", FP), ("disp", FP), ("weights", FP), ("z_vals", FP), ("rgb_in", FP),
         ("ray_mask", C.POINTER(C.c_uint8)),
         ("st_grid", FP), ("st_vol_feat", FP), ("st_rgb_feat", FP), ("st_mask", FP), ("st_raw", FP),
+        ("samples_done", C.POINTER(C.c_int32)), ("term_eps", C.c_float),
     ]
 
 
@@ -178,11 +179,13 @@ def build_occupancy(scene):
     return occ
 
 
-def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None, want_weights=True, occ=None, flip=None):
+def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None, want_weights=True, occ=None, flip=None, term_eps=0.0):
     """Run the oracle over all rays of a synthetic scene; returns a dict of numpy arrays.
     neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); default = neg_ray for the dense renderer
     and False for the progressive one, which never flips (demo_render.py:329-344).
-    occ: masks3d -> the progressive renderer's per-sample rules (pinned by tests/golden/demo_*.npz)."""
+    occ: masks3d -> the progressive renderer's per-sample rules (pinned by tests/golden/demo_*.npz).
+    term_eps > 0: the build's per-ray early termination (not in the reference): a ray stops at the first sample at whose start its
+    transmittance is below term_eps; adds `samples_done`."""
     if flip is None:
         flip = bool(neg_ray) and occ is None
     fr = Frame(scene)
@@ -212,6 +215,10 @@ def render(scene, n_samples, neg_ray=False, stages=False, n_threads=0, rays=None
     o.ray_mask = res["ray_mask"].ctypes.data_as(C.POINTER(C.c_uint8))
     if want_weights:
         o.weights, o.z_vals = _p(res["weights"]), _p(res["z_vals"])
+    if term_eps > 0:
+        res["samples_done"] = np.zeros(N, np.int32)
+        o.samples_done = res["samples_done"].ctypes.data_as(C.POINTER(C.c_int32))
+        o.term_eps = float(term_eps)
     if stages:
         for k in ("st_grid", "st_vol_feat", "st_rgb_feat", "st_mask", "st_raw"):
             setattr(o, k, _p(res[k]))

@@ -68,6 +68,14 @@ def test_config3_512x512x128_early_termination_against_the_oracle(split_f16, fm,
     for j, i in enumerate(idx):
         assert ref["weights"][j, done[i]:].sum() <= eps * 1.01
     assert np.abs(cut["weights"][idx] - ref["weights"]).max() < 2e-5
+    # (2b) the oracle with the same per-ray rule (a ray stops at the first sample at whose start its T is below the threshold):
+    # same stopping sample -- except where T sits within rounding of the threshold -- and the same maps, ray_mask included
+    ref_et = oracle.render(sc, S, rays=rays_h[idx], term_eps=eps)
+    same = done[idx] == ref_et["samples_done"]
+    assert same.mean() > 0.98, same.mean()
+    for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map", "weights"):
+        assert_close(cut[k][idx], ref_et[k], 2e-5, f"config 3 {k} vs the oracle's per-ray termination")
+    assert np.array_equal(cut["ray_mask"][idx][same].astype(bool), ref_et["ray_mask"][same].astype(bool))
     # (3) invariants over all 262 144 rays; every ray stops on its own: after the first sample that takes ITS transmittance
     # below the threshold (read off the unterminated launch's weights)
     check_invariants(cut, S)
