@@ -182,3 +182,26 @@ def test_a_frames_last_partial_round_runs_several_samples_per_step(n_rays, S, sp
     g = fm.render_fused(fr, rays, S, want=want + ("guard_tiles",), split_f16=split_f16, guard=True) if split_f16 else None
     if g is not None:
         assert int(g["guard_tiles"]) == 0 and torch.equal(g["rgb_map"], a["rgb_map"])
+
+
+def test_every_launch_form_runs_on_the_callers_stream(fm, syn):
+    """The library enqueues on the stream it is handed (torch's current stream) and nowhere else: the same calls inside
+    `torch.cuda.stream(side)` give the same bits, and the side stream alone orders them (the default stream is kept busy)."""
+    sc = syn.make_scene(H=96, W=96, seed=11, fill="full", pose="identity", sigma_bias=1.0)
+    fr = build_frame(fm, sc)
+    base = rays_of(sc)
+    rays = base[torch.arange(70000, device=base.device) % base.shape[0]].contiguous()
+    calls = [dict(), dict(split_f16=True), dict(early_term=True, term_eps=1e-5), dict(early_term=True, term_eps=1e-5, split_f16=True)]
+    ref = [fm.render_fused(fr, rays, 48, **kw) for kw in calls]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    busy = torch.empty((64, 1024, 1024), device=rays.device)
+    with torch.cuda.stream(side):
+        got = []
+        for kw in calls:
+            busy.normal_()                               # work on the DEFAULT stream would not order anything here
+            got.append(fm.render_fused(fr, rays, 48, **kw))
+    side.synchronize()
+    for a, b in zip(ref, got):
+        for k in ("rgb_map", "depth_map", "acc_map", "weights", "z_vals"):
+            assert torch.equal(a[k], b[k]), k
