@@ -205,3 +205,31 @@ def test_every_launch_form_runs_on_the_callers_stream(fm, syn):
     for a, b in zip(ref, got):
         for k in ("rgb_map", "depth_map", "acc_map", "weights", "z_vals"):
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(early_term=True, term_eps=1e-5), dict(split_f16=True), dict(early_term=True, term_eps=1e-5, split_f16=True)],
+                         ids=["plain", "early_term", "split_guard", "early_term_split_guard"])
+def test_a_calls_launch_sequence_captures_into_a_hip_graph(kw, fm, syn):
+    """gpnerf_render_fused only enqueues (memsets + kernels; every length the later launches need -- ray lists of the segmented
+    form, the guard's flag count -- stays on the device), so the whole call captures into a HIP graph and replays with the same
+    bits: a caller with a launch-bound loop around it can take the host out of that loop."""
+    sc = syn.make_scene(H=96, W=96, seed=11, fill="full", pose="identity", sigma_bias=1.0)
+    fr = build_frame(fm, sc)
+    base = rays_of(sc)
+    rays = base[torch.arange(70000, device=base.device) % base.shape[0]].contiguous()
+    ref = fm.render_fused(fr, rays, 48, **kw)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fm.render_fused(fr, rays, 48, **kw)              # warm-up on the capture stream (allocator pool, kernel attributes)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = fm.render_fused(fr, rays, 48, **kw)
+    for _ in range(3):
+        for v in out.values():
+            v.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for k in ("rgb_map", "depth_map", "acc_map", "weights", "z_vals"):
+            assert torch.equal(out[k], ref[k]), k
