@@ -30,7 +30,7 @@ from . import parallel as P_
 
 class Renderer(nn.Module):
     def __init__(self, encoder, nerfhead, is_train=False, neg_ray_train=False, neg_ray_val=False, n_rays=1024,
-                 n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=False, term_eps=1e-5,
+                 n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=None, term_eps=1e-5,
                  progressive=False, split_f16=None, sharded_outputs="all"):
         super().__init__()
         self.encoder = encoder
@@ -44,7 +44,13 @@ class Renderer(nn.Module):
         self.voxel_size = np.array(voxel_size)
         self.chunk = chunk          # kept for interface parity; the fused kernel tiles rays itself
         self.mesh_th = mesh_th
-        self.early_term, self.term_eps = early_term, term_eps
+        # early_term (not in the reference): rays stop once their transmittance is below term_eps (rgb / acc change by at most
+        # term_eps, depth by term_eps * far).  Off by default; GPNERF_EARLY_TERM=1 (and GPNERF_TERM_EPS) turn it on from outside,
+        # e.g. for the reference's tools/inference.py run, which has no config key for it.
+        if early_term is None:
+            early_term = os.environ.get("GPNERF_EARLY_TERM", "0") == "1"
+            term_eps = float(os.environ.get("GPNERF_TERM_EPS", term_eps))
+        self.early_term, self.term_eps = bool(early_term), float(term_eps)
         # progressive=True: the inference renderer's path (libs/renders/demo_render.py): rays are selected from the
         # occupied voxels of the frame's volume, samples are occupancy-culled, and the result is returned as `pred_img`
         self.progressive = progressive

@@ -422,3 +422,41 @@ def test_progressive_renderer_on_an_empty_volume(plugins, syn):
     with torch.no_grad():
         ret = r.render(b)
     assert ret["rgb_map"].shape == (0, 3) and not ret["mask_at_box"].any() and np.abs(ret["pred_img"]).max() == 0
+
+
+def test_renderer_with_early_termination_stays_inside_the_bound(plugins, full_scene):
+    """`Renderer(early_term=True)` (or GPNERF_EARLY_TERM=1) through the reference's entry point on the full 512x512x64 frame:
+    the segmented per-ray form, against the same renderer without termination: rgb / acc within term_eps, depth within
+    term_eps * far, and the dict has the reference's keys and shapes."""
+    from types import SimpleNamespace as NS
+    hip_render = importlib.import_module("hip_render")
+    sc = full_scene
+    cfg = NS(encoder=NS(file="hip_encoder", name="resnet34", out_ch=32),
+             head=NS(file="hip_head", rgb=NS(use_rgbhead=True), sigma=NS(code_dim=32, n_heads=4, n_layers=4, n_smpl=6890, outdims=[32, 32, 32, 32])),
+             dataset=NS(train=NS(name="zju_mocap", chunk=400), test=NS(name="zju_mocap", chunk=2000), voxel_size=[0.005] * 3),
+             train=NS(n_rays=1024, n_samples=64), test=NS(mesh_th=50))
+    dev = torch.device("cuda:0")
+    r = hip_render.build_render(cfg).to(dev).eval()
+    sd = r.state_dict()
+    for k, v in sc["head"].items():
+        sd["nerfhead." + k] = torch.from_numpy(v.copy())
+    sd["nerfhead.rgbhead.out_geometry_fc.6.bias"] = sd["nerfhead.rgbhead.out_geometry_fc.6.bias"] + 1.0       # rays become opaque
+    r.load_state_dict(sd, strict=True)
+    keys = ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "feature", "coord", "out_sh", "bounds", "Rh", "R", "Th", "body_msk",
+            "mask_at_box")
+    b = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in keys}
+    b["featmaps"] = torch.from_numpy(sc["featmaps"]).to(dev)
+    b["volumes"] = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in sc["volumes"]]
+    with torch.no_grad():
+        assert r.early_term is False
+        full = r.render(b)
+        r.early_term, r.term_eps = True, 1e-5
+        cut = r.render(b)
+    n = b["ray_o"].shape[1]
+    far = float(b["far"].max())
+    assert cut["rgb_map"].shape == (1, n, 3) and cut["alpha"].shape == (1, n, 64) and cut["z_vals"].shape == (1, n, 64)
+    assert float((cut["rgb_map"] - full["rgb_map"]).abs().max()) < 2e-5 and float((cut["acc_map"] - full["acc_map"]).abs().max()) < 2e-5
+    assert float((cut["depth_map"] - full["depth_map"]).abs().max()) < 1e-5 * far + 1e-5
+    assert torch.equal(cut["z_vals"], full["z_vals"])
+    evaluated = float((cut["alpha"] != 0).float().mean())
+    assert evaluated < 0.6, evaluated                   # termination really fires on this scene
