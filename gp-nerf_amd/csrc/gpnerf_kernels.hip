@@ -742,6 +742,10 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     unsigned* count_out;
     long p_cap;               // chain_plan(): 32 x the wavefronts the launch's remainder units may spread over
     long first_slot, first_items;   // segment 0 (no list) renders launch slots [first_slot, first_slot + first_items)
+    // occupancy culling: bit k of cull_mask[slot * 2 + (k >> 6)] = launch slot `slot` keeps its sample of composite step k
+    // (occupancy_mask_kernel, one pass over every sample before the launch); nullptr: the sample loop tests as it goes
+    const unsigned long long* cull_mask;
+    const int* tile_order;    // with cull_mask: the launch's tiles, most steps first (order_tiles_by_steps); nullptr: as they come
     // range guard of the split form: guard[0] = number of flagged tiles, guard[64 + tile] = 1 when an MFMA operand of the tile
     // reached the f16 range; the fix-up launch (FORM_F32_FIXUP) renders exactly the flagged tiles again in the fp32 form
     unsigned* guard;
@@ -858,8 +862,9 @@ DEV ChainPlan chain_plan(kargs_cptr k) {
 // 32 / P rays, P consecutive samples of each side by side in P neighbouring lanes, and walks a segment in 16 / P steps.  Every
 // lane of a ray's group composites the group's P samples in order from values fetched across the lanes, so the ray's state is
 // replicated in the group and the arithmetic per ray -- and with it every output bit -- is the same as with P = 1.
-template <int FORM, bool CHAIN, int P = 1>
+template <int FORM, bool CHAIN, int P = 1, bool CULL = false>
 DEV bool render_tile(float* lds, const int lane, const long tile, const int seg, const long entry_base = 0) {
+    static_assert(!CULL || (!CHAIN && P == 1), "occupancy culling: plain form only");
     static_assert(P == 1 || CHAIN, "several samples per step: chained form only");
     constexpr int RAYS = RAYS_PER_WAVE / P;             // rays per wavefront
     constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
@@ -895,7 +900,9 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0;             // Projector front test
     const bool flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;       // raw2outputs(neg=True)
     const bool early = (flags & GPNERF_FLAG_EARLY_TERM) != 0;
-    const bool cull = (flags & GPNERF_FLAG_OCC_CULL) != 0 && k0->fr.occ != nullptr;
+    // occupancy culling: CULL = the form that walks keep bits computed before the launch (its own instantiation); without them
+    // (outputs that need every step written, no workspace) the plain instantiation tests sample by sample
+    const bool cull = !CULL && (flags & GPNERF_FLAG_OCC_CULL) != 0 && k0->fr.occ != nullptr;
 
     const f32x4 r0 = *reinterpret_cast<const f32x4*>(k0->rays + (size_t)ray * 8);
     const f32x4 r1 = *reinterpret_cast<const f32x4*>(k0->rays + (size_t)ray * 8 + 4);
@@ -925,7 +932,28 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         rin[1] = c[0]; rin[2] = c[1]; rin[3] = c[2]; rin[4] = c[3];
         rin[5] = d[0]; rin[6] = d[1]; rin[7] = d[2]; rin[8] = d[3];
     }
+    // occupancy culling with the keep bits computed beforehand (occupancy_mask_kernel): the wavefront walks only the steps at
+    // which one of its rays keeps its sample; a skipped step costs nothing (tested as it goes, it cost ~12 % of a full step:
+    // sample position, grid coordinates, eight occupancy taps, a ballot -- 3.4 ms for a frame that evaluates 14.5 % of its steps)
+    unsigned long long my_keep[2] = {0ull, 0ull}, any_keep[2] = {0ull, 0ull};
+    constexpr bool masked = CULL;
+    if (masked) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            my_keep[w] = active ? k0->cull_mask[(size_t)slot * 2 + w] : 0ull;
+            unsigned lo = (unsigned)my_keep[w], hi = (unsigned)(my_keep[w] >> 32);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { lo |= (unsigned)__shfl_xor((int)lo, o); hi |= (unsigned)__shfl_xor((int)hi, o); }
+            any_keep[w] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+        }
+    }
     for (; k < k_end; k += P) {
+        if (masked) {                           // the next step >= k at which the tile has anything to do
+            const unsigned long long w0 = k < 64 ? (any_keep[0] >> k) << k : 0ull;
+            const unsigned long long w1 = k < 64 ? any_keep[1] : (k < 128 ? (any_keep[1] >> (k - 64)) << (k - 64) : 0ull);
+            k = w0 ? __builtin_ctzll(w0) : (w1 ? 64 + __builtin_ctzll(w1) : k_end);
+            if (k >= k_end) break;
+        }
         kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         const __attribute__((address_space(4))) FrameK& fr = kp->fr;
@@ -947,7 +975,9 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         // progressive culling (demo_render.py:270-283): evaluate only samples whose occupancy interpolates to > 0;
         // a tile whose 32 samples are all culled skips its gathers and the MLP (alpha = 0 for all of them)
         bool keep = true;
-        if (cull) {
+        if constexpr (masked) {
+            keep = ((k < 64 ? my_keep[0] >> k : my_keep[1] >> (k - 64)) & 1ull) != 0ull;
+        } else if (cull) {
             keep = sample_occupancy(fr.occ, fr.vol_dhw[0][0], fr.vol_dhw[0][1], fr.vol_dhw[0][2], gx, gy, gz) > 0.f;
             if (!__any(keep)) {
                 if (writer) {
@@ -1000,7 +1030,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         float sigma, rgb[3];
         if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
-        if (cull) {
+        if (CULL || cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
         }
@@ -1161,7 +1191,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 // 8-wave workgroup resident per CU a static grid holds the CU until its slowest tile is done -- the queue hands the next
 // tile to whichever wave is free.  Static launches (one unit per wave, XCD-aware remap) remain for frames smaller than
 // one round and for the sample-split geometry.
-template <int FORM, bool CHAIN>
+template <int FORM, bool CHAIN, bool CULL = false>
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const KArgs ka) {
     constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
@@ -1216,6 +1246,7 @@ render_fused_kernel(const KArgs ka) {
                 continue;
             }
             tile = queue_tile(kq->chunk, qx, t);
+            if constexpr (CULL) { if (kq->tile_order) tile = kq->tile_order[tile]; }
             if constexpr (CHAIN) {
                 seg = kq->seg;
                 samples_per_step = 1; entry_base = 0;
@@ -1232,11 +1263,88 @@ render_fused_kernel(const KArgs ka) {
             else if (samples_per_step == 2) render_tile<F, true, 2>(lds, lane, tile, seg, entry_base);
             else render_tile<F, true, 1>(lds, lane, tile, seg, entry_base);
         } else {
-            render_tile<F, false>(lds, lane, tile, seg);
+            render_tile<F, false, 1, CULL>(lds, lane, tile, seg);
         }
     }
 }
 
+
+// The keep bits of occupancy culling for every sample of a launch, before it: one wavefront per (launch slot, 64 samples), lane =
+// sample; the position, grid coordinate and occupancy arithmetic is the sample loop's own (same functions), so the bits are
+// what the loop would decide.  mask[slot * 2 + w] bit j <-> composite step 64 w + j (which evaluates sample S-1-k under flip).
+__global__ void __launch_bounds__(256) occupancy_mask_kernel(const FrameK fr, const float* __restrict__ rays, const int32_t* __restrict__ order,
+                                                             const long n_rays, const int S, const int flip,
+                                                             unsigned long long* __restrict__ mask) {
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool two = S > 64;                    // one wavefront per ray up to 64 samples, two beyond
+    const long slot = two ? unit >> 1 : unit;
+    if (slot >= n_rays) return;
+    const int w = two ? (int)(unit & 1) : 0, lane = threadIdx.x & 63, k = w * 64 + lane;
+    const int ray = order ? order[slot] : (int)slot;
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rays + (size_t)ray * 8);
+    const f32x4 r1 = *reinterpret_cast<const f32x4*>(rays + (size_t)ray * 8 + 4);
+    bool keep = false;
+    if (k < S) {
+        const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
+        const int ks = flip ? (S - 1 - k) : k;
+        const float t = (S > 1) ? linspace01(ks, S, step) : 0.f;
+        const float z = r1[2] * (1.f - t) + r1[3] * t;
+        const float px = r0[0] + r0[3] * z, py = r0[1] + r1[0] * z, pz = r0[2] + r1[1] * z;
+        float gx, gy, gz;
+        grid_coords(fr, px, py, pz, gx, gy, gz);
+        keep = sample_occupancy(fr.occ, fr.vol_dhw[0][0], fr.vol_dhw[0][1], fr.vol_dhw[0][2], gx, gy, gz) > 0.f;
+    }
+    const unsigned long long bits = __ballot(keep);
+    if (lane == 0) {
+        mask[slot * 2 + w] = bits;
+        if (!two) mask[slot * 2 + 1] = 0ull;
+    }
+}
+
+// Under culling a tile costs as many steps as its 32 rays keep samples at (the union of their masks): 0 ... S, known before the
+// launch.  Handed out in launch order, the long tiles that come late set the frame's time (10 % occupied blocks: 56 steps on the
+// busiest wavefront slot against 37 on average); longest first, the queue packs them (38).  tile_steps_kernel counts, and
+// tile_sort_kernel -- one workgroup, a STABLE counting sort over 16 classes of step counts -- orders: tiles of one class keep
+// their launch order, so neighbouring tiles still follow each other (an order that scatters them costs the gathers their L2
+// locality: +1.2 ms on a frame that culls nothing).
+constexpr int CULL_CLASSES = 16, SORT_THREADS = 1024;
+__global__ void __launch_bounds__(256) tile_steps_kernel(const unsigned long long* __restrict__ mask, const long n_rays, int* __restrict__ steps) {
+    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long m0 = 0ull, m1 = 0ull;
+    if (slot < n_rays) { m0 = mask[slot * 2]; m1 = mask[slot * 2 + 1]; }
+    unsigned a = (unsigned)m0, b = (unsigned)(m0 >> 32), c = (unsigned)m1, d = (unsigned)(m1 >> 32);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        a |= (unsigned)__shfl_xor((int)a, o); b |= (unsigned)__shfl_xor((int)b, o);
+        c |= (unsigned)__shfl_xor((int)c, o); d |= (unsigned)__shfl_xor((int)d, o);
+    }
+    if ((threadIdx.x & 31) == 0 && slot < n_rays) steps[slot / RAYS_PER_WAVE] = __popc(a) + __popc(b) + __popc(c) + __popc(d);
+}
+__global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(const int* __restrict__ steps, const int n_tiles, const int S, int* __restrict__ order) {
+    __shared__ int cnt[CULL_CLASSES * SORT_THREADS];           // [class][thread], class 0 = most steps; 64 KB
+    __shared__ int part[SORT_THREADS];
+    const int i = threadIdx.x, per = (n_tiles + SORT_THREADS - 1) / SORT_THREADS, width = (S + CULL_CLASSES - 1) / CULL_CLASSES;
+    const int lo = min(i * per, n_tiles), hi = min(lo + per, n_tiles);
+    auto cls = [&](int t) { return CULL_CLASSES - 1 - min(CULL_CLASSES - 1, steps[t] / width); };
+    for (int c = 0; c < CULL_CLASSES; ++c) cnt[c * SORT_THREADS + i] = 0;
+    for (int t = lo; t < hi; ++t) ++cnt[cls(t) * SORT_THREADS + i];
+    __syncthreads();
+    // exclusive prefix over the flattened [class][thread] table: thread i owns entries 16 i ... 16 i + 15 (all of one class)
+    int sum = 0;
+    for (int e = 0; e < CULL_CLASSES; ++e) sum += cnt[i * CULL_CLASSES + e];
+    part[i] = sum;
+    __syncthreads();
+    for (int o = 1; o < SORT_THREADS; o <<= 1) {
+        const int v = i >= o ? part[i - o] : 0;
+        __syncthreads();
+        part[i] += v;
+        __syncthreads();
+    }
+    int run = part[i] - sum;
+    for (int e = 0; e < CULL_CLASSES; ++e) { const int v = cnt[i * CULL_CLASSES + e]; cnt[i * CULL_CLASSES + e] = run; run += v; }
+    __syncthreads();
+    for (int t = lo; t < hi; ++t) order[cnt[cls(t) * SORT_THREADS + i]++] = t;
+}
 
 // merge the per-segment partial composites of a ray front to back: out = sum_s (prod_{j<s} T_j) * partial_s
 __global__ void combine_segments_kernel(const float* __restrict__ part, const long n_rays, const int S, const int split,
@@ -1770,6 +1878,11 @@ size_t chain_ctrl_bytes(int n_seg) { return align256((size_t)n_seg * 9 * sizeof(
 size_t guard_bytes(int64_t n_rays) {
     return align256((GUARD_HEADER_WORDS + (size_t)((n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE)) * sizeof(unsigned));
 }
+// occupancy culling: keep bits per ray, then per tile its step count and its place in the longest-first order
+size_t cull_tiles(int64_t n_rays) { return (size_t)((n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE); }
+size_t cull_mask_bytes(int64_t n_rays) {
+    return align256((size_t)n_rays * 2 * sizeof(unsigned long long)) + 2 * align256(cull_tiles(n_rays) * sizeof(int));
+}
 size_t chain_bytes(int64_t n_rays, int S) {
     if (chain_segs(S) < 2 || n_rays >= ((int64_t)1 << 31)) return 0;
     return chain_ctrl_bytes(chain_segs(S)) + 2 * align256((size_t)n_rays * sizeof(int)) + (size_t)n_rays * 16 * sizeof(float);
@@ -1829,6 +1942,10 @@ int device_ready(int* cus) {
             d.ok = lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, false, true>), lds_split) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT_GUARD, false, true>), lds_split + GUARD_LDS_SLOTS * 8) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, false>), lds_split) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, true>), lds_split) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT_GUARD, false>), lds_split + GUARD_LDS_SLOTS * 8) &&
@@ -2055,7 +2172,17 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const size_t lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
     int n_cus = 0;
     if (device_ready(&n_cus) != GPNERF_OK) return GPNERF_E_DEVICE;
+    const bool culling = (flags & GPNERF_FLAG_OCC_CULL) != 0 && f->occ != nullptr;
     if (flags & GPNERF_FLAG_OCC_CULL) k.voxel[0] = k.voxel[1] = k.voxel[2] = 0.005f;   // demo_render.py:91 `xyz / 0.005`
+    // occupancy culling: the keep bits of every sample in one pass before the launch (occupancy_mask_kernel), in the last
+    // cull_mask_bytes() of the workspace (before the guard's block); outputs that need every step written keep the in-loop test
+    unsigned long long* cull_mask = nullptr;
+    static int f_mask = -1;
+    if (f_mask < 0) { const char* e = getenv("GPNERF_CULL_MASK"); f_mask = e ? atoi(e) : 3; }       // experiments: 1 = keep bits, 2 = + tile order
+    if ((f_mask & 1) && culling && workspace && n_samples <= 128 && !out->weights && !out->raw && workspace_bytes >= QUEUE_BYTES + cull_mask_bytes(n_rays)) {
+        workspace_bytes = (workspace_bytes - cull_mask_bytes(n_rays)) & ~(size_t)255;
+        cull_mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + workspace_bytes);
+    }
     // workspace layout: [0, QUEUE_BYTES) the tile queue's counters, then the per-segment partial composites
     const size_t seg_bytes = workspace && workspace_bytes > QUEUE_BYTES ? workspace_bytes - QUEUE_BYTES : 0;
     float* const seg_part = seg_bytes ? reinterpret_cast<float*>(static_cast<char*>(workspace) + QUEUE_BYTES) : nullptr;
@@ -2096,8 +2223,12 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         kf.split = 1; kf.part = nullptr; kf.dynamic = 1; kf.queue = guard_words + 8; kf.wave_cap = 0;
         kf.chain = 0; kf.seg = 0; kf.list_in = nullptr; kf.count_in = nullptr; kf.list_out = nullptr; kf.count_out = nullptr;
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
-        hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FIXUP, false>), dim3((unsigned)(wg < n_cus ? wg : n_cus)), full_block, lds_bytes,
-                           S_(stream), kf);
+        if (kf.cull_mask)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FIXUP, false, true>), dim3((unsigned)(wg < n_cus ? wg : n_cus)), full_block, lds_bytes,
+                               S_(stream), kf);
+        else
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FIXUP, false>), dim3((unsigned)(wg < n_cus ? wg : n_cus)), full_block, lds_bytes,
+                               S_(stream), kf);
         return launch_status();
     };
     static int f_cap = -1;
@@ -2115,7 +2246,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // bench frame a ray needs 20 % of its samples, a fixed 32-ray tile 35-43 % (until its last ray is opaque).  The launches
     // are enqueued unconditionally -- one that finds its list empty returns before it stages anything.
     // (frames of less than one round of waves gain nothing from it, and every XCD's queue needs workgroups of its own)
-    const size_t need_chain = (flags & GPNERF_FLAG_EARLY_TERM) && f_dynamic && tiles >= (int64_t)n_cus * GPNERF_MAX_WAVES && n_cus >= 8
+    const size_t need_chain = (flags & GPNERF_FLAG_EARLY_TERM) && !culling && f_dynamic && tiles >= (int64_t)n_cus * GPNERF_MAX_WAVES && n_cus >= 8
                                   ? chain_bytes(n_rays, n_samples) : 0;
     if (need_chain && workspace && workspace_bytes >= need_chain) {
         const int n_seg = chain_segs(n_samples);
@@ -2155,7 +2286,31 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // P), S / 8 steps each, with the plain form's arithmetic per ray (term_eps = 0: nothing is ever frozen).  Bit-identical
     // results; 576x576x64: 18.8 -> 18.0 ms.  (A larger remainder is better left to the queue: CUs with few waves step faster.)
     if (do_remainder) ka.n_rays = (long)((tiles - rem_tiles) * RAYS_PER_WAVE);
-    if (guard)
+    if (cull_mask) {
+        ka.cull_mask = cull_mask;
+        {
+            const long units = (long)n_rays * (n_samples > 64 ? 2 : 1);
+            hipLaunchKernelGGL(occupancy_mask_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, S_(stream), k, rays, ok.order, (long)n_rays,
+                               (int)n_samples, (flags & GPNERF_FLAG_FLIP_SAMPLES) ? 1 : 0, cull_mask);
+            if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
+            if (dynamic && (f_mask & 2)) {      // longest tiles first (see tile_steps_kernel)
+                char* const after = reinterpret_cast<char*>(cull_mask) + align256((size_t)n_rays * 2 * sizeof(unsigned long long));
+                int* const steps = reinterpret_cast<int*>(after);
+                int* const order = reinterpret_cast<int*>(after + align256(cull_tiles(n_rays) * sizeof(int)));
+                hipLaunchKernelGGL(tile_steps_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream), (const unsigned long long*)cull_mask,
+                                   (long)n_rays, steps);
+                hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(SORT_THREADS), 0, S_(stream), (const int*)steps, (int)tiles, (int)n_samples, order);
+                if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
+                ka.tile_order = order;
+            }
+        }
+        if (guard)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
+        else if (split16)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
+        else
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
+    } else if (guard)
         hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
     else if (split16)
         hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
@@ -2194,7 +2349,8 @@ size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples) {
     // sample segments per ray, 16 floats each; or what the chained segments of an early-terminating launch need
     const size_t plain = QUEUE_BYTES + (n_rays <= 131072 ? (size_t)n_rays * GPNERF_MAX_SPLIT * 16 * sizeof(float) : 0);
     const size_t chain = chain_bytes(n_rays, n_samples);
-    return align256(plain > chain ? plain : chain) + guard_bytes(n_rays);      // + the split form's range-guard flags
+    // + the keep bits of occupancy culling + the split form's range-guard flags
+    return align256(plain > chain ? plain : chain) + cull_mask_bytes(n_rays) + guard_bytes(n_rays);
 }
 
 size_t gpnerf_render_guard_bytes(int64_t n_rays) { return n_rays > 0 ? guard_bytes(n_rays) : 0; }
