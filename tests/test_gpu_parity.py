@@ -289,3 +289,32 @@ def test_render_is_deterministic(split_f16, fm, syn):
         b = fm.render_fused(fr, rays, 32, split_f16=split_f16, load_balance=lb)
         for k in a:
             assert torch.equal(a[k], b[k]), (k, lb)
+
+
+@pytest.mark.parametrize("size,S,neg,split_f16,occupancy", [(24, 48, False, False, 0.35), (24, 48, True, True, 0.35), (40, 100, False, False, 0.2),
+                                                            (272, 32, False, False, 0.1), (272, 24, False, True, 0.3)])
+def test_culling_with_precomputed_keep_bits_equals_in_loop_test(size, S, neg, split_f16, occupancy, fm, oracle, syn):
+    """Occupancy culling without per-sample outputs takes the form that computes every sample's keep bit before the launch, walks
+    only the steps a tile keeps and (frames of more than one round of workgroups: the 272x272 cases) hands tiles out longest
+    first.  Same bits as the form that tests inside the sample loop (chosen by asking for `weights`), and both match the oracle's
+    restatement of demo_render.py:270-344."""
+    sc = syn.make_scene(H=size, W=size, seed=91, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1,
+                        vol_occupancy=occupancy, neg_cams=neg)
+    fr = build_frame(fm, sc)
+    fr.build_occupancy()
+    rays = rays_of(sc)
+    order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], size, size, 4, 8)).to("cuda:0")
+    kw = dict(neg_ray=neg, occ_cull=True, split_f16=split_f16, load_balance=False, ray_order=order)
+    in_loop = cpu(fm.render_fused(fr, rays, S, want=("weights",), **kw))
+    masked = cpu(fm.render_fused(fr, rays, S, want=(), **kw))
+    assert "weights" not in masked
+    for k in masked:
+        assert np.array_equal(masked[k].view(np.int32), in_loop[k].view(np.int32)), k
+    again = cpu(fm.render_fused(fr, rays, S, want=(), **kw))
+    for k in masked:
+        assert np.array_equal(masked[k].view(np.int32), again[k].view(np.int32)), k
+    pick = np.random.default_rng(5).choice(size * size, 256, replace=False)
+    ref = oracle.render(sc, S, neg_ray=neg, rays=rays.cpu().numpy()[pick], occ=oracle.build_occupancy(sc))
+    for k in ("rgb_map", "acc_map", "depth_map"):
+        assert_close(masked[k][pick], ref[k], TOL, k)
+    assert (in_loop["weights"].sum(-1) == 0).mean() > 0.05, "no ray of the scene is culled entirely"
