@@ -43,7 +43,11 @@ extern "C" {
                                       GPNERF_FLAG_FLIP_SAMPLES; the progressive renderer's integral never flips */
 #define GPNERF_FLAG_FLIP_SAMPLES 16u /* raw2outputs(neg=True): rgb and sigma reversed along the ray before compositing, z not
                                       (BaseRender.py:86-88,101); rgb_in_map pairs the weights with the un-flipped rgb_in (:147) */
-#define GPNERF_FLAG_EARLY_TERM 2u  /* stop a 32-ray wave tile once every ray has T < term_eps (not in the reference) */
+#define GPNERF_FLAG_EARLY_TERM 2u  /* a ray stops at the first sample at whose start its transmittance T < term_eps (not in the
+                                      reference; everything dropped is bounded by term_eps, depth by term_eps * far).  With the
+                                      workspace and at least one round of wavefronts the samples are walked in 16-sample segments,
+                                      one launch each, the rays still alive re-packed 32 to a wavefront (same bits per ray in any
+                                      ray order); otherwise a 32-ray tile stops once all its rays have */
 #define GPNERF_FLAG_SPLIT_F16 8u   /* dense layers on f16 MFMA with every fp32 operand split into f16 hi + lo (three MFMAs per
                                       k-step, f32 accumulation): ~fp32 accuracy (1e-6 on rgb), 3/16 of the fp32 MFMA cost.
                                       Needs frame->head_blob_split; operands must stay below the f16 range (65504):
@@ -57,7 +61,9 @@ extern "C" {
                                       with its literal voxel size 0.005 instead of frame->voxel (:87-95), a sample is evaluated
                                       only where the occupancy volume (frame->occ) interpolates to > 0 (:270-283), culled
                                       samples carry alpha = 0, colour is kept only where alpha > 1e-14 (:317,:329-341);
-                                      ray_mask counts kept samples only */
+                                      ray_mask counts kept samples only.  With the workspace and no per-sample output (weights,
+                                      raw) the keep decisions are made in a pass before the launch and the tiles are handed out
+                                      longest first; same bits either way */
 
 /* Per-frame constants (everything render_rays reads that does not depend on the ray).
  * Layouts are channels-last so that one bilinear / trilinear tap is one contiguous
