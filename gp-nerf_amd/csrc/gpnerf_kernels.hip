@@ -56,9 +56,24 @@ struct Stamps {
     }
 };
 #define STAMP(st, i) (st).mark(i)
+#define STAMP_T0() const unsigned long long stamp_t0 = Stamps::now()
+#define STAMP_ADD(i, lane) do { if ((lane) == 0) { atomicAdd(&g_stamps[i], Stamps::now() - stamp_t0); atomicAdd(&g_stamps[(i) + 4], 1ull); } } while (0)
 #else
 struct Stamps { DEV void start() {} DEV void flush(int) {} };
 #define STAMP(st, i) ((void)0)
+#define STAMP_T0() ((void)0)
+#define STAMP_ADD(i, lane) ((void)0)
+#endif
+// ---- diagnostic build only (-DGPNERF_WAVETIMES): when each wavefront enters the kernel, has its weights, ends its first sample
+// step and leaves (100 MHz real-time counter, comparable across the chip) ----
+#ifdef GPNERF_WAVETIMES
+__device__ unsigned long long g_wt[16384 * 4];
+#define WT(i) do { if ((threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    g_wt[((blockIdx.x * 8u + (threadIdx.x >> 6)) & 16383u) * 4u + (i)] = t_; } } while (0)
+#define WT_COUNT() do { if ((threadIdx.x & 63) == 0) g_wt[((blockIdx.x * 8u + (threadIdx.x >> 6)) & 16383u) * 4u + 2] += 1ull << 48; } while (0)
+#else
+#define WT(i) ((void)0)
+#define WT_COUNT() ((void)0)
 #endif
 
 DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }       // v_exp_f32
@@ -734,7 +749,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     // [seg * chain, (seg + 1) * chain) of the rays listed in `list_in` (nullptr: every ray, segment 0), 32 list entries per
     // wavefront, and appends the rays that are neither finished nor opaque to `list_out` for the next launch
     int chain, seg, wave_cap;
-    int stagger;              // experiment: waves 4..7 of a workgroup start this many x 64 cycles late
+    int stagger;              // experiment: wavefronts start up to this many x 1.7 us late, scattered over the chip
     int chunk;                // tiles per chunk of the XCD queues (queue_tile())
     const int* list_in;
     const unsigned* count_in;
@@ -886,6 +901,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     const int split = k0->split;
     const unsigned* const lw = reinterpret_cast<const unsigned*>(lds);
 
+    Stamps st;
+    st.start();
     const int n = lane & 31, half = lane >> 5;
     const int sub = n & (P - 1), rn = n / P;            // which of the step's P samples this lane evaluates, which ray of the wavefront
     const long ray0 = entry_base + tile * RAYS;      // (entry_base: where the launch's remainder units start in the ray list)
@@ -916,8 +933,6 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0) && (sub == 0);
 
-    Stamps st;
-    st.start();
     const int chain = CHAIN ? k0->chain : 0;        // the chained form is its own instantiation: the plain sample loop stays as it was
     const int k_end = CHAIN ? min((seg + 1) * chain, S) : (int)(((long)S * (seg + 1)) / split);
     int k = CHAIN ? seg * chain : (int)(((long)S * seg) / split);
@@ -947,6 +962,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
             any_keep[w] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
         }
     }
+    STAMP(st, 7);
     for (; k < k_end; k += P) {
         if (masked) {                           // the next step >= k at which the tile has anything to do
             const unsigned long long w0 = k < 64 ? (any_keep[0] >> k) << k : 0ull;
@@ -1002,7 +1018,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
             if (l & 1) __builtin_amdgcn_sched_barrier(0);    // at most two levels' 64 loads in flight (register pressure)
 
         }
-        STAMP(st, 0);
+        STAMP(st, (k == k_begin ? 10 : (k == k_begin + P ? 11 : 0)));
         float sf[32];
         Frag sff[4];
         if constexpr (SPLIT) geo_eval_s(gmax, lw, lane, fv, sff);
@@ -1196,6 +1212,7 @@ __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const KArgs ka) {
     constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    WT(0);
     if constexpr (FORM == FORM_F32_FIXUP) {
         if (__hip_atomic_load(ka.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;     // nothing was flagged
     }
@@ -1211,13 +1228,16 @@ render_fused_kernel(const KArgs ka) {
         }
     }
     __syncthreads();
+    WT(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int home = blockIdx.x & 7;            // workgroups are dealt to the XCDs round-robin
     int qx = home, dry = 0;
     int samples_per_step = 1;                   // chained form: render_tile's P and list offset of the current unit
     long entry_base = 0;
-    if (ka.stagger && wave >= 4)
-        for (int i = 0; i < ka.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    if (ka.stagger) {
+        const int u = (int)((blockIdx.x * 8u + (unsigned)wave) * 2654435761u >> 27);        // 0..31, scattered over the chip
+        for (int i = 0; i < ((u * ka.stagger) >> 5); ++i) __builtin_amdgcn_s_sleep(64);
+    }
     for (;;) {
         typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
         kargs_ptr kq = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1239,7 +1259,9 @@ render_fused_kernel(const KArgs ka) {
             // than the first workgroups to arrive running eight and the rest none
             const long share = kq->wave_cap ? (long)kq->wave_cap : (n_tiles + gridDim.x - 1) / gridDim.x;
             if (wave >= share) return;
+            STAMP_T0();
             const unsigned t = wave_add(kq->queue + qx, 1u, lane);
+            STAMP_ADD(9, lane);
             if ((long)t >= queue_len(n_tiles, kq->chunk, qx)) {     // this XCD's queue is dry: move on to the next one
                 qx = (qx + 1) & 7;
                 if (++dry == 8) return;
@@ -1257,6 +1279,7 @@ render_fused_kernel(const KArgs ka) {
             }
         }
         constexpr int F = FORM == FORM_F32_FIXUP ? FORM_F32 : FORM;
+        STAMP_T0();
         if constexpr (CHAIN) {
             if (samples_per_step == 8) render_tile<F, true, 8>(lds, lane, tile, seg, entry_base);
             else if (samples_per_step == 4) render_tile<F, true, 4>(lds, lane, tile, seg, entry_base);
@@ -1265,6 +1288,9 @@ render_fused_kernel(const KArgs ka) {
         } else {
             render_tile<F, false, 1, CULL>(lds, lane, tile, seg);
         }
+        STAMP_ADD(8, lane);
+        WT(3);
+        WT_COUNT();
     }
 }
 
@@ -2032,6 +2058,13 @@ int64_t gpnerf_head_blob_floats(void) { return gpl::BLOB_FLOATS; }
 int32_t gpnerf_rays_per_tile(void) { return RAYS_PER_WAVE; }
 const char* gpnerf_build_info(void) { return "gpnerf-hip gfx950 fp32-mfma32x32x2 waves<=8"; }
 
+#ifdef GPNERF_WAVETIMES
+// diagnostic library only: the per-wavefront time stamps of the last launch
+int gpnerf_debug_read_wavetimes(unsigned long long* out, int n_waves) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wt), sizeof(unsigned long long) * 4 * (size_t)n_waves) != hipSuccess) return GPNERF_E_DEVICE;
+    return GPNERF_OK;
+}
+#endif
 #ifdef GPNERF_STAMPS
 // diagnostic library only: read and clear the per-phase cycle sums
 int gpnerf_debug_read_stamps(unsigned long long* out16) {

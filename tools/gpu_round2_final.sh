@@ -7,7 +7,7 @@ timeout 300 python bench.py --steps 10 --warmup 3 --samples 128 --early-term --n
 timeout 300 python bench.py --steps 10 --warmup 3 --split-f16 --no-cpu-baseline --no-extras > $o/bench_split_guarded.json 2> $o/bench_split.err
 timeout 300 python bench.py --steps 10 --warmup 3 --size 1024 --no-cpu-baseline --no-extras > $o/bench_1024.json 2> $o/bench_1024.err
 timeout 300 python bench.py --steps 10 --warmup 3 --size 64 --samples 32 --no-cpu-baseline --no-extras > $o/bench_64.json 2> $o/bench_64.err
-timeout 300 python bench.py --steps 10 --warmup 3 --occ-cull --occupancy 0.1 --patch 4x8 --no-cpu-baseline --no-extras > $o/bench_cull10.json 2> $o/bench_cull.err
+timeout 300 python bench.py --steps 10 --warmup 3 --occ-cull --occupancy 0.1 --outputs light --no-cpu-baseline --no-extras > $o/bench_cull10.json 2> $o/bench_cull.err
 timeout 200 python tools/time_render_api.py > $o/render_api.txt 2>&1
 timeout 200 python tools/guard_probe.py > $o/guard_probe.txt 2>&1
 python - <<'PY'

@@ -18,7 +18,9 @@ syn = importlib.import_module("gp-nerf_amd.synthetic")
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 split = len(sys.argv) > 2 and sys.argv[2] == "split"
-S = 64
+chain = len(sys.argv) > 2 and sys.argv[2] == "chain"          # segmented early-termination form, nothing terminating (term_eps 0)
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+kw = dict(early_term=True, term_eps=0.0) if chain else {}
 dev = torch.device("cuda:0")
 sc = syn.make_scene(H=size, W=size, seed=0, fill="full", pose="identity")
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -28,12 +30,12 @@ rays = t(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None],
 lib = L.lib()
 lib.gpnerf_debug_read_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
 buf = (C.c_ulonglong * 16)()
-fm.render_fused(fr, rays, S, want=(), split_f16=split)
+fm.render_fused(fr, rays, S, want=(), split_f16=split, **kw)
 torch.cuda.synchronize()
 lib.gpnerf_debug_read_stamps(buf)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-fm.render_fused(fr, rays, S, want=(), split_f16=split)
+fm.render_fused(fr, rays, S, want=(), split_f16=split, **kw)
 e1.record()
 torch.cuda.synchronize()
 lib.gpnerf_debug_read_stamps(buf)
@@ -44,3 +46,6 @@ print(f"stamped kernel {e0.elapsed_time(e1):.2f} ms; per wave per sample cycles 
 for i, n in enumerate(names):
     print(f"  {n:28s} {buf[i] / waves / S:9.0f}  {100.0 * buf[i] / tot:5.1f}%")
 print(f"  total {tot / waves / S:.0f}")
+print(f"  volume-gather phase of a visit's first step {buf[10] / max(1, buf[12]):.0f}, second step {buf[11] / max(1, buf[12]):.0f}")
+print(f"  per tile visit: prologue (entry -> first sample) {buf[7] / max(1, buf[12]):.0f}, whole visit {buf[8] / max(1, buf[12]):.0f}, "
+      f"queue pop {buf[9] / max(1, buf[12]):.0f}; loop phases {tot / max(1, buf[12]):.0f}; visits {buf[12]}")
