@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--split-f16", action="store_true",
                     help="dense layers on f16 MFMA with fp32 operands split into hi+lo (GPNERF_FLAG_SPLIT_F16)")
+    ap.add_argument("--no-fold", action="store_true", help="fp32 form without the folded volumes (gpnerf_fold_volumes): the sigma feature layer per sample")
     ap.add_argument("--no-guard", action="store_true", help="with --split-f16: without the range guard (GPNERF_FLAG_SPLIT_GUARD)")
     ap.add_argument("--occ-cull", action="store_true",
                     help="progressive sample culling (demo_render.py semantics) on a sparse synthetic pyramid")
@@ -167,9 +168,11 @@ def main():
                 self.buf = torch.empty((world, wl.n, 4), device=dev if backend == "nccl" else "cpu") if world > 1 else None
                 self.rays_per_step = wl.n * world
             self.n_local = self.rays.shape[0]
+            # the fold is per-frame work and the bench re-uses one Frame: True = fold again in every step, inside the timed region
+            self.fold = bool(not args.no_fold and not args.split_f16)
 
         def render(self):
-            return fm.render_fused(self.wl.frame, self.rays, self.wl.S, want=self.want, ray_order=self.order, **kw)
+            return fm.render_fused(self.wl.frame, self.rays, self.wl.S, want=self.want, ray_order=self.order, fold=self.fold, **kw)
 
         def step(self, events=None):
             if events:
@@ -229,7 +232,7 @@ def main():
         alive_after = None
         if args.early_term or args.occ_cull:
             # the units a launch processes are the samples it evaluates: terminated / culled samples are not work done
-            done = fm.render_fused(wl.frame, flow.rays, S, want=("samples_done",), ray_order=flow.order, **kw)["samples_done"]
+            done = fm.render_fused(wl.frame, flow.rays, S, want=("samples_done",), ray_order=flow.order, fold=flow.fold, **kw)["samples_done"]
             evaluated = float(done.float().mean()) / S
             alive_after = {str(k): float((done > k).float().mean()) for k in range(32, S, 32)}
             flops_per_launch *= evaluated
@@ -254,7 +257,7 @@ def main():
                        "ray_order": args.ray_order, "patch": args.patch if args.ray_order == "patch" else None, "outputs": "rgb+depth (the all-gather payload)" if strong else
                        ("rgb,depth,acc,disp,weights,z_vals,rgb_in (Renderer.render's dict)" if args.outputs == "api" else "rgb,depth,acc,disp"),
                        "early_term": bool(args.early_term), "term_eps": args.term_eps if args.early_term else None, "sigma_bias": sigma_bias,
-                       "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "split_guard": bool(args.split_f16 and not args.no_guard), "vol_occupancy": args.occupancy,
+                       "folded_volumes": bool(flow.fold), "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "split_guard": bool(args.split_f16 and not args.no_guard), "vol_occupancy": args.occupancy,
                        "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
@@ -306,7 +309,7 @@ def beside_headline(args, fm, wl, kw, flow):
                                      ("api_outputs_raster_order", API_OUTPUTS, None, {}),
                                      ("split_f16_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True}),
                                      ("split_f16_unguarded_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True, "guard": False})):
-        k2 = dict(kw)
+        k2 = dict(kw, fold=flow.fold and not extra.get("split_f16", False))
         k2.update(extra)
         ms, o = time_launches(lambda: fm.render_fused(wl.frame, wl.rays, S, want=want, ray_order=order, **k2), st, wu)
         res[name] = {"kernel_ms": ms, "rays_per_sec": wl.n / (ms * 1e-3)}

@@ -32,6 +32,7 @@ class GpnerfFrame(C.Structure):
         ("head_blob", C.c_void_p),
         ("head_blob_split", C.c_void_p),
         ("occ", C.c_void_p),
+        ("vol_folded", C.c_void_p * LEVELS),
     ]
 
 
@@ -65,6 +66,7 @@ FLAG_OCC_CULL = 4
 FLAG_SPLIT_F16 = 8
 FLAG_FLIP_SAMPLES = 16
 FLAG_SPLIT_GUARD = 32
+FOLD_FIRST_LEVEL = 2
 
 # every symbol include/gpnerf_hip.h declares: (restype, argtypes)
 SYMBOLS = {
@@ -74,6 +76,7 @@ SYMBOLS = {
     "gpnerf_pack_head_split": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
     "gpnerf_render_fused": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float,
                                       C.c_void_p, C.POINTER(GpnerfOutputs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpnerf_fold_volumes": (C.c_int, [C.POINTER(GpnerfFrame), C.POINTER(C.c_void_p), C.c_void_p]),
     "gpnerf_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "gpnerf_render_guard_bytes": (C.c_size_t, [C.c_int64]),
     "gpnerf_sample_points": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,

@@ -643,6 +643,67 @@ DEV void gather_volume(const float* __restrict__ vol, int D, int H, int W, float
         }
 }
 
+// The sigma feature layer is linear in the volume features and trilinear sampling is linear in the voxels, so
+//   W (sum_t w_t v_t) = sum_t w_t (W v_t):
+// gpnerf_fold_volumes applies out_geometry_fc's 32 columns of level l to every voxel of level l once per frame (64 values per
+// voxel, laid out [half][tile][16] = the accumulator registers of the two output tiles), and the sample loop interpolates the
+// layer's PRE-ACTIVATION directly: 32 values per lane and tap instead of 16, and none of the layer's 128 MFMAs per step.
+// 32 values of one tap, already in registers: 16 v_pk_fma_f32
+DEV void fma32(const f32x4 (&q)[8], float w, f32x16& g0, f32x16& g1) {
+    const f32x2 w2 = {w, w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 a = q[i], b = q[4 + i];
+        const f32x2 r0 = __builtin_elementwise_fma(f32x2{a[0], a[1]}, w2, f32x2{g0[4 * i], g0[4 * i + 1]});
+        const f32x2 r1 = __builtin_elementwise_fma(f32x2{a[2], a[3]}, w2, f32x2{g0[4 * i + 2], g0[4 * i + 3]});
+        const f32x2 r2 = __builtin_elementwise_fma(f32x2{b[0], b[1]}, w2, f32x2{g1[4 * i], g1[4 * i + 1]});
+        const f32x2 r3 = __builtin_elementwise_fma(f32x2{b[2], b[3]}, w2, f32x2{g1[4 * i + 2], g1[4 * i + 3]});
+        g0[4 * i] = r0[0]; g0[4 * i + 1] = r0[1]; g0[4 * i + 2] = r1[0]; g0[4 * i + 3] = r1[1];
+        g1[4 * i] = r2[0]; g1[4 * i + 1] = r2[1]; g1[4 * i + 2] = r3[0]; g1[4 * i + 3] = r3[1];
+    }
+}
+// trilinear sample of one folded level [D][H][W][2 halves][2 tiles][16] -> added to this half's two accumulator tiles.
+// A tap is 128 bytes per lane = 32 registers, and left to itself the compiler walks the taps one at a time, a full L2 round trip
+// each (32 per step: the kernel then waits more than it computes).  The taps go four at a time: 32 loads in flight, then their FMAs.
+constexpr int FOLD_BATCH = 4;
+// Levels FOLD_FROM .. 3 are folded.  Measured on the 512x512x64 frame (every variant with the batched view gather): none 13.73 ms,
+// the coarsest 13.86, the two coarse levels 13.22, three 13.43, all four 13.59 (+0.17 ms and 400 MB to fold the 1.4 M voxels of
+// level 0).  A folded tap is twice the bytes per lane, and what the matrix pipe saves the gathers' round trips take back -- except
+// on the coarse levels, whose tables (6 MB folded) stay in the L2s and whose 32 rays share a handful of voxels.
+constexpr int FOLD_FROM = GPNERF_FOLD_FIRST_LEVEL;
+DEV void gather_folded(const float* __restrict__ vol, int D, int H, int W, float gx, float gy, float gz, int half,
+                       f32x16& g0, f32x16& g1) {
+    const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
+    const unsigned zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1};
+    const float zw[2] = {az.w0, az.w1}, yw[2] = {ay.w0, ay.w1}, xw[2] = {ax.w0, ax.w1};
+    const unsigned row_bytes = (unsigned)W * 256u;                              // one x-row: W voxels x 64 values x 4 B
+    const unsigned xb[2] = {ax.i0 * 256u + (unsigned)half * 128u, ax.i1 * 256u + (unsigned)half * 128u};
+    unsigned off[8];
+    float wt[8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const unsigned rowb = __umul24(mad24(zi[a], (unsigned)H, yi[b]), row_bytes);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { off[4 * a + 2 * b + e] = rowb + xb[e]; wt[4 * a + 2 * b + e] = (xw[e] * yw[b]) * zw[a]; }
+        }
+#pragma unroll
+    for (int t0 = 0; t0 < 8; t0 += FOLD_BATCH) {
+        f32x4 q[FOLD_BATCH][8];
+#pragma unroll
+        for (int t = 0; t < FOLD_BATCH; ++t) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(at_byte(vol, off[t0 + t]));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[t][i] = p[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < FOLD_BATCH; ++t) fma32(q[t], wt[t0 + t], g0, g1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // F.grid_sample of the single-channel occupancy volume (demo_render.py:274-279), same coordinates as the features
 DEV float sample_occupancy(const float* __restrict__ occ, int D, int H, int W, float gx, float gy, float gz) {
     const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
@@ -666,7 +727,7 @@ struct ViewSample {
 
 // Projector.compute for one view (libs/renders/BaseRender.py:301-324,296-299,283-294,352-362):
 // project p, bilinear RGB from imgs[v] (NHWC4) and 16 feature channels from featmaps[v] (NHWC32).
-template <class MP>
+template <bool BATCH = false, class MP>
 DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
                            const float* __restrict__ fm, int fh, int fw, float px, float py, float pz, bool neg,
                            int half, float* f) {
@@ -682,28 +743,64 @@ DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
     const float nx = 2.f * u / wm1 - 1.f, ny = 2.f * w / hm1 - 1.f;
     ViewSample s;
     s.valid = (front && inb) ? 1.f : 0.f;
-    {   // RGB from the full-resolution image
-        const Axis ax = axis_taps(nx, iw), ay = axis_taps(ny, ih);
-        const unsigned r0 = __umul24(ay.i0, (unsigned)iw * 16u), r1 = __umul24(ay.i1, (unsigned)iw * 16u);
-        const unsigned x0 = ax.i0 * 16u, x1 = ax.i1 * 16u;
-        const f32x4 nw = *reinterpret_cast<const f32x4*>(at_byte(img, r0 + x0));
-        const f32x4 ne = *reinterpret_cast<const f32x4*>(at_byte(img, r0 + x1));
-        const f32x4 sw = *reinterpret_cast<const f32x4*>(at_byte(img, r1 + x0));
-        const f32x4 se = *reinterpret_cast<const f32x4*>(at_byte(img, r1 + x1));
-        const float wnw = ax.w0 * ay.w0, wne = ax.w1 * ay.w0, wsw = ax.w0 * ay.w1, wse = ax.w1 * ay.w1;
+    // All eight taps of the view (4 image texels, 4 x 64 B of the feature map) are loaded before the first is used: 20 loads in
+    // flight and one round trip per view, where the compiler on its own walks the taps one at a time (BATCH: the folded form,
+    // which has no matrix work between its two gather phases to cover them).
+    const Axis ix = axis_taps(nx, iw), iy = axis_taps(ny, ih);
+    const unsigned ir0 = __umul24(iy.i0, (unsigned)iw * 16u), ir1 = __umul24(iy.i1, (unsigned)iw * 16u);
+    const unsigned ix0 = ix.i0 * 16u, ix1 = ix.i1 * 16u;
+    const Axis ax = axis_taps(nx, fw), ay = axis_taps(ny, fh);
+    const unsigned r0 = __umul24(ay.i0, (unsigned)fw * 128u), r1 = __umul24(ay.i1, (unsigned)fw * 128u);
+    const unsigned x0 = ax.i0 * 128u + (unsigned)half * 64u, x1 = ax.i1 * 128u + (unsigned)half * 64u;
+    if constexpr (BATCH) {
+        const f32x4 nw = *reinterpret_cast<const f32x4*>(at_byte(img, ir0 + ix0));
+        const f32x4 ne = *reinterpret_cast<const f32x4*>(at_byte(img, ir0 + ix1));
+        const f32x4 sw = *reinterpret_cast<const f32x4*>(at_byte(img, ir1 + ix0));
+        const f32x4 se = *reinterpret_cast<const f32x4*>(at_byte(img, ir1 + ix1));
+        const unsigned fo[4] = {r0 + x0, r0 + x1, r1 + x0, r1 + x1};
+        const float fwt[4] = {ax.w0 * ay.w0, ax.w1 * ay.w0, ax.w0 * ay.w1, ax.w1 * ay.w1};
+        f32x4 q[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(at_byte(fm, fo[t]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[t][i] = p[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float wnw = ix.w0 * iy.w0, wne = ix.w1 * iy.w0, wsw = ix.w0 * iy.w1, wse = ix.w1 * iy.w1;
 #pragma unroll
         for (int c = 0; c < 3; ++c) s.rgb[c] = fmaf(se[c], wse, fmaf(sw[c], wsw, fmaf(ne[c], wne, nw[c] * wnw)));
-    }
-    {   // features from the quarter-resolution map, same normalised coordinates
-        const Axis ax = axis_taps(nx, fw), ay = axis_taps(ny, fh);
 #pragma unroll
         for (int c = 0; c < 16; ++c) f[c] = 0.f;
-        const unsigned r0 = __umul24(ay.i0, (unsigned)fw * 128u), r1 = __umul24(ay.i1, (unsigned)fw * 128u);
-        const unsigned x0 = ax.i0 * 128u + (unsigned)half * 64u, x1 = ax.i1 * 128u + (unsigned)half * 64u;
-        fma16(at_byte(fm, r0 + x0), ax.w0 * ay.w0, f);
-        fma16(at_byte(fm, r0 + x1), ax.w1 * ay.w0, f);
-        fma16(at_byte(fm, r1 + x0), ax.w0 * ay.w1, f);
-        fma16(at_byte(fm, r1 + x1), ax.w1 * ay.w1, f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x2 w2 = {fwt[t], fwt[t]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 a = __builtin_elementwise_fma(f32x2{q[t][i][0], q[t][i][1]}, w2, f32x2{f[4 * i], f[4 * i + 1]});
+                const f32x2 b = __builtin_elementwise_fma(f32x2{q[t][i][2], q[t][i][3]}, w2, f32x2{f[4 * i + 2], f[4 * i + 3]});
+                f[4 * i] = a[0]; f[4 * i + 1] = a[1]; f[4 * i + 2] = b[0]; f[4 * i + 3] = b[1];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        {   // RGB from the full-resolution image
+            const f32x4 nw = *reinterpret_cast<const f32x4*>(at_byte(img, ir0 + ix0));
+            const f32x4 ne = *reinterpret_cast<const f32x4*>(at_byte(img, ir0 + ix1));
+            const f32x4 sw = *reinterpret_cast<const f32x4*>(at_byte(img, ir1 + ix0));
+            const f32x4 se = *reinterpret_cast<const f32x4*>(at_byte(img, ir1 + ix1));
+            const float wnw = ix.w0 * iy.w0, wne = ix.w1 * iy.w0, wsw = ix.w0 * iy.w1, wse = ix.w1 * iy.w1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s.rgb[c] = fmaf(se[c], wse, fmaf(sw[c], wsw, fmaf(ne[c], wne, nw[c] * wnw)));
+        }
+        {   // features from the quarter-resolution map, same normalised coordinates
+#pragma unroll
+            for (int c = 0; c < 16; ++c) f[c] = 0.f;
+            fma16(at_byte(fm, r0 + x0), ax.w0 * ay.w0, f);
+            fma16(at_byte(fm, r0 + x1), ax.w1 * ay.w0, f);
+            fma16(at_byte(fm, r1 + x0), ax.w0 * ay.w1, f);
+            fma16(at_byte(fm, r1 + x1), ax.w1 * ay.w1, f);
+        }
     }
     return s;
 }
@@ -724,6 +821,7 @@ struct FrameK {           // GpnerfFrame by value (kernel argument; lands in SGP
     const float* head_blob;
     const float* head_blob_split;   // f16 hi/lo image (GPNERF_FLAG_SPLIT_F16) or nullptr
     const float* occ;     // level-1-sized occupancy volume or nullptr
+    const float* vol_fold[GPNERF_LEVELS];    // folded volumes (gpnerf_fold_volumes) or nullptr: FORM_F32_FOLD
 };
 
 struct OutK {
@@ -767,7 +865,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
 };
 
 // the forms of the fused kernel
-constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3;
+constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3, FORM_F32_FOLD = 4;
 constexpr int GUARD_HEADER_WORDS = 64;
 
 // bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
@@ -1009,20 +1107,46 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         // of the ray alone, so it does not matter which rays are packed together); the plain form stops a tile as a whole
         const bool dead = CHAIN && P == 1 && T < term_eps;     // (P > 1: decided sample by sample in the composite below)
         if constexpr (P == 1) n_done += dead ? 0 : 1;
-        // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
-        float fv[64];
-#pragma unroll
-        for (int l = 0; l < GPNERF_LEVELS; ++l)
-        {
-            gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
-            if (l & 1) __builtin_amdgcn_sched_barrier(0);    // at most two levels' 64 loads in flight (register pressure)
-
-        }
-        STAMP(st, (k == k_begin ? 10 : (k == k_begin + P ? 11 : 0)));
         float sf[32];
         Frag sff[4];
-        if constexpr (SPLIT) geo_eval_s(gmax, lw, lane, fv, sff);
-        else geo_eval(lds, lane, fv, sf);
+        if constexpr (FORM == FORM_F32_FOLD) {
+            // the sigma feature layer's pre-activation: levels FOLD_FROM.. interpolated from the folded volumes (see gather_folded),
+            // the finer levels' features through the layer's first 16 FOLD_FROM k-steps as before
+            int hb = half;
+            asm volatile("" : "+v"(hb));                  // the bias reads stay in the loop (hoisted, they hold 32 registers across it)
+            f32x16 g0 = bias_tile<gpl::GEO>(lds, 0, hb), g1 = bias_tile<gpl::GEO>(lds, 1, hb);
+            float fu[FOLD_FROM > 0 ? 16 * FOLD_FROM : 1];
+#pragma unroll
+            for (int l = 0; l < FOLD_FROM; ++l)
+                gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fu + 16 * l);
+            if constexpr (FOLD_FROM > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int l = FOLD_FROM; l < GPNERF_LEVELS; ++l) {
+                gather_folded(fr.vol_fold[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, g0, g1);
+            }
+            STAMP(st, 0);
+            if constexpr (FOLD_FROM > 0) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                mfma_tile<16 * FOLD_FROM>(wtile<gpl::GEO>(lds, 0), ln, fu, g0);
+                mfma_tile<16 * FOLD_FROM>(wtile<gpl::GEO>(lds, 1), ln, fu, g1);
+            }
+            elus_n<16>(g0, sf);
+            elus_n<16>(g1, sf + 16);
+        } else {
+            // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
+            float fv[64];
+#pragma unroll
+            for (int l = 0; l < GPNERF_LEVELS; ++l)
+            {
+                gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
+                if (l & 1) __builtin_amdgcn_sched_barrier(0);    // at most two levels' 64 loads in flight (register pressure)
+
+            }
+            STAMP(st, (k == k_begin ? 10 : (k == k_begin + P ? 11 : 0)));
+            if constexpr (SPLIT) geo_eval_s(gmax, lw, lane, fv, sff);
+            else geo_eval(lds, lane, fv, sf);
+        }
         STAMP(st, 1);
 
         // Projector.compute (:326-363)
@@ -1031,7 +1155,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         float vrgb[NV][3];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const ViewSample s = gather_view(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
+            const ViewSample s = gather_view<FORM == FORM_F32_FOLD || FORM == FORM_F32>(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
                                              fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
                                              px, py, pz, neg, half, x[v]);
             x[v][16] = half ? s.rgb[1] : s.rgb[0];
@@ -1374,6 +1498,45 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(const int* __re
     for (int e = 0; e < CULL_CLASSES; ++e) { const int v = cnt[i * CULL_CLASSES + e]; cnt[i * CULL_CLASSES + e] = run; run += v; }
     __syncthreads();
     for (int t = lo; t < hi; ++t) order[cnt[cls(t) * SORT_THREADS + i]++] = t;
+}
+
+// gpnerf_fold_volumes: out_geometry_fc's 32 columns of level l applied to every voxel of level l (see gather_folded).  One
+// wavefront per 32 voxels: B operand = the voxel's 32 channels in the sample loop's own k-step order, A = the layer's two weight
+// tiles from the head image (k-steps 16 l ... 16 l + 15), fp32 MFMA; the lane of (voxel, half) stores its 2 x 16 accumulator
+// registers as 128 contiguous bytes, which is what the lane of (ray, half) reads back per tap.  No bias: it is added once, after
+// the interpolation (out-of-volume taps contribute nothing, exactly as zero padding does before the layer).
+__global__ void __launch_bounds__(256) fold_volume_kernel(const float* __restrict__ head_blob, const float* __restrict__ vol, const long n_vox,
+                                                          const int level, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float w[2 * 16 * 64];          // [tile][4 groups][64 lanes][4 k-steps]
+    for (int i = threadIdx.x; i < 2 * 16 * 64 / 4; i += blockDim.x) {
+        const int m = i / 256, r = i % 256;
+        reinterpret_cast<f32x4*>(w)[i] =
+            reinterpret_cast<const f32x4*>(head_blob + gpl::w_off(gpl::GEO) + m * gpl::NT[gpl::GEO] * 64 + level * 16 * 64)[r];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const long n_tiles = (n_vox + 31) / 32;
+    for (long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (long)gridDim.x * 4) {
+        const long vox = tile * 32 + n;
+        const long v = vox < n_vox ? vox : n_vox - 1;
+        const f32x4* q = reinterpret_cast<const f32x4*>(vol + v * GPNERF_CH + half * 16);
+        float b[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const f32x4 a = q[i]; b[4 * i] = a[0]; b[4 * i + 1] = a[1]; b[4 * i + 2] = a[2]; b[4 * i + 3] = a[3]; }
+        f32x16 g0, g1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+        mfma_tile<16>(w, lane, b, g0);
+        mfma_tile<16>(w + 16 * 64, lane, b, g1);
+        if (vox < n_vox) {
+            f32x4* o = reinterpret_cast<f32x4*>(out + vox * (2 * GPNERF_CH) + half * GPNERF_CH);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i] = f32x4{g0[4 * i], g0[4 * i + 1], g0[4 * i + 2], g0[4 * i + 3]};
+                o[4 + i] = f32x4{g1[4 * i], g1[4 * i + 1], g1[4 * i + 2], g1[4 * i + 3]};
+            }
+        }
+    }
 }
 
 // merge the per-segment partial composites of a ray front to back: out = sum_s (prod_{j<s} T_j) * partial_s
@@ -1944,6 +2107,20 @@ Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, 
 }
 
 hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// The counters a launch sequence starts from (tile queues, list lengths, the guard's flags) are zeroed by a kernel of the library's
+// own, not by hipMemsetAsync: captured into a HIP graph, the memset node was not reliably ordered before the kernel node that
+// follows it (replays after the first found the previous replay's counters -- exhausted queues -- and rendered nothing;
+// tests/test_gpu_guard.py, tools/graph_probe2.py), kernel after kernel is.
+__global__ void zero_words_kernel(unsigned* __restrict__ p, const long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+bool zero_async(void* p, size_t bytes, void* stream) {          // bytes: a multiple of 4
+    const long n = (long)(bytes / sizeof(unsigned));
+    const long wgs = (n + 255) / 256;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(wgs < 1024 ? (wgs > 0 ? wgs : 1) : 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<unsigned*>(p), n);
+    return hipGetLastError() == hipSuccess;
+}
 
 // Per-device facts and one-time setup, keyed by the CURRENT device of the calling thread: the architecture check
 // (GPNERF_E_DEVICE on anything but gfx950), the CU count the launch geometry balances over, and the opt-in to > 64 KB of
@@ -1970,6 +2147,9 @@ int device_ready(int* cus) {
                 return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
             };
             d.ok = lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, true>), lds_bytes) &&
@@ -2027,6 +2207,13 @@ bool to_framek(const GpnerfFrame* f, FrameK& k, bool need_vol, bool need_img) {
     k.head_blob = f->head_blob;
     k.head_blob_split = f->head_blob_split;
     k.occ = f->occ;
+    // folded volumes: all four levels or none; 64 values per voxel must still be addressable with 32-bit byte offsets
+    bool fold = true;
+    for (int l = GPNERF_FOLD_FIRST_LEVEL; l < GPNERF_LEVELS; ++l) {
+        const int64_t D = f->vol_dhw[l][0], H = f->vol_dhw[l][1], W = f->vol_dhw[l][2];
+        fold = fold && f->vol_folded[l] && D * H * W * GPNERF_CH * 8 < lim_bytes && W * GPNERF_CH * 8 < lim24;
+    }
+    for (int l = GPNERF_FOLD_FIRST_LEVEL; l < GPNERF_LEVELS; ++l) k.vol_fold[l] = fold ? f->vol_folded[l] : nullptr;
     return true;
 }
 
@@ -2181,6 +2368,20 @@ int gpnerf_pack_head_split(const GpnerfHeadParams* p, float* blob) {
     return GPNERF_OK;
 }
 
+int gpnerf_fold_volumes(const GpnerfFrame* f, float* const* out, void* stream) {
+    if (!f || !out || !f->head_blob) return GPNERF_E_ARG;
+    for (int l = FOLD_FROM; l < GPNERF_LEVELS; ++l)
+        if (!f->vol[l] || !out[l] || f->vol_dhw[l][0] < 1 || f->vol_dhw[l][1] < 1 || f->vol_dhw[l][2] < 1) return GPNERF_E_ARG;
+    if (device_ready(nullptr) != GPNERF_OK) return GPNERF_E_DEVICE;
+    for (int l = FOLD_FROM; l < GPNERF_LEVELS; ++l) {
+        const long n_vox = (long)f->vol_dhw[l][0] * f->vol_dhw[l][1] * f->vol_dhw[l][2];
+        const long wgs = ((n_vox + 31) / 32 + 3) / 4;
+        hipLaunchKernelGGL(fold_volume_kernel, dim3((unsigned)(wgs < 8192 ? wgs : 8192)), dim3(256), 0, S_(stream), f->head_blob, f->vol[l], n_vox, l,
+                           out[l]);
+    }
+    return launch_status();
+}
+
 int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays, int32_t n_samples, uint32_t flags,
                         float term_eps, const int32_t* ray_order, const GpnerfOutputs* out, void* workspace,
                         size_t workspace_bytes, void* stream) {
@@ -2193,6 +2394,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const int64_t tiles = (n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
     const bool split16 = (flags & GPNERF_FLAG_SPLIT_F16) != 0;
+    const bool folded = !split16 && k.vol_fold[GPNERF_LEVELS - 1] != nullptr;       // the fp32 form interpolates the folded volumes when the frame has them
     if (split16 && !f->head_blob_split) return GPNERF_E_ARG;
     // GPNERF_FLAG_SPLIT_GUARD: the split form records the tiles in which an MFMA operand reached the f16 range, and a second
     // launch renders exactly those again in the fp32 form (it returns at once when there are none).  The flags live in the
@@ -2204,7 +2406,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         if (!workspace || workspace_bytes < QUEUE_BYTES + gb) return GPNERF_E_ARG;
         workspace_bytes = (workspace_bytes - gb) & ~(size_t)255;
         guard_words = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + workspace_bytes);
-        if (hipMemsetAsync(guard_words, 0, gb, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+        if (!zero_async(guard_words, gb, stream)) return GPNERF_E_LAUNCH;
     }
     const size_t lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
     int n_cus = 0;
@@ -2239,7 +2441,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (f_dynamic < 0) { const char* e = getenv("GPNERF_DYNAMIC"); f_dynamic = e ? atoi(e) : 1; }
     const bool dynamic = f_dynamic && workspace && workspace_bytes >= QUEUE_BYTES && g.split == 1 && blocks > n_cus;
     if (dynamic) {
-        if (hipMemsetAsync(workspace, 0, QUEUE_BYTES, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+        if (!zero_async(workspace, QUEUE_BYTES, stream)) return GPNERF_E_LAUNCH;
         blocks = n_cus;
     }
     const bool do_remainder = remainder && dynamic;
@@ -2291,7 +2493,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         unsigned* const ctrl = reinterpret_cast<unsigned*>(base);                      // [n_seg][8] queue counters, then [n_seg] list lengths
         const size_t list_bytes = align256((size_t)n_rays * sizeof(int));
         int* const lists[2] = {reinterpret_cast<int*>(base + chain_ctrl_bytes(n_seg)), reinterpret_cast<int*>(base + chain_ctrl_bytes(n_seg) + list_bytes)};
-        if (hipMemsetAsync(base, 0, chain_ctrl_bytes(n_seg), S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+        if (!zero_async(base, chain_ctrl_bytes(n_seg), stream)) return GPNERF_E_LAUNCH;
         ka.split = 1; ka.dynamic = 1; ka.chain = chain_len(n_samples);
         ka.part = reinterpret_cast<float*>(base + chain_ctrl_bytes(n_seg) + 2 * list_bytes);
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
@@ -2311,6 +2513,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
                 hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3(grid), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
             else if (split16)
                 hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3(grid), full_block, lds_split, S_(stream), ka);
+            else if (folded)
+                hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
             else
                 hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
             if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
@@ -2344,12 +2548,16 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
             hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
         else if (split16)
             hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
+        else if (folded)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
         else
             hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     } else if (guard)
         hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
     else if (split16)
         hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
+    else if (folded)
+        hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     else
         hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     if (do_remainder) {
@@ -2368,6 +2576,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
             hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3((unsigned)n_cus), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), kr);
         else if (split16)
             hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3((unsigned)n_cus), full_block, lds_split, S_(stream), kr);
+        else if (folded)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
         else
             hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
     }

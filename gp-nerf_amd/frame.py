@@ -181,6 +181,18 @@ class Frame:
         self.c.occ = self.occ.data_ptr()
         return self.occ
 
+    def fold_volumes(self):
+        """gpnerf_fold_volumes: the sigma feature layer applied to every voxel of the two coarse levels (64 values per voxel), so
+        that the fp32 form interpolates their share of the layer's pre-activation instead of running it per sample.  Per-frame
+        work (~10 us): the buffers are allocated once per Frame, every call recomputes them on the current stream."""
+        if getattr(self, "vols_folded", None) is None:
+            self.vols_folded = [torch.empty(tuple(v.shape[:3]) + (2 * L.CH,), device=v.device, dtype=torch.float32) if l >= L.FOLD_FIRST_LEVEL
+                                else None for l, v in enumerate(self.vols)]
+        ptrs = (C.c_void_p * L.LEVELS)(*[v.data_ptr() if v is not None else None for v in self.vols_folded])
+        L.check(L.lib().gpnerf_fold_volumes(C.byref(self.c), ptrs, _stream_ptr(self.vols[0].device)), "gpnerf_fold_volumes")
+        self._folded_valid = True
+        return self.vols_folded
+
     @classmethod
     def for_volumes(cls, volumes, head_blob):
         """A frame that carries only the 4 dense levels (enough for gpnerf_sample_volume)."""
@@ -239,7 +251,7 @@ def patch_order_device(mask, H, W, patch_w=4, patch_h=8):
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
-                 split_f16=False, flip=None, subset=False, guard=None):
+                 split_f16=False, flip=None, subset=False, guard=None, fold=None):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); defaults to neg_ray for the dense renderer
     (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
@@ -252,7 +264,10 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     form (GPNERF_FLAG_SPLIT_GUARD; default on whenever the kernel has a workspace).  want=("guard_tiles",) returns how many
     32-ray tiles that were (int32 tensor [1]).
     subset: ray_order lists the rows of `rays` to render (any number of distinct rows); outputs keep rays' row count, rows
-    that are not listed come back zero."""
+    that are not listed come back zero.
+    fold: the fp32 form with the coarse levels folded (Frame.fold_volumes).  None: yes, folding once per Frame; True: fold now (a
+    caller that re-uses one Frame for many frames' worth of calls, like the bench, pays the per-frame fold every time); False:
+    the sigma feature layer entirely per sample (what the split form's fix-up launch does)."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()
@@ -310,6 +325,17 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         if ray_order.dtype != torch.int32 or not ray_order.is_contiguous() or (ray_order.numel() != N and not subset):
             raise L.GpnerfError("ray_order must be a contiguous int32 tensor with one entry per ray")
     n_launch = int(ray_order.numel()) if subset else N
+    refold = fold is True
+    if fold is None:
+        fold = not split_f16
+    if fold and not split_f16:
+        if refold or not getattr(frame, "_folded_valid", False):
+            frame.fold_volumes()
+        for l in range(L.FOLD_FIRST_LEVEL, L.LEVELS):
+            frame.c.vol_folded[l] = frame.vols_folded[l].data_ptr()
+    else:
+        for l in range(L.LEVELS):
+            frame.c.vol_folded[l] = None
     if subset and any(k in want for k in ("weights", "z_vals", "raw")):
         raise L.GpnerfError("subset launches return the per-ray maps only")
     ws_bytes = int(lib.gpnerf_render_workspace_bytes(n_launch, S)) if load_balance else 0

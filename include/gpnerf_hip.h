@@ -37,6 +37,8 @@ extern "C" {
 #define GPNERF_E_LAUNCH (-2)   /* hipLaunchKernel failed; see hipGetLastError */
 #define GPNERF_E_DEVICE (-3)   /* not a gfx950 device / no device */
 
+#define GPNERF_FOLD_FIRST_LEVEL 2   /* vol_folded / gpnerf_fold_volumes: the two coarse levels of the four */
+
 /* flags of gpnerf_render_fused */
 #define GPNERF_FLAG_NEG_RAY 1u     /* Projector(neg_ray=True): a sample is in front of a source view iff h_z < 0
                                       (BaseRender.py:317-320, demo_render.py:550-553).  The dense renderer pairs it with
@@ -85,6 +87,11 @@ typedef struct GpnerfFrame {
     const float* head_blob_split;           /* device or NULL; gpnerf_pack_head_split() image (GPNERF_FLAG_SPLIT_F16) */
     const float* occ;                       /* device or NULL; [D_1][H_1][W_1] occupancy `masks3d` at level-1 size
                                                (SparseConvNet.py:135-139), read only with GPNERF_FLAG_OCC_CULL */
+    const float* vol_folded[GPNERF_LEVELS]; /* device or NULL; levels GPNERF_FOLD_FIRST_LEVEL.. (all of them or none; the finer
+                                               levels' entries are ignored): [D_k][H_k][W_k][64], written by gpnerf_fold_volumes
+                                               from vol[] and head_blob.  With them the fp32 form of gpnerf_render_fused
+                                               interpolates these levels' share of the sigma feature layer's pre-activation
+                                               instead of running it per sample (same result up to fp32 rounding) */
 } GpnerfFrame;
 
 /* The per-ray MLP parameters in PyTorch layout (weight [out][in] row-major, bias [out]),
@@ -131,6 +138,13 @@ int gpnerf_pack_head(const GpnerfHeadParams* params_host, float* blob_host);
 /* The same parameters as f16 hi/lo pairs in v_mfma_f32_32x32x16_f16 A-operand order (GPNERF_FLAG_SPLIT_F16). */
 int64_t gpnerf_head_blob_split_floats(void);
 int gpnerf_pack_head_split(const GpnerfHeadParams* params_host, float* blob_host);
+
+/* sigmahead.out_geometry_fc (trainhead.py:39-40,58) is linear in the 4 x 32 volume features, and F.grid_sample
+ * (SparseConvNet.py:113-116) is linear in the voxels: Linear(sum_t w_t v_t) = sum_t w_t Linear(v_t).  For the coarse levels
+ * k >= GPNERF_FOLD_FIRST_LEVEL this applies the layer's 32 columns of level k (without the bias) to every voxel of vol[k] --
+ * once per frame instead of once per sample -- and writes 64 values per voxel in the order the sample loop accumulates them.
+ * out: host array of GPNERF_LEVELS device pointers (entries below GPNERF_FOLD_FIRST_LEVEL unused), D_k * H_k * W_k * 64 floats. */
+int gpnerf_fold_volumes(const GpnerfFrame* frame, float* const* out, void* stream);
 
 /* Fused sample -> gather -> MLP -> composite over N rays.
  * Replaces Renderer.batchify_rays + render_rays with is_train=False
