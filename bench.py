@@ -169,7 +169,7 @@ def main():
                 self.rays_per_step = wl.n * world
             self.n_local = self.rays.shape[0]
             # the fold is per-frame work and the bench re-uses one Frame: True = fold again in every step, inside the timed region
-            self.fold = bool(not args.no_fold and not args.split_f16)
+            self.fold = bool(not args.no_fold and not args.split_f16 and not args.occ_cull)
 
         def render(self):
             return fm.render_fused(self.wl.frame, self.rays, self.wl.S, want=self.want, ray_order=self.order, fold=self.fold, **kw)

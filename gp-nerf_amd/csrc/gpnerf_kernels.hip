@@ -746,13 +746,13 @@ DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
     // All eight taps of the view (4 image texels, 4 x 64 B of the feature map) are loaded before the first is used: 20 loads in
     // flight and one round trip per view, where the compiler on its own walks the taps one at a time (BATCH: the folded form,
     // which has no matrix work between its two gather phases to cover them).
-    const Axis ix = axis_taps(nx, iw), iy = axis_taps(ny, ih);
-    const unsigned ir0 = __umul24(iy.i0, (unsigned)iw * 16u), ir1 = __umul24(iy.i1, (unsigned)iw * 16u);
-    const unsigned ix0 = ix.i0 * 16u, ix1 = ix.i1 * 16u;
-    const Axis ax = axis_taps(nx, fw), ay = axis_taps(ny, fh);
-    const unsigned r0 = __umul24(ay.i0, (unsigned)fw * 128u), r1 = __umul24(ay.i1, (unsigned)fw * 128u);
-    const unsigned x0 = ax.i0 * 128u + (unsigned)half * 64u, x1 = ax.i1 * 128u + (unsigned)half * 64u;
     if constexpr (BATCH) {
+        const Axis ix = axis_taps(nx, iw), iy = axis_taps(ny, ih);
+        const unsigned ir0 = __umul24(iy.i0, (unsigned)iw * 16u), ir1 = __umul24(iy.i1, (unsigned)iw * 16u);
+        const unsigned ix0 = ix.i0 * 16u, ix1 = ix.i1 * 16u;
+        const Axis ax = axis_taps(nx, fw), ay = axis_taps(ny, fh);
+        const unsigned r0 = __umul24(ay.i0, (unsigned)fw * 128u), r1 = __umul24(ay.i1, (unsigned)fw * 128u);
+        const unsigned x0 = ax.i0 * 128u + (unsigned)half * 64u, x1 = ax.i1 * 128u + (unsigned)half * 64u;
         const f32x4 nw = *reinterpret_cast<const f32x4*>(at_byte(img, ir0 + ix0));
         const f32x4 ne = *reinterpret_cast<const f32x4*>(at_byte(img, ir0 + ix1));
         const f32x4 sw = *reinterpret_cast<const f32x4*>(at_byte(img, ir1 + ix0));
@@ -785,17 +785,23 @@ DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
         __builtin_amdgcn_sched_barrier(0);
     } else {
         {   // RGB from the full-resolution image
-            const f32x4 nw = *reinterpret_cast<const f32x4*>(at_byte(img, ir0 + ix0));
-            const f32x4 ne = *reinterpret_cast<const f32x4*>(at_byte(img, ir0 + ix1));
-            const f32x4 sw = *reinterpret_cast<const f32x4*>(at_byte(img, ir1 + ix0));
-            const f32x4 se = *reinterpret_cast<const f32x4*>(at_byte(img, ir1 + ix1));
-            const float wnw = ix.w0 * iy.w0, wne = ix.w1 * iy.w0, wsw = ix.w0 * iy.w1, wse = ix.w1 * iy.w1;
+            const Axis ax = axis_taps(nx, iw), ay = axis_taps(ny, ih);
+            const unsigned r0 = __umul24(ay.i0, (unsigned)iw * 16u), r1 = __umul24(ay.i1, (unsigned)iw * 16u);
+            const unsigned x0 = ax.i0 * 16u, x1 = ax.i1 * 16u;
+            const f32x4 nw = *reinterpret_cast<const f32x4*>(at_byte(img, r0 + x0));
+            const f32x4 ne = *reinterpret_cast<const f32x4*>(at_byte(img, r0 + x1));
+            const f32x4 sw = *reinterpret_cast<const f32x4*>(at_byte(img, r1 + x0));
+            const f32x4 se = *reinterpret_cast<const f32x4*>(at_byte(img, r1 + x1));
+            const float wnw = ax.w0 * ay.w0, wne = ax.w1 * ay.w0, wsw = ax.w0 * ay.w1, wse = ax.w1 * ay.w1;
 #pragma unroll
             for (int c = 0; c < 3; ++c) s.rgb[c] = fmaf(se[c], wse, fmaf(sw[c], wsw, fmaf(ne[c], wne, nw[c] * wnw)));
         }
         {   // features from the quarter-resolution map, same normalised coordinates
+            const Axis ax = axis_taps(nx, fw), ay = axis_taps(ny, fh);
 #pragma unroll
             for (int c = 0; c < 16; ++c) f[c] = 0.f;
+            const unsigned r0 = __umul24(ay.i0, (unsigned)fw * 128u), r1 = __umul24(ay.i1, (unsigned)fw * 128u);
+            const unsigned x0 = ax.i0 * 128u + (unsigned)half * 64u, x1 = ax.i1 * 128u + (unsigned)half * 64u;
             fma16(at_byte(fm, r0 + x0), ax.w0 * ay.w0, f);
             fma16(at_byte(fm, r0 + x1), ax.w1 * ay.w0, f);
             fma16(at_byte(fm, r1 + x0), ax.w0 * ay.w1, f);

@@ -265,9 +265,10 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     32-ray tiles that were (int32 tensor [1]).
     subset: ray_order lists the rows of `rays` to render (any number of distinct rows); outputs keep rays' row count, rows
     that are not listed come back zero.
-    fold: the fp32 form with the coarse levels folded (Frame.fold_volumes).  None: yes, folding once per Frame; True: fold now (a
-    caller that re-uses one Frame for many frames' worth of calls, like the bench, pays the per-frame fold every time); False:
-    the sigma feature layer entirely per sample (what the split form's fix-up launch does)."""
+    fold: the fp32 form with the coarse levels folded (Frame.fold_volumes).  None: yes for dense launches of whatever size -- a
+    shard of a frame's rays must give the bits the whole frame gives -- folding once per Frame (culled frames evaluate too few
+    samples to gain); True: fold now (a caller that re-uses one Frame for many frames' worth of calls, like the bench, pays the per-frame
+    fold every time); False: the sigma feature layer entirely per sample (what the split form's fix-up launch does)."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()
@@ -327,7 +328,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     n_launch = int(ray_order.numel()) if subset else N
     refold = fold is True
     if fold is None:
-        fold = not split_f16
+        fold = not split_f16 and not occ_cull
     if fold and not split_f16:
         if refold or not getattr(frame, "_folded_valid", False):
             frame.fold_volumes()
