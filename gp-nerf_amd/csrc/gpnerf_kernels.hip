@@ -855,6 +855,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     int chain, seg, wave_cap;
     int stagger;              // experiment: wavefronts start up to this many x 1.7 us late, scattered over the chip
     int chunk;                // tiles per chunk of the XCD queues (queue_tile())
+    int tail_p;               // chain_plan(): samples per step of the units the last whole round is cut into
     const int* list_in;
     const unsigned* count_in;
     int* list_out;
@@ -963,11 +964,17 @@ DEV ChainPlan chain_plan(kargs_cptr k) {
     c.bulk_tiles = n32; c.rem_tiles = 0; c.rem_p = 1;
     if ((k->flags & GPNERF_FLAG_OCC_CULL) || k->p_cap <= 0) return c;
     const long slots = k->p_cap / RAYS_PER_WAVE;
-    c.bulk_tiles = (n32 / slots) * slots;
+    long rounds = n32 / slots;
+    // The last whole round of a launch of two rounds or more also runs as units of tail_p samples per step: a SIMD serves its older
+    // wavefront first (it walks 5 units of 8, the younger 3), and with whole 16-step units the older ones walk their last alone
+    // (tools/wave_times.py); units a quarter as long let both finish together (512x512x128 bench frame: 9.02 -> 8.82 ms; 2: 8.91, 8: 9.2)
+    if (k->tail_p > 1 && rounds >= 2) --rounds;
+    c.bulk_tiles = rounds * slots;
     const long rem = n - c.bulk_tiles * RAYS_PER_WAVE;
     if (rem <= 0) { c.bulk_tiles = n32; return c; }
     int p = 1;
     while (p < 8 && rem * (2 * p) <= k->p_cap) p *= 2;
+    if (k->tail_p > p) p = k->tail_p;
     c.rem_p = p;
     c.rem_tiles = (rem * p + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     return c;
@@ -2485,6 +2492,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     static int f_chunk = -1;
     if (f_chunk < 0) { const char* e = getenv("GPNERF_QUEUE_CHUNK"); f_chunk = e ? atoi(e) : 64; }
     ka.chunk = f_chunk > 0 ? f_chunk : (int)((tiles + 7) / 8);        // 0: one contiguous run per XCD
+    static int f_tail = -1;
+    if (f_tail < 0) { const char* e = getenv("GPNERF_CHAIN_TAILP"); f_tail = e ? atoi(e) : 4; }
+    ka.tail_p = f_tail;
     // Early termination on frames of at least one round of wavefronts: the samples are walked in segments of chain_len(), one
     // persistent-queue launch per segment.  A ray that is opaque stops (per ray, not per tile); the rays that go on park 16
     // floats and are appended to the next launch's list, so every launch packs the survivors 32 to a wavefront again: on the
