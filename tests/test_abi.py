@@ -124,3 +124,21 @@ def test_render_fused_rejects_bad_arguments_on_the_host(pkg):
     f.head_blob = None
     assert call(f) == -1
     assert lib.gpnerf_strerror(-1) == b"invalid argument"
+
+
+def test_fold_volumes_rejects_bad_arguments_on_the_host(pkg):
+    """gpnerf_fold_volumes checks its arguments before it touches the device: the frame, its head image, the coarse levels
+    (GPNERF_FOLD_FIRST_LEVEL..) and their output pointers; the finer levels' entries are not looked at."""
+    L = pkg._lib
+    lib = L.lib()
+    outs = (C.c_void_p * L.LEVELS)(None, None, 0x1000, 0x1000)
+    assert lib.gpnerf_fold_volumes(None, outs, None) == -1
+    assert lib.gpnerf_fold_volumes(C.byref(_frame(L)), None, None) == -1
+    f = _frame(L)
+    f.head_blob = None
+    assert lib.gpnerf_fold_volumes(C.byref(f), outs, None) == -1
+    f = _frame(L)
+    f.vol[L.FOLD_FIRST_LEVEL] = None
+    assert lib.gpnerf_fold_volumes(C.byref(f), outs, None) == -1
+    assert lib.gpnerf_fold_volumes(C.byref(_frame(L)), (C.c_void_p * L.LEVELS)(0x1000, 0x1000, 0x1000, None), None) == -1
+    assert L.FOLD_FIRST_LEVEL == 2 and "GPNERF_FOLD_FIRST_LEVEL 2" in open(os.path.join(ROOT, "include", "gpnerf_hip.h")).read()
