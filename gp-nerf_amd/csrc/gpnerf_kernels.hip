@@ -1513,36 +1513,45 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(const int* __re
     for (int t = lo; t < hi; ++t) order[cnt[cls(t) * SORT_THREADS + i]++] = t;
 }
 
-// gpnerf_fold_volumes: out_geometry_fc's 32 columns of level l applied to every voxel of level l (see gather_folded).  One
-// wavefront per 32 voxels: B operand = the voxel's 32 channels in the sample loop's own k-step order, A = the layer's two weight
+// gpnerf_fold_volumes: out_geometry_fc's 32 columns of level l applied to every voxel of level l (see gather_folded), both
+// folded levels in one launch.  One wavefront per 32 voxels: B operand = the voxel's 32 channels in the sample loop's own k-step order, A = the layer's two weight
 // tiles from the head image (k-steps 16 l ... 16 l + 15), fp32 MFMA; the lane of (voxel, half) stores its 2 x 16 accumulator
 // registers as 128 contiguous bytes, which is what the lane of (ray, half) reads back per tap.  No bias: it is added once, after
 // the interpolation (out-of-volume taps contribute nothing, exactly as zero padding does before the layer).
-__global__ void __launch_bounds__(256) fold_volume_kernel(const float* __restrict__ head_blob, const float* __restrict__ vol, const long n_vox,
-                                                          const int level, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float w[2 * 16 * 64];          // [tile][4 groups][64 lanes][4 k-steps]
-    for (int i = threadIdx.x; i < 2 * 16 * 64 / 4; i += blockDim.x) {
-        const int m = i / 256, r = i % 256;
-        reinterpret_cast<f32x4*>(w)[i] =
-            reinterpret_cast<const f32x4*>(head_blob + gpl::w_off(gpl::GEO) + m * gpl::NT[gpl::GEO] * 64 + level * 16 * 64)[r];
+struct FoldArgs {                  // the levels GPNERF_FOLD_FIRST_LEVEL .. of one frame, one launch
+    const float* vol[GPNERF_LEVELS - GPNERF_FOLD_FIRST_LEVEL];
+    float* out[GPNERF_LEVELS - GPNERF_FOLD_FIRST_LEVEL];
+    long tiles_before[GPNERF_LEVELS - GPNERF_FOLD_FIRST_LEVEL + 1];      // 32-voxel tiles of the levels before this one
+    long n_vox[GPNERF_LEVELS - GPNERF_FOLD_FIRST_LEVEL];
+};
+__global__ void __launch_bounds__(256) fold_volume_kernel(const float* __restrict__ head_blob, const FoldArgs a) {
+    constexpr int NL = GPNERF_LEVELS - GPNERF_FOLD_FIRST_LEVEL;
+    __shared__ __attribute__((aligned(16))) float w[NL * 2 * 16 * 64];     // [level][tile][4 groups][64 lanes][4 k-steps]
+    for (int i = threadIdx.x; i < NL * 2 * 16 * 64 / 4; i += blockDim.x) {
+        const int l = i / 512, m = (i % 512) / 256, r = i % 256;
+        reinterpret_cast<f32x4*>(w)[i] = reinterpret_cast<const f32x4*>(head_blob + gpl::w_off(gpl::GEO) + m * gpl::NT[gpl::GEO] * 64 +
+                                                                         (GPNERF_FOLD_FIRST_LEVEL + l) * 16 * 64)[r];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
-    const long n_tiles = (n_vox + 31) / 32;
-    for (long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (long)gridDim.x * 4) {
+    for (long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6); unit < a.tiles_before[NL]; unit += (long)gridDim.x * 4) {
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < NL; ++i) l = unit >= a.tiles_before[i] ? i : l;
+        const long tile = unit - a.tiles_before[l], n_vox = a.n_vox[l];
         const long vox = tile * 32 + n;
         const long v = vox < n_vox ? vox : n_vox - 1;
-        const f32x4* q = reinterpret_cast<const f32x4*>(vol + v * GPNERF_CH + half * 16);
+        const f32x4* q = reinterpret_cast<const f32x4*>(a.vol[l] + v * GPNERF_CH + half * 16);
         float b[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const f32x4 a = q[i]; b[4 * i] = a[0]; b[4 * i + 1] = a[1]; b[4 * i + 2] = a[2]; b[4 * i + 3] = a[3]; }
+        for (int i = 0; i < 4; ++i) { const f32x4 t = q[i]; b[4 * i] = t[0]; b[4 * i + 1] = t[1]; b[4 * i + 2] = t[2]; b[4 * i + 3] = t[3]; }
         f32x16 g0, g1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
-        mfma_tile<16>(w, lane, b, g0);
-        mfma_tile<16>(w + 16 * 64, lane, b, g1);
+        mfma_tile<16>(w + l * 2048, lane, b, g0);
+        mfma_tile<16>(w + l * 2048 + 16 * 64, lane, b, g1);
         if (vox < n_vox) {
-            f32x4* o = reinterpret_cast<f32x4*>(out + vox * (2 * GPNERF_CH) + half * GPNERF_CH);
+            f32x4* o = reinterpret_cast<f32x4*>(a.out[l] + vox * (2 * GPNERF_CH) + half * GPNERF_CH);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 o[i] = f32x4{g0[4 * i], g0[4 * i + 1], g0[4 * i + 2], g0[4 * i + 3]};
@@ -2386,12 +2395,16 @@ int gpnerf_fold_volumes(const GpnerfFrame* f, float* const* out, void* stream) {
     for (int l = FOLD_FROM; l < GPNERF_LEVELS; ++l)
         if (!f->vol[l] || !out[l] || f->vol_dhw[l][0] < 1 || f->vol_dhw[l][1] < 1 || f->vol_dhw[l][2] < 1) return GPNERF_E_ARG;
     if (device_ready(nullptr) != GPNERF_OK) return GPNERF_E_DEVICE;
+    FoldArgs a;
+    a.tiles_before[0] = 0;
     for (int l = FOLD_FROM; l < GPNERF_LEVELS; ++l) {
-        const long n_vox = (long)f->vol_dhw[l][0] * f->vol_dhw[l][1] * f->vol_dhw[l][2];
-        const long wgs = ((n_vox + 31) / 32 + 3) / 4;
-        hipLaunchKernelGGL(fold_volume_kernel, dim3((unsigned)(wgs < 8192 ? wgs : 8192)), dim3(256), 0, S_(stream), f->head_blob, f->vol[l], n_vox, l,
-                           out[l]);
+        const int i = l - FOLD_FROM;
+        a.vol[i] = f->vol[l]; a.out[i] = out[l];
+        a.n_vox[i] = (long)f->vol_dhw[l][0] * f->vol_dhw[l][1] * f->vol_dhw[l][2];
+        a.tiles_before[i + 1] = a.tiles_before[i] + (a.n_vox[i] + 31) / 32;
     }
+    const long wgs = (a.tiles_before[GPNERF_LEVELS - FOLD_FROM] + 3) / 4;
+    hipLaunchKernelGGL(fold_volume_kernel, dim3((unsigned)(wgs < 8192 ? wgs : 8192)), dim3(256), 0, S_(stream), f->head_blob, a);
     return launch_status();
 }
 
