@@ -2136,6 +2136,12 @@ hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 __global__ void zero_words_kernel(unsigned* __restrict__ p, const long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
 }
+__global__ void zero_bytes_kernel(uint8_t* __restrict__ p, const long n) {      // p: 4-byte aligned
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) *reinterpret_cast<unsigned*>(p + i) = 0u;
+        else for (long j = i; j < n; ++j) p[j] = 0;
+    }
+}
 bool zero_async(void* p, size_t bytes, void* stream) {          // bytes: a multiple of 4
     const long n = (long)(bytes / sizeof(unsigned));
     const long wgs = (n + 255) / 256;
@@ -2728,7 +2734,11 @@ int gpnerf_select_pixels(const float* occ, int32_t D, int32_t H, int32_t W, floa
     memcpy(g.Th, Th, sizeof(g.Th));
     memcpy(g.pose, pose, sizeof(g.pose));
     memcpy(g.K, K, sizeof(g.K));
-    if (hipMemsetAsync(pixel_sel, 0, (size_t)img_h * img_w, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+    {
+        const long nb = (long)img_h * img_w, wgs = (nb / 4 + 255) / 256;
+        hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)(wgs < 1 ? 1 : (wgs > 2048 ? 2048 : wgs))), dim3(256), 0, S_(stream), pixel_sel, nb);
+        if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
+    }
     hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(64), 0, S_(stream), (int*)world_minmax);
     const long n = (long)D * H * W;
     const long want_blocks = (n + 255) / 256;

@@ -290,6 +290,21 @@ __global__ void dense_kernel(const float* __restrict__ feat, const int c, const 
 }
 
 hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// Buffers are (re)set by a kernel of the library's own rather than hipMemsetAsync: a memset node captured into a HIP graph was not
+// reliably ordered before the kernel node after it (gpnerf_kernels.hip, zero_words_kernel).  n_words 32-bit words of `value`.
+__global__ void __launch_bounds__(256) fill_words_kernel(unsigned* __restrict__ p, const long n_words, const unsigned value) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const long n4 = n_words / 4, stride = (long)gridDim.x * blockDim.x, first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const u4 v = {value, value, value, value};
+    for (long i = first; i < n4; i += stride) reinterpret_cast<u4*>(p)[i] = v;          // (hipMalloc / torch allocations: 16-byte aligned)
+    for (long i = n4 * 4 + first; i < n_words; i += stride) p[i] = value;
+}
+bool fill_async(void* p, size_t bytes, unsigned value, void* stream) {     // bytes: a multiple of 4; p: 16-byte aligned
+    const long n = (long)(bytes / 4), wgs = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)(wgs < 1 ? 1 : (wgs > 16384 ? 16384 : wgs))), dim3(256), 0, S_(stream),
+                       static_cast<unsigned*>(p), n, value);
+    return hipGetLastError() == hipSuccess;
+}
 int status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
 bool bad(const int32_t* dims) { return !dims || dims[0] < 1 || dims[1] < 1 || dims[2] < 1; }
 
@@ -363,7 +378,7 @@ int gpnerf_sparse_index(const int32_t* coords, const int32_t* m_dev, int32_t m_c
                         void* stream) {
     if (!coords || !grid || bad(dims) || m_cap < 0) return GPNERF_E_ARG;
     const Dims s{dims[0], dims[1], dims[2]};
-    if (hipMemsetAsync(grid, 0xFF, sizeof(int32_t) * (size_t)s.d * s.h * s.w, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;
+    if (!fill_async(grid, sizeof(int32_t) * (size_t)s.d * s.h * s.w, 0xFFFFFFFFu, stream)) return GPNERF_E_LAUNCH;
     if (m_cap == 0) return GPNERF_OK;
     hipLaunchKernelGGL(index_kernel, dim3((m_cap + 255) / 256), dim3(256), 0, S_(stream), coords, (const int*)m_dev, (int)m_cap, s, grid);
     return status();
@@ -424,8 +439,7 @@ int gpnerf_sparse_down_sites(const int32_t* in_coords, const int32_t* m_in_dev, 
     if (!in_coords || bad(out_dims) || !out_grid || !out_coords || !m_out_dev || m_in_cap < 0 || m_out_cap < 0) return GPNERF_E_ARG;
     const Dims s{out_dims[0], out_dims[1], out_dims[2]};
     const long cells = (long)s.d * s.h * s.w;
-    if (hipMemsetAsync(out_grid, 0xFF, sizeof(int32_t) * (size_t)cells, S_(stream)) != hipSuccess ||
-        hipMemsetAsync(m_out_dev, 0, sizeof(int32_t), S_(stream)) != hipSuccess)
+    if (!fill_async(out_grid, sizeof(int32_t) * (size_t)cells, 0xFFFFFFFFu, stream) || !fill_async(m_out_dev, sizeof(int32_t), 0u, stream))
         return GPNERF_E_LAUNCH;
     if (m_in_cap == 0) return GPNERF_OK;
     hipLaunchKernelGGL(mark_kernel, dim3((m_in_cap + 255) / 256), dim3(256), 0, S_(stream), in_coords, (const int*)m_in_dev,
@@ -440,7 +454,7 @@ int gpnerf_sparse_merge_duplicates(float* feat, int32_t channels, const int32_t*
     if (!feat || !coords || !grid || !scratch || bad(dims) || channels < 1 || channels > 32 || m < 0) return GPNERF_E_ARG;
     if (m == 0) return GPNERF_OK;
     const Dims s{dims[0], dims[1], dims[2]};
-    if (hipMemsetAsync(scratch, 0, sizeof(int32_t) * (size_t)m, S_(stream)) != hipSuccess) return GPNERF_E_LAUNCH;     // the counts
+    if (!fill_async(scratch, sizeof(int32_t) * (size_t)m, 0u, stream)) return GPNERF_E_LAUNCH;     // the counts
     hipLaunchKernelGGL(count_duplicates_kernel, dim3((m + 255) / 256), dim3(256), 0, S_(stream), coords, grid, (int)m, s, scratch);
     hipLaunchKernelGGL(merge_duplicates_kernel, dim3((m + 3) / 4), dim3(256), 0, S_(stream), feat, (int)channels, coords, grid,
                        (int)m, s, (const int32_t*)scratch);
@@ -451,8 +465,7 @@ int gpnerf_sparse_to_dense(const float* feat, int32_t channels, const int32_t* c
                            int32_t m_cap, const int32_t* dims, float* vol_ndhwc, void* stream) {
     if (!feat || !coords || !grid || bad(dims) || !vol_ndhwc || channels < 1 || channels > 32 || m_cap < 0) return GPNERF_E_ARG;
     const Dims s{dims[0], dims[1], dims[2]};
-    if (hipMemsetAsync(vol_ndhwc, 0, sizeof(float) * (size_t)s.d * s.h * s.w * channels, S_(stream)) != hipSuccess)
-        return GPNERF_E_LAUNCH;
+    if (!fill_async(vol_ndhwc, sizeof(float) * (size_t)s.d * s.h * s.w * channels, 0u, stream)) return GPNERF_E_LAUNCH;
     if (m_cap == 0) return GPNERF_OK;
     hipLaunchKernelGGL(dense_kernel, dim3((m_cap + 7) / 8), dim3(256), 0, S_(stream), feat, (int)channels, coords, grid,
                        (const int*)m_dev, (int)m_cap, s, vol_ndhwc);
