@@ -346,11 +346,17 @@ def run_demo_case(name, scene_kw, n_samples, neg_ray=False, probe=96):
           f"rgb mean={out['rgb_map'].mean():.4f} max={out['rgb_map'].max():.4f} -> {os.path.getsize(path)} B")
 
 
-def run_e2e_case(name, scene_kw, n_samples, seed):
+def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400):
     """The evaluation loop's per-frame chain with the reference's REAL image encoder (BASELINE.json configs[4] in miniature;
     the ZJU-MoCap data itself is not in the tree): libs/encoders/UNet.py ResUNet.forward -> libs/renders/BaseRender.py
     Renderer.render, then libs/evaluators/if_nerf.py Evaluator.psnr_metric on the result against a seeded ground truth.
-    Source images are the structured encoder images; the 4 dense levels stay inputs (spconv is not available)."""
+    Source images are the structured encoder images; the 4 dense levels stay inputs (spconv is not available).
+
+    `ray_stride` (the config-5-sized case: 512x512 sources, 128x128 feature maps, ~75 k rays x 64 samples): the maps are
+    stored for every `ray_stride`-th ray plus a SHA-256 over the full arrays (so that a regeneration is checked bit for bit),
+    the feature maps for every 4th texel plus per-(view, channel) float64 means, and the ground truth of the PSNR as the
+    8-bit image a dataset would hold (clip(render + noise) rounded to 1/255) for ALL rays, so the evaluator's PSNR over the
+    whole frame is pinned to the reference evaluator's value."""
     syn = importlib.import_module("gp-nerf_amd.synthetic")
     UNet = importlib.import_module("UNet")
     sk = types.ModuleType("skimage"); skm = types.ModuleType("skimage.measure"); skm.compare_ssim = None
@@ -359,6 +365,7 @@ def run_e2e_case(name, scene_kw, n_samples, seed):
     scene = syn.make_scene(**scene_kw)
     scene["src_imgs"] = syn.make_encoder_images(scene_kw["H"], scene_kw["W"], seed)[None]
     r, BaseRender, trainhead = build_reference_renderer(scene, n_samples, False)
+    r.chunk = chunk
     enc = UNet.ResUNet(encoder="resnet34", out_ch=32)
     enc_state = syn.make_encoder_weights(seed)
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in enc_state.items()}, strict=True)
@@ -370,6 +377,9 @@ def run_e2e_case(name, scene_kw, n_samples, seed):
     rgb = ret["rgb_map"][0].numpy()
     g = np.random.Generator(np.random.PCG64([seed, 909]))
     rgb_gt = np.clip(rgb + 0.05 * g.standard_normal(rgb.shape, dtype=np.float32), 0, 1).astype(np.float32)
+    if ray_stride is not None:
+        gt_u8 = np.round(rgb_gt * np.float32(255.0)).astype(np.uint8)
+        rgb_gt = gt_u8.astype(np.float32) / np.float32(255.0)
     ev = if_nerf.Evaluator(None, "seq")
     psnr = float(ev.psnr_metric(rgb, rgb_gt))
     h = hashlib.sha256()
@@ -379,6 +389,15 @@ def run_e2e_case(name, scene_kw, n_samples, seed):
     out = {"rgb_map": rgb, "depth_map": ret["depth_map"][0, :, 0].numpy(), "acc_map": ret["acc_map"][0, :, 0].numpy(),
            "rgb_in_map": ret["rgb_in_map"][0].numpy(), "featmaps": featmaps.astype(np.float32), "rgb_gt": rgb_gt,
            "psnr": np.float64(psnr), "mse": np.float64(np.mean((rgb - rgb_gt) ** 2))}
+    if ray_stride is not None:
+        full = hashlib.sha256()
+        for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map", "featmaps"):
+            full.update(np.ascontiguousarray(out[k]).tobytes())
+        fm = out.pop("featmaps")
+        out = {k: (v[::ray_stride] if k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map") else v) for k, v in out.items() if k != "rgb_gt"}
+        out.update(rgb_gt_u8=gt_u8, ray_stride=np.int64(ray_stride), featmaps_sub=np.ascontiguousarray(fm[:, :, ::4, ::4]),
+                   featmaps_stride=np.int64(4), featmaps_chan_mean=fm.astype(np.float64).mean(axis=(2, 3)),
+                   featmaps_absmax=np.float64(np.abs(fm).max()), outputs_sha256=np.frombuffer(full.digest(), np.uint8))
     meta = {"scene_kw": scene_kw, "n_samples": n_samples, "seed": seed, "n_rays": int(rgb.shape[0]), "sha256_inputs": h.hexdigest(),
             "torch": torch.__version__, "reference": "UNet.ResUNet.forward -> BaseRender.Renderer.render -> if_nerf.Evaluator.psnr_metric, eval, CPU fp32"}
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -415,10 +434,12 @@ CASES = [
 ]
 
 
-def run_encoder_case(name, H, W, seed):
+def run_encoder_case(name, H, W, seed, stride=None):
     """libs/encoders/UNet.py ResUNet.forward on seeded images with seeded parameters.  The parameters
     come from gp-nerf_amd/synthetic.py by state_dict key, and are loaded strict=True into the reference's module, so the
-    vector also pins the key/shape map."""
+    vector also pins the key/shape map.  `stride` (the 512x512 case, the size BASELINE configs[4] encodes at): every
+    `stride`-th texel of the [3,32,H/4,W/4] result is stored, with a SHA-256 over the whole result, per-(view, channel)
+    float64 means and mean squares, and the per-channel max-abs."""
     syn = importlib.import_module("gp-nerf_amd.synthetic")
     UNet = importlib.import_module("UNet")
     state = syn.make_encoder_weights(seed)
@@ -434,7 +455,16 @@ def run_encoder_case(name, H, W, seed):
         h.update(np.ascontiguousarray(state[k]).tobytes())
     meta = dict(name=name, H=H, W=W, seed=seed, inputs_sha256=h.hexdigest(), torch=torch.__version__,
                 reference="libs/encoders/UNet.py ResUNet(resnet34, out_ch=32).forward, eval, CPU fp32")
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), featmaps=out.astype(np.float32), meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    out = out.astype(np.float32)
+    if stride is None:
+        arrs = dict(featmaps=out)
+    else:
+        o64 = out.astype(np.float64)
+        arrs = dict(featmaps_sub=np.ascontiguousarray(out[:, :, ::stride, ::stride]), featmaps_stride=np.int64(stride),
+                    featmaps_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest(), np.uint8),
+                    featmaps_chan_mean=o64.mean(axis=(2, 3)), featmaps_chan_meansq=(o64 * o64).mean(axis=(2, 3)),
+                    featmaps_chan_absmax=np.abs(out).max(axis=(2, 3)))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrs)
     print(name, out.shape, float(np.abs(out).max()))
 
 
@@ -481,9 +511,15 @@ def main():
     for name, n, d, seed in (("attention_d16", 257, 16, 5), ("attention_d32", 300, 32, 6)):
         if not only or name in only:
             run_attention_case(name, n, d, seed)
-    for name, H, W, seed in (("encoder_64x64", 64, 64, 3), ("encoder_72x88", 72, 88, 4)):
+    for name, H, W, seed, stride in (("encoder_64x64", 64, 64, 3, None), ("encoder_72x88", 72, 88, 4, None),
+                                     ("encoder_512x512", 512, 512, 11, 4)):
         if not only or name in only:
-            run_encoder_case(name, H, W, seed)
+            run_encoder_case(name, H, W, seed, stride)
+    if not only or "e2e_512_survey" in only:
+        # the size BASELINE.json configs[4] runs at: 512x512 sources (1024 x ratio 0.5), full-size SMPL box, literal f = 1.05 W
+        # camera of SURVEY.md 8d, 64 samples per ray (configs/trainzju_valzju.yaml train.n_samples), test chunk 2000
+        run_e2e_case("e2e_512_survey", dict(H=512, W=512, seed=33, fill="survey", pose="random", bias_std=0.1, sigma_bias=0.3),
+                     64, 33, ray_stride=16, chunk=2000)
 
 
 if __name__ == "__main__":

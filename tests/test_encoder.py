@@ -10,6 +10,22 @@ import torch
 
 from golden_cases import assert_close, encoder_case_names, load
 
+
+def check_featmaps(out, z, tol):
+    """`out` [V,32,h,w] against an encoder_* fixture: whole maps for the small cases; for the strided 512x512 case every
+    stored texel plus the per-(view, channel) means / mean squares of the WHOLE map (a reduction over 16 384 texels: a
+    localised error the stride skipped still moves them) and the per-channel max-abs."""
+    out = np.asarray(out)
+    if "featmaps" in z:
+        return assert_close(out, z["featmaps"], tol, "featmaps")
+    st = int(z["featmaps_stride"])
+    err = assert_close(out[:, :, ::st, ::st], z["featmaps_sub"], tol, "featmaps (strided subset)")
+    o64 = out.astype(np.float64)
+    assert_close(o64.mean(axis=(2, 3)), z["featmaps_chan_mean"], tol, "featmaps per-channel mean")
+    assert_close((o64 * o64).mean(axis=(2, 3)), z["featmaps_chan_meansq"], 10 * tol, "featmaps per-channel mean square")
+    assert_close(np.abs(out).max(axis=(2, 3)), z["featmaps_chan_absmax"], tol, "featmaps per-channel max-abs")
+    return err
+
 syn = importlib.import_module("gp-nerf_amd.synthetic")
 enc = importlib.import_module("gp-nerf_amd.encoder")
 
@@ -54,14 +70,16 @@ def test_encoder_restatement_matches_reference_golden_cpu(name):
     assert _sha(imgs, state) == meta["inputs_sha256"]
     with torch.no_grad():
         out = ref.encoder(net, torch.from_numpy(imgs)).numpy()
-    assert_close(out, z["featmaps"], 1e-4, "featmaps")
+    check_featmaps(out, z, 1e-4)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", encoder_case_names())
 def test_encoder_on_gpu_feeds_frame_without_relayout(name):
-    """MIOpen convolutions (other algorithms, other summation order) stay inside north_star's 1e-4 of the reference vectors
-    (measured 3e-5 on O(5) activations); and the output is physically [V,h,w,32], which Frame takes by pointer."""
+    """The hand-written convolutions (gpnerf_conv.hip: split-f16 MFMA implicit GEMMs, their own summation order) stay inside
+    north_star's 1e-4 of the reference vectors, including the 512x512 case (128x128 feature maps, K up to 2 304, InstanceNorm
+    reductions over up to 65 536 pixels: the size BASELINE configs[4] encodes at); and the output is physically [V,h,w,32],
+    which Frame takes by pointer."""
     fm = importlib.import_module("gp-nerf_amd.frame")
     z, meta = load(name)
     net, _ = _net(meta["seed"])
@@ -69,7 +87,8 @@ def test_encoder_on_gpu_feeds_frame_without_relayout(name):
     imgs = torch.from_numpy(syn.make_encoder_images(meta["H"], meta["W"], meta["seed"])).to("cuda:0")
     with torch.no_grad():
         out = net(imgs)
-    assert_close(out.cpu().numpy(), z["featmaps"], 1e-4, "featmaps")
+    err = check_featmaps(out.cpu().numpy(), z, 1e-4)
+    print(f"{name}: encoder max-abs vs the reference vector {err:.3e}")
     assert out.is_contiguous(memory_format=torch.channels_last)
     sc = syn.make_scene(H=meta["H"], W=meta["W"], seed=1, aabb_half=(0.12, 0.16, 0.05))
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")

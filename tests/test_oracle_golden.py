@@ -94,3 +94,32 @@ def test_oracle_matches_the_progressive_renderer(name, oracle):
     if meta["neg_ray"]:      # the fixture discriminates the two readings of neg_ray: flipping the samples is far off
         bad = oracle.render(sc, meta["n_samples"], neg_ray=True, flip=True, occ=occ, rays=np.concatenate([ro, rd, near[:, None], far[:, None]], 1))
         assert np.abs(bad["rgb_map"] - z["rgb_map"]).max() > 1e-2
+
+
+def test_oracle_and_encoder_restatement_at_the_config5_size(oracle, syn):
+    """tests/golden/e2e_512_survey.npz (reference ResUNet.forward -> BaseRender.Renderer.render on a 512x512 frame, 112 475
+    rays x 64 samples, the size BASELINE.json configs[4] runs at): the torch-operator restatement of the encoder against every
+    stored feature texel, then the C oracle on every 64th ray with those feature maps."""
+    import importlib
+    import torch
+    from oracle import producers_ref as ref
+    enc = importlib.import_module("gp-nerf_amd.encoder")
+    z, meta = load("e2e_512_survey")
+    sc = scene_of(meta)
+    sc["src_imgs"] = syn.make_encoder_images(512, 512, meta["seed"])[None]
+    net = enc.ResUNet(encoder="resnet34", out_ch=32)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_encoder_weights(meta["seed"]).items()}, strict=True)
+    with torch.no_grad():
+        fm = ref.encoder(net.eval(), torch.from_numpy(sc["src_imgs"][0])).numpy()
+    fst, st = int(z["featmaps_stride"]), int(z["ray_stride"])
+    assert_close(fm[:, :, ::fst, ::fst], z["featmaps_sub"], 1e-4, "feature maps (every 4th texel)")
+    assert_close(fm.astype(np.float64).mean(axis=(2, 3)), z["featmaps_chan_mean"], 1e-4, "feature maps (channel means)")
+    sc["featmaps"] = fm
+    rays = oracle.rays_of(sc)
+    assert rays.shape[0] == meta["n_rays"]
+    sub = rays[::st][::4]
+    res = oracle.render(sc, meta["n_samples"], rays=np.ascontiguousarray(sub), want_weights=False)
+    assert_close(res["rgb_map"], z["rgb_map"][::4], 1e-4, "rgb_map")          # featmaps carry the restatement's own 1e-5
+    assert_close(res["depth_map"], z["depth_map"][::4], 1e-4, "depth_map")
+    assert_close(res["acc_map"], z["acc_map"][::4], 1e-4, "acc_map")
+    assert_close(res["rgb_in_map"], z["rgb_in_map"][::4], TOL, "rgb_in_map")
