@@ -4,8 +4,8 @@
 //
 // Convolution = implicit GEMM on the matrix cores in the render kernel's transposed form,
 //     out[co][pixel] += W[co][(tap, ci)] * in[(tap, ci)][pixel],
-// with every fp32 operand written as f16 hi + lo (hi = f16(x) toward zero, lo = f16(x - hi)) and three
-// v_mfma_f32_32x32x16_f16 per 16-deep k-step (Wlo.xhi + Whi.xlo + Whi.xhi, f32 accumulation): ~22 significant bits per
+// with every fp32 operand written as f16 hi + lo (hi = f16(x) to nearest, lo = f16(x - hi)) and three
+// v_mfma_f32_32x32x16_f16 per 16-deep k-step (Wlo.xhi + Whi.xlo + Whi.xhi, f32 accumulation): ~23 significant bits per
 // operand at 3/16 of the fp32-MFMA cost -- the same arithmetic as GPNERF_FLAG_SPLIT_F16 (head_layout.h, namespace gph), whose
 // precondition (operands below the f16 range) holds here by construction for InstanceNorm'd / ReLU'd activations of images.
 //   A operand (weights): packed once per parameter version by pack_conv_weight_kernel into [chunk = (tap, 16 input channels)]
@@ -35,7 +35,12 @@ constexpr int STEP_BYTES = 2048;     // one (chunk, output tile): 64 lanes x 8 h
 constexpr int PT = 2;                // 32-pixel tiles per wave
 constexpr int WAVES = 4;             // waves per workgroup -> 256 output pixels per workgroup
 
-DEV unsigned pk_rtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// hi = f16(x) rounded to NEAREST (v_cvt_pk_f16_f32, new on gfx950): |x - hi| <= 2^-12 |x|, so lo = f16(x - hi) leaves
+// |x - hi - lo| <= 2^-23 |x| and the dropped lo.lo product is <= 2^-22 of the full one.  (Rounding hi toward zero, as
+// v_cvt_pkrtz does and round 2 shipped, doubles the residual: 4x the dropped product, 2x the operand error -- measured on the
+// 512x512 reference vector: 4.2e-5 -> see DESIGN.md 4.4.)
+DEV unsigned pk_hi(float a, float b) { const h2 r = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, r); }
 DEV unsigned lo_pair(unsigned w, float x0, float x1) {
     unsigned r;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(x0));
@@ -45,10 +50,10 @@ DEV unsigned lo_pair(unsigned w, float x0, float x1) {
 struct Frag { h8 hi, lo; };
 DEV Frag make_frag(const f32x4 a, const f32x4 b) {
     u32x4 H, Lo;
-    H[0] = pk_rtz(a[0], a[1]); Lo[0] = lo_pair(H[0], a[0], a[1]);
-    H[1] = pk_rtz(a[2], a[3]); Lo[1] = lo_pair(H[1], a[2], a[3]);
-    H[2] = pk_rtz(b[0], b[1]); Lo[2] = lo_pair(H[2], b[0], b[1]);
-    H[3] = pk_rtz(b[2], b[3]); Lo[3] = lo_pair(H[3], b[2], b[3]);
+    H[0] = pk_hi(a[0], a[1]); Lo[0] = lo_pair(H[0], a[0], a[1]);
+    H[1] = pk_hi(a[2], a[3]); Lo[1] = lo_pair(H[1], a[2], a[3]);
+    H[2] = pk_hi(b[0], b[1]); Lo[2] = lo_pair(H[2], b[0], b[1]);
+    H[3] = pk_hi(b[2], b[3]); Lo[3] = lo_pair(H[3], b[2], b[3]);
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
     f.lo = __builtin_bit_cast(h8, Lo);
@@ -85,8 +90,8 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const int C
         ci = k % Cin;
     }
     const float v = (co < Cout && in_k) ? w[((long)co * Cin + ci) * KS * KS + tap] : 0.f;
-    const unsigned hw = pk_rtz(v, 0.f);
-    const _Float16 hi = __builtin_bit_cast(_Float16, (uint16_t)(hw & 0xFFFFu));
+    const _Float16 hi = (_Float16)v;                          // round to nearest, as the activations' hi
+    const unsigned hw = __builtin_bit_cast(uint16_t, hi);
     const _Float16 lo = (_Float16)(v - (float)hi);
     uint16_t* dst = packed + step * (STEP_BYTES / 2);
     dst[lane * 8 + j] = (uint16_t)(hw & 0xFFFFu);
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             if (item < PITEMS) {
                 const int pp = item >> 2, qd = item & 3;
                 const f32x4 v = preg[s];
-                const unsigned h0 = pk_rtz(v[0], v[1]), h1 = pk_rtz(v[2], v[3]);
+                const unsigned h0 = pk_hi(v[0], v[1]), h1 = pk_hi(v[2], v[3]);
                 unsigned* d = reinterpret_cast<unsigned*>(pb + pp * PPX + qd * 8);
                 d[0] = h0; d[1] = h1;
                 d[8] = lo_pair(h0, v[0], v[1]); d[9] = lo_pair(h1, v[2], v[3]);       // lo block starts 32 bytes in

@@ -356,7 +356,10 @@ def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400):
     stored for every `ray_stride`-th ray plus a SHA-256 over the full arrays (so that a regeneration is checked bit for bit),
     the feature maps for every 4th texel plus per-(view, channel) float64 means, and the ground truth of the PSNR as the
     8-bit image a dataset would hold (clip(render + noise) rounded to 1/255) for ALL rays, so the evaluator's PSNR over the
-    whole frame is pinned to the reference evaluator's value."""
+    whole frame is pinned to the reference evaluator's value.  The same case is also run with the reference's encoder switched
+    to float64 (`ResUNet.double()`, its output rounded to float32 before the renderer, everything else unchanged): the distance
+    between the two runs (`spread_*`, max over ALL rays, and `*_enc64` for the stored rays) is what the reference's own float32
+    rounding inside the encoder does to each map at this size -- the yardstick for any other float32 encoder."""
     syn = importlib.import_module("gp-nerf_amd.synthetic")
     UNet = importlib.import_module("UNet")
     sk = types.ModuleType("skimage"); skm = types.ModuleType("skimage.measure"); skm.compare_ssim = None
@@ -390,11 +393,24 @@ def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400):
            "rgb_in_map": ret["rgb_in_map"][0].numpy(), "featmaps": featmaps.astype(np.float32), "rgb_gt": rgb_gt,
            "psnr": np.float64(psnr), "mse": np.float64(np.mean((rgb - rgb_gt) ** 2))}
     if ray_stride is not None:
+        import copy
+        with torch.no_grad():
+            fm64 = copy.deepcopy(enc).double()(batch["src_imgs"][0].double()).float()
+            r.encoder = _FixedEncoder(fm64)
+            ret64 = r.render(batch)
+        r.encoder = enc
+        pairs = (("rgb_map", ret64["rgb_map"][0].numpy()), ("depth_map", ret64["depth_map"][0, :, 0].numpy()),
+                 ("acc_map", ret64["acc_map"][0, :, 0].numpy()))
+        for k, v in pairs:
+            out["spread_" + k] = np.float64(np.abs(v.astype(np.float64) - out[k]).max())
+            out[k + "_enc64"] = v[::ray_stride]
+        out["spread_featmaps"] = np.float64(np.abs(fm64.numpy().astype(np.float64) - featmaps).max())
         full = hashlib.sha256()
         for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map", "featmaps"):
             full.update(np.ascontiguousarray(out[k]).tobytes())
         fm = out.pop("featmaps")
         out = {k: (v[::ray_stride] if k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map") else v) for k, v in out.items() if k != "rgb_gt"}
+        print("   float32-vs-float64 encoder spread of the reference:", {k: float(v) for k, v in out.items() if k.startswith("spread_")})
         out.update(rgb_gt_u8=gt_u8, ray_stride=np.int64(ray_stride), featmaps_sub=np.ascontiguousarray(fm[:, :, ::4, ::4]),
                    featmaps_stride=np.int64(4), featmaps_chan_mean=fm.astype(np.float64).mean(axis=(2, 3)),
                    featmaps_absmax=np.float64(np.abs(fm).max()), outputs_sha256=np.frombuffer(full.digest(), np.uint8))

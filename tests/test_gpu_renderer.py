@@ -399,10 +399,20 @@ def test_config5_sized_frame_with_the_real_encoder_matches_the_reference(plugins
     x 64 samples, test chunk 2000.  tests/golden/e2e_512_survey.npz holds what the reference's ResUNet.forward ->
     BaseRender.Renderer.render (libs/renders/BaseRender.py:211-254) produced for every 16th ray, every 4th feature texel, the
     per-channel feature means, and the PSNR its evaluator (libs/evaluators/if_nerf.py:15-18) returned over ALL rays against an
-    8-bit ground truth.  hip_encoder + hip_head + hip_render on the same bytes: maps <= 1e-4, PSNR within 1e-3 dB."""
+    8-bit ground truth.  Three checks on the same bytes:
+      A. hip_encoder's feature maps <= 1e-4 from the reference's;
+      B. the per-ray path on IDENTICAL inputs (north_star's contract): hip_head + hip_render fed the feature maps of the oracle's
+         torch-operator encoder (checked against the stored texels first) -> every map <= 1e-4;
+      C. the chain hip_encoder -> hip_head -> hip_render: PSNR within 1e-3 dB of the reference evaluator's value; each map within
+         max(1e-4, 2 x spread), where spread is what the REFERENCE's own float32 rounding inside its encoder does to that map at this
+         size (the fixture's second run with ResUNet.double(): rgb 6.7e-5, acc 8.8e-5, depth 2.2e-4 for 2.0e-5 on the feature
+         maps) -- a float32 encoder with any other summation order sits that far from the reference's, so 1e-4 on depth is below
+         the reference's own arithmetic noise here; the measured distances are printed."""
     hip_render, _ = plugins
     syn = importlib.import_module("gp-nerf_amd.synthetic")
     ev = importlib.import_module("gp-nerf_amd.evaluator")
+    encm = importlib.import_module("gp-nerf_amd.encoder")
+    from oracle import producers_ref as ref
     z, meta = load("e2e_512_survey")
     sc = scene_of(meta)
     sc["src_imgs"] = syn.make_encoder_images(512, 512, meta["seed"])[None]
@@ -410,29 +420,44 @@ def test_config5_sized_frame_with_the_real_encoder_matches_the_reference(plugins
     c.encoder.file = "hip_encoder"
     r = hip_render.build_render(c).to("cuda:0").eval()
     load_head(r, sc)
-    r.encoder.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_encoder_weights(meta["seed"]).items()}, strict=True)
+    enc_state = {k: torch.from_numpy(v) for k, v in syn.make_encoder_weights(meta["seed"]).items()}
+    r.encoder.load_state_dict(enc_state, strict=True)
     b = batch_of(sc, with_products=False)
     b["volumes"] = [torch.from_numpy(v).to("cuda:0") for v in sc["volumes"]]
     b["mask_at_box"] = torch.from_numpy(sc["mask_at_box"]).to("cuda:0")
     n, st, fst = meta["n_rays"], int(z["ray_stride"]), int(z["featmaps_stride"])
     assert sc["ray_o"].shape[1] == n == z["rgb_gt_u8"].shape[0]
+    cpu_net = encm.ResUNet(encoder="resnet34", out_ch=32)
+    cpu_net.load_state_dict(enc_state, strict=True)
     with torch.no_grad():
+        fm_oracle = ref.encoder(cpu_net.eval(), torch.from_numpy(sc["src_imgs"][0]))
         fmaps = r.encoder(b["src_imgs"][0])
         ret = r.render(b)
+        ret_same = r.render(dict(b, featmaps=fm_oracle.to("cuda:0")))
+    # A
     fm = fmaps.cpu().numpy()
     e_fm = assert_close(fm[:, :, ::fst, ::fst], z["featmaps_sub"], TOL, "encoder feature maps (every 4th texel)")
     assert_close(fm.astype(np.float64).mean(axis=(2, 3)), z["featmaps_chan_mean"], TOL, "encoder feature maps (channel means)")
     assert abs(float(np.abs(fm).max()) - float(z["featmaps_absmax"])) < TOL
+    # B
+    assert_close(fm_oracle.numpy()[:, :, ::fst, ::fst], z["featmaps_sub"], 1e-5, "the oracle encoder's feature maps")
+    same = {}
+    for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map"):
+        same[k] = assert_close(ret_same[k][0, ::st].cpu().numpy().reshape(z[k].shape), z[k], TOL, k + " (identical inputs)")
+    # C
     assert ret["rgb_map"].shape == (1, n, 3)
-    e_rgb = assert_close(ret["rgb_map"][0, ::st].cpu().numpy(), z["rgb_map"], TOL, "rgb_map")
-    e_dep = assert_close(ret["depth_map"][0, ::st, 0].cpu().numpy(), z["depth_map"], TOL, "depth_map")
-    assert_close(ret["acc_map"][0, ::st, 0].cpu().numpy(), z["acc_map"], TOL, "acc_map")
-    assert_close(ret["rgb_in_map"][0, ::st].cpu().numpy(), z["rgb_in_map"], TOL, "rgb_in_map")
+    chain = {}
+    for k in ("rgb_map", "depth_map", "acc_map"):
+        tol = max(TOL, 2.0 * float(z["spread_" + k]))
+        chain[k] = assert_close(ret[k][0, ::st].cpu().numpy().reshape(z[k].shape), z[k], tol, k + " (chain)")
     e = ev.Evaluator(NS(dataset=NS(H=512, W=512, ratio=1.0)), "seq")
     gt = torch.from_numpy(z["rgb_gt_u8"]).to("cuda:0").float() / 255.0
     e.evaluate(ret, {"rgb": gt[None], "mask_at_box": b["mask_at_box"]})
     m = e.summarize()
-    print(f"e2e_512_survey: featmaps {e_fm:.2e} rgb {e_rgb:.2e} depth {e_dep:.2e} psnr {m['psnr']:.5f} vs {float(z['psnr']):.5f}")
+    fmt = lambda d: {k: float(f"{v:.2e}") for k, v in d.items()}
+    spread = fmt({k: float(z["spread_" + k]) for k in chain})
+    print(f"e2e_512_survey: featmaps {e_fm:.2e}; identical inputs {fmt(same)}; chain {fmt(chain)} (reference's own spread "
+          f"{spread}); psnr {m['psnr']:.5f} vs {float(z['psnr']):.5f}")
     assert abs(m["psnr"] - float(z["psnr"])) < 1e-3, (m["psnr"], float(z["psnr"]))
 
 
