@@ -8,8 +8,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# GPNERF_LIB_PATH: a differently built library for A/B measurements (tools/); the product always uses the in-tree build
-LIB_PATH = os.environ.get("GPNERF_LIB_PATH") or os.path.join(HERE, "csrc", "libgpnerf_hip.so")
+# The product loads the in-tree build, always.  GPNERF_LIB_PATH (a differently built library for the A/B measurements of
+# tools/) is honoured only together with GPNERF_DEBUG=1, the switch that also enables the launcher's experiment knobs.
+_DEBUG = os.environ.get("GPNERF_DEBUG", "0") == "1"
+LIB_PATH = (os.environ.get("GPNERF_LIB_PATH") if _DEBUG else None) or os.path.join(HERE, "csrc", "libgpnerf_hip.so")
 
 VIEWS, CH, LEVELS = 3, 32, 4
 FP = C.POINTER(C.c_float)

@@ -591,7 +591,11 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     // two output tiles per workgroup reuse the staged patch twice; layers whose grid would not give every CU a workgroup that
     // way (the 256-channel layers at 1/8 resolution: 48 workgroups) take one tile each instead
     static int f_cot = -1;
-    if (f_cot < 0) { const char* e = getenv("GPNERF_CONV_COT"); f_cot = e ? atoi(e) : 0; }
+    if (f_cot < 0) {                       // experiment knob, honoured only under GPNERF_DEBUG=1, clamped
+        const char* d = getenv("GPNERF_DEBUG");
+        const char* e = (d && d[0] == '1') ? getenv("GPNERF_CONV_COT") : nullptr;
+        f_cot = e ? min(max(atoi(e), 0), 2) : 0;
+    }
     int cot = (a.CT % 2 == 0) ? 2 : 1;
     if (f_cot == 1 || (f_cot == 0 && cot == 2 && (long)tiles * N * (a.CT / 2) < 192)) cot = 1;
     const size_t lds = 2 * (size_t)PATCH_BYTES + 2 * (size_t)9 * cot * STEP_BYTES;

@@ -2078,12 +2078,25 @@ constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue c
 // Early termination walks the samples in segments of chain_len(), one launch per segment over the rays still alive (see
 // gpnerf_render_fused); the workspace then holds a control block (per segment: 8 queue counters + the length of its output
 // list), two ray lists (written and read alternately) and 16 floats of parked state per ray.
+// Experiment knobs (tools/*.sh A/B runs): read ONLY when GPNERF_DEBUG=1 is set, and clamped to [lo, hi] -- a stray GPNERF_*
+// variable in a production environment changes nothing.
+const char* dbg_env(const char* name) {
+    static int on = -1;
+    if (on < 0) { const char* d = getenv("GPNERF_DEBUG"); on = (d && d[0] == '1') ? 1 : 0; }
+    return on ? getenv(name) : nullptr;
+}
+int dbg_int(const char* name, int dflt, int lo, int hi) {
+    const char* e = dbg_env(name);
+    if (!e) return dflt;
+    const int v = atoi(e);
+    return v < lo ? lo : (v > hi ? hi : v);
+}
 constexpr int CHAIN_SEG = 16;
 constexpr int CHAIN_MAX_SEGS = 64;
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 int chain_len(int S) {
     static int f_seg = -1;
-    if (f_seg < 0) { const char* e = getenv("GPNERF_CHAIN_SEG"); f_seg = e ? atoi(e) : CHAIN_SEG; }
+    if (f_seg < 0) f_seg = dbg_int("GPNERF_CHAIN_SEG", CHAIN_SEG, 1, 256);
     const int least = (S + CHAIN_MAX_SEGS - 1) / CHAIN_MAX_SEGS;
     return f_seg > least ? f_seg : least;
 }
@@ -2107,8 +2120,8 @@ struct Geometry { int waves, split; };
 Geometry choose_geometry(int64_t tiles, int S, bool may_split, size_t ws_bytes, int64_t n_rays, int n_cus) {
     static int f_waves = -1, f_split = -1;
     if (f_waves < 0) {
-        const char* e = getenv("GPNERF_WAVES"); f_waves = e ? atoi(e) : 0;
-        const char* g = getenv("GPNERF_SPLIT"); f_split = g ? atoi(g) : 0;
+        f_waves = dbg_int("GPNERF_WAVES", 0, 0, 8);
+        f_split = dbg_int("GPNERF_SPLIT", 0, 0, 8);
     }
     const int64_t cus = n_cus > 0 ? n_cus : 256;
     Geometry best{8, 1};
@@ -2449,7 +2462,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // cull_mask_bytes() of the workspace (before the guard's block); outputs that need every step written keep the in-loop test
     unsigned long long* cull_mask = nullptr;
     static int f_mask = -1;
-    if (f_mask < 0) { const char* e = getenv("GPNERF_CULL_MASK"); f_mask = e ? atoi(e) : 3; }       // experiments: 1 = keep bits, 2 = + tile order
+    if (f_mask < 0) f_mask = dbg_int("GPNERF_CULL_MASK", 3, 0, 3);       // experiments: 1 = keep bits, 2 = + tile order
     if ((f_mask & 1) && culling && workspace && n_samples <= 128 && !out->weights && !out->raw && workspace_bytes >= QUEUE_BYTES + cull_mask_bytes(n_rays)) {
         workspace_bytes = (workspace_bytes - cull_mask_bytes(n_rays)) & ~(size_t)255;
         cull_mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + workspace_bytes);
@@ -2461,16 +2474,16 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     Geometry g = choose_geometry(tiles, n_samples, may_split, seg_bytes, n_rays, n_cus);
     // whole rounds of full workgroups + a remainder launch (below) when the frame is that shape
     static int f_rem = -1;
-    if (f_rem < 0) { const char* e = getenv("GPNERF_REMAINDER"); f_rem = e ? atoi(e) : 1; }
+    if (f_rem < 0) f_rem = dbg_int("GPNERF_REMAINDER", 1, 0, 1);
     const int64_t slots = (int64_t)n_cus * GPNERF_MAX_WAVES;
     const int64_t rem_tiles = tiles % slots;
     const bool remainder = f_rem && workspace && workspace_bytes >= QUEUE_BYTES && !(flags & (GPNERF_FLAG_EARLY_TERM | GPNERF_FLAG_OCC_CULL)) &&
-                           n_cus >= 8 && tiles > slots && rem_tiles > 0 && rem_tiles * 8 <= slots && n_samples >= 8 && !getenv("GPNERF_WAVES");
+                           n_cus >= 8 && tiles > slots && rem_tiles > 0 && rem_tiles * 8 <= slots && n_samples >= 8 && !dbg_env("GPNERF_WAVES");
     if (remainder) { g.waves = GPNERF_MAX_WAVES; g.split = 1; }
     int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
     // more than one round of workgroups and nothing split: persistent workgroups + tile queue (see render_fused_kernel)
     static int f_dynamic = -1;
-    if (f_dynamic < 0) { const char* e = getenv("GPNERF_DYNAMIC"); f_dynamic = e ? atoi(e) : 1; }
+    if (f_dynamic < 0) f_dynamic = dbg_int("GPNERF_DYNAMIC", 1, 0, 1);
     const bool dynamic = f_dynamic && workspace && workspace_bytes >= QUEUE_BYTES && g.split == 1 && blocks > n_cus;
     if (dynamic) {
         if (!zero_async(workspace, QUEUE_BYTES, stream)) return GPNERF_E_LAUNCH;
@@ -2503,16 +2516,16 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         return launch_status();
     };
     static int f_cap = -1;
-    if (f_cap < 0) { const char* e = getenv("GPNERF_WAVE_CAP"); f_cap = e ? atoi(e) : 0; }      // experiments: waves per CU that pull tiles
+    if (f_cap < 0) f_cap = dbg_int("GPNERF_WAVE_CAP", 0, 0, 8);      // experiments: waves per CU that pull tiles
     ka.wave_cap = f_cap;
     static int f_stagger = -1;
-    if (f_stagger < 0) { const char* e = getenv("GPNERF_STAGGER"); f_stagger = e ? atoi(e) : 0; }
+    if (f_stagger < 0) f_stagger = dbg_int("GPNERF_STAGGER", 0, 0, 4096);
     ka.stagger = f_stagger;
     static int f_chunk = -1;
-    if (f_chunk < 0) { const char* e = getenv("GPNERF_QUEUE_CHUNK"); f_chunk = e ? atoi(e) : 64; }
+    if (f_chunk < 0) f_chunk = dbg_int("GPNERF_QUEUE_CHUNK", 64, 1, 4096);
     ka.chunk = f_chunk > 0 ? f_chunk : (int)((tiles + 7) / 8);        // 0: one contiguous run per XCD
     static int f_tail = -1;
-    if (f_tail < 0) { const char* e = getenv("GPNERF_CHAIN_TAILP"); f_tail = e ? atoi(e) : 4; }
+    if (f_tail < 0) f_tail = dbg_int("GPNERF_CHAIN_TAILP", 4, 1, 8);
     ka.tail_p = f_tail;
     // Early termination on frames of at least one round of wavefronts: the samples are walked in segments of chain_len(), one
     // persistent-queue launch per segment.  A ray that is opaque stops (per ray, not per tile); the rays that go on park 16
@@ -2534,7 +2547,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
         const unsigned grid = (unsigned)(wg < n_cus ? wg : n_cus);
         static float f_fill = -1.f;
-        if (f_fill < 0.f) { const char* e = getenv("GPNERF_CHAIN_PFILL"); f_fill = e ? (float)atof(e) : 1.f; }
+        if (f_fill < 0.f) { const char* e = dbg_env("GPNERF_CHAIN_PFILL"); f_fill = e ? fminf(fmaxf((float)atof(e), 0.f), 8.f) : 1.f; }
         ka.p_cap = (long)((double)grid * GPNERF_MAX_WAVES * RAYS_PER_WAVE * f_fill);
         ka.first_slot = 0; ka.first_items = (long)n_rays;
         for (int sg = 0; sg < n_seg; ++sg) {

@@ -51,24 +51,22 @@ def _nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
-_packed = {}      # id(conv module) -> (parameter version key, packed device image, fp32 source kept alive)
-
-
 def _packed_weight(conv):
-    """gpnerf_conv_pack_weight image of a conv's weight (f16 hi/lo, MFMA A-operand order), re-packed when the parameter changes."""
+    """gpnerf_conv_pack_weight image of a conv's weight (f16 hi/lo, MFMA A-operand order), re-packed when the parameter changes.
+    The image lives ON the module (not in a table keyed by id(): ids and device pointers are re-used once a model is freed, and
+    a second checkpoint would have found the first one's image), so it is freed with the module; the fp32 source the pack kernel
+    reads needs no keeping -- stream order protects it."""
     w = conv.weight
     key = (str(w.device), w.data_ptr(), w._version)
-    hit = _packed.get(id(conv))
+    hit = conv.__dict__.get("_gpnerf_packed")
     if hit is None or hit[0] != key:
         lib = L.lib()
         cout, cin, ks, _ = w.shape
         buf = torch.empty((int(lib.gpnerf_conv_packed_bytes(cout, cin, ks)),), dtype=torch.uint8, device=w.device)
         src = w.detach().float().contiguous()
         L.check(lib.gpnerf_conv_pack_weight(src.data_ptr(), cout, cin, ks, buf.data_ptr(), _st(w)), "gpnerf_conv_pack_weight")
-        hit = (key, buf, src)
-        if len(_packed) > 256:
-            _packed.clear()
-        _packed[id(conv)] = hit
+        hit = (key, buf)
+        conv.__dict__["_gpnerf_packed"] = hit
     return hit[1]
 
 
@@ -190,6 +188,14 @@ class ResUNet(nn.Module):
         self.upconv2 = UpsampleConv(128, 64, 3, 2)
         self.iconv2 = ConvNormELU(skip1 + 64, out_ch, 3)
         self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
+
+    def out_shape(self, H, W):
+        """(C, h, w) of forward()'s result for [.,3,H,W] images: the stem and the three stages each halve with ceil (k = 7 / 3,
+        pad k // 2, stride 2), the decoder doubles twice and pads the skips up to that size (UNet.py:199-211)."""
+        h, w = int(H), int(W)
+        for _ in range(4):
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        return self.out_conv.out_channels, 4 * h, 4 * w
 
     def forward(self, x):
         """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the result leaves with channels-last strides, which `Frame`

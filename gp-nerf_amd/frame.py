@@ -151,6 +151,12 @@ class Frame:
     def _set_volumes(self, f, volumes, keep):
         lib = L.lib()
         self.vols = []
+        # whatever was derived from the previous levels goes with them: the folded coarse levels and the occupancy volume
+        # would otherwise be read with the NEW levels' dimensions
+        self._folded_valid, self.vols_folded, self.occ = False, None, None
+        f.occ = None
+        for l in range(L.LEVELS):
+            f.vol_folded[l] = None
         for l, v in enumerate(volumes):
             _require_gpu(v, f"volumes[{l}]")
             if getattr(v, "_gpnerf_ndhwc", False):            # already channels-last (gpnerf_sparse_to_dense): no copy
@@ -249,7 +255,7 @@ def patch_order_device(mask, H, W, patch_w=4, patch_h=8):
     return t[t >= 0].contiguous()
 
 
-def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-4,
+def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-5,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
                  split_f16=False, flip=None, subset=False, guard=None, fold=None):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].

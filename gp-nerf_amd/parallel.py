@@ -13,6 +13,12 @@ collective is a plain `all_gather_into_tensor` of a preallocated [share, C] buff
 no host-side index building per frame (the index tensors live on the device and are cached per (n_rays, world)).
 
 Backend: torch.distributed -- "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+
+Sharding is OPT-IN: every entry point takes the process group explicitly and does nothing collective without one
+(`group=None`).  It is meant for ranks that hold the SAME batch and want one frame faster.  The reference's own distributed
+flow (tools/train.py: DistributedDataParallel + a DistributedSampler for the evaluation loader) hands every rank a DIFFERENT
+frame; sharding a frame there would mix the ranks' images, which is why the existence of a default process group alone never
+switches it on.
 """
 import torch
 import torch.distributed as dist
@@ -108,14 +114,16 @@ def all_gather_pixels(out, gathered):
     return gathered
 
 
-def gather_frame(local, plan, keys, group=None, buffer=None):
+def gather_frame(local, plan, keys, group=None, buffer=None, row_of_ray=None):
     """ONE collective: every rank contributes its packed [share, C] maps, every rank gets the frame's maps in ray order.
-    buffer: optional preallocated [world * share, C] tensor (the bench passes one; Renderer.render lets the allocator cache it)."""
+    buffer: optional preallocated [world * share, C] tensor (the bench passes one; Renderer.render lets the allocator cache it).
+    row_of_ray: int64 [n_rays], row of the gathered buffer holding ray i, when the bands were cut from a permuted list
+    (default: plan.inverse)."""
     packed, cols = pack_maps(local, keys)
     if buffer is None or buffer.shape != (plan.world * plan.share, packed.shape[1]) or buffer.device != packed.device:
         buffer = torch.empty((plan.world * plan.share, packed.shape[1]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(buffer, packed.contiguous(), group=group)
-    full = plan.unpermute(buffer)
+    full = plan.unpermute(buffer) if row_of_ray is None else buffer.index_select(0, row_of_ray)
     res = {}
     for k, (a, b, nd, dt) in cols.items():
         v = full[:, a:b] if nd > 1 else full[:, a]
@@ -123,26 +131,74 @@ def gather_frame(local, plan, keys, group=None, buffer=None):
     return res
 
 
-def render_sharded(render_fn, rays, keys=("rgb_map", "depth_map", "acc_map", "disp_map"), group=None, band=INTERLEAVE_BAND):
+def resolve_group(group):
+    """None -> None (no sharding).  "world" / True -> the default process group (it must be initialised).  A ProcessGroup -> itself.
+    A group of one rank resolves to None."""
+    if group is None or group is False:
+        return None
+    if group is True or (isinstance(group, str) and group == "world"):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("sharding over the default process group was asked for, but torch.distributed is not initialised")
+        group = dist.group.WORLD
+    return None if dist.get_world_size(group) == 1 else group
+
+
+def render_sharded(render_fn, rays, keys=("rgb_map", "depth_map", "acc_map", "disp_map"), group=None, band=INTERLEAVE_BAND, order=None):
     """Strong scaling of one frame: every rank renders its share of `rays` with `render_fn(rays_share) -> dict` and receives
-    the requested maps of the whole frame (one packed all-gather).  With no process group this is just render_fn(rays)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    the requested maps of the whole frame (one packed all-gather).  Every rank of `group` must call this with the SAME rays.
+    group=None: no collective, this is just render_fn(rays).
+    order: optional int64 permutation of the ray list (Renderer.render's patch-major order): the bands are cut from
+    rays[order], so that a rank's 32-ray tiles are the same compact pixel patches the unsharded launch renders; the maps
+    come back in the ORIGINAL list order (the two permutations are composed into one index_select)."""
+    group = resolve_group(group)
+    if group is None:
         return render_fn(rays)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     plan = plan_for(rays.shape[0], world, rays.device, band)
-    local = render_fn(plan.take(rays, rank))
-    return gather_frame(local, plan, keys, group)
+    if order is None:
+        local = render_fn(plan.take(rays, rank))
+        return gather_frame(local, plan, keys, group)
+    order = order.long()
+    local = render_fn(rays.index_select(0, order.index_select(0, plan.index[rank])))
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), device=order.device)
+    return gather_frame(local, plan, keys, group, row_of_ray=plan.inverse.index_select(0, inv))
 
 
-def encode_views_sharded(encoder, src_imgs, group=None):
-    """The per-frame image encoder with one source view per rank (views are independent: the encoder normalises per image,
-    libs/encoders/UNet.py:40-53): rank r encodes view r mod V and one all-gather hands every rank all V feature maps.
-    Falls back to the plain call without a process group or with fewer ranks than views."""
-    V = src_imgs.shape[0]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < V:
+def view_owner(v, V, world):
+    """Rank that encodes source view v: with at least V ranks view v belongs to rank v (the others only receive), with fewer the
+    views go round-robin (two ranks, three views: rank 0 encodes views 0 and 2, rank 1 view 1)."""
+    return v if world >= V else v % world
+
+
+def encode_views_sharded(encoder, src_imgs, group=None, out_shape=None):
+    """The per-frame image encoder with the source views dealt out over the ranks (views are independent: the encoder
+    normalises per image, libs/encoders/UNet.py:40-53).  Every view is encoded by exactly one rank (`view_owner`) and handed
+    to the others by a broadcast from its owner into one [V,h,w,C] buffer -- the PHYSICAL layout of the encoder's
+    channels-last result, so nothing is re-laid out on either side and `Frame` takes the returned tensor by pointer.  Ranks
+    beyond the V-th encode nothing.  Every rank of `group` must hold the same `src_imgs`.
+    group=None: the plain call.  out_shape: (C, h, w) of the encoder's result when the caller knows it; otherwise
+    `encoder.out_shape(H, W)` is asked, and an encoder without it makes every rank encode its own copy (no collective)."""
+    group = resolve_group(group)
+    if group is None:
         return encoder(src_imgs)
+    V = src_imgs.shape[0]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    mine = encoder(src_imgs[rank % V: rank % V + 1]).contiguous()          # [1,C,h,w]
-    allv = torch.empty((world,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
-    dist.all_gather_into_tensor(allv, mine, group=group)
-    return allv[:V]
+    if out_shape is None and hasattr(encoder, "out_shape"):
+        out_shape = encoder.out_shape(int(src_imgs.shape[-2]), int(src_imgs.shape[-1]))
+    if out_shape is None:
+        return encoder(src_imgs)
+    C, h, w = (int(x) for x in out_shape)
+    mine = [v for v in range(V) if view_owner(v, V, world) == rank]
+    allv = torch.empty((V, h, w, C), dtype=torch.float32, device=src_imgs.device)
+    if mine:
+        out = encoder(src_imgs[mine])
+        phys = out.permute(0, 2, 3, 1)                       # the channels-last result viewed in its physical order: no copy
+        if tuple(phys.shape[1:]) != (h, w, C):
+            raise RuntimeError(f"encoder.out_shape promised {(C, h, w)}, the encoder returned {tuple(out.shape[1:])}")
+        allv[mine] = phys.to(torch.float32)
+    ranks = dist.get_process_group_ranks(group)
+    work = [dist.broadcast(allv[v], src=ranks[view_owner(v, V, world)], group=group, async_op=True) for v in range(V)]
+    for wk in work:
+        wk.wait()
+    return allv.permute(0, 3, 1, 2)                          # logical [V,C,h,w] with channels-last strides

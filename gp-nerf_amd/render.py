@@ -31,7 +31,7 @@ from . import parallel as P_
 class Renderer(nn.Module):
     def __init__(self, encoder, nerfhead, is_train=False, neg_ray_train=False, neg_ray_val=False, n_rays=1024,
                  n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=None, term_eps=1e-5,
-                 progressive=False, split_f16=None, sharded_outputs="all"):
+                 progressive=False, split_f16=None, sharded_outputs="all", shard_group=None):
         super().__init__()
         self.encoder = encoder
         self.nerfhead = nerfhead
@@ -54,7 +54,16 @@ class Renderer(nn.Module):
         # progressive=True: the inference renderer's path (libs/renders/demo_render.py): rays are selected from the
         # occupied voxels of the frame's volume, samples are occupancy-culled, and the result is returned as `pred_img`
         self.progressive = progressive
-        # under a process group: "all" = the reference's full dict on every rank (one packed all-gather),
+        # shard_group (not in the reference): OPT-IN strong scaling of one frame over the ranks of a torch.distributed process
+        # group -- a ProcessGroup, or "world" for the default one (GPNERF_SHARD=1 in the environment means "world", for runs
+        # through the reference's tools/inference.py, which has no config key for it).  Every rank of the group must call
+        # render() with the SAME batch; each renders a share of the rays and encodes a share of the source views, and all get
+        # the whole frame.  None (default): no collective is ever issued, whatever process groups exist -- under the
+        # reference's DistributedSampler the ranks hold different frames (tools/train.py), and sharding would mix them.
+        if shard_group is None and os.environ.get("GPNERF_SHARD", "0") == "1":
+            shard_group = "world"
+        self.shard_group = shard_group
+        # with a shard_group: "all" = the reference's full dict on every rank (one packed all-gather),
         # "pixels" = rgb_map + depth_map only (16 B/ray over xGMI)
         self.sharded_outputs = sharded_outputs
         # split_f16: dense layers on f16 MFMA with hi/lo operand pairs (GPNERF_FLAG_SPLIT_F16); same 1e-4 parity bound,
@@ -74,8 +83,8 @@ class Renderer(nn.Module):
         src_imgs = batch["src_imgs"]
         if src_imgs.shape[0] != 1:
             raise L.GpnerfError("only batch_size=1 is supported (as BaseRender.py:336 asserts)")
-        # with a process group: one source view per rank + one all-gather of the feature maps (parallel.py)
-        featmaps = batch["featmaps"] if "featmaps" in batch else P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0))
+        # with a shard_group: the source views dealt out over the ranks + a broadcast of each feature map (parallel.py)
+        featmaps = batch["featmaps"] if "featmaps" in batch else P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0), group=self.shard_group)
         return featmaps[0] if featmaps.dim() == 5 else featmaps
 
     def prepare_sp_input(self, batch, out_sh=None):
@@ -240,12 +249,13 @@ class Renderer(nn.Module):
         rays = torch.cat([batch["ray_o"], batch["ray_d"], batch["near"].unsqueeze(-1), batch["far"].unsqueeze(-1)], dim=-1)[0]
         neg = self._neg_ray(batch)
         n = rays.shape[0]
-        sharded = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        group = P_.resolve_group(self.shard_group)
+        sharded = group is not None
         # Which 32 rays share a wavefront is the launch's choice (results do not depend on it): when the batch says which
         # pixels the rays are (`mask_at_box`, ZjumocapDataset.py:505), lay them out as 32x8-pixel patches so that the rays of
-        # a workgroup hit the same cache lines.  A sharded frame keeps list order (its bands are re-ordered by the plan).
+        # a workgroup hit the same cache lines.  A sharded frame cuts its round-robin bands from the same patch-major list.
         order = None
-        if not sharded and "mask_at_box" in batch:
+        if "mask_at_box" in batch:
             Hs, Ws = batch["src_imgs"].shape[-2:]
             m = batch["mask_at_box"].reshape(-1)
             if m.numel() == Hs * Ws and m.is_cuda:
@@ -265,14 +275,15 @@ class Renderer(nn.Module):
         frame = self.build_frame(batch, featmaps, consts, prepared)
 
         def fn(r):
+            # sharded: `r` is this rank's share, already in patch-major order
             return F_.render_fused(frame, r, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
-                                   split_f16=self.split_f16, ray_order=order, want=("weights", "z_vals", "rgb_in"))
+                                   split_f16=self.split_f16, ray_order=None if sharded else order, want=("weights", "z_vals", "rgb_in"))
 
         # every map of the reference's dict travels in ONE packed all-gather; sharded_outputs = "pixels" keeps the exchange at
         # the 16 B/ray of rgb + depth (what an evaluation loop reads, libs/evaluators/if_nerf.py:50-56) and returns only those
         all_keys = ("rgb_map", "depth_map", "acc_map", "disp_map", "weights", "z_vals", "rgb_in_map")
         keys = P_.PIXEL_KEYS if (sharded and self.sharded_outputs == "pixels") else all_keys
-        o = P_.render_sharded(fn, rays, keys=keys)
+        o = P_.render_sharded(fn, rays, keys=keys, group=group, order=order if sharded else None)
         torch.cuda.synchronize(dev)
         t2 = time.time()
         # etime = the encoder alone, rtime = everything else of the call (demo_render.py:441-446,494-497 keeps these two clocks;
@@ -293,7 +304,8 @@ class Renderer(nn.Module):
 
 
 def build_render(cfg, progressive=False):
-    """Same cfg keys as BaseRender.py:367-403; encoder / head come from the plugins cfg names."""
+    """Same cfg keys as BaseRender.py:367-403; encoder / head come from the plugins cfg names.  One optional key the reference
+    does not have: `cfg.render.shard` ("world" or a ProcessGroup) opts into sharding one frame over a process group."""
     encoder = getattr(impm(cfg.encoder.file), "build_encoder")(cfg)
     nerfhead = getattr(impm(cfg.head.file), "build_head")(cfg)
     if not hasattr(nerfhead, "head_blob"):
@@ -303,4 +315,5 @@ def build_render(cfg, progressive=False):
     mesh_th = -1 if cfg.head.rgb.use_rgbhead else 1.0 / cfg.test.mesh_th
     return Renderer(encoder=encoder, nerfhead=nerfhead, is_train=False, neg_ray_train=neg_ray_train,
                     neg_ray_val=neg_ray_val, n_rays=cfg.train.n_rays, n_samples=cfg.train.n_samples,
-                    voxel_size=cfg.dataset.voxel_size, chunk=cfg.dataset.test.chunk, mesh_th=mesh_th, progressive=progressive)
+                    voxel_size=cfg.dataset.voxel_size, chunk=cfg.dataset.test.chunk, mesh_th=mesh_th, progressive=progressive,
+                    shard_group=getattr(getattr(cfg, "render", None), "shard", None) or None)

@@ -345,3 +345,22 @@ def test_folded_coarse_levels_equal_the_layer_per_sample(size, S, neg, kw, fm, o
         ref = oracle.render(sc, S, neg_ray=neg, rays=rays.cpu().numpy()[pick])
         for k in ("rgb_map", "acc_map", "depth_map"):
             assert_close(b[k][pick], ref[k], TOL, k)
+
+
+def test_a_frame_that_gets_new_volumes_drops_what_it_derived_from_the_old_ones(fm, syn):
+    """Frame._set_volumes on a used Frame (ADVICE r2): the folded coarse levels and the occupancy volume belong to the old levels;
+    kept, the next dense launch would interpolate the old tables with the new levels' dimensions."""
+    a = syn.make_scene(H=16, W=16, seed=61, fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1)
+    b = syn.make_scene(H=16, W=16, seed=62, fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1)
+    fr = build_frame(fm, a)
+    rays = rays_of(a)
+    first = fm.render_fused(fr, rays, 32)                         # folds level 2 and 3 of scene a
+    fr.build_occupancy()
+    assert fr._folded_valid and fr.c.occ
+    fr._set_volumes(fr.c, [to_dev(v * 0.5) for v in b["volumes"]], fr._keep)
+    assert not fr._folded_valid and fr.vols_folded is None and fr.occ is None and not fr.c.occ
+    got = fm.render_fused(fr, rays, 32)
+    fresh_scene = dict(a, volumes=[v * 0.5 for v in b["volumes"]])
+    want = fm.render_fused(build_frame(fm, fresh_scene), rays, 32)
+    assert torch.equal(got["rgb_map"], want["rgb_map"]) and torch.equal(got["depth_map"], want["depth_map"])
+    assert not torch.equal(got["rgb_map"], first["rgb_map"])

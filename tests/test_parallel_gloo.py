@@ -54,6 +54,9 @@ def _fake_render(rays):
 class _Enc(torch.nn.Module):
     calls = 0
 
+    def out_shape(self, H, W):
+        return 2, H // 2, W // 2
+
     def forward(self, x):              # per-image function: [v,3,H,W] -> [v,2,H/2,W/2]
         _Enc.calls += x.shape[0]
         return torch.stack([x.mean(1)[:, ::2, ::2], x.amax(1)[:, ::2, ::2] - x.mean(dim=(1, 2, 3))[:, None, None]], 1)
@@ -70,9 +73,15 @@ def _worker(rank, world, port, n, q):
     # the 16 B/ray form, the default key set, and every map Renderer.render returns: one collective each, bit-equal
     for keys in (par.PIXEL_KEYS, ("rgb_map", "depth_map", "acc_map", "disp_map"), tuple(ref)):
         for band in (par.INTERLEAVE_BAND, 64):
-            full = par.render_sharded(_fake_render, rays, keys=keys, band=band)
-            ok = ok and set(full) == set(keys)
-            ok = ok and all(torch.equal(full[k], ref[k]) and full[k].dtype == ref[k].dtype and full[k].shape == ref[k].shape for k in keys)
+            for order in (None, torch.randperm(n, generator=g)):      # bands cut from a permuted (patch-major) list
+                full = par.render_sharded(_fake_render, rays, keys=keys, band=band, group="world", order=order)
+                ok = ok and set(full) == set(keys)
+                ok = ok and all(torch.equal(full[k], ref[k]) and full[k].dtype == ref[k].dtype and full[k].shape == ref[k].shape for k in keys)
+    # sharding is opt-in: without a group nothing is split, whatever process groups exist (under the reference's
+    # DistributedSampler the ranks hold different frames)
+    seen = []
+    par.render_sharded(lambda r: seen.append(r.shape[0]) or _fake_render(r), rays)
+    ok = ok and seen == [n]
     # preallocated gather buffer, as the bench uses it
     plan = par.plan_for(n, world, rays.device)
     buf = torch.empty((world * plan.share, 4))
@@ -88,8 +97,13 @@ def _worker(rank, world, port, n, q):
     # one source view per rank
     imgs = torch.rand((3, 3, 8, 12), generator=g)
     enc = _Enc()
-    fm = par.encode_views_sharded(enc, imgs)
-    ok = ok and torch.equal(fm, _Enc()(imgs)) and (_Enc.calls == (1 + 3 if world >= 3 else 3 + 3))
+    # every source view is encoded by exactly one rank and broadcast in its physical [h,w,C] layout; ranks beyond the V-th encode nothing
+    fm = par.encode_views_sharded(enc, imgs, group=dist.group.WORLD)
+    mine = sum(1 for v in range(3) if par.view_owner(v, 3, world) == rank)
+    ok = ok and _Enc.calls == mine and mine == ({0: 2, 1: 1}[rank] if world == 2 else (1 if rank < 3 else 0))
+    ok = ok and torch.equal(fm, _Enc()(imgs)) and fm.shape == (3, 2, 4, 6) and fm.permute(0, 2, 3, 1).is_contiguous()
+    calls = _Enc.calls
+    ok = ok and torch.equal(par.encode_views_sharded(enc, imgs), fm) and _Enc.calls == calls + 3          # no group: the plain call
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,4 +1,5 @@
 # A/B of differently built libraries on the headline frame (diagnostic):
+export GPNERF_DEBUG=1   # the experiment knobs / GPNERF_LIB_PATH below are honoured only under this switch
 #   tools/ab_libs.sh [--split] build/ab/a.so build/ab/b.so ...
 extra=""; if [ "$1" = "--split" ]; then extra="--split-f16"; shift; fi
 for lib in "$@"; do

@@ -1,6 +1,7 @@
 #!/bin/bash
+export GPNERF_DEBUG=1   # the experiment knobs / GPNERF_LIB_PATH below are honoured only under this switch
 # early-termination frame (512x512x128): item length (GPNERF_CHAIN_SEG) x queue chunk (GPNERF_QUEUE_CHUNK)
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3))"; }
 for seg in 16 32; do for c in 32 64 72 96; do
 GPNERF_QUEUE_CHUNK=$c GPNERF_CHAIN_SEG=$seg timeout 120 python bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras 2>&1 | tail -1 | ms "ET128 item=$seg chunk=$c"

@@ -1,4 +1,5 @@
 # round-2 GPU check: full GPU test suite, headline bench, configs[2] bench, static-vs-queue launch comparison
+export GPNERF_DEBUG=1   # the experiment knobs / GPNERF_LIB_PATH below are honoured only under this switch
 mkdir -p gpurun_out/r2a
 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r2a/bench_default.json 2> gpurun_out/r2a/bench_default.err; python - <<'PY'
