@@ -423,6 +423,7 @@ def cpu_baseline(sc, rays_h, S, target_s):
     from oracle import blocked, oracle
     half = 0.5 * target_s
     fr = blocked.Frame(sc)                            # per-frame preparation (channels-last copies), not timed -- as the GPU Frame
+    hw_threads = blocked.max_threads()
 
     def best_threads(render_t, hi):
         """Thread count with the highest rate on a short probe: the GPU boxes show more hardware threads than the job may use at
@@ -441,8 +442,8 @@ def cpu_baseline(sc, rays_h, S, target_s):
             th //= 2
         return best
 
-    threads = best_threads(lambda r, t: blocked.render(fr, r, S, want=(), n_threads=t), blocked.max_threads())
-    o_threads = best_threads(lambda r, t: oracle.render(sc, S, rays=r, want_weights=False, n_threads=t), oracle.max_threads())
+    threads = best_threads(lambda r, t: blocked.render(fr, r, S, want=(), n_threads=t), hw_threads)
+    o_threads = best_threads(lambda r, t: oracle.render(sc, S, rays=r, want_weights=False, n_threads=t), hw_threads)
     nb, tb = _timed_sample(lambda r: blocked.render(fr, r, S, want=(), n_threads=threads), rays_h, half)
     no, to = _timed_sample(lambda r: oracle.render(sc, S, rays=r, want_weights=False, n_threads=o_threads), rays_h, half)
     check = rays_h[:: max(1, rays_h.shape[0] // 512)][:512]
@@ -455,7 +456,7 @@ def cpu_baseline(sc, rays_h, S, target_s):
             "sample": f"{nb} evenly spaced rays of the same frame x {S} samples, {tb:.1f} s on {threads} OpenMP threads "
                       f"(oracle/gpnerf_cpu_blocked.c, gcc -O3 -march=native, channels-last frame prepared outside the timed call)",
             "max_abs_vs_scalar_oracle": err,
-            "threads_available": blocked.max_threads(),
+            "threads_available": hw_threads,
             "scalar_oracle": {"value": no / to, "unit": "rays/s", "cores": o_threads, "kind": "port",
                               "ms_per_frame": n_frame / (no / to) * 1e3,
                               "sample": f"{no} evenly spaced rays x {S} samples, {to:.1f} s on {o_threads} OpenMP threads "

@@ -367,8 +367,12 @@ template <int N> DEV void guard_n(Guard&, const float* v) {
     // Branch-free on purpose: lanes in range write a dummy word.  With `if (__any(...))` here -- a branch in the middle of the
     // layer chain, never taken -- this kernel's results came out 2e-5 off and different from run to run (measured; a minimal
     // kernel does not reproduce it, tools/micro/mfma_branch_hazard.hip, so the cause is not established).
+#ifdef GPNERF_X_BRANCHGUARD       // diagnostic build only (tools/probes/branch_guard.sh): the guard as first written, with a branch
+    if (__any(!(m < F16_RANGE))) { if (!(m < F16_RANGE)) guard_slot()[0] = 1u; }
+#else
     unsigned* const sl = guard_slot();
     (m < F16_RANGE ? sl + GUARD_LDS_SLOTS : sl)[0] = 1u;
+#endif
 }
 
 // x = hi + lo with hi = f16(x) toward zero (never overflows to inf), lo = f16(x - hi): ~22 significant bits

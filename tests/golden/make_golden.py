@@ -351,7 +351,7 @@ def run_demo_case(name, scene_kw, n_samples, neg_ray=False, probe=96):
           f"rgb mean={out['rgb_map'].mean():.4f} max={out['rgb_map'].max():.4f} -> {os.path.getsize(path)} B")
 
 
-def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400):
+def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400, spread=False):
     """The evaluation loop's per-frame chain with the reference's REAL image encoder (BASELINE.json configs[4] in miniature;
     the ZJU-MoCap data itself is not in the tree): libs/encoders/UNet.py ResUNet.forward -> libs/renders/BaseRender.py
     Renderer.render, then libs/evaluators/if_nerf.py Evaluator.psnr_metric on the result against a seeded ground truth.
@@ -397,8 +397,9 @@ def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400):
     out = {"rgb_map": rgb, "depth_map": ret["depth_map"][0, :, 0].numpy(), "acc_map": ret["acc_map"][0, :, 0].numpy(),
            "rgb_in_map": ret["rgb_in_map"][0].numpy(), "featmaps": featmaps.astype(np.float32), "rgb_gt": rgb_gt,
            "psnr": np.float64(psnr), "mse": np.float64(np.mean((rgb - rgb_gt) ** 2))}
-    if ray_stride is not None:
+    if ray_stride is not None or spread:
         import copy
+        rs = ray_stride or 1
         with torch.no_grad():
             fm64 = copy.deepcopy(enc).double()(batch["src_imgs"][0].double()).float()
             r.encoder = _FixedEncoder(fm64)
@@ -408,8 +409,10 @@ def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400):
                  ("acc_map", ret64["acc_map"][0, :, 0].numpy()))
         for k, v in pairs:
             out["spread_" + k] = np.float64(np.abs(v.astype(np.float64) - out[k]).max())
-            out[k + "_enc64"] = v[::ray_stride]
+            out[k + "_enc64"] = v[::rs]
         out["spread_featmaps"] = np.float64(np.abs(fm64.numpy().astype(np.float64) - featmaps).max())
+        print("   float32-vs-float64 encoder spread of the reference:", {k: float(v) for k, v in out.items() if k.startswith("spread_")})
+    if ray_stride is not None:
         full = hashlib.sha256()
         for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map", "featmaps"):
             full.update(np.ascontiguousarray(out[k]).tobytes())
@@ -521,7 +524,7 @@ def main():
             continue
         run_case(name, kw, S, **extra)
     if not only or "e2e_64x64_s32" in only:
-        run_e2e_case("e2e_64x64_s32", dict(H=64, W=64, seed=31, fill="full", pose="random", **dict(SMALL, sigma_bias=0.3)), 32, 31)
+        run_e2e_case("e2e_64x64_s32", dict(H=64, W=64, seed=31, fill="full", pose="random", **dict(SMALL, sigma_bias=0.3)), 32, 31, spread=True)
     for name, kw, S, extra in DEMO_CASES:
         if not only or name in only:
             run_demo_case(name, kw, S, **extra)
