@@ -47,8 +47,17 @@ DEV unsigned lo_pair(unsigned w, float x0, float x1) {
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(w), "v"(x1));
     return r;
 }
+// Operand scales (exact powers of two, undone on the accumulators): x = hi + lo carries x to 2^-23 only while lo is a NORMAL f16,
+// i.e. |x| >= 2^-14 * 2^12 = 0.25; below that lo is a subnormal with a fixed 2^-24 spacing -- for a typical deep-layer weight of
+// 0.03 that is a RELATIVE error of 1e-6, sixteen times the 2^-23 aimed at, and it was the encoder's largest error term (gpu vs
+// the exact float64 result 1.7x the reference's own float32 error before).  Weights are packed as 2^12 w
+// (range |w| < 16, checked at pack time; full precision down to |w| = 6e-5), activations are staged as 2^4 x (range |x| < 4094:
+// an InstanceNorm'd value is bounded by sqrt(h w) |gamma|; full precision down to 0.016, absolute error 2e-9 below).
+constexpr float W_SCALE = 4096.f, X_SCALE = 16.f, ACC_UNSCALE = 1.f / (4096.f * 16.f);
 struct Frag { h8 hi, lo; };
-DEV Frag make_frag(const f32x4 a, const f32x4 b) {
+DEV Frag make_frag(f32x4 a, f32x4 b) {
+    a *= X_SCALE;
+    b *= X_SCALE;
     u32x4 H, Lo;
     H[0] = pk_hi(a[0], a[1]); Lo[0] = lo_pair(H[0], a[0], a[1]);
     H[1] = pk_hi(a[2], a[3]); Lo[1] = lo_pair(H[1], a[2], a[3]);
@@ -89,7 +98,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const int C
         tap = k / Cin;
         ci = k % Cin;
     }
-    const float v = (co < Cout && in_k) ? w[((long)co * Cin + ci) * KS * KS + tap] : 0.f;
+    const float v = W_SCALE * ((co < Cout && in_k) ? w[((long)co * Cin + ci) * KS * KS + tap] : 0.f);
     const _Float16 hi = (_Float16)v;                          // round to nearest, as the activations' hi
     const unsigned hw = __builtin_bit_cast(uint16_t, hi);
     const _Float16 lo = (_Float16)(v - (float)hi);
@@ -255,6 +264,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
             const h8 wh = __builtin_bit_cast(h8, wl[lane]), wlo = __builtin_bit_cast(h8, wl[64 + lane]);
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
+#ifdef GPNERF_X_LOLO
+                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b[t].lo, acc[t][c], 0, 0, 0);
+#endif
                 acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b[t].hi, acc[t][c], 0, 0, 0);
                 acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].lo, acc[t][c], 0, 0, 0);
                 acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].hi, acc[t][c], 0, 0, 0);
@@ -264,6 +276,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
         __syncthreads();
     }
     // epilogue: accumulator register r of half h holds output channel 32 ct + ft(r, h): four runs of 4 consecutive channels
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
     if (a.bias) {
 #pragma unroll
         for (int c = 0; c < COT; ++c)
@@ -358,7 +374,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             const int item = s * (WAVES * 64) + (int)threadIdx.x;
             if (item < PITEMS) {
                 const int pp = item >> 2, qd = item & 3;
-                const f32x4 v = preg[s];
+                const f32x4 v = preg[s] * X_SCALE;
                 const unsigned h0 = pk_hi(v[0], v[1]), h1 = pk_hi(v[2], v[3]);
                 unsigned* d = reinterpret_cast<unsigned*>(pb + pp * PPX + qd * 8);
                 d[0] = h0; d[1] = h1;
@@ -404,6 +420,12 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
         for (int tap = 0; tap < 9; ++tap) {
             const int cur = tap & 1;
             if (tap + 1 < 9) read_tap(tap + 1, cur ^ 1);
+#ifdef GPNERF_X_LOLO
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[cur][c], b[cur][t].lo, acc[t][c], 0, 0, 0);
+#endif
 #pragma unroll
             for (int c = 0; c < COT; ++c)
 #pragma unroll
@@ -424,6 +446,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
     bool valid[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) valid[t] = (ty0 + 2 * wave + t) < a.Ho && ox < a.Wo;
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
     if (a.bias) {
 #pragma unroll
         for (int c = 0; c < COT; ++c)
@@ -497,7 +523,7 @@ template <class T>
 __global__ void __launch_bounds__(256) nhwc_norm_finalize_kernel(const T* __restrict__ partial, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const long hw, const int C,
                                                                  const int nchunks, const float eps,
-                                                                 float* __restrict__ scale_shift /* [N][2][C] */) {
+                                                                 float* __restrict__ scale_shift /* [N][3][C]: mean, scale, beta */) {
     __shared__ double red[2][256];
     const int n = blockIdx.y, cl = threadIdx.x & 31, kl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double ts = 0, tq = 0;
@@ -516,9 +542,12 @@ __global__ void __launch_bounds__(256) nhwc_norm_finalize_kernel(const T* __rest
     const double mean = ts / (double)hw;
     double var = tq / (double)hw - mean * mean;             // biased variance, as InstanceNorm2d normalises with
     if (var < 0) var = 0;
+    // y = (x - mean) * scale + beta, the reference's order (F.instance_norm subtracts first): folding the mean into a shift
+    // (x * scale + (beta - mean * scale)) cancels two large terms when |mean| >> sigma and loses |mean| / sigma ulps
     const float g = gamma[c] / sqrtf((float)var + eps);
-    scale_shift[((size_t)n * 2 + 0) * C + c] = g;
-    scale_shift[((size_t)n * 2 + 1) * C + c] = beta[c] - (float)mean * g;
+    scale_shift[((size_t)n * 3 + 0) * C + c] = (float)mean;
+    scale_shift[((size_t)n * 3 + 1) * C + c] = g;
+    scale_shift[((size_t)n * 3 + 2) * C + c] = beta[c];
 }
 
 __global__ void __launch_bounds__(256) nhwc_norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_shift,
@@ -530,14 +559,15 @@ __global__ void __launch_bounds__(256) nhwc_norm_apply_kernel(const float* __res
     const int g4 = (int)(i % c4);
     const size_t off = (size_t)n * hw * C + (size_t)i * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale_shift + ((size_t)n * 2 + 0) * C + 4 * g4);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(scale_shift + ((size_t)n * 2 + 1) * C + 4 * g4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(scale_shift + ((size_t)n * 3 + 0) * C + 4 * g4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale_shift + ((size_t)n * 3 + 1) * C + 4 * g4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(scale_shift + ((size_t)n * 3 + 2) * C + 4 * g4);
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
     if (residual) r = *reinterpret_cast<const f32x4*>(residual + off);
     f32x4 y;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float t = fmaf(v[k], sc[k], sh[k]) + r[k];
+        float t = fmaf(v[k] - mu[k], sc[k], sh[k]) + r[k];
         if (act == 1) t = fmaxf(t, 0.f);
         else if (act == 2) t = t > 0.f ? t : expm1f(t);
         y[k] = t;
@@ -664,8 +694,8 @@ int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t 
 
 int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c) {
     if (n < 1 || hw < 1 || c < 1) return 0;
-    // per-chunk partial sums (double), then the [N][2][C] scale / shift table
-    return (int64_t)n * ((hw + PCH - 1) / PCH) * c * 2 * (int64_t)sizeof(double) + (int64_t)n * 2 * c * (int64_t)sizeof(float);
+    // per-chunk partial sums (double), then the [N][3][C] mean / scale / beta table
+    return (int64_t)n * ((hw + PCH - 1) / PCH) * c * 2 * (int64_t)sizeof(double) + (int64_t)n * 3 * c * (int64_t)sizeof(float);
 }
 
 int gpnerf_instance_norm_act_nhwc(const float* x, const float* tile_stats, int32_t n_tiles, const float* gamma, const float* beta,

@@ -15,6 +15,8 @@ entered with stride 2 (there is no max-pool), all 3x3 / 7x7 convolutions reflect
 InstanceNorm without running statistics -> two (bilinear x2, align_corners) + conv + concat-skip decoder steps with
 InstanceNorm + ELU -> 1x1 output convolution.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -84,6 +86,8 @@ def _conv(conv, x, stats=False):
     out = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
     lib = L.lib()
+    if stats and L._DEBUG and os.environ.get("GPNERF_ENC_STATS") == "pass":     # diagnostic: statistics from a separate double-precision pass
+        stats = False
     ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, cin, ks, stride)), cout, 2), device=x.device, dtype=torch.float32) if stats else None
     L.check(lib.gpnerf_conv2d_nhwc(x.data_ptr(), n, h, w, cin, _packed_weight(conv).data_ptr(),
                                    bias.data_ptr() if bias is not None else None, cout, ks, stride, out.data_ptr(),
