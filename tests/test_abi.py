@@ -7,6 +7,8 @@ import subprocess
 import sys
 import tempfile
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "gpnerf_hip.h")
 
@@ -142,3 +144,42 @@ def test_fold_volumes_rejects_bad_arguments_on_the_host(pkg):
     assert lib.gpnerf_fold_volumes(C.byref(f), outs, None) == -1
     assert lib.gpnerf_fold_volumes(C.byref(_frame(L)), (C.c_void_p * L.LEVELS)(0x1000, 0x1000, 0x1000, None), None) == -1
     assert L.FOLD_FIRST_LEVEL == 2 and "GPNERF_FOLD_FIRST_LEVEL 2" in open(os.path.join(ROOT, "include", "gpnerf_hip.h")).read()
+
+
+def _isa_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_mfma_hazards", os.path.join(ROOT, "tools", "isa_mfma_hazards.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_no_consumer_sits_inside_an_mfma_shadow_in_the_shipped_code():
+    """gfx950 does not interlock a VALU / memory instruction that touches an MFMA's destination VGPRs before the MFMA has
+    written them; LLVM pads such consumers with s_nop -- except `asm()` statements, which it cannot see into (the kernels
+    convert operands with inline v_fma_mixlo/hi_f16).  tools/micro/mfma_asm_hazard.hip shows the failure on hardware (65 535 of
+    65 536 results wrong); tools/isa_mfma_hazards.py walks the built library's ISA and must find no such pair."""
+    import shutil
+    if not (shutil.which("llvm-objdump") or os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    tool = _isa_tool()
+    res = tool.scan(os.path.join(ROOT, "gp-nerf_amd", "csrc", "libgpnerf_hip.so"))
+    assert len(res) >= 30 and sum(n for _, n, _, _ in res) > 10000, "the disassembly did not find the MFMA kernels"
+    bad = [(name, b[:2]) for name, _, _, b in res if b]
+    assert not bad, bad
+
+
+def test_the_hazard_checker_flags_an_opaque_consumer(tmp_path):
+    """The checker itself: on the micro kernel the asm consumer right behind the MFMA is reported, the compiler-visible consumer
+    and the asm consumer behind `s_nop 11` are not."""
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "hz.s"
+    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(ROOT, "tools", "micro", "mfma_asm_hazard.hip")], stderr=subprocess.DEVNULL)
+    res = {name: bad for name, _, _, bad in _isa_tool().scan(str(out))}
+    by_mode = {m: next(b for n, b in res.items() if f"ILi{m}E" in n) for m in (0, 1, 2)}
+    assert not by_mode[0] and not by_mode[2]
+    assert len(by_mode[1]) == 1 and by_mode[1][0][5] is True and "v_add_f32" in by_mode[1][0][1]
