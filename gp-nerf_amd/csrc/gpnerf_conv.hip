@@ -115,7 +115,62 @@ struct ConvArgs {
     float* y;                 // [N][Ho][Wo][Cout]
     float* stats;             // [N][tiles][Cout][2] per-workgroup sum / sum of squares of the outputs (for the InstanceNorm behind), or nullptr
     int H, W, Cin, Ho, Wo, Cout, CB, CT;
+    // the InstanceNorm in FRONT of the convolution, applied while the input is staged (3x3 stride-1 kernel only):
+    const float* in_tab;      // [N][3][Cin] mean / scale / beta, or nullptr
+    int in_act;               // 0 none, 1 ReLU
+    // the InstanceNorm BEHIND it: the last workgroup of an (image, channel group) turns the tile sums into the table
+    float* out_tab;           // [N][3][Cout] mean / gamma * rstd / beta, or nullptr (needs stats)
+    const float* gamma;
+    const float* beta;
+    float eps;
+    unsigned* counters;       // [N][gridDim.z], zero before the launch, left zero
 };
+
+// Last-arriving workgroup of (image n, channel group ct0 .. ct0 + COT): every workgroup has written its tile sums; the one whose
+// atomic ticket is the last adds the tiles of its COT * 32 channels in double, in tile order (so the result does not depend on
+// which workgroup that is), and writes mean / gamma * rstd / beta.  256 threads: 256 / (COT * 32) tile lanes per channel.
+template <int COT>
+DEV void finalize_if_last(const ConvArgs& a, const int n, const int ct0, const int ntiles, double* red /* [2][256] doubles of LDS */) {
+    // No agent-scope fence here: a release fence would write back this XCD's whole L2 (the convolution's output has just
+    // dirtied it; measured: the encoder 1.35 -> 1.9 ms).  The tile sums were stored with agent-scope atomics (write-through);
+    // the workgroup-scope release below is an s_waitcnt on those stores' acknowledgements, the ticket is a relaxed agent-scope
+    // atomic issued after it, and the last workgroup reads the sums back with agent-scope atomic loads (past its own L2).
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(&a.counters[(size_t)n * gridDim.z + blockIdx.z], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev + 1u == gridDim.x ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    constexpr int NCH = COT * 32, LANES = 256 / NCH;
+    const int ch = threadIdx.x % NCH, kl = threadIdx.x / NCH, co = 32 * ct0 + ch;
+    double ts = 0, tq = 0;
+    if (co < a.Cout)
+        for (int k = kl; k < ntiles; k += LANES) {
+            const float* o = a.stats + (((size_t)n * ntiles + k) * a.Cout + co) * 2;
+            ts += (double)__hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tq += (double)__hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    red[threadIdx.x] = ts;
+    red[256 + threadIdx.x] = tq;
+    __syncthreads();
+    if (kl == 0 && co < a.Cout) {
+        ts = 0; tq = 0;
+#pragma unroll
+        for (int k = 0; k < LANES; ++k) { ts += red[k * NCH + ch]; tq += red[256 + k * NCH + ch]; }
+        const double hw = (double)a.Ho * (double)a.Wo;
+        const double mean = ts / hw;
+        double var = tq / hw - mean * mean;
+        if (var < 0) var = 0;
+        const float g = a.gamma[co] / sqrtf((float)var + a.eps);
+        a.out_tab[((size_t)n * 3 + 0) * a.Cout + co] = (float)mean;
+        a.out_tab[((size_t)n * 3 + 1) * a.Cout + co] = g;
+        a.out_tab[((size_t)n * 3 + 2) * a.Cout + co] = a.beta[co];
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&a.counters[(size_t)n * gridDim.z + blockIdx.z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
 
 // Per-channel sum and sum of squares of a workgroup's output tile, from the accumulators (the InstanceNorm that follows every
 // convolution but the last would otherwise re-read the whole tensor for them).  Accumulator register r of half h holds channel
@@ -158,9 +213,11 @@ DEV void tile_stats(const f32x16 (&acc)[2][COT], const bool (&valid)[2], float* 
         for (int w = 0; w < WAVES; ++w) { s += red[(w * COT * 32 + ch) * 2]; q += red[(w * COT * 32 + ch) * 2 + 1]; }
         const int co = 32 * ct0 + ch;
         if (co < a.Cout) {
+            // agent-scope stores: written through to the device's coherence point, so that the last workgroup (possibly on
+            // another XCD, behind another L2) can read them without any cache being flushed -- see finalize_if_last
             float* o = a.stats + (((size_t)n * ntiles + tile) * a.Cout + co) * 2;
-            o[0] = s;
-            o[1] = q;
+            __hip_atomic_store(o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -292,6 +349,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
             }
     }
     if (a.stats) tile_stats<COT>(acc, valid, reinterpret_cast<float*>(wbuf[0]), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
+    if (a.out_tab) {
+        __shared__ double fin_red[512];
+        finalize_if_last<COT>(a, n, ct0, (int)gridDim.x, fin_red);
+    }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (!valid[t]) continue;
@@ -327,6 +388,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
     constexpr int WBYTES = 9 * COT * STEP_BYTES;
     unsigned char* const patch0 = smem;                     // [2][PATCH_BYTES]
     unsigned char* const wts0 = smem + 2 * PATCH_BYTES;     // [2][WBYTES]
+    float* const itab = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 2 * WBYTES);      // [3][Cin] when a.in_tab
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
     const int tiles_x = (a.Wo + TW - 1) / TW;
     const int ty0 = ((int)blockIdx.x / tiles_x) * TH, tx0 = ((int)blockIdx.x % tiles_x) * TW;
@@ -340,7 +402,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
 
-    // staging work of one thread per channel block: patch items (pixel, 4-channel quad) and 16-byte weight pieces
+    // staging work of one thread per channel block: patch items (pixel, 4-channel quad) and 16-byte weight pieces.
+    // (A second register set, so that the loads of blocks cb + 1 AND cb + 2 are in flight, was built and measured: no gain,
+    // 1.33 -> 1.37 ms per frame.  The loop's ~2.3 us per block against 0.7 us of MFMAs is not a global round trip: with COT = 1
+    // a tap costs 6 ds_read_b128 for 6 MFMAs, and four waves x 8 LDS cycles per read fill the 32 cycles an MFMA gives them.)
     constexpr int PITEMS = PH * PW * 4, PPASS = (PITEMS + WAVES * 64 - 1) / (WAVES * 64);
     constexpr int WPIECES = 9 * COT * (STEP_BYTES / 16), WPASS = (WPIECES + WAVES * 64 - 1) / (WAVES * 64);
     f32x4 preg[PPASS];
@@ -363,18 +428,29 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             if (piece < WPIECES) {
                 const int tap = piece / (COT * (STEP_BYTES / 16)), rest = piece % (COT * (STEP_BYTES / 16));
                 wreg[s] = *(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.packed) +
-                                                            (((size_t)tap * a.CB + cb) * a.CT + ct0) * STEP_BYTES) + rest);
+                                                               (((size_t)tap * a.CB + cb) * a.CT + ct0) * STEP_BYTES) + rest);
             }
         }
     };
-    auto park = [&](int buf) {
+    auto park = [&](int buf, int pcb) {
         unsigned char* const pb = patch0 + buf * PATCH_BYTES;
 #pragma unroll
         for (int s = 0; s < PPASS; ++s) {
             const int item = s * (WAVES * 64) + (int)threadIdx.x;
             if (item < PITEMS) {
                 const int pp = item >> 2, qd = item & 3;
-                const f32x4 v = preg[s] * X_SCALE;
+                f32x4 v = preg[s];
+                if (a.in_tab) {                              // the InstanceNorm (+ ReLU) in front of this convolution, as nhwc_norm_apply_kernel computes it
+                    const int c0 = 16 * pcb + 4 * qd;
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(itab + c0), sc = *reinterpret_cast<const f32x4*>(itab + a.Cin + c0),
+                                be = *reinterpret_cast<const f32x4*>(itab + 2 * a.Cin + c0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float t = fmaf(v[k] - mu[k], sc[k], be[k]);
+                        v[k] = a.in_act == 1 ? fmaxf(t, 0.f) : t;
+                    }
+                }
+                v *= X_SCALE;
                 const unsigned h0 = pk_hi(v[0], v[1]), h1 = pk_hi(v[2], v[3]);
                 unsigned* d = reinterpret_cast<unsigned*>(pb + pp * PPX + qd * 8);
                 d[0] = h0; d[1] = h1;
@@ -388,16 +464,11 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             if (piece < WPIECES) wb[piece] = wreg[s];
         }
     };
-    fetch(0);
-    park(0);
-    __syncthreads();
-    for (int cb = 0; cb < a.CB; ++cb) {
-        const int buf = cb & 1;
-        if (cb + 1 < a.CB) fetch(cb + 1);                   // the next block's loads fly under this block's 54 x COT MFMAs
+    // the 54 x COT MFMAs of one staged block: operands of tap 0, then per tap: read the next tap's operands, run this tap's
+    // MFMAs -- the three products of one accumulator are issued COT * PT MFMAs apart (back-to-back they would wait on each other)
+    auto compute = [&](int buf) {
         const unsigned char* const pb = patch0 + buf * PATCH_BYTES;
         const unsigned char* const wb = wts0 + buf * WBYTES;
-        // operands of tap 0, then per tap: read the next tap's operands, run this tap's MFMAs -- the three products of one
-        // accumulator are issued COT * PT MFMAs apart (back-to-back they would wait on each other)
         Frag b[2][PT];
         h8 wh[2][COT], wlo[2][COT];
         auto read_tap = [&](int tap, int slot) {
@@ -439,7 +510,19 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
 #pragma unroll
                 for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cur][c], b[cur][t].hi, acc[t][c], 0, 0, 0);
         }
-        if (cb + 1 < a.CB) park(buf ^ 1);
+    };
+    fetch(0);
+    if (a.in_tab) {
+        for (int i = threadIdx.x; i < 3 * a.Cin; i += WAVES * 64) itab[i] = a.in_tab[(size_t)n * 3 * a.Cin + i];
+        __syncthreads();
+    }
+    park(0, 0);
+    __syncthreads();
+    for (int cb = 0; cb < a.CB; ++cb) {
+        const int buf = cb & 1;
+        if (cb + 1 < a.CB) fetch(cb + 1);                   // the next block's loads fly under this block's 54 x COT MFMAs
+        compute(buf);
+        if (cb + 1 < a.CB) park(buf ^ 1, cb + 1);
         __syncthreads();
     }
     const int ox = tx0 + px;
@@ -462,6 +545,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             }
     }
     if (a.stats) tile_stats<COT>(acc, valid, reinterpret_cast<float*>(smem), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
+    if (a.out_tab) finalize_if_last<COT>(a, n, ct0, (int)gridDim.x, reinterpret_cast<double*>(smem + 8192));
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (!valid[t]) continue;
@@ -551,8 +635,8 @@ __global__ void __launch_bounds__(256) nhwc_norm_finalize_kernel(const T* __rest
 }
 
 __global__ void __launch_bounds__(256) nhwc_norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_shift,
-                                                              const float* __restrict__ residual, const long hw, const int C,
-                                                              const int act, float* __restrict__ out) {
+                                                              const float* __restrict__ residual, const float* __restrict__ res_tab,
+                                                              const long hw, const int C, const int act, float* __restrict__ out) {
     const int n = blockIdx.y, c4 = C >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;           // float4 element of image n
     if (i >= hw * c4) return;
@@ -564,6 +648,13 @@ __global__ void __launch_bounds__(256) nhwc_norm_apply_kernel(const float* __res
     const f32x4 sh = *reinterpret_cast<const f32x4*>(scale_shift + ((size_t)n * 3 + 2) * C + 4 * g4);
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
     if (residual) r = *reinterpret_cast<const f32x4*>(residual + off);
+    if (res_tab) {                                            // the shortcut's own InstanceNorm (no activation), applied on the fly
+        const f32x4 rm = *reinterpret_cast<const f32x4*>(res_tab + ((size_t)n * 3 + 0) * C + 4 * g4);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(res_tab + ((size_t)n * 3 + 1) * C + 4 * g4);
+        const f32x4 rb = *reinterpret_cast<const f32x4*>(res_tab + ((size_t)n * 3 + 2) * C + 4 * g4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = fmaf(r[k] - rm[k], rs[k], rb[k]);
+    }
     f32x4 y;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -628,7 +719,7 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     }
     int cot = (a.CT % 2 == 0) ? 2 : 1;
     if (f_cot == 1 || (f_cot == 0 && cot == 2 && (long)tiles * N * (a.CT / 2) < 192)) cot = 1;
-    const size_t lds = 2 * (size_t)PATCH_BYTES + 2 * (size_t)9 * cot * STEP_BYTES;
+    const size_t lds = 2 * (size_t)PATCH_BYTES + 2 * (size_t)9 * cot * STEP_BYTES + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
     const void* fn = cot == 2 ? reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<2>) : reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<1>);
     // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
@@ -666,8 +757,9 @@ int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int
     return (ho * wo + WAVES * PT * 32 - 1) / (WAVES * PT * 32);
 }
 
-int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
-                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, void* stream) {
+int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* in_table, int32_t in_act,
+                            const void* packed, const float* bias, int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats,
+                            const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, void* stream) {
     if (n == 0) return GPNERF_OK;
     if (!x || !packed || !y || n < 0 || h < 1 || w < 1 || cin < 1 || cout < 4 || (cout & 3)) return GPNERF_E_ARG;
     if ((ks != 1 && ks != 3 && ks != 7) || (stride != 1 && stride != 2)) return GPNERF_E_ARG;
@@ -675,11 +767,15 @@ int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t 
     if (h <= pad || w <= pad) return GPNERF_E_ARG;                       // reflection needs pad < size
     const bool narrow = cin < 8;
     if (!narrow && (cin & 15)) return GPNERF_E_ARG;                       // full 16-channel chunks, 32-byte aligned loads
+    if (in_table && !(ks == 3 && stride == 1 && !narrow)) return GPNERF_E_ARG;      // the staged form is the 3x3 stride-1 kernel's
+    if (in_table && (in_act < 0 || in_act > 1 || cin > 1024)) return GPNERF_E_ARG;
+    if (out_table && (!tile_stats || !gamma || !beta || !counters)) return GPNERF_E_ARG;
     ConvArgs a;
     a.x = x; a.packed = reinterpret_cast<const uint16_t*>(packed); a.bias = bias; a.y = y; a.stats = tile_stats;
     a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
     a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
     a.CB = narrow ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16; a.CT = (cout + 31) / 32;
+    a.in_tab = in_table; a.in_act = in_act; a.out_tab = out_table; a.gamma = gamma; a.beta = beta; a.eps = eps; a.counters = counters;
     if (narrow) {
         if (ks == 7 && stride == 2) return launch_conv<7, 2, true>(a, n, stream);
         if (ks == 3 && stride == 1) return launch_conv<3, 1, true>(a, n, stream);
@@ -690,6 +786,12 @@ int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t 
     if (ks == 1 && stride == 1) return launch_conv<1, 1, false>(a, n, stream);
     if (ks == 1 && stride == 2) return launch_conv<1, 2, false>(a, n, stream);
     return GPNERF_E_ARG;
+}
+
+int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
+                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, void* stream) {
+    return gpnerf_conv2d_norm_nhwc(x, n, h, w, cin, nullptr, 0, packed, bias, cout, ks, stride, y, tile_stats, nullptr, nullptr, 0.f, nullptr,
+                                   nullptr, stream);
 }
 
 int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c) {
@@ -718,7 +820,17 @@ int gpnerf_instance_norm_act_nhwc(const float* x, const float* tile_stats, int32
                            (int)c, nchunks, eps, table);
     }
     hipLaunchKernelGGL(nhwc_norm_apply_kernel, dim3((unsigned)((elems + 255) / 256), (unsigned)n), dim3(256), 0, S_(stream), x,
-                       (const float*)table, residual, (long)hw, (int)c, (int)act, out);
+                       (const float*)table, residual, (const float*)nullptr, (long)hw, (int)c, (int)act, out);
+    return status();
+}
+
+int gpnerf_norm_apply_nhwc(const float* x, const float* table, const float* residual, const float* res_table, int32_t n, int64_t hw,
+                           int32_t c, int32_t act, float* out, void* stream) {
+    if (n == 0 || c == 0 || hw == 0) return GPNERF_OK;
+    if (!x || !table || !out || n < 0 || c < 4 || (c & 3) || hw < 0 || act < 0 || act > 2 || (res_table && !residual)) return GPNERF_E_ARG;
+    const long elems = (long)hw * (c >> 2);
+    hipLaunchKernelGGL(nhwc_norm_apply_kernel, dim3((unsigned)((elems + 255) / 256), (unsigned)n), dim3(256), 0, S_(stream), x, table,
+                       residual, res_table, (long)hw, (int)c, (int)act, out);
     return status();
 }
 

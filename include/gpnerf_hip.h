@@ -308,12 +308,28 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
  *   act 0 none / 1 ReLU / 2 ELU (UNet.py:38-53,117-120,180-183); statistics from tile_stats (n_tiles rows per image) when
  *   given, else from a pass over x; either way added up in double in a fixed order (deterministic);
  *   scratch: gpnerf_instance_norm_nhwc_scratch_bytes() bytes.
+ * conv2d_norm_nhwc = conv2d_nhwc with the InstanceNorms on either side of it fused in (a residual unit is conv - norm - ReLU -
+ *   conv - norm, UNet.py:38-53):
+ *     in_table  NULL, or [N][3][cin] floats (mean, gamma * rstd, beta per channel, what out_table below produces): the
+ *               convolution then reads act((x - mean) * scale + beta) instead of x while it stages its input, act = ReLU for
+ *               in_act 1, identity for 0 -- the normalised tensor is never written.  3x3 stride-1 convolutions with cin % 16 == 0.
+ *     out_table NULL, or [N][3][cout] floats that receive mean / gamma * rstd / beta of InstanceNorm2d(y; gamma, beta, eps): the
+ *               last workgroup to finish an (image, 32..64-channel group) adds that group's tile_stats rows in double, in tile
+ *               order (deterministic), so no separate reduction launch follows the convolution.  Needs tile_stats, gamma, beta and
+ *               `counters`: at least N * ceil(cout / 32) uint32 words that are zero before the call; they are zero again after it.
+ * norm_apply_nhwc = act((x - mean) * scale + beta [+ residual]) from such a table; with res_table the residual is itself
+ *   normalised on the fly ((residual - rmean) * rscale + rbeta: the projected shortcut's InstanceNorm, UNet.py:48-51).
  * upsample2x_nhwc = F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (UNet.py:129). */
 int64_t gpnerf_conv_packed_bytes(int32_t cout, int32_t cin, int32_t ks);
 int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, void* packed, void* stream);
 int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t stride);
 int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
                        int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, void* stream);
+int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* in_table, int32_t in_act,
+                            const void* packed, const float* bias, int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats,
+                            const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, void* stream);
+int gpnerf_norm_apply_nhwc(const float* x, const float* table, const float* residual, const float* res_table, int32_t n, int64_t hw,
+                           int32_t c, int32_t act, float* out, void* stream);
 int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c);
 int gpnerf_instance_norm_act_nhwc(const float* x, const float* tile_stats, int32_t n_tiles, const float* gamma, const float* beta,
                                   const float* residual, int32_t n, int64_t hw, int32_t c, float eps, int32_t act, float* out,

@@ -102,3 +102,34 @@ def test_conv_entry_point_rejects_unsupported_shapes():
     assert lib.gpnerf_conv2d_nhwc(None, 0, 8, 8, 16, p, None, 32, 3, 1, p, None, None) == 0     # nothing to do
     assert lib.gpnerf_conv_out_tiles(128, 128, 64, 3, 1) == 16 * 4 and lib.gpnerf_conv_out_tiles(128, 128, 64, 3, 2) == 16
     assert lib.gpnerf_conv_packed_bytes(64, 3, 7) == 10 * 2 * 2048      # the 3-channel stem: K = 147 flattened into 10 chunks of 16
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 33, 47), (128, 128, 16, 20), (256, 256, 9, 7), (64, 96, 40, 40)])
+def test_fused_norms_around_a_convolution_match_the_separate_launches(cin, cout, H, W, enc):
+    """gpnerf_conv2d_norm_nhwc: (a) the table its last workgroup writes equals the separate reduction's normalisation;
+    (b) reading relu(norm(x)) while staging equals convolving the materialised tensor -- bit for bit (same arithmetic, same order);
+    (c) the ticket words are zero again; (d) against float64 torch."""
+    g = torch.Generator().manual_seed(cin + cout + H)
+    dev = "cuda:0"
+    c0 = torch.nn.Conv2d(cin, cin, 3, padding=1, bias=False, padding_mode="reflect").to(dev)
+    n0 = torch.nn.InstanceNorm2d(cin, track_running_stats=False, affine=True).to(dev)
+    c1 = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=True, padding_mode="reflect").to(dev)
+    n1 = torch.nn.InstanceNorm2d(cout, track_running_stats=False, affine=True).to(dev)
+    with torch.no_grad():
+        for m in (n0, n1):
+            m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=g))
+            m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+        x = (torch.randn((3, cin, H, W), generator=g) * 2 + 0.5).to(dev)
+        y0, t0 = enc._conv_norm(c0, n0, x)
+        a_sep = enc._norm_act(n0, enc._conv(c0, x, stats=True), 1)                   # separate finalize + apply launches
+        a_tab = enc._apply(y0, t0, 1)
+        assert torch.equal(a_sep, a_tab)
+        y_mat, t_mat = enc._conv_norm(c1, n1, a_tab)                                  # materialised input
+        y_fus, t_fus = enc._conv_norm(c1, n1, y0, in_tab=t0, in_act=1)                # normalised + ReLU'd while staging
+        assert torch.equal(y_mat, y_fus) and torch.equal(t_mat, t_fus)
+        assert int(enc._ticket_words(x.device).abs().sum()) == 0
+        ref = n1.double()(c1.double()(F.relu(n0.double()(c0.double()(x.double())))))
+        assert float((enc._apply(y_fus, t_fus, 0).double() - ref).abs().max()) < 5e-5
+        if cin == cout:
+            out = enc._apply(y_fus, t_fus, 1, residual=y0, res_tab=t0)                # shortcut normalised on the fly
+            assert float((out.double() - F.relu(ref + n0(c0(x.double())))).abs().max()) < 5e-5
