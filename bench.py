@@ -326,15 +326,26 @@ def beside_headline(args, fm, wl, kw, flow):
         res["renderer_api"] = renderer_api_wall(args, wl)
     except Exception as e:                       # the API timing must never take the headline down with it
         res["renderer_api"] = {"error": repr(e)[:200]}
+    try:                                         # the ZJU-sized frame: SURVEY.md 8d's literal f = 1.05 W camera, ~74 k rays
+        res["renderer_api_survey_frame"] = renderer_api_wall(args, None, survey=True)
+    except Exception as e:
+        res["renderer_api_survey_frame"] = {"error": repr(e)[:200]}
     return res
 
 
-def renderer_api_wall(args, wl):
+def renderer_api_wall(args, wl, survey=False):
     """Wall time of `build_render(cfg).render(batch)` (the reference's entry point, tools/inference.py:61 + BaseTrainer.py:267) on
     the bench frame: with feature maps and volumes handed in (frame build + render + dict), and with the per-frame producers
-    (image encoder, vertex attention, sparse volume builder) running too."""
+    (image encoder, vertex attention, sparse volume builder) running too.  survey=True: the same call, producers running, on the
+    frame a real evaluation loop renders (512x512 sources, the full-size SMPL box seen through SURVEY.md 8d's f = 1.05 W camera:
+    ~74 k rays x 64 samples), where the producers are a third of the call instead of a sixth."""
     import torch
     from types import SimpleNamespace as NS
+    if survey:
+        syn = importlib.import_module("gp-nerf_amd.synthetic")
+        dev0 = torch.device("cuda", torch.cuda.current_device())
+        sc = syn.make_scene(H=512, W=512, seed=args.seed, fill="survey", pose="identity", make_volumes=False)
+        wl = NS(S=64, sc=sc, rays=torch.empty((0, 8), device=dev0), vols_dev=None)
     p = os.path.join(ROOT, "gp-nerf_amd", "plugins")
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -355,7 +366,9 @@ def renderer_api_wall(args, wl):
     b = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in keys}
     res = {}
     with torch.no_grad():
-        for name, extra in (("products_in_batch", {"featmaps": torch.from_numpy(sc["featmaps"]).to(dev), "volumes": wl.vols_dev}), ("with_producers", {})):
+        legs = (("with_producers", {}),) if survey else (("products_in_batch", {"featmaps": torch.from_numpy(sc["featmaps"]).to(dev), "volumes": wl.vols_dev}),
+                                                          ("with_producers", {}))
+        for name, extra in legs:
             bb = dict(b, **extra)
             for _ in range(2):
                 r.render(bb)
@@ -368,7 +381,7 @@ def renderer_api_wall(args, wl):
                 ts.append((time.perf_counter() - t0) * 1e3)
                 et.append(ret["etime"] * 1e3)
             res[name] = {"wall_ms": float(np.median(ts)), "etime_ms": float(np.median(et)), "rtime_ms": float(ret["rtime"] * 1e3),
-                         "returns": sorted(k for k in ret if k not in ("etime", "rtime"))}
+                         "rays": int(ret["rgb_map"].shape[1]), "returns": sorted(k for k in ret if k not in ("etime", "rtime"))}
     res["note"] = ("products_in_batch: batch carries featmaps + the 4 dense levels; with_producers: hip_encoder + vertex attention + sparse "
                    "volume builder run per frame (their volumes are sparse, the per-ray kernel's work is the same)")
     return res

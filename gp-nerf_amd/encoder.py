@@ -276,6 +276,50 @@ class ResUNet(nn.Module):
         return _conv(self.out_conv, x)
 
 
+class _EncoderGraph:
+    """One HIP graph of ResUNet.forward for one (input shape, device, parameter versions): the ~60 launches of a frame's encoding
+    replayed with ONE host call.  The kernels themselves take as long as before (1.3 ms at 3x512x512, and a replay is as
+    GPU-bound as the eager launches) -- what the graph removes is the ~1.4 ms the HOST needs to enqueue them one by one through
+    Python, during which it cannot prepare the rest of the frame: Renderer.render's device then idled ~0.7 ms per call waiting
+    for the frame build's launches (tools/probes/render_phases.py)."""
+
+    def __init__(self, net, x):
+        dev = x.device
+        self.static_in = torch.empty(tuple(x.shape), device=dev, dtype=torch.float32)
+        self.static_in.copy_(x)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                 # eager warm-up: packs the weights, sets the kernels' LDS attributes
+            net.forward(self.static_in)
+            net.forward(self.static_in)
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = net.forward(self.static_in)
+
+    def __call__(self, x):
+        self.static_in.copy_(x)
+        self.graph.replay()
+        return self.static_out.clone()                # the caller owns its result (the next replay overwrites static_out)
+
+
+def _graph_key(net, x):
+    return (tuple(x.shape), str(x.device), x.dtype, tuple((p.data_ptr(), p._version) for p in net.parameters()))
+
+
+def forward_graphed(net, x):
+    """net(x) through a cached HIP graph (re-captured when the input shape, the device or any parameter changes).  Same bits as
+    the eager call (tests/test_encoder.py)."""
+    _require_gpu_inference(x, net.training)
+    key = _graph_key(net, x)
+    hit = net.__dict__.get("_gpnerf_graph")
+    if hit is None or hit[0] != key:
+        hit = (key, _EncoderGraph(net, x.float()))
+        net.__dict__["_gpnerf_graph"] = hit
+    return hit[1](x)
+
+
 def build_encoder(cfg):
     """Same cfg keys as UNet.py:236-242."""
     return ResUNet(encoder=cfg.encoder.name, out_ch=cfg.encoder.out_ch)

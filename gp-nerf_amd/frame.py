@@ -241,7 +241,7 @@ def patch_order(mask_at_box, H, W, patch_w=32, patch_h=8):
     return t[t >= 0].astype(np.int32)
 
 
-def patch_order_device(mask, H, W, patch_w=4, patch_h=8):
+def patch_order_device(mask, H, W, patch_w=4, patch_h=8, n_kept=None):
     """patch_order() on the device for a bool mask [H*W]: int32 permutation that lays the kept pixels out patch by patch,
     so that a wavefront's 32 rays cover a compact patch_w x patch_h block instead of a 32-pixel row.  With sample culling a
     compact block is empty or full together far more often (measured: -10 % frame time at 10-30 % occupancy)."""
@@ -252,6 +252,11 @@ def patch_order_device(mask, H, W, patch_w=4, patch_h=8):
     if (Hp, Wp) != (H, W):
         idx = torch.nn.functional.pad(idx, (0, Wp - W, 0, Hp - H), value=-1)
     t = idx.view(Hp // patch_h, patch_h, Wp // patch_w, patch_w).permute(0, 2, 1, 3).reshape(-1)
+    if n_kept is not None:
+        # the caller knows how many pixels the mask keeps (it holds their rays): compaction with a static size, no host round trip
+        # (boolean indexing synchronises to learn the count); a wrong n_kept shows up as -1 entries / a short list and is rejected
+        pos = torch.nonzero_static(t >= 0, size=int(n_kept), fill_value=-1).squeeze(1)
+        return t.index_select(0, pos.clamp_min(0)).masked_fill_(pos < 0, -1).contiguous()
     return t[t >= 0].contiguous()
 
 

@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import encoder as E_
 from . import frame as F_
 from . import parallel as P_
 
@@ -31,7 +32,7 @@ from . import parallel as P_
 class Renderer(nn.Module):
     def __init__(self, encoder, nerfhead, is_train=False, neg_ray_train=False, neg_ray_val=False, n_rays=1024,
                  n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=None, term_eps=1e-5,
-                 progressive=False, split_f16=None, sharded_outputs="all", shard_group=None):
+                 progressive=False, split_f16=None, sharded_outputs="all", shard_group=None, encoder_graph=None):
         super().__init__()
         self.encoder = encoder
         self.nerfhead = nerfhead
@@ -66,6 +67,10 @@ class Renderer(nn.Module):
         # with a shard_group: "all" = the reference's full dict on every rank (one packed all-gather),
         # "pixels" = rgb_map + depth_map only (16 B/ray over xGMI)
         self.sharded_outputs = sharded_outputs
+        # encoder_graph: replay the image encoder's launches as one HIP graph per (image shape, parameter versions) when the encoder
+        # offers it (hip_encoder does): same bits, ~1.3 ms less host time per frame (the host then prepares the frame while the
+        # device encodes).  GPNERF_ENCODER_GRAPH=0 switches it off.
+        self.encoder_graph = (os.environ.get("GPNERF_ENCODER_GRAPH", "1") != "0") if encoder_graph is None else bool(encoder_graph)
         # split_f16: dense layers on f16 MFMA with hi/lo operand pairs (GPNERF_FLAG_SPLIT_F16); same 1e-4 parity bound,
         # ~1.8x faster.  Default: exact fp32 MFMA, unless GPNERF_SPLIT_F16=1 is set in the environment.
         self.split_f16 = (os.environ.get("GPNERF_SPLIT_F16", "0") == "1") if split_f16 is None else bool(split_f16)
@@ -84,7 +89,12 @@ class Renderer(nn.Module):
         if src_imgs.shape[0] != 1:
             raise L.GpnerfError("only batch_size=1 is supported (as BaseRender.py:336 asserts)")
         # with a shard_group: the source views dealt out over the ranks + a broadcast of each feature map (parallel.py)
-        featmaps = batch["featmaps"] if "featmaps" in batch else P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0), group=self.shard_group)
+        if "featmaps" in batch:
+            featmaps = batch["featmaps"]
+        elif self.encoder_graph and P_.resolve_group(self.shard_group) is None and src_imgs.is_cuda and isinstance(self.encoder, E_.ResUNet):
+            featmaps = E_.forward_graphed(self.encoder, src_imgs.squeeze(0))
+        else:
+            featmaps = P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0), group=self.shard_group)
         return featmaps[0] if featmaps.dim() == 5 else featmaps
 
     def prepare_sp_input(self, batch, out_sh=None):
@@ -240,38 +250,46 @@ class Renderer(nn.Module):
         dev = batch["ray_o"].device
         torch.cuda.synchronize(dev)
         te = time.time()
-        # Everything that needs the host to wait for the device happens HERE, while the queue is empty: the frame's small
-        # constants in one copy, and the patch order (its boolean index is a synchronisation).  From the encoder's first launch
-        # to the end of the per-ray kernel the host only enqueues, so it runs ahead of the device and the ~180 launches of a
-        # frame go back to back (with a synchronisation after the encoder and five more in the frame build the device idled
-        # 1.4 ms of an 18.4 ms call).
-        consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
-        rays = torch.cat([batch["ray_o"], batch["ray_d"], batch["near"].unsqueeze(-1), batch["far"].unsqueeze(-1)], dim=-1)[0]
-        neg = self._neg_ray(batch)
-        n = rays.shape[0]
-        group = P_.resolve_group(self.shard_group)
-        sharded = group is not None
-        # Which 32 rays share a wavefront is the launch's choice (results do not depend on it): when the batch says which
-        # pixels the rays are (`mask_at_box`, ZjumocapDataset.py:505), lay them out as 32x8-pixel patches so that the rays of
-        # a workgroup hit the same cache lines.  A sharded frame cuts its round-robin bands from the same patch-major list.
-        order = None
-        if "mask_at_box" in batch:
-            Hs, Ws = batch["src_imgs"].shape[-2:]
-            m = batch["mask_at_box"].reshape(-1)
-            if m.numel() == Hs * Ws and m.is_cuda:
-                # with early termination a wavefront's 32 rays are a compact 8x4-pixel block rather than a 32-pixel row: the rays of
-                # a block become opaque together far more often (bench frame: 43 % -> 35 % of the samples evaluated)
-                pw, ph = (8, 4) if self.early_term else (32, 8)
-                order = F_.patch_order_device(m.bool(), Hs, Ws, patch_w=pw, patch_h=ph)
-                if order.numel() != n:
-                    order = None
+        # The encoder goes FIRST: it needs nothing but the source images, and its ~1.4 ms on the device cover everything the host
+        # has to wait for -- the frame's small constants (one device-to-host copy) and the patch order -- which happen on a SIDE
+        # stream meanwhile (the copy's synchronisation then waits for that stream's few microseconds, not for the encoder).  From
+        # there to the end of the per-ray kernel the host only enqueues and runs ahead of the device, so a frame's ~130 launches
+        # go back to back.  (Round 2 fetched the constants before the encoder's first launch: the device idled ~0.3 ms per call.)
         # the encoder's time comes from two events on the stream instead of two host synchronisations around it
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        prepared = self.prepare_builder_inputs(batch, consts)          # before the encoder: see there
         blob = self.nerfhead.head_blob(dev)                            # (cached; packs on a parameter change)
         ev0.record()
         featmaps = self.encode(batch)
         ev1.record()
+        main = torch.cuda.current_stream(dev)
+        side = self.__dict__.get("_side_stream")
+        if side is None or side.device != dev:
+            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+        group = P_.resolve_group(self.shard_group)
+        sharded = group is not None
+        with torch.cuda.stream(side):              # the batch's tensors are complete: render() synchronised at its top
+            consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
+            rays = torch.cat([batch["ray_o"], batch["ray_d"], batch["near"].unsqueeze(-1), batch["far"].unsqueeze(-1)], dim=-1)[0]
+            n = rays.shape[0]
+            # Which 32 rays share a wavefront is the launch's choice (results do not depend on it): when the batch says which
+            # pixels the rays are (`mask_at_box`, ZjumocapDataset.py:505), lay them out as 32x8-pixel patches so that the rays of
+            # a workgroup hit the same cache lines.  A sharded frame cuts its round-robin bands from the same patch-major list.
+            order = None
+            if "mask_at_box" in batch:
+                Hs, Ws = batch["src_imgs"].shape[-2:]
+                m = batch["mask_at_box"].reshape(-1)
+                if m.numel() == Hs * Ws and m.is_cuda:
+                    # with early termination a wavefront's 32 rays are a compact 8x4-pixel block rather than a 32-pixel row: the
+                    # rays of a block become opaque together far more often (bench frame: 43 % -> 35 % of the samples evaluated)
+                    pw, ph = (8, 4) if self.early_term else (32, 8)
+                    mb = m.bool()
+                    order = F_.patch_order_device(mb, Hs, Ws, patch_w=pw, patch_h=ph, n_kept=n)
+                    # a mask that does not keep exactly the n pixels the rays belong to cannot order them: fall back to list
+                    # order, decided on the device (reading the count on the host would be a synchronisation)
+                    order = torch.where(mb.sum() == n, order, torch.arange(n, device=dev, dtype=order.dtype))
+            prepared = self.prepare_builder_inputs(batch, consts)      # what the builder needs that does not depend on the encoder
+        main.wait_stream(side)
+        neg = self._neg_ray(batch)
         frame = self.build_frame(batch, featmaps, consts, prepared)
 
         def fn(r):

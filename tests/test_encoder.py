@@ -113,3 +113,26 @@ def test_encoder_is_bit_deterministic_at_full_size():
         outs = [net(imgs).clone() for _ in range(3)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     assert bool(torch.isfinite(outs[0]).all())
+
+
+@pytest.mark.gpu
+def test_encoder_through_a_hip_graph_gives_the_eager_bits_and_follows_its_parameters():
+    """forward_graphed: one replay instead of ~60 launches; re-captured when the input shape or a parameter changes; the result is
+    the caller's own tensor (a later replay must not change it)."""
+    net, _ = _net(5)
+    net = net.to("cuda:0")
+    a = torch.from_numpy(syn.make_encoder_images(96, 128, 5)).to("cuda:0")
+    b = torch.from_numpy(syn.make_encoder_images(96, 128, 6)).to("cuda:0")
+    with torch.no_grad():
+        ea, eb = net(a), net(b)
+        ga = enc.forward_graphed(net, a)
+        g1 = net.__dict__["_gpnerf_graph"][1]
+        gb = enc.forward_graphed(net, b)
+        assert net.__dict__["_gpnerf_graph"][1] is g1                      # same shape, same parameters: the same graph
+        assert torch.equal(ga, ea) and torch.equal(gb, eb) and ga.is_contiguous(memory_format=torch.channels_last)
+        c = torch.from_numpy(syn.make_encoder_images(64, 64, 7)).to("cuda:0")
+        assert torch.equal(enc.forward_graphed(net, c), net(c))            # other shape: re-captured
+        net.layer2[1].conv2.weight.mul_(1.5)
+        net.out_conv.bias.add_(0.25)
+        assert torch.equal(enc.forward_graphed(net, c), net(c))            # parameters changed: re-packed and re-captured
+        assert torch.equal(ga, ea)                                         # earlier results untouched
