@@ -857,13 +857,15 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     // [seg * chain, (seg + 1) * chain) of the rays listed in `list_in` (nullptr: every ray, segment 0), 32 list entries per
     // wavefront, and appends the rays that are neither finished nor opaque to `list_out` for the next launch
     int chain, seg, wave_cap;
+    int k_begin, k_end;       // chained form: the launch's sample range [k_begin, k_end) (segments need not be equally long, chain_schedule())
     int stagger;              // experiment: wavefronts start up to this many x 1.7 us late, scattered over the chip
     int chunk;                // tiles per chunk of the XCD queues (queue_tile())
     int tail_p;               // chain_plan(): samples per step of the units the last whole round is cut into
     const int* list_in;
     const unsigned* count_in;
-    int* list_out;
-    unsigned* count_out;
+    int* list_out;            // SPARSE: entry i of this launch's input writes its launch slot (or -1: finished / opaque) at [i]
+    unsigned* count_out;      // (written by compact_list_kernel, not by the render kernel)
+    unsigned* chunk_cnt;      // survivors per LIST_CHUNK input entries (one atomic per wavefront), zero at launch
     long p_cap;               // chain_plan(): 32 x the wavefronts the launch's remainder units may spread over
     long first_slot, first_items;   // segment 0 (no list) renders launch slots [first_slot, first_slot + first_items)
     // occupancy culling: bit k of cull_mask[slot * 2 + (k >> 6)] = launch slot `slot` keeps its sample of composite step k
@@ -953,6 +955,7 @@ DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
 #ifndef GPNERF_MAX_WAVES
 #define GPNERF_MAX_WAVES 8
 #endif
+constexpr int LIST_CHUNK_SHIFT = 11, LIST_CHUNK = 1 << LIST_CHUNK_SHIFT;      // entries per survivor counter / per compaction workgroup
 // number of launch slots a chained launch renders: the previous segment's survivors, or every ray (segment 0)
 typedef const __attribute__((address_space(4))) KArgs* kargs_cptr;
 DEV long chain_items(kargs_cptr k) { return k->list_in ? (long)*k->count_in : k->first_items; }
@@ -982,6 +985,52 @@ DEV ChainPlan chain_plan(kargs_cptr k) {
     c.rem_p = p;
     c.rem_tiles = (rem * p + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     return c;
+}
+
+// Between two chained launches: the sparse list of the launch just finished (launch slot or -1 per input entry) becomes the dense
+// input list of the next, survivors in input order -- which is the patch-major order the frame was launched in, so the 32 rays
+// of a wavefront and the wavefronts of a CU stay neighbours in the image at every level.  One workgroup per LIST_CHUNK entries:
+// its offset is the sum of the chunk counters before it (the render kernel's wavefronts filled them), its own entries are ranked
+// with ballots.  The workgroup that holds the last entry writes the list's length.
+__global__ void __launch_bounds__(256) compact_list_kernel(const int* __restrict__ sparse, const unsigned* __restrict__ chunk_cnt,
+                                                           const unsigned* __restrict__ count_in, const long first_items,
+                                                           int* __restrict__ dense, unsigned* __restrict__ count_out) {
+    const long n_items = count_in ? (long)*count_in : first_items;
+    const long start = (long)blockIdx.x * LIST_CHUNK;
+    if (start >= n_items) return;
+    __shared__ unsigned red[256 / 64];
+    __shared__ unsigned wave_base[256 / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned part = 0;
+    for (unsigned i = threadIdx.x; i < blockIdx.x; i += 256) part += chunk_cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) red[wave] = part;
+    // this thread's 8 consecutive entries
+    const long e0 = start + (long)threadIdx.x * 8;
+    int v[8];
+    unsigned mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = (e0 + j < n_items) ? sparse[e0 + j] : -1;
+        mine += v[j] >= 0;
+    }
+    unsigned incl = mine;                      // inclusive scan over the wavefront
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_base[wave] = incl;
+    __syncthreads();
+    unsigned offset = red[0] + red[1] + red[2] + red[3];
+    unsigned before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_base[w];
+    unsigned pos = offset + before + incl - mine;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (v[j] >= 0) dense[pos++] = v[j];
+    if (start + LIST_CHUNK >= n_items && threadIdx.x == 255) *count_out = offset + before + incl;
 }
 
 // One work unit = (32-ray tile, sample segment) rendered by one wavefront: with split > 1 the samples of a tile are divided
@@ -1048,9 +1097,9 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0) && (sub == 0);
 
-    const int chain = CHAIN ? k0->chain : 0;        // the chained form is its own instantiation: the plain sample loop stays as it was
-    const int k_end = CHAIN ? min((seg + 1) * chain, S) : (int)(((long)S * (seg + 1)) / split);
-    int k = CHAIN ? seg * chain : (int)(((long)S * seg) / split);
+    // the chained form is its own instantiation: the plain sample loop stays as it was
+    const int k_end = CHAIN ? min(k0->k_end, S) : (int)(((long)S * (seg + 1)) / split);
+    int k = CHAIN ? k0->k_begin : (int)(((long)S * seg) / split);
     const int k_begin = k;
     if (CHAIN && k > 0) {       // resume: what the previous segment of this ray left behind (the 16 floats of a split segment)
         const f32x4* p = reinterpret_cast<const f32x4*>(k0->part + (size_t)slot * 16);
@@ -1285,24 +1334,26 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         // z_vals is a function of (near, far, k): segment 0 writes every row completely
         if (out.z_vals && seg == 0)
             write_z_vals(out.z_vals, lane, (int)ray, near, far, (int)min((long)RAYS, n_items - ray0), S, step, 0, S, P);
-        // a ray goes on in the next launch unless it has walked all S samples or is opaque; the survivors of the wavefront
-        // take consecutive places in list_out (one atomic per wavefront) and park their 16 floats of state
+        // a ray goes on in the next launch unless it has walked all S samples or is opaque.  Every ray of the launch writes its
+        // launch slot (or -1) at ITS OWN position of the sparse list, and the wavefront adds its survivors to the counter of the
+        // LIST_CHUNK entries it belongs to; compact_list_kernel then closes the gaps IN ORDER.  (Round 2 appended the survivors
+        // to a dense list with one atomic per wavefront: the next launch then walked the rays in the order their wavefronts had
+        // happened to finish, neighbouring wavefronts rendered unrelated patches of the image, and the re-packed levels read
+        // 2-4x the bytes of level 0 with a quarter of its rays -- L2 hit rate 75-85 % against 96 %.)
         const bool goes_on = writer && k_end < S && !(T < term_eps);
-        const unsigned long long alive = __ballot(goes_on);
-        if (alive) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(kp->count_out, (unsigned)__popcll(alive));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (goes_on) {
-                kp->list_out[base + __popcll(alive & ((1ull << lane) - 1ull))] = (int)slot;
-                f32x4* p = reinterpret_cast<f32x4*>(part + (size_t)slot * 16);
-                f32x4 a, b, c, d;
-                a[0] = c_r; a[1] = c_g; a[2] = c_b; a[3] = depth;
-                b[0] = acc; b[1] = T; b[2] = (float)(n_two + 4096 * n_done); b[3] = rin[0];
-                c[0] = rin[1]; c[1] = rin[2]; c[2] = rin[3]; c[3] = rin[4];
-                d[0] = rin[5]; d[1] = rin[6]; d[2] = rin[7]; d[3] = rin[8];
-                p[0] = a; p[1] = b; p[2] = c; p[3] = d;
-            }
+        if (kp->list_out) {
+            if (writer) kp->list_out[ray0 + rn] = goes_on ? (int)slot : -1;
+            const unsigned long long alive = __ballot(goes_on);
+            if (alive && lane == 0) atomicAdd(kp->chunk_cnt + (ray0 >> LIST_CHUNK_SHIFT), (unsigned)__popcll(alive));
+        }
+        if (goes_on) {
+            f32x4* p = reinterpret_cast<f32x4*>(part + (size_t)slot * 16);
+            f32x4 a, b, c, d;
+            a[0] = c_r; a[1] = c_g; a[2] = c_b; a[3] = depth;
+            b[0] = acc; b[1] = T; b[2] = (float)(n_two + 4096 * n_done); b[3] = rin[0];
+            c[0] = rin[1]; c[1] = rin[2]; c[2] = rin[3]; c[3] = rin[4];
+            d[0] = rin[5]; d[1] = rin[6]; d[2] = rin[7]; d[3] = rin[8];
+            p[0] = a; p[1] = b; p[2] = c; p[3] = d;
         }
         if (goes_on || !writer) return false;
     } else {
@@ -2104,8 +2155,29 @@ int chain_len(int S) {
     const int least = (S + CHAIN_MAX_SEGS - 1) / CHAIN_MAX_SEGS;
     return f_seg > least ? f_seg : least;
 }
-int chain_segs(int S) { const int len = chain_len(S); return (S + len - 1) / len; }
-size_t chain_ctrl_bytes(int n_seg) { return align256((size_t)n_seg * 9 * sizeof(unsigned)); }
+int chain_segs(int S) { const int len = chain_len(S); return (S + len - 1) / len; }      // upper bound (workspace sizing)
+// The launches' sample ranges.  Default: equal segments of chain_len().  GPNERF_CHAIN_MERGE_AFTER=k (experiment knob, under
+// GPNERF_DEBUG=1): from sample k on every segment is as long as all the samples before it ([0,16) .. [48,64), [64,128), ...).
+// Measured on the 512x512x128 bench frame, where 5 % of the rays are alive after 64 samples: 8.82 ms with equal segments,
+// 8.89 ms with the four tail launches merged into one -- the tail levels already run several samples of a ray per step
+// (chain_plan's P), so their launches cost little, and inside a long segment an opaque ray idles to the segment's end.
+// begins[] gets n + 1 entries; returns n <= chain_segs(S).
+int chain_schedule(int S, int* begins) {
+    static int f_merge = -1;
+    if (f_merge < 0) f_merge = dbg_int("GPNERF_CHAIN_MERGE_AFTER", 0, 0, 1 << 20);       // 0 (default): equal segments throughout
+    const int len = chain_len(S);
+    int n = 0, k = 0, cur = len;
+    while (k < S) {
+        begins[n++] = k;
+        if (f_merge > 0 && k >= f_merge) { cur = k; }                 // from here on every segment is as long as all before it
+        k += cur;
+    }
+    begins[n] = S;
+    return n;
+}
+size_t chain_chunks(int64_t n_rays) { return (size_t)((n_rays + 2047) / 2048); }       // LIST_CHUNK entries each
+// control block: per segment 8 queue counters, the length of its output list, and one survivor counter per LIST_CHUNK input entries
+size_t chain_ctrl_bytes(int n_seg, int64_t n_rays) { return align256((size_t)n_seg * (9 + chain_chunks(n_rays)) * sizeof(unsigned)); }
 // range guard of the split form: header (flag count, the fix-up launch's queue counters) + one word per tile, at the workspace's end
 size_t guard_bytes(int64_t n_rays) {
     return align256((GUARD_HEADER_WORDS + (size_t)((n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE)) * sizeof(unsigned));
@@ -2117,7 +2189,7 @@ size_t cull_mask_bytes(int64_t n_rays) {
 }
 size_t chain_bytes(int64_t n_rays, int S) {
     if (chain_segs(S) < 2 || n_rays >= ((int64_t)1 << 31)) return 0;
-    return chain_ctrl_bytes(chain_segs(S)) + 2 * align256((size_t)n_rays * sizeof(int)) + (size_t)n_rays * 16 * sizeof(float);
+    return chain_ctrl_bytes(chain_segs(S), n_rays) + 3 * align256((size_t)n_rays * sizeof(int)) + (size_t)n_rays * 16 * sizeof(float);
 }
 struct Geometry { int waves, split; };
 
@@ -2542,25 +2614,32 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (need_chain && workspace && workspace_bytes >= need_chain) {
         const int n_seg = chain_segs(n_samples);
         char* const base = static_cast<char*>(workspace);
-        unsigned* const ctrl = reinterpret_cast<unsigned*>(base);                      // [n_seg][8] queue counters, then [n_seg] list lengths
-        const size_t list_bytes = align256((size_t)n_rays * sizeof(int));
-        int* const lists[2] = {reinterpret_cast<int*>(base + chain_ctrl_bytes(n_seg)), reinterpret_cast<int*>(base + chain_ctrl_bytes(n_seg) + list_bytes)};
-        if (!zero_async(base, chain_ctrl_bytes(n_seg), stream)) return GPNERF_E_LAUNCH;
+        unsigned* const ctrl = reinterpret_cast<unsigned*>(base);      // [n_seg][8] queue counters, [n_seg] list lengths, [n_seg][chunks] survivor counters
+        const size_t list_bytes = align256((size_t)n_rays * sizeof(int)), ctrl_bytes = chain_ctrl_bytes(n_seg, n_rays);
+        const size_t n_chunks = chain_chunks(n_rays);
+        int* const lists[2] = {reinterpret_cast<int*>(base + ctrl_bytes), reinterpret_cast<int*>(base + ctrl_bytes + list_bytes)};
+        int* const sparse = reinterpret_cast<int*>(base + ctrl_bytes + 2 * list_bytes);
+        if (!zero_async(base, ctrl_bytes, stream)) return GPNERF_E_LAUNCH;
         ka.split = 1; ka.dynamic = 1; ka.chain = chain_len(n_samples);
-        ka.part = reinterpret_cast<float*>(base + chain_ctrl_bytes(n_seg) + 2 * list_bytes);
+        ka.part = reinterpret_cast<float*>(base + ctrl_bytes + 3 * list_bytes);
         const int64_t wg = (tiles + GPNERF_MAX_WAVES - 1) / GPNERF_MAX_WAVES;
         const unsigned grid = (unsigned)(wg < n_cus ? wg : n_cus);
         static float f_fill = -1.f;
         if (f_fill < 0.f) { const char* e = dbg_env("GPNERF_CHAIN_PFILL"); f_fill = e ? fminf(fmaxf((float)atof(e), 0.f), 8.f) : 1.f; }
         ka.p_cap = (long)((double)grid * GPNERF_MAX_WAVES * RAYS_PER_WAVE * f_fill);
         ka.first_slot = 0; ka.first_items = (long)n_rays;
-        for (int sg = 0; sg < n_seg; ++sg) {
+        int begins[CHAIN_MAX_SEGS + 2];
+        const int n_launch = chain_schedule((int)n_samples, begins);
+        for (int sg = 0; sg < n_launch; ++sg) {
             ka.seg = sg;
+            ka.k_begin = begins[sg]; ka.k_end = begins[sg + 1];
             ka.queue = ctrl + 8 * sg;
             ka.list_in = sg ? lists[(sg - 1) & 1] : nullptr;
             ka.count_in = sg ? ctrl + 8 * n_seg + (sg - 1) : nullptr;
-            ka.list_out = lists[sg & 1];
+            const bool last = sg + 1 == n_launch;
+            ka.list_out = last ? nullptr : sparse;
             ka.count_out = ctrl + 8 * n_seg + sg;
+            ka.chunk_cnt = ctrl + 9 * n_seg + (size_t)sg * n_chunks;
             if (guard)
                 hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3(grid), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
             else if (split16)
@@ -2569,6 +2648,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
                 hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
             else
                 hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
+            if (!last)     // close the gaps of the sparse list, in order: the next launch's dense input
+                hipLaunchKernelGGL(compact_list_kernel, dim3((unsigned)n_chunks), dim3(256), 0, S_(stream), (const int*)sparse,
+                                   (const unsigned*)ka.chunk_cnt, (const unsigned*)ka.count_in, ka.first_items, lists[sg & 1], ka.count_out);
             if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         }
         return fixup();
@@ -2618,10 +2700,11 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         kr.n_rays = (long)n_rays;
         kr.queue = static_cast<unsigned*>(workspace) + 8;             // the second set of queue counters of the QUEUE_BYTES block
         kr.chain = (int)n_samples; kr.seg = 0; kr.term_eps = 0.f;
+        kr.k_begin = 0; kr.k_end = (int)n_samples;
         kr.first_slot = ka.n_rays; kr.first_items = (long)n_rays - ka.n_rays;
         kr.list_in = nullptr; kr.count_in = nullptr;
-        kr.list_out = reinterpret_cast<int*>(static_cast<unsigned*>(workspace) + 32);        // never written: nothing goes on after segment 0 of 1
-        kr.count_out = static_cast<unsigned*>(workspace) + 16;
+        kr.list_out = nullptr;                                        // nothing goes on after segment 0 of 1
+        kr.count_out = nullptr; kr.chunk_cnt = nullptr;
         kr.part = nullptr;
         kr.p_cap = (long)(slots * RAYS_PER_WAVE);
         if (guard)
