@@ -279,8 +279,14 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
     for (int v = 0; v < NV; ++v) {
         // the three views share these weights; keep the compiler from holding ~100 VGPRs of them across views
         asm volatile("" : "+v"(lane));
+#ifdef GPNERF_X_VIEWFOLD_SKIP      // proxy (wrong results): what the matrix pipe would save if base_fc.0's per-view columns were folded
+        const float x4[4] = {x[v][16], x[v][17], x[v][0], x[v][1]};
+        f32x16 a0 = mfma_tile_from<4>(wtile<gpl::BV>(lds, 0), lane, x4, s0);
+        f32x16 a1 = mfma_tile_from<4>(wtile<gpl::BV>(lds, 1), lane, x4, s1);
+#else
         f32x16 a0 = mfma_tile_from<18>(wtile<gpl::BV>(lds, 0), lane, x[v], s0);
         f32x16 a1 = mfma_tile_from<18>(wtile<gpl::BV>(lds, 1), lane, x[v], s1);
+#endif
         float h1[32];
         elus_n<16>(a0, h1);
         elus_n<16>(a1, h1 + 16);
@@ -734,7 +740,7 @@ struct ViewSample {
 template <bool BATCH = false, class MP>
 DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
                            const float* __restrict__ fm, int fh, int fw, float px, float py, float pz, bool neg,
-                           int half, float* f) {
+                           int half, float* f, const float* __restrict__ ftab = nullptr) {
     const float hx = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3];
     const float hy = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7];
     const float hz = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11];
@@ -787,6 +793,28 @@ DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef GPNERF_X_VIEWFOLD_GATHER    // proxy (results unchanged): what the folded table's taps would cost -- 64 values per texel, 32 per lane, 2 taps in flight
+        if (ftab) {
+            f32x16 g0, g1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+#pragma unroll
+            for (int t0 = 0; t0 < 4; t0 += 2) {
+                f32x4 q2[2][8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4* p = reinterpret_cast<const f32x4*>(at_byte(ftab, fo[t0 + t] * 2u));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q2[t][i] = p[i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fma32(q2[t], fwt[t0 + t], g0, g1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("" ::"v"(g0), "v"(g1));
+        }
+#endif
     } else {
         {   // RGB from the full-resolution image
             const Axis ax = axis_taps(nx, iw), ay = axis_taps(ny, ih);
@@ -1223,7 +1251,11 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         for (int v = 0; v < NV; ++v) {
             const ViewSample s = gather_view<FORM == FORM_F32_FOLD || FORM == FORM_F32>(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
                                              fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
-                                             px, py, pz, neg, half, x[v]);
+                                             px, py, pz, neg, half, x[v]
+#ifdef GPNERF_X_VIEWFOLD_GATHER
+                                             , fr.vol_fold[0] ? fr.vol_fold[0] + (size_t)v * fr.feat_h * fr.feat_w * 64 : nullptr
+#endif
+                                             );
             x[v][16] = half ? s.rgb[1] : s.rgb[0];
             x[v][17] = half ? 0.f : s.rgb[2];
             vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];

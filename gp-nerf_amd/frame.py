@@ -4,6 +4,7 @@ torch is used for device memory and streams only; all arithmetic of the path run
 the HIP library (include/gpnerf_hip.h).  Nothing here falls back to PyTorch ops.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -345,6 +346,10 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
             frame.fold_volumes()
         for l in range(L.FOLD_FIRST_LEVEL, L.LEVELS):
             frame.c.vol_folded[l] = frame.vols_folded[l].data_ptr()
+        if L._DEBUG and os.environ.get("GPNERF_X_VIEWTAB") == "1":       # tools/probes/view_fold_proxy.sh: a [V][h][w][64] table for the diagnostic builds
+            if getattr(frame, "_viewtab", None) is None:
+                frame._viewtab = torch.randn((L.VIEWS, frame.c.feat_h, frame.c.feat_w, 64), device=rays.device)
+            frame.c.vol_folded[0] = frame._viewtab.data_ptr()
     else:
         for l in range(L.LEVELS):
             frame.c.vol_folded[l] = None
