@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/gpnerf_hip.h"
 
@@ -148,10 +149,18 @@ DEV void finalize_if_last(const ConvArgs& a, const int n, const int ct0, const i
     const int ch = threadIdx.x % NCH, kl = threadIdx.x / NCH, co = 32 * ct0 + ch;
     double ts = 0, tq = 0;
     if (co < a.Cout)
-        for (int k = kl; k < ntiles; k += LANES) {
-            const float* o = a.stats + (((size_t)n * ntiles + k) * a.Cout + co) * 2;
-            ts += (double)__hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tq += (double)__hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k0 = kl; k0 < ntiles; k0 += 8 * LANES) {     // eight tiles' loads in flight, added in tile order
+            float vs[8], vq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j * LANES;
+                const float* o = a.stats + (((size_t)n * ntiles + (k < ntiles ? k : kl)) * a.Cout + co) * 2;
+                vs[j] = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vq[j] = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j * LANES < ntiles) { ts += (double)vs[j]; tq += (double)vq[j]; }
         }
     red[threadIdx.x] = ts;
     red[256 + threadIdx.x] = tq;
@@ -385,10 +394,8 @@ constexpr int PATCH_BYTES = PH * PW * PPX;                  // 27 200
 template <int COT>
 __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WBYTES = 9 * COT * STEP_BYTES;
     unsigned char* const patch0 = smem;                     // [2][PATCH_BYTES]
-    unsigned char* const wts0 = smem + 2 * PATCH_BYTES;     // [2][WBYTES]
-    float* const itab = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 2 * WBYTES);      // [3][Cin] when a.in_tab
+    float* const itab = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);      // [3][Cin] when a.in_tab
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
     const int tiles_x = (a.Wo + TW - 1) / TW;
     const int ty0 = ((int)blockIdx.x / tiles_x) * TH, tx0 = ((int)blockIdx.x % tiles_x) * TW;
@@ -402,15 +409,34 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
 
-    // staging work of one thread per channel block: patch items (pixel, 4-channel quad) and 16-byte weight pieces.
-    // (A second register set, so that the loads of blocks cb + 1 AND cb + 2 are in flight, was built and measured: no gain,
-    // 1.33 -> 1.37 ms per frame.  The loop's ~2.3 us per block against 0.7 us of MFMAs is not a global round trip: with COT = 1
-    // a tap costs 6 ds_read_b128 for 6 MFMAs, and four waves x 8 LDS cycles per read fill the 32 cycles an MFMA gives them.)
+    // The A operand (weights) goes from global memory (the layer's packed image: <= 2.4 MB, L2-resident, every workgroup reads
+    // the same bytes) straight into registers: a lane's hi and lo quads of every (tap, output tile) of one 16-channel block,
+    // 9 x COT x 2 x 4 registers.  A tap's registers are re-loaded with the NEXT block's weights right after the tap's MFMAs
+    // have been issued, so every load has eight taps of matrix work (~a block) to arrive.  (Round 2 staged the weights through
+    // LDS like the patch: with COT = 1 a tap then cost 6 ds_read_b128 for 6 MFMAs, and four waves x 8 LDS cycles per read fill
+    // the 32 cycles an MFMA gives them -- the loop ran at 2.3 us per block against 0.7 us of MFMAs.  Now LDS carries the
+    // B operand only: 4 reads per tap.)
+    u32x4 wreg[9][COT][2];
+    auto wload = [&](int tap, int cb) {
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+            const u32x4* wl = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.packed) +
+                                                             (((size_t)tap * a.CB + cb) * a.CT + ct0 + c) * STEP_BYTES);
+            wreg[tap][c][0] = wl[lane];
+            wreg[tap][c][1] = wl[64 + lane];
+        }
+    };
+    // staging work of one thread per channel block: PPASS patch items (pixel, 4-channel quad).  TWO register sets: while block
+    // cb is in its MFMAs, block cb + 1's values sit in one set (loaded a block ago) and are converted and written to LDS ONE ITEM
+    // AFTER EACH TAP's MFMAs -- the ~25 vector instructions of an item run in the shadow of the tap's 6 x COT matrix
+    // instructions (the f16 MFMA leaves the issue port free) -- while block cb + 2's loads fill the other set.  (Measured per
+    // 256-channel 32x32 convolution, graph-timed: 30.7 us with the whole conversion behind the MFMAs, of which 15.1 us matrix work
+    // + LDS reads, 7.6 us conversion + LDS writes, 1.4 us issuing loads, 1.7 us barriers; tools/probes/conv_layer_time.py.)
     constexpr int PITEMS = PH * PW * 4, PPASS = (PITEMS + WAVES * 64 - 1) / (WAVES * 64);
-    constexpr int WPIECES = 9 * COT * (STEP_BYTES / 16), WPASS = (WPIECES + WAVES * 64 - 1) / (WAVES * 64);
-    f32x4 preg[PPASS];
-    u32x4 wreg[WPASS];
-    auto fetch = [&](int cb) {
+    static_assert(PPASS <= 9, "one patch item per tap");
+    f32x4 preg[2][PPASS];
+    auto fetch = [&](int cb, auto SET) {
+        constexpr int S = decltype(SET)::value;
 #pragma unroll
         for (int s = 0; s < PPASS; ++s) {
             const int item = s * (WAVES * 64) + (int)threadIdx.x;
@@ -419,58 +445,41 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
                 const int iy = reflect(ty0 + pp / PW - 1, a.H), ix = reflect(tx0 + pp % PW - 1, a.W);
                 // tiles may hang far over the image, where the reflection itself leaves it: clamp (those outputs are never written)
                 const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-                preg[s] = *reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + cy) * a.W + cx) * a.Cin + 16 * cb + 4 * qd);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < WPASS; ++s) {
-            const int piece = s * (WAVES * 64) + (int)threadIdx.x;
-            if (piece < WPIECES) {
-                const int tap = piece / (COT * (STEP_BYTES / 16)), rest = piece % (COT * (STEP_BYTES / 16));
-                wreg[s] = *(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.packed) +
-                                                               (((size_t)tap * a.CB + cb) * a.CT + ct0) * STEP_BYTES) + rest);
+                preg[S][s] = *reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + cy) * a.W + cx) * a.Cin + 16 * cb + 4 * qd);
             }
         }
     };
-    auto park = [&](int buf, int pcb) {
+    // item s of block pcb: normalise (optional), scale, split into hi / lo, write to patch buffer `buf`
+    auto park_item = [&](int s, int buf, int pcb, auto SET) {
+        constexpr int S = decltype(SET)::value;
         unsigned char* const pb = patch0 + buf * PATCH_BYTES;
+        const int item = s * (WAVES * 64) + (int)threadIdx.x;
+        if (item < PITEMS) {
+            const int pp = item >> 2, qd = item & 3;
+            f32x4 v = preg[S][s];
+            if (a.in_tab) {                                  // the InstanceNorm (+ ReLU) in front of this convolution, as nhwc_norm_apply_kernel computes it
+                const int c0 = 16 * pcb + 4 * qd;
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(itab + c0), sc = *reinterpret_cast<const f32x4*>(itab + a.Cin + c0),
+                            be = *reinterpret_cast<const f32x4*>(itab + 2 * a.Cin + c0);
 #pragma unroll
-        for (int s = 0; s < PPASS; ++s) {
-            const int item = s * (WAVES * 64) + (int)threadIdx.x;
-            if (item < PITEMS) {
-                const int pp = item >> 2, qd = item & 3;
-                f32x4 v = preg[s];
-                if (a.in_tab) {                              // the InstanceNorm (+ ReLU) in front of this convolution, as nhwc_norm_apply_kernel computes it
-                    const int c0 = 16 * pcb + 4 * qd;
-                    const f32x4 mu = *reinterpret_cast<const f32x4*>(itab + c0), sc = *reinterpret_cast<const f32x4*>(itab + a.Cin + c0),
-                                be = *reinterpret_cast<const f32x4*>(itab + 2 * a.Cin + c0);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float t = fmaf(v[k] - mu[k], sc[k], be[k]);
-                        v[k] = a.in_act == 1 ? fmaxf(t, 0.f) : t;
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    float t = fmaf(v[k] - mu[k], sc[k], be[k]);
+                    v[k] = a.in_act == 1 ? fmaxf(t, 0.f) : t;
                 }
-                v *= X_SCALE;
-                const unsigned h0 = pk_hi(v[0], v[1]), h1 = pk_hi(v[2], v[3]);
-                unsigned* d = reinterpret_cast<unsigned*>(pb + pp * PPX + qd * 8);
-                d[0] = h0; d[1] = h1;
-                d[8] = lo_pair(h0, v[0], v[1]); d[9] = lo_pair(h1, v[2], v[3]);       // lo block starts 32 bytes in
             }
-        }
-        u32x4* const wb = reinterpret_cast<u32x4*>(wts0 + buf * WBYTES);
-#pragma unroll
-        for (int s = 0; s < WPASS; ++s) {
-            const int piece = s * (WAVES * 64) + (int)threadIdx.x;
-            if (piece < WPIECES) wb[piece] = wreg[s];
+            v *= X_SCALE;
+            const unsigned h0 = pk_hi(v[0], v[1]), h1 = pk_hi(v[2], v[3]);
+            unsigned* d = reinterpret_cast<unsigned*>(pb + pp * PPX + qd * 8);
+            d[0] = h0; d[1] = h1;
+            d[8] = lo_pair(h0, v[0], v[1]); d[9] = lo_pair(h1, v[2], v[3]);           // lo block starts 32 bytes in
         }
     };
-    // the 54 x COT MFMAs of one staged block: operands of tap 0, then per tap: read the next tap's operands, run this tap's
-    // MFMAs -- the three products of one accumulator are issued COT * PT MFMAs apart (back-to-back they would wait on each other)
-    auto compute = [&](int buf) {
+    // the 54 x COT MFMAs of the block staged in `buf`: B operands of tap 0, then per tap: read the next tap's B operands, run this
+    // tap's MFMAs (the three products of one accumulator are issued COT * PT MFMAs apart: back-to-back they would wait on each
+    // other), fetch this tap's weights of block cb_next into the registers just used, and park one item of block cb_next
+    auto compute = [&](int buf, int cb_next, auto SET) {
         const unsigned char* const pb = patch0 + buf * PATCH_BYTES;
-        const unsigned char* const wb = wts0 + buf * WBYTES;
         Frag b[2][PT];
-        h8 wh[2][COT], wlo[2][COT];
         auto read_tap = [&](int tap, int slot) {
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
@@ -479,50 +488,60 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
                 b[slot][t].hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q));
                 b[slot][t].lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q + 32));
             }
-#pragma unroll
-            for (int c = 0; c < COT; ++c) {
-                const u32x4* wl = reinterpret_cast<const u32x4*>(wb + (tap * COT + c) * STEP_BYTES);
-                wh[slot][c] = __builtin_bit_cast(h8, wl[lane]);
-                wlo[slot][c] = __builtin_bit_cast(h8, wl[64 + lane]);
-            }
         };
         read_tap(0, 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int cur = tap & 1;
             if (tap + 1 < 9) read_tap(tap + 1, cur ^ 1);
+            h8 wh[COT], wlo[COT];
+#pragma unroll
+            for (int c = 0; c < COT; ++c) { wh[c] = __builtin_bit_cast(h8, wreg[tap][c][0]); wlo[c] = __builtin_bit_cast(h8, wreg[tap][c][1]); }
 #ifdef GPNERF_X_LOLO
 #pragma unroll
             for (int c = 0; c < COT; ++c)
 #pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[cur][c], b[cur][t].lo, acc[t][c], 0, 0, 0);
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[c], b[cur][t].lo, acc[t][c], 0, 0, 0);
 #endif
 #pragma unroll
             for (int c = 0; c < COT; ++c)
 #pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[cur][c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[c], b[cur][t].hi, acc[t][c], 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < COT; ++c)
 #pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cur][c], b[cur][t].lo, acc[t][c], 0, 0, 0);
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], b[cur][t].lo, acc[t][c], 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < COT; ++c)
 #pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cur][c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+            if (cb_next >= 0) {
+                wload(tap, cb_next);
+                if (tap < PPASS) park_item(tap, buf ^ 1, cb_next, SET);
+            }
         }
     };
-    fetch(0);
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    fetch(0, S0);
+    if (a.CB > 1) fetch(1, S1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wload(tap, 0);
     if (a.in_tab) {
         for (int i = threadIdx.x; i < 3 * a.Cin; i += WAVES * 64) itab[i] = a.in_tab[(size_t)n * 3 * a.Cin + i];
         __syncthreads();
     }
-    park(0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < PPASS; ++s2) park_item(s2, 0, 0, S0);
     __syncthreads();
-    for (int cb = 0; cb < a.CB; ++cb) {
-        const int buf = cb & 1;
-        if (cb + 1 < a.CB) fetch(cb + 1);                   // the next block's loads fly under this block's 54 x COT MFMAs
-        compute(buf);
-        if (cb + 1 < a.CB) park(buf ^ 1, cb + 1);
+    for (int cb = 0; cb < a.CB; cb += 2) {
+        // even block: staged in buffer 0; set 1 holds block cb + 1 (in flight since the block before); set 0 is free for block cb + 2
+        if (cb + 2 < a.CB) fetch(cb + 2, S0);
+        compute(0, cb + 1 < a.CB ? cb + 1 : -1, S1);
+        __syncthreads();
+        if (cb + 1 >= a.CB) break;
+        if (cb + 3 < a.CB) fetch(cb + 3, S1);
+        compute(1, cb + 2 < a.CB ? cb + 2 : -1, S0);
         __syncthreads();
     }
     const int ox = tx0 + px;
@@ -719,7 +738,9 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     }
     int cot = (a.CT % 2 == 0) ? 2 : 1;
     if (f_cot == 1 || (f_cot == 0 && cot == 2 && (long)tiles * N * (a.CT / 2) < 192)) cot = 1;
-    const size_t lds = 2 * (size_t)PATCH_BYTES + 2 * (size_t)9 * cot * STEP_BYTES + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
+    // two patch buffers (+ the input norm's table); never less than what the epilogue's reductions use (tile sums, finalize)
+    size_t lds = 2 * (size_t)PATCH_BYTES + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
+    if (lds < 16384) lds = 16384;
     const void* fn = cot == 2 ? reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<2>) : reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<1>);
     // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
