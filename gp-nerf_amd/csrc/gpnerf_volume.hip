@@ -70,58 +70,62 @@ __global__ void __launch_bounds__(256) conv_kernel(const float* __restrict__ in,
 // (lane = site + 32*half), 27 * cin/2 MFMAs per tile.  The VALU form above walks cin*27 dependent FMAs per site.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x16v __attribute__((ext_vector_type(16)));
+// One workgroup of four wavefronts per tile of 32 output sites; the 27 taps are dealt out over the wavefronts (wave w takes taps
+// w, w + 4, ...: 7, 7, 7, 6 of them), each accumulates its own 32 x 32 tile, and the four partial tiles meet in LDS and are added
+// in wave order (deterministic).  With one wavefront per tile (round 2) a convolution was ONE chain of 27 x cin / 2 dependent fp32
+// MFMAs on a single accumulator -- 432 x 64 cycles = 11.5 us of pure matrix latency for ~200 wavefronts on a 1 024-SIMD chip,
+// 29 us per launch measured, 14 launches per frame.
 template <bool STRIDED>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict__ in, const int cin, const int32_t* __restrict__ in_grid,
                                                         const Dims in_dims, const int32_t* __restrict__ out_coords,
                                                         const int* __restrict__ m_ptr, const int m_cap, const float* __restrict__ Wp,
                                                         const int cout, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63, s = lane & 31, half = lane >> 5;
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, s = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
     const int m = m_ptr ? min(*m_ptr, m_cap) : m_cap;
-    const int site = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + s;
-    if (site - s >= m) return;                                  // whole tile past the end (wave-uniform)
+    const int site = (int)blockIdx.x * 32 + s;
+    if (site - s >= m) return;                                  // whole tile past the end (uniform over the workgroup)
     const bool valid = site < m;
     const int od = valid ? out_coords[3 * site] : 0, oh = valid ? out_coords[3 * site + 1] : 0, ow = valid ? out_coords[3 * site + 2] : 0;
     const int half_c = cin >> 1, ng = cin >> 3;
     f32x16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // all 27 neighbour rows first (independent loads, one round trip), then the taps with the next tap's channels in
-    // flight while this tap's MFMAs run
-    int nbr[KV];
+    constexpr int TAPS = (KV + 3) / 4;                          // taps per wavefront (the last wavefront has one fewer)
+    // this wavefront's neighbour rows first (independent loads, one round trip), then its taps, weights and rows prefetched
+    int nbr[TAPS];
 #pragma unroll
-    for (int k = 0; k < KV; ++k) {
+    for (int j = 0; j < TAPS; ++j) {
+        const int k = wave + 4 * j;
         const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
         const int d = (STRIDED ? 2 * od : od) - 1 + kd, h = (STRIDED ? 2 * oh : oh) - 1 + kh, w = (STRIDED ? 2 * ow : ow) - 1 + kw;
-        const bool inb = valid && d >= 0 && d < in_dims.d && h >= 0 && h < in_dims.h && w >= 0 && w < in_dims.w;
-        nbr[k] = inb ? in_grid[cell_of(in_dims, d, h, w)] : -1;
+        const bool inb = valid && k < KV && d >= 0 && d < in_dims.d && h >= 0 && h < in_dims.h && w >= 0 && w < in_dims.w;
+        nbr[j] = inb ? in_grid[cell_of(in_dims, d, h, w)] : -1;
     }
     const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_tap = [&](int k, f32x4v (&b)[4]) {
-        const int j = nbr[k];
-        const float* x = in + (size_t)(j < 0 ? 0 : j) * cin + half * half_c;
+    auto load_tap = [&](int j, f32x4v (&b)[4]) {
+        const int jj = nbr[j];
+        const float* x = in + (size_t)(jj < 0 ? 0 : jj) * cin + half * half_c;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b[g] = (g < ng && j >= 0) ? *reinterpret_cast<const f32x4v*>(x + 4 * g) : zero4;
+        for (int g = 0; g < 4; ++g) b[g] = (g < ng && jj >= 0) ? *reinterpret_cast<const f32x4v*>(x + 4 * g) : zero4;
     };
-    // The neighbour rows and the packed weights come from L2 (a round trip each) and a tap's 4 * ng MFMAs take ~0.4 us: with the
-    // weights loaded right before their MFMAs and only the next tap's rows in flight the wave spent its time waiting (46 us per
-    // launch); DEPTH taps ahead, weights included, it does not.  The MFMA chain
-    // is branch-free (absent neighbours contribute zeros): once the weights are prefetched the kernel is not bound by the MFMAs
-    // it could skip, and a never-taken branch inside an MFMA chain is what once broke the fused kernel.
-    constexpr int DEPTH = 4;
-    f32x4v buf[DEPTH][4], wbuf[DEPTH][4];                       // a tap's neighbour channels and its packed weights (L2-resident)
-    auto load_w = [&](int k, f32x4v (&a)[4]) {
+    // The MFMA chain is branch-free (absent neighbours and the fourth wavefront's missing tap contribute zeros).
+    auto load_w = [&](int j, f32x4v (&a)[4]) {
+        const int k = min(wave + 4 * j, KV - 1);
         const float* wk = Wp + ((size_t)k * ng * 64 + lane) * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) a[g] = g < ng ? *reinterpret_cast<const f32x4v*>(wk + (size_t)g * 256) : zero4;
     };
+    constexpr int DEPTH = 4;
+    f32x4v buf[DEPTH][4], wbuf[DEPTH][4];                       // a tap's neighbour channels and its packed weights (L2-resident)
 #pragma unroll
-    for (int k = 0; k < DEPTH - 1; ++k) { load_tap(k, buf[k]); load_w(k, wbuf[k]); }
+    for (int j = 0; j < DEPTH - 1; ++j) { load_tap(j, buf[j]); load_w(j, wbuf[j]); }
 #pragma unroll
-    for (int k = 0; k < KV; ++k) {
-        if (k + DEPTH - 1 < KV) { load_tap(k + DEPTH - 1, buf[(k + DEPTH - 1) % DEPTH]); load_w(k + DEPTH - 1, wbuf[(k + DEPTH - 1) % DEPTH]); }
-        const f32x4v(&cur)[4] = buf[k % DEPTH];
-        const f32x4v(&wa)[4] = wbuf[k % DEPTH];
+    for (int j = 0; j < TAPS; ++j) {
+        if (j + DEPTH - 1 < TAPS) { load_tap(j + DEPTH - 1, buf[(j + DEPTH - 1) % DEPTH]); load_w(j + DEPTH - 1, wbuf[(j + DEPTH - 1) % DEPTH]); }
+        const f32x4v(&cur)[4] = buf[j % DEPTH];
+        const f32x4v(&wa)[4] = wbuf[j % DEPTH];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g < ng) {
@@ -132,11 +136,17 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict_
             }
         }
     }
-    if (!valid) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (!valid) return;
+    // wavefront w finishes accumulator registers 4 w .. 4 w + 3: the four partial tiles added in wave order
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * wave + i;
+        const float v = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
         const int co = (r & 3) + 8 * (r >> 2) + 4 * half;       // 32x32 accumulator: row of register r in lane half `half`
-        if (co < cout) out[(size_t)site * cout + co] = fmaxf(fmaf(acc[r], scale[co], shift[co]), 0.f);
+        if (co < cout) out[(size_t)site * cout + co] = fmaxf(fmaf(v, scale[co], shift[co]), 0.f);
     }
 }
 
@@ -424,7 +434,7 @@ int gpnerf_sparse_conv3_mfma(int32_t strided, const float* in, int32_t cin, cons
     if (cin < 8 || cin > 32 || cin % 8 || cout < 1 || cout > 32 || m_cap < 0) return GPNERF_E_ARG;
     if (m_cap == 0) return GPNERF_OK;
     const Dims s{in_dims[0], in_dims[1], in_dims[2]};
-    const dim3 grid((unsigned)((m_cap + 127) / 128)), block(256);
+    const dim3 grid((unsigned)((m_cap + 31) / 32)), block(256);         // one workgroup (4 wavefronts, taps dealt out) per 32 sites
     if (strided)
         hipLaunchKernelGGL(conv_mfma_kernel<true>, grid, block, 0, S_(stream), in, (int)cin, in_grid, s, out_coords, (const int*)m_dev,
                            (int)m_cap, packed_weight, (int)cout, bn_scale, bn_shift, out);
