@@ -2582,7 +2582,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     Geometry g = choose_geometry(tiles, n_samples, may_split, seg_bytes, n_rays, n_cus);
     // whole rounds of full workgroups + a remainder launch (below) when the frame is that shape
     static int f_rem = -1;
-    if (f_rem < 0) f_rem = dbg_int("GPNERF_REMAINDER", 1, 0, 1);
+    if (f_rem < 0) f_rem = dbg_int("GPNERF_REMAINDER", 2, 0, 2);     // 1: two launches (whole rounds, then the remainder); 2: one launch (below)
     const int64_t slots = (int64_t)n_cus * GPNERF_MAX_WAVES;
     const int64_t rem_tiles = tiles % slots;
     const bool remainder = f_rem && workspace && workspace_bytes >= QUEUE_BYTES && !(flags & (GPNERF_FLAG_EARLY_TERM | GPNERF_FLAG_OCC_CULL)) &&
@@ -2635,6 +2635,29 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     static int f_tail = -1;
     if (f_tail < 0) f_tail = dbg_int("GPNERF_CHAIN_TAILP", 4, 1, 8);
     ka.tail_p = f_tail;
+    // ONE launch for a frame of whole rounds + a few tiles: the segmented form's kernel over all S samples as a single segment
+    // (term_eps = 0: nothing is ever frozen), whose work units are the whole rounds' 32-ray tiles at one sample per step AND the
+    // remaining tiles at eight samples of a ray per step (chain_plan), all on one tile queue.  In a lone round a SIMD's older
+    // wavefront is through its tile after ~2.7 ms and the younger after ~4.0 ms: the short remainder units fill exactly that
+    // gap, where a second launch (f_rem = 1) had to wait for the first to drain.  73 689-ray frame: 4.58 -> 4.36 ms.
+    if (do_remainder && f_rem == 2 && tiles < 2 * slots && !out->samples_done) {      // (several whole rounds: the plain kernel's loop is ~2 % faster than the segmented form's, two launches win: 576x576x64 17.08 against 17.46 ms)
+        KArgs ku = ka;
+        ku.split = 1; ku.dynamic = 1; ku.part = nullptr;
+        ku.chain = (int)n_samples; ku.seg = 0; ku.term_eps = 0.f;
+        ku.k_begin = 0; ku.k_end = (int)n_samples;
+        ku.first_slot = 0; ku.first_items = (long)n_rays;
+        ku.list_in = nullptr; ku.count_in = nullptr; ku.list_out = nullptr; ku.count_out = nullptr; ku.chunk_cnt = nullptr;
+        ku.p_cap = (long)(slots * RAYS_PER_WAVE);
+        if (guard)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3((unsigned)n_cus), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ku);
+        else if (split16)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3((unsigned)n_cus), full_block, lds_split, S_(stream), ku);
+        else if (folded)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), ku);
+        else
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), ku);
+        return fixup();
+    }
     // Early termination on frames of at least one round of wavefronts: the samples are walked in segments of chain_len(), one
     // persistent-queue launch per segment.  A ray that is opaque stops (per ray, not per tile); the rays that go on park 16
     // floats and are appended to the next launch's list, so every launch packs the survivors 32 to a wavefront again: on the
