@@ -199,15 +199,15 @@ DEV float half_sum(float v) {             // valid in lanes 16..31 (half 0) and 
     return dpp_add<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
 }
 
-template <int COT>
-DEV void tile_stats(const f32x16 (&acc)[2][COT], const bool (&valid)[2], float* red, const ConvArgs& a, const int n, const int tile,
+template <int COT, int NP = 2>
+DEV void tile_stats(const f32x16 (&acc)[NP][COT], const bool (&valid)[NP], float* red, const ConvArgs& a, const int n, const int tile,
                     const int ntiles, const int ct0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
 #pragma unroll
     for (int c = 0; c < COT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v0 = valid[0] ? acc[0][c][r] : 0.f, v1 = valid[1] ? acc[1][c][r] : 0.f;
+            const float v0 = valid[0] ? acc[0][c][r] : 0.f, v1 = (NP > 1 && valid[NP - 1]) ? acc[NP - 1][c][r] : 0.f;
             const float s = half_sum(v0 + v1), q = half_sum(fmaf(v1, v1, v0 * v0));
             if ((lane & 31) == 16) {
                 const int ch = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -386,13 +386,16 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
 // LDS, already split into f16 hi / lo (so the nine taps read their B operand straight from LDS, no conversion in the loop),
 // together with the nine taps' weights, double-buffered against the MFMAs of the previous block: 54 x COT MFMAs per wave
 // between two barriers, global loads 9x fewer and all in flight together.
-constexpr int TH = 8, TW = 32;                              // output tile: rows x columns (wave w owns rows 2w, 2w + 1)
-constexpr int PW = TW + 2, PH = TH + 2;                     // input patch with its one-pixel halo
+constexpr int TW = 32, PW = TW + 2;                         // output tile columns; input patch columns (one-pixel halo)
+// rows per wave RW: 2 (an 8-row tile per workgroup) or 1 (4 rows): small images take the 4-row tile, which doubles the workgroups of
+// a layer that cannot fill the chip anyway and halves every workgroup's serial chain (conv3x3_rows())
+__host__ __device__ constexpr int tile_rows(int rw) { return WAVES * rw; }
 constexpr int PPX = 80;                                     // bytes per patch pixel: 16 hi halfs | 16 lo halfs | 16 pad (bank spread)
-constexpr int PATCH_BYTES = PH * PW * PPX;                  // 27 200
+__host__ __device__ constexpr int patch_bytes(int rw) { return (tile_rows(rw) + 2) * PW * PPX; }    // 27 200 for 8 rows, 16 320 for 4
 
-template <int COT>
+template <int COT, int RW>
 __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvArgs a) {
+    constexpr int TH = tile_rows(RW), PH = TH + 2, PATCH_BYTES = patch_bytes(RW), PT = RW;     // (PT shadows the direct kernel's pixel-tile count)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const patch0 = smem;                     // [2][PATCH_BYTES]
     float* const itab = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);      // [3][Cin] when a.in_tab
@@ -484,7 +487,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
-                const unsigned char* q = pb + ((2 * wave + t + ky) * PW + px + kx) * PPX + half * 16;
+                const unsigned char* q = pb + ((RW * wave + t + ky) * PW + px + kx) * PPX + half * 16;
                 b[slot][t].hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q));
                 b[slot][t].lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q + 32));
             }
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
     const int ox = tx0 + px;
     bool valid[PT];
 #pragma unroll
-    for (int t = 0; t < PT; ++t) valid[t] = (ty0 + 2 * wave + t) < a.Ho && ox < a.Wo;
+    for (int t = 0; t < PT; ++t) valid[t] = (ty0 + RW * wave + t) < a.Ho && ox < a.Wo;
 #pragma unroll
     for (int t = 0; t < PT; ++t)
 #pragma unroll
@@ -563,12 +566,12 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
                 for (int t = 0; t < PT; ++t) acc[t][c][r] += bv;
             }
     }
-    if (a.stats) tile_stats<COT>(acc, valid, reinterpret_cast<float*>(smem), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
+    if (a.stats) tile_stats<COT, RW>(acc, valid, reinterpret_cast<float*>(smem), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
     if (a.out_tab) finalize_if_last<COT>(a, n, ct0, (int)gridDim.x, reinterpret_cast<double*>(smem + 8192));
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (!valid[t]) continue;
-        float* yp = a.y + (((size_t)n * a.Ho + ty0 + 2 * wave + t) * a.Wo + ox) * a.Cout;
+        float* yp = a.y + (((size_t)n * a.Ho + ty0 + RW * wave + t) * a.Wo + ox) * a.Cout;
 #pragma unroll
         for (int c = 0; c < COT; ++c) {
             const int co0 = 32 * (ct0 + c);
@@ -726,8 +729,38 @@ int launch_conv(const ConvArgs& a, int N, void* stream) {
     return status();
 }
 
+// rows per wave of the 3x3 kernel for an (Ho x Wo) output: images of at most eight 8-row tiles (32 x 32 and smaller) take 4-row tiles.
+// A function of the output size ALONE, so that gpnerf_conv_out_tiles() can tell the caller how many tile rows the statistics have.
+int conv3x3_rows(int ho, int wo) {
+    static int f_rows = -1, f_max = -1;
+    if (f_rows < 0) {                      // experiment knobs, honoured only under GPNERF_DEBUG=1, clamped
+        const char* d = getenv("GPNERF_DEBUG");
+        const bool dbg = d && d[0] == '1';
+        const char* e = dbg ? getenv("GPNERF_CONV_ROWS") : nullptr;
+        const char* m = dbg ? getenv("GPNERF_CONV_ROWS_MAXTILES") : nullptr;
+        f_rows = e ? min(max(atoi(e), 0), 2) : 0;
+        f_max = m ? min(max(atoi(m), 0), 1 << 20) : 8;
+    }
+    if (f_rows) return f_rows;
+    return ((ho + 7) / 8) * ((wo + TW - 1) / TW) <= f_max && ho > 4 ? 1 : 2;
+}
+
+template <int COT, int RW>
+int launch_conv3x3_as(const ConvArgs& a, int N, int tiles, void* stream) {
+    // two patch buffers (+ the input norm's table); never less than what the epilogue's reductions use (tile sums, finalize)
+    size_t lds = 2 * (size_t)patch_bytes(RW) + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
+    if (lds < 16384) lds = 16384;
+    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW>);
+    // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
+    const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / COT));
+    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW>), grid, dim3(WAVES * 64), lds, S_(stream), a);
+    return status();
+}
+
 int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
-    const int tiles = ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
+    const int rw = conv3x3_rows(a.Ho, a.Wo), th = tile_rows(rw);
+    const int tiles = ((a.Ho + th - 1) / th) * ((a.Wo + TW - 1) / TW);
     // two output tiles per workgroup reuse the staged patch twice; layers whose grid would not give every CU a workgroup that
     // way (the 256-channel layers at 1/8 resolution: 48 workgroups) take one tile each instead
     static int f_cot = -1;
@@ -738,16 +771,8 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     }
     int cot = (a.CT % 2 == 0) ? 2 : 1;
     if (f_cot == 1 || (f_cot == 0 && cot == 2 && (long)tiles * N * (a.CT / 2) < 192)) cot = 1;
-    // two patch buffers (+ the input norm's table); never less than what the epilogue's reductions use (tile sums, finalize)
-    size_t lds = 2 * (size_t)PATCH_BYTES + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
-    if (lds < 16384) lds = 16384;
-    const void* fn = cot == 2 ? reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<2>) : reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<1>);
-    // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
-    const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / cot));
-    if (cot == 2) hipLaunchKernelGGL(conv3x3_s1_nhwc_kernel<2>, grid, dim3(WAVES * 64), lds, S_(stream), a);
-    else hipLaunchKernelGGL(conv3x3_s1_nhwc_kernel<1>, grid, dim3(WAVES * 64), lds, S_(stream), a);
-    return status();
+    if (rw == 1) return cot == 2 ? launch_conv3x3_as<2, 1>(a, N, tiles, stream) : launch_conv3x3_as<1, 1>(a, N, tiles, stream);
+    return cot == 2 ? launch_conv3x3_as<2, 2>(a, N, tiles, stream) : launch_conv3x3_as<1, 2>(a, N, tiles, stream);
 }
 
 }  // namespace
@@ -774,7 +799,7 @@ int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int3
 int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t stride) {
     if (h < 1 || w < 1 || (ks != 1 && ks != 3 && ks != 7) || (stride != 1 && stride != 2)) return 0;
     const int pad = ks / 2, ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
-    if (ks == 3 && stride == 1 && cin >= 8) return ((ho + TH - 1) / TH) * ((wo + TW - 1) / TW);
+    if (ks == 3 && stride == 1 && cin >= 8) { const int th = tile_rows(conv3x3_rows(ho, wo)); return ((ho + th - 1) / th) * ((wo + TW - 1) / TW); }
     return (ho * wo + WAVES * PT * 32 - 1) / (WAVES * PT * 32);
 }
 
