@@ -761,16 +761,15 @@ int launch_conv3x3_as(const ConvArgs& a, int N, int tiles, void* stream) {
 int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     const int rw = conv3x3_rows(a.Ho, a.Wo), th = tile_rows(rw);
     const int tiles = ((a.Ho + th - 1) / th) * ((a.Wo + TW - 1) / TW);
-    // two output tiles per workgroup reuse the staged patch twice; layers whose grid would not give every CU a workgroup that
-    // way (the 256-channel layers at 1/8 resolution: 48 workgroups) take one tile each instead
     static int f_cot = -1;
     if (f_cot < 0) {                       // experiment knob, honoured only under GPNERF_DEBUG=1, clamped
         const char* d = getenv("GPNERF_DEBUG");
         const char* e = (d && d[0] == '1') ? getenv("GPNERF_CONV_COT") : nullptr;
         f_cot = e ? min(max(atoi(e), 0), 2) : 0;
     }
-    int cot = (a.CT % 2 == 0) ? 2 : 1;
-    if (f_cot == 1 || (f_cot == 0 && cot == 2 && (long)tiles * N * (a.CT / 2) < 192)) cot = 1;
+    // one 32-channel output tile per workgroup everywhere: with the weights in registers and 54 KB of LDS two workgroups share a CU,
+    // and one's staging runs under the other's MFMAs (two tiles per workgroup, GPNERF_CONV_COT=2: 1.19 -> 1.38 ms per frame)
+    const int cot = (f_cot == 2 && a.CT % 2 == 0) ? 2 : 1;
     if (rw == 1) return cot == 2 ? launch_conv3x3_as<2, 1>(a, N, tiles, stream) : launch_conv3x3_as<1, 1>(a, N, tiles, stream);
     return cot == 2 ? launch_conv3x3_as<2, 2>(a, N, tiles, stream) : launch_conv3x3_as<1, 2>(a, N, tiles, stream);
 }
