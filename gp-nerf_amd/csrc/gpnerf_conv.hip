@@ -729,7 +729,7 @@ int launch_conv(const ConvArgs& a, int N, void* stream) {
     return status();
 }
 
-// rows per wave of the 3x3 kernel for an (Ho x Wo) output: images of at most eight 8-row tiles (32 x 32 and smaller) take 4-row tiles.
+// rows per wave of the 3x3 kernel for an (Ho x Wo) output: images of at most sixteen 8-row tiles (64 x 64 and smaller) take 4-row tiles (threshold swept: 8: 1.165, 16: 1.147, 64: 1.203 ms per frame).
 // A function of the output size ALONE, so that gpnerf_conv_out_tiles() can tell the caller how many tile rows the statistics have.
 int conv3x3_rows(int ho, int wo) {
     static int f_rows = -1, f_max = -1;
@@ -739,7 +739,7 @@ int conv3x3_rows(int ho, int wo) {
         const char* e = dbg ? getenv("GPNERF_CONV_ROWS") : nullptr;
         const char* m = dbg ? getenv("GPNERF_CONV_ROWS_MAXTILES") : nullptr;
         f_rows = e ? min(max(atoi(e), 0), 2) : 0;
-        f_max = m ? min(max(atoi(m), 0), 1 << 20) : 8;
+        f_max = m ? min(max(atoi(m), 0), 1 << 20) : 16;
     }
     if (f_rows) return f_rows;
     return ((ho + 7) / 8) * ((wo + TW - 1) / TW) <= f_max && ho > 4 ? 1 : 2;
