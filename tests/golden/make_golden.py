@@ -161,7 +161,7 @@ def to_batch(scene):
     return {k: torch.from_numpy(np.ascontiguousarray(scene[k])) for k in keys}
 
 
-def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays=32, outputs_only=False):
+def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays=32, outputs_only=False, ray_stride=None, chunk=400):
     syn = importlib.import_module("gp-nerf_amd.synthetic")
     scene = syn.make_scene(**scene_kw)
     if stretch is not None:
@@ -171,6 +171,7 @@ def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays
         scene["near"] = (mid - stretch * half).astype(np.float32)
         scene["far"] = (mid + stretch * half).astype(np.float32)
     r, BaseRender, trainhead = build_reference_renderer(scene, n_samples, neg_ray)
+    r.chunk = chunk
     batch = to_batch(scene)
     with torch.no_grad():
         ret = r.render(batch)
@@ -223,6 +224,15 @@ def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays
             "st_vol_feat": vol_feat[0].t().contiguous().numpy().reshape(idx.size, n_samples, 128)[heavy].reshape(-1, 128),
             "st_ray_mask": ray_mask.numpy(), "st_alpha": alpha.numpy(), "st_rays": idx, "st_heavy": idx[heavy],
         })
+    if ray_stride is not None:
+        # BASELINE.json's full-size configurations: every `ray_stride`-th ray of the reference's maps + a SHA-256 over all of them
+        assert outputs_only
+        full = hashlib.sha256()
+        for k in ("rgb_map", "depth_map", "acc_map", "disp_map", "rgb_in_map"):
+            full.update(np.ascontiguousarray(out[k]).tobytes())
+        out = {k: np.ascontiguousarray(v[::ray_stride]) for k, v in out.items()}
+        out["ray_stride"] = np.int64(ray_stride)
+        out["outputs_sha256"] = np.frombuffer(full.digest(), np.uint8)
     meta = {"scene_kw": scene_kw, "n_samples": n_samples, "neg_ray": bool(neg_ray), "stretch": stretch,
             "n_rays": int(scene["ray_o"].shape[1]), "sha256_inputs": sha_inputs(scene),
             "torch": torch.__version__, "numpy": np.__version__}
@@ -457,6 +467,15 @@ CASES = [
                                aabb_half=(0.25, 0.45, 0.125), voxel=0.005), 32, dict(outputs_only=True)),
 ]
 
+# BASELINE.json configs[1..3] at FULL size, on the very scenes bench.py and tests/test_gpu_configs.py render: the reference's
+# Renderer.render over every ray (test chunk 2000), every 64th / 256th ray stored.  Slow (1 - 5 minutes each on 8 CPU threads).
+FULL_CASES = [
+    ("config2_512x512_s64", dict(H=512, W=512, seed=0, fill="full", pose="identity"), 64, dict(outputs_only=True, ray_stride=64, chunk=2000)),
+    ("config3_512x512_s128", dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=1.0), 128,
+     dict(outputs_only=True, ray_stride=64, chunk=2000)),
+    ("config4_1024x1024_s64", dict(H=1024, W=1024, seed=0, fill="full", pose="identity"), 64, dict(outputs_only=True, ray_stride=256, chunk=2000)),
+]
+
 
 def run_encoder_case(name, H, W, seed, stride=None):
     """libs/encoders/UNet.py ResUNet.forward on seeded images with seeded parameters.  The parameters
@@ -519,7 +538,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
-    for name, kw, S, extra in CASES:
+    for name, kw, S, extra in CASES + FULL_CASES:
         if only and name not in only:
             continue
         run_case(name, kw, S, **extra)

@@ -12,7 +12,12 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("rays_", "encoder_", "attention_", "demo_", "e2e_")))
+                  if not os.path.basename(p).startswith(("rays_", "encoder_", "attention_", "demo_", "e2e_", "config2_", "config3_", "config4_")))
+
+
+def full_size_case_names():
+    """BASELINE.json configs[1..3] at full size: the reference's maps for every 64th / 256th ray (make_golden.py FULL_CASES)"""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "config[234]_*.npz")))
 
 
 def demo_case_names():

@@ -149,3 +149,30 @@ def test_config4_1024x1024x64_and_its_8_way_sharding(fm, oracle, syn):
     # (4) the split-precision form at this size
     fast = cpu(fm.render_fused(fr, rays, S, split_f16=True, want=()))
     assert np.abs(fast["rgb_map"] - got["rgb_map"]).max() < 2e-5 and np.abs(fast["depth_map"] - got["depth_map"]).max() < 1e-4
+
+
+# ---- the reference's own output at BASELINE.json's full sizes ------------------------------------------------------------
+def _full_names():
+    from golden_cases import full_size_case_names
+    return full_size_case_names()
+
+
+@pytest.mark.parametrize("name", _full_names())
+def test_full_size_frames_match_the_reference_itself(name, fm):
+    """configs[1] (512x512x64), configs[2] (512x512x128) and configs[3] (1024x1024x64) on the scenes bench.py renders, against what
+    the REFERENCE's Renderer.render produced for every 64th / 256th ray (tests/golden/make_golden.py FULL_CASES; 262 144 - 1 048 576
+    rays through libs/renders/BaseRender.py on the CPU): both kernel forms, and for configs[2] the early-terminated render too
+    (its bound: the kernel's error + what termination drops, term_eps = 1e-5)."""
+    from golden_cases import load, scene_of
+    z, meta = load(name)
+    sc = scene_of(meta)
+    S, st = meta["n_samples"], int(z["ray_stride"])
+    fr = build_frame(fm, sc)
+    rays = to_dev(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32))
+    assert rays.shape[0] == meta["n_rays"]
+    worst = {}
+    for label, kw in (("fp32", {}), ("split", {"split_f16": True})) + ((("fp32+early-term", {"early_term": True, "term_eps": 1e-5}),) if S == 128 else ()):
+        got = cpu(fm.render_fused(fr, rays, S, want=("rgb_in",), **kw))
+        for k in ("rgb_map", "depth_map", "acc_map") + (("rgb_in_map",) if "early" not in label else ()):
+            worst[(label, k)] = assert_close(got[k][::st], z[k], TOL, f"{name} {label} {k}")
+    print(name, {f"{a}:{k}": float(f"{v:.2e}") for (a, k), v in worst.items()})

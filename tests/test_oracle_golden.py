@@ -124,3 +124,21 @@ def test_oracle_and_encoder_restatement_at_the_config5_size(oracle, syn):
     assert_close(res["depth_map"], z["depth_map"][::4], 1e-4, "depth_map")
     assert_close(res["acc_map"], z["acc_map"][::4], 1e-4, "acc_map")
     assert_close(res["rgb_in_map"], z["rgb_in_map"][::4], TOL, "rgb_in_map")
+
+
+def test_oracle_at_baseline_full_sizes(oracle):
+    """BASELINE.json configs[1..3] at FULL size: the fixtures hold the reference's Renderer.render for every 64th / 256th ray of
+    the very scenes bench.py renders (make_golden.py FULL_CASES).  The oracle on every 8th stored ray."""
+    from golden_cases import full_size_case_names
+    names = full_size_case_names()
+    assert "config2_512x512_s64" in names
+    for name in names:
+        z, meta = load(name)
+        sc = scene_of(meta)
+        assert sha_inputs(sc) == meta["sha256_inputs"], "synthetic inputs are not byte-identical to the golden run"
+        st = int(z["ray_stride"])
+        rays = oracle.rays_of(sc)
+        assert rays.shape[0] == meta["n_rays"]
+        res = oracle.render(sc, meta["n_samples"], rays=np.ascontiguousarray(rays[::st][::8]), want_weights=False)
+        for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map"):
+            assert_close(res[k], z[k][::8], 5e-5 if k == "depth_map" else TOL, f"{name} {k}")
