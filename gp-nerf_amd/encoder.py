@@ -305,7 +305,12 @@ class _EncoderGraph:
 
 
 def _graph_key(net, x):
-    return (tuple(x.shape), str(x.device), x.dtype, tuple((p.data_ptr(), p._version) for p in net.parameters()))
+    # the parameter OBJECTS are looked up once (walking the module tree costs ~0.1 ms per call, and this runs before the frame's
+    # first launch, with the device idle); their storage and version are what is compared per call
+    plist = net.__dict__.get("_gpnerf_params")
+    if plist is None:
+        plist = net.__dict__["_gpnerf_params"] = list(net.parameters())
+    return (tuple(x.shape), x.device.index, x.dtype, tuple([(p.data_ptr(), p._version) for p in plist]))
 
 
 def forward_graphed(net, x):

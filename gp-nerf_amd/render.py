@@ -257,10 +257,10 @@ class Renderer(nn.Module):
         # go back to back.  (Round 2 fetched the constants before the encoder's first launch: the device idled ~0.3 ms per call.)
         # the encoder's time comes from two events on the stream instead of two host synchronisations around it
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        blob = self.nerfhead.head_blob(dev)                            # (cached; packs on a parameter change)
         ev0.record()
         featmaps = self.encode(batch)
         ev1.record()
+        self.nerfhead.head_blob(dev)                                   # (cached; packs on a parameter change)
         main = torch.cuda.current_stream(dev)
         side = self.__dict__.get("_side_stream")
         if side is None or side.device != dev:
