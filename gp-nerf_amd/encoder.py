@@ -315,7 +315,9 @@ def _graph_key(net, x):
 
 def forward_graphed(net, x):
     """net(x) through a cached HIP graph (re-captured when the input shape, the device or any parameter changes).  Same bits as
-    the eager call (tests/test_encoder.py)."""
+    the eager call (tests/test_encoder.py).  "Any parameter changes" = the storage pointer or the version counter of one of the
+    module's Parameter OBJECTS (load_state_dict, optimiser steps, .to(), in-place edits); the list of those objects is looked up
+    once -- after REPLACING a Parameter object (`net.conv1.weight = nn.Parameter(...)`) call `forget_graph(net)`."""
     _require_gpu_inference(x, net.training)
     key = _graph_key(net, x)
     hit = net.__dict__.get("_gpnerf_graph")
@@ -323,6 +325,12 @@ def forward_graphed(net, x):
         hit = (key, _EncoderGraph(net, x.float()))
         net.__dict__["_gpnerf_graph"] = hit
     return hit[1](x)
+
+
+def forget_graph(net):
+    """Drop the cached graph and parameter list of `net` (see forward_graphed)."""
+    net.__dict__.pop("_gpnerf_graph", None)
+    net.__dict__.pop("_gpnerf_params", None)
 
 
 def build_encoder(cfg):
