@@ -255,6 +255,72 @@ class ResUNet(nn.Module):
         self.iconv2 = ConvNormELU(skip1 + 64, out_ch, 3)
         self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
 
+    # ---- operand range of the split-f16 convolutions (csrc/gpnerf_conv.hip: weights staged as 2^12 w, activations as 2^4 x) ----
+    W_LIMIT, X_LIMIT = 15.99, 4094.0
+
+    def check_operand_range(self, H, W):
+        """The convolutions' f16 hi/lo operands hold |w| < 16 and |x| < 4 094.  Weights are checked directly; activations through
+        the bound InstanceNorm gives them: a normalised value is at most sqrt(h w - 1) in magnitude, so a norm's output is bounded by
+        sqrt(h w) max|gamma| + max|beta| whatever the data, a residual unit's by that plus its shortcut's bound, and bilinear
+        upsampling / concatenation / ReLU / ELU do not raise a bound.  Raises GpnerfError naming the first layer whose input could
+        leave the range (for the reference's initialisation and any InstanceNorm scale below ~10 it cannot); cached per (H, W,
+        parameter versions): ONE device-to-host copy per parameter change.  The images themselves must stay below 255 in
+        magnitude (the dataset hands over values in [-1, 1])."""
+        key = (int(H), int(W), _graph_key(self, next(self.parameters()))[3])
+        hit = self.__dict__.get("_gpnerf_range_ok")
+        if hit == key:
+            return
+        names, tensors = zip(*[(n, p) for n, p in self.named_parameters()])
+        mx = dict(zip(names, torch.stack([t.detach().abs().max().float() for t in tensors]).cpu().tolist()))
+        for n, v in mx.items():
+            if n.endswith("weight") and n.rsplit(".", 1)[0] in self._conv_names() and not v < self.W_LIMIT:
+                raise L.GpnerfError(f"encoder: |{n}| reaches {v:.3g}; the split-f16 convolution holds weights below 16")
+
+        def norm_bound(prefix, hw):
+            return (hw ** 0.5) * mx[prefix + ".weight"] + mx[prefix + ".bias"]
+
+        def need(name, bound):
+            if not bound < self.X_LIMIT:
+                raise L.GpnerfError(f"encoder: the input of {name} can reach {bound:.4g} (InstanceNorm scales too large for this image "
+                                    f"size); the split-f16 convolution holds activations below {self.X_LIMIT:.0f}")
+
+        half = lambda n: (n - 1) // 2 + 1
+        h, w = half(int(H)), half(int(W))
+        need("conv1", 255.0)
+        b = norm_bound("bn1", h * w)
+        sizes, bounds = {}, {}
+        for stage, units in (("layer1", 3), ("layer2", 4), ("layer3", 6)):
+            for u in range(units):
+                p = f"{stage}.{u}"
+                if u == 0:
+                    need(p + ".downsample.0", b)
+                    need(p + ".conv1", b)
+                    h, w = half(h), half(w)
+                    idn = norm_bound(p + ".downsample.1", h * w)
+                else:
+                    need(p + ".conv1", b)
+                    idn = b
+                need(p + ".conv2", norm_bound(p + ".bn1", h * w))
+                b = norm_bound(p + ".bn2", h * w) + idn
+            sizes[stage], bounds[stage] = (h, w), b
+        need("upconv3.conv.conv", bounds["layer3"])
+        h, w = 2 * sizes["layer3"][0], 2 * sizes["layer3"][1]
+        b = max(norm_bound("upconv3.conv.bn", h * w), bounds["layer2"])
+        need("iconv3.conv", b)
+        b = norm_bound("iconv3.bn", h * w)
+        need("upconv2.conv.conv", b)
+        h, w = 2 * h, 2 * w
+        b = max(norm_bound("upconv2.conv.bn", h * w), bounds["layer1"])
+        need("iconv2.conv", b)
+        need("out_conv", norm_bound("iconv2.bn", h * w))
+        self.__dict__["_gpnerf_range_ok"] = key
+
+    def _conv_names(self):
+        names = self.__dict__.get("_gpnerf_conv_names")
+        if names is None:
+            names = self.__dict__["_gpnerf_conv_names"] = {n for n, m in self.named_modules() if isinstance(m, nn.Conv2d)}
+        return names
+
     def out_shape(self, H, W):
         """(C, h, w) of forward()'s result for [.,3,H,W] images: the stem and the three stages each halve with ceil (k = 7 / 3,
         pad k // 2, stride 2), the decoder doubles twice and pads the skips up to that size (UNet.py:199-211)."""
@@ -267,6 +333,7 @@ class ResUNet(nn.Module):
         """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the result leaves with channels-last strides, which `Frame`
         recognises (no re-layout launch)."""
         _require_gpu_inference(x, self.training)
+        self.check_operand_range(x.shape[-2], x.shape[-1])
         x = _apply(*_conv_norm(self.conv1, self.bn1, x.float()), 1)
         x1 = self.layer1(x)
         x2 = self.layer2(x1)

@@ -136,3 +136,24 @@ def test_encoder_through_a_hip_graph_gives_the_eager_bits_and_follows_its_parame
         net.out_conv.bias.add_(0.25)
         assert torch.equal(enc.forward_graphed(net, c), net(c))            # parameters changed: re-packed and re-captured
         assert torch.equal(ga, ea)                                         # earlier results untouched
+
+
+def test_operand_range_is_checked_by_construction():
+    """The split-f16 convolutions hold |w| < 16 and |x| < 4 094 (weights staged as 2^12 w, activations as 2^4 x).  There is no
+    per-operand guard in the encoder's kernels: instead the module refuses parameters for which InstanceNorm's bound
+    sqrt(h w) |gamma| + |beta| (+ the shortcut's) cannot keep a convolution's input inside the range -- on the host, from the
+    parameters alone, once per parameter version."""
+    L = importlib.import_module("gp-nerf_amd._lib")
+    net, _ = _net(3)
+    net.check_operand_range(512, 512)
+    net.check_operand_range(1024, 1024)                      # the reference's full-resolution images
+    with torch.no_grad():
+        net.layer3[2].bn1.weight.mul_(200.0)
+    with pytest.raises(L.GpnerfError, match="layer3.2.conv2"):
+        net.check_operand_range(512, 512)
+    with torch.no_grad():
+        net.layer3[2].bn1.weight.div_(200.0)
+        net.check_operand_range(512, 512)
+        net.layer2[0].conv1.weight[0, 0, 0, 0] = 17.0
+    with pytest.raises(L.GpnerfError, match="layer2.0.conv1.weight"):
+        net.check_operand_range(512, 512)
