@@ -1313,7 +1313,11 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 rin[3 * v + 2] = fmaf(wgt, irgb[v][2], rin[3 * v + 2]);
             }
             if (writer) {
+#ifdef GPNERF_X_WT            // experiment: sample-major store (a wave's 32 lanes write one full line); timing only, the layout is wrong
+                if (out.weights) out.weights[(size_t)k * (size_t)kp->n_rays + (size_t)slot] = wgt;
+#else
                 if (out.weights) out.weights[(size_t)ray * S + k] = wgt;
+#endif
             }
         } else {
             // the group's P samples in order, in every lane of the group alike: sample j's values come from lane (group base + j)
