@@ -124,6 +124,9 @@ SYMBOLS = {
                                            C.c_void_p, C.c_int32, C.c_void_p]),
     "gpnerf_sparse_to_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
+    "gpnerf_zero_volume": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]),
+    "gpnerf_sparse_scatter_dense": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                              C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_featmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -471,11 +471,21 @@ int gpnerf_sparse_merge_duplicates(float* feat, int32_t channels, const int32_t*
     return status();
 }
 
+int gpnerf_zero_volume(float* vol_ndhwc, int32_t channels, const int32_t* dims, void* stream) {
+    if (!vol_ndhwc || bad(dims) || channels < 1) return GPNERF_E_ARG;
+    return fill_async(vol_ndhwc, sizeof(float) * (size_t)dims[0] * dims[1] * dims[2] * channels, 0u, stream) ? GPNERF_OK : GPNERF_E_LAUNCH;
+}
+
 int gpnerf_sparse_to_dense(const float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, const int32_t* m_dev,
                            int32_t m_cap, const int32_t* dims, float* vol_ndhwc, void* stream) {
+    return gpnerf_sparse_scatter_dense(feat, channels, coords, grid, m_dev, m_cap, dims, vol_ndhwc, 0, stream);
+}
+
+int gpnerf_sparse_scatter_dense(const float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, const int32_t* m_dev,
+                                int32_t m_cap, const int32_t* dims, float* vol_ndhwc, int32_t prezeroed, void* stream) {
     if (!feat || !coords || !grid || bad(dims) || !vol_ndhwc || channels < 1 || channels > 32 || m_cap < 0) return GPNERF_E_ARG;
     const Dims s{dims[0], dims[1], dims[2]};
-    if (!fill_async(vol_ndhwc, sizeof(float) * (size_t)s.d * s.h * s.w * channels, 0u, stream)) return GPNERF_E_LAUNCH;
+    if (!prezeroed && !fill_async(vol_ndhwc, sizeof(float) * (size_t)s.d * s.h * s.w * channels, 0u, stream)) return GPNERF_E_LAUNCH;
     if (m_cap == 0) return GPNERF_OK;
     hipLaunchKernelGGL(dense_kernel, dim3((m_cap + 7) / 8), dim3(256), 0, S_(stream), feat, (int)channels, coords, grid,
                        (const int*)m_dev, (int)m_cap, s, vol_ndhwc);

@@ -42,10 +42,11 @@ class NeRFSigmaHead(nn.Module):
 
     def build_volumes(self, sp_input, smpl_feat_sampled):
         """Embedding -> attention over the V views -> sparse conv net -> 4 dense levels
-        (trainhead.py:48-56, SparseConvNet.py:105-111).  Per frame, not per ray."""
+        (trainhead.py:48-56, SparseConvNet.py:105-111).  Per frame, not per ray.  sp_input["plan"]: the pyramid's structure laid
+        out earlier (SparseConvNet.plan_levels; Renderer.render does that while the image encoder runs)."""
         code = self.c.weight                        # = self.c(arange(n_smpl)) (trainhead.py:48): every row, in order
         fused = self.xyzc_attn.fuse_vertices(code, smpl_feat_sampled.flatten(0, 1))          # HIP only: raises on CPU / in training
-        return self.xyzc_net.dense_levels_hip(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"])
+        return self.xyzc_net.dense_levels_hip(fused, sp_input["coord"], sp_input["out_sh"], sp_input["batch_size"], plan=sp_input.get("plan"))
 
 
     def _blob(self, device):

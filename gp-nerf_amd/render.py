@@ -121,7 +121,13 @@ class Renderer(nn.Module):
         out_sh = consts[6].ravel() if (consts is not None and batch["out_sh"].shape[0] == 1) else None
         xyz = batch["feature"][..., :3].float()
         smpl_xyz = torch.bmm(xyz, batch["Rh"].float().transpose(1, 2)) + batch["Th"].float()
-        return self.prepare_sp_input(batch, out_sh), smpl_xyz
+        sp = self.prepare_sp_input(batch, out_sh)
+        net = getattr(getattr(self.nerfhead, "sigmahead", None), "xyzc_net", None)
+        if hasattr(net, "plan_levels") and not net.training and sp["coord"].is_cuda:
+            # the pyramid's structure (index grids, coarse site lists, zeroed volumes) needs the voxel coordinates only: laid out
+            # here, i.e. on Renderer.render's side stream while the encoder runs, instead of between the encoder and the per-ray kernel
+            sp["plan"] = net.plan_levels(sp["coord"], sp["out_sh"])
+        return sp, smpl_xyz
 
     def _placeholder_volumes(self, dev):
         """Four one-voxel channels-last levels: what a Frame carries until the builder's volumes are attached (cached per device)."""

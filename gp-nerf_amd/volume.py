@@ -147,20 +147,59 @@ class SparseConvNet(nn.Module):
             cache[id(mod)] = hit
         return hit[1]
 
-    def dense_levels_hip(self, code, coord, out_sh, batch_size=1):
-        """code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) -> the 4 dense levels of
-        SparseConvNet.py:105-111, computed by the HIP sparse-convolution kernels and returned directly in the render kernel's
-        channels-last layout: a list of 4 tensors [D_k,H_k,W_k,C] (tagged `_gpnerf_ndhwc`)."""
-        if int(batch_size) != 1:
-            raise ValueError("the per-ray path renders one frame at a time (BaseRender.py:336 asserts batch 1)")
+    def plan_levels(self, coord, out_sh, channels=None):
+        """The STRUCTURE of a frame's pyramid, which depends on the vertices' voxel coordinates only: the full-resolution index
+        grid, for each of the 4 levels its coarse site list + index grid (gpnerf_sparse_down_sites), and the zeroed dense volumes.
+        No features are touched, so Renderer.render enqueues this on a side stream while the image encoder runs (~150 us of
+        small launches off the critical path); `dense_levels_hip(..., plan=)` then only runs the convolutions and the scatters."""
         if any(int(v) % 16 for v in out_sh):
             # the reference's datasets round out_sh up to a multiple of 32 (ZjumocapDataset.py:243-254); with odd sizes spconv's
             # strided output shape (n - 1) // 2 + 1 and the n // 2 used below would part ways
             raise L.GpnerfError(f"out_sh {tuple(out_sh)} must be a multiple of 16 in every dimension")
+        if not coord.is_cuda:
+            raise L.GpnerfError("the HIP volume builder needs GPU tensors (no CPU fallback)")
+        lib = L.lib()
+        dev = coord.device
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        I3 = C.c_int32 * 3
+        dims = tuple(int(v) for v in out_sh)
+        coords = coord[:, 1:].to(torch.int32).contiguous()
+        m_cap, m_dev = coords.shape[0], None
+        grid = torch.empty(dims, device=dev, dtype=torch.int32)
+        L.check(lib.gpnerf_sparse_index(coords.data_ptr(), None, m_cap, I3(*dims), grid.data_ptr(), st), "gpnerf_sparse_index")
+        plan = {"level0": (grid, dims, coords, m_dev, m_cap), "dup": torch.empty((9 * m_cap,), device=dev, dtype=torch.int32), "levels": []}
+        ch = [int(c) for c in (channels or [self.net[2 * i + 2][3].cout for i in range(self.n_layers)])]
+        for i in range(self.n_layers):
+            odims = tuple(n // 2 for n in dims)
+            cells = odims[0] * odims[1] * odims[2]
+            ocap = int(min(cells, 8 * m_cap))                       # a fine site reaches at most 2^3 coarse sites
+            ogrid = torch.empty(odims, device=dev, dtype=torch.int32)
+            ocoords = torch.empty((ocap, 3), device=dev, dtype=torch.int32)
+            om = torch.empty((1,), device=dev, dtype=torch.int32)
+            L.check(lib.gpnerf_sparse_down_sites(coords.data_ptr(), m_dev.data_ptr() if m_dev is not None else None, m_cap,
+                                                 I3(*odims), ogrid.data_ptr(), ocoords.data_ptr(), om.data_ptr(), ocap, st),
+                    "gpnerf_sparse_down_sites")
+            vol = torch.empty(odims + (ch[i],), device=dev, dtype=torch.float32)
+            L.check(lib.gpnerf_zero_volume(vol.data_ptr(), ch[i], I3(*odims), st), "gpnerf_zero_volume")
+            plan["levels"].append((ogrid, odims, ocoords, om, ocap, vol))
+            grid, dims, coords, m_dev, m_cap = ogrid, odims, ocoords, om, ocap
+        return plan
+
+    def dense_levels_hip(self, code, coord, out_sh, batch_size=1, plan=None):
+        """code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) -> the 4 dense levels of
+        SparseConvNet.py:105-111, computed by the HIP sparse-convolution kernels and returned directly in the render kernel's
+        channels-last layout: a list of 4 tensors [D_k,H_k,W_k,C] (tagged `_gpnerf_ndhwc`).  plan: `plan_levels(coord, out_sh)`
+        made earlier (on whatever stream, as long as this stream waits for it)."""
+        if int(batch_size) != 1:
+            raise ValueError("the per-ray path renders one frame at a time (BaseRender.py:336 asserts batch 1)")
+        if any(int(v) % 16 for v in out_sh):
+            raise L.GpnerfError(f"out_sh {tuple(out_sh)} must be a multiple of 16 in every dimension")       # (see plan_levels)
         if self.training:
             raise L.GpnerfError("the HIP volume builder folds BatchNorm running statistics: call .eval() first")
         if not code.is_cuda:
             raise L.GpnerfError("the HIP volume builder needs GPU tensors (no CPU fallback)")
+        if plan is None:
+            plan = self.plan_levels(coord, out_sh)
         lib = L.lib()
         dev = code.device
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -182,38 +221,26 @@ class SparseConvNet(nn.Module):
                                                 out.data_ptr(), st), "gpnerf_sparse_conv3")
             return out
 
-        dims = tuple(int(v) for v in out_sh)
-        coords = coord[:, 1:].to(torch.int32).contiguous()
-        m_cap, m_dev = coords.shape[0], None
-        grid = torch.empty(dims, device=dev, dtype=torch.int32)
-        L.check(lib.gpnerf_sparse_index(coords.data_ptr(), None, m_cap, I3(*dims), grid.data_ptr(), st), "gpnerf_sparse_index")
+        grid, dims, coords, m_dev, m_cap = plan["level0"]
         x = code.detach().float().contiguous()
         with torch.no_grad():
             dc = self.net[0]                                            # double_conv at full resolution
             x = conv(False, dc[0], dc[1], x, grid, dims, coords, m_dev, m_cap)
             x = conv(False, dc[3], dc[4], x, grid, dims, coords, m_dev, m_cap)
-            dup = torch.empty((9 * m_cap,), device=dev, dtype=torch.int32)       # a count + eight row slots per row
             L.check(lib.gpnerf_sparse_merge_duplicates(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_cap,
-                                                       I3(*dims), dup.data_ptr(), st), "gpnerf_sparse_merge_duplicates")
+                                                       I3(*dims), plan["dup"].data_ptr(), st), "gpnerf_sparse_merge_duplicates")
             levels = []
             for i in range(self.n_layers):
                 sc, dc = self.net[2 * i + 1], self.net[2 * i + 2]
-                odims = tuple(n // 2 for n in dims)
-                cells = odims[0] * odims[1] * odims[2]
-                ocap = int(min(cells, 8 * m_cap))                       # a fine site reaches at most 2^3 coarse sites
-                ogrid = torch.empty(odims, device=dev, dtype=torch.int32)
-                ocoords = torch.empty((ocap, 3), device=dev, dtype=torch.int32)
-                om = torch.empty((1,), device=dev, dtype=torch.int32)
-                L.check(lib.gpnerf_sparse_down_sites(coords.data_ptr(), m_dev.data_ptr() if m_dev is not None else None, m_cap,
-                                                     I3(*odims), ogrid.data_ptr(), ocoords.data_ptr(), om.data_ptr(), ocap, st),
-                        "gpnerf_sparse_down_sites")
+                ogrid, odims, ocoords, om, ocap, vol = plan["levels"][i]
                 x = conv(True, sc[0], sc[1], x, grid, dims, ocoords, om, ocap)
                 grid, dims, coords, m_dev, m_cap = ogrid, odims, ocoords, om, ocap
                 x = conv(False, dc[0], dc[1], x, grid, dims, coords, m_dev, m_cap)
                 x = conv(False, dc[3], dc[4], x, grid, dims, coords, m_dev, m_cap)
-                vol = torch.empty(dims + (x.shape[1],), device=dev, dtype=torch.float32)
-                L.check(lib.gpnerf_sparse_to_dense(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_dev.data_ptr(),
-                                                   m_cap, I3(*dims), vol.data_ptr(), st), "gpnerf_sparse_to_dense")
+                if vol.shape[-1] != x.shape[1]:
+                    raise L.GpnerfError("plan_levels: channel count of the planned volume does not match the network")
+                L.check(lib.gpnerf_sparse_scatter_dense(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_dev.data_ptr(),
+                                                        m_cap, I3(*dims), vol.data_ptr(), 1, st), "gpnerf_sparse_scatter_dense")
                 vol._gpnerf_ndhwc = True
                 levels.append(vol)
         return levels

@@ -286,6 +286,12 @@ int gpnerf_sparse_down_sites(const int32_t* in_coords, const int32_t* m_in_dev, 
 /* .dense(): zero-filled [D][H][W][C] volume with the active sites' features (channels-last, as GpnerfFrame.vol wants). */
 int gpnerf_sparse_to_dense(const float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, const int32_t* m_dev,
                            int32_t m_cap, const int32_t* dims, float* vol_ndhwc, void* stream);
+/* The same in two steps, for callers that lay out a frame's pyramid BEFORE its features exist (the structure of the pyramid --
+ * index grids, coarse site lists, zeroed dense volumes -- depends on the vertices' voxel coordinates only, so it can be enqueued
+ * on a side stream while the image encoder runs): gpnerf_zero_volume now, gpnerf_sparse_scatter_dense(prezeroed = 1) later. */
+int gpnerf_zero_volume(float* vol_ndhwc, int32_t channels, const int32_t* dims, void* stream);
+int gpnerf_sparse_scatter_dense(const float* feat, int32_t channels, const int32_t* coords, const int32_t* grid, const int32_t* m_dev,
+                                int32_t m_cap, const int32_t* dims, float* vol_ndhwc, int32_t prezeroed, void* stream);
 
 /* Vertex-code attention of the volume builder (libs/nerfheads/trainhead.py:48-52, networks/MultiHeadAttention.py:61-98 with
  * sum=False): q [n][d_model] vertex codes, kv [n][views][kv_dim] the vertices' per-view features, weights in PyTorch
