@@ -391,11 +391,19 @@ constexpr int TW = 32, PW = TW + 2;                         // output tile colum
 // a layer that cannot fill the chip anyway and halves every workgroup's serial chain (conv3x3_rows())
 __host__ __device__ constexpr int tile_rows(int rw) { return WAVES * rw; }
 constexpr int PPX = 80;                                     // bytes per patch pixel: 16 hi halfs | 16 lo halfs | 16 pad (bank spread)
-__host__ __device__ constexpr int patch_bytes(int rw) { return (tile_rows(rw) + 2) * PW * PPX; }    // 27 200 for 8 rows, 16 320 for 4
+// input patch of a tile: (STRIDE * rows + 3 - STRIDE) x (STRIDE * 32 + 3 - STRIDE) pixels.  Stride 2 keeps the even and the odd
+// patch columns in separate planes ([row][parity][33 columns]), so that a tap's 32 lanes -- which read every second column --
+// still walk consecutive pixels of one plane (80-byte pitch, conflict-free) instead of every second pixel of one row
+__host__ __device__ constexpr int patch_rows(int rw, int stride) { return stride * tile_rows(rw) + 3 - stride; }
+__host__ __device__ constexpr int patch_cols(int stride) { return stride == 1 ? PW : 66; }              // stride 2: 65 columns in 2 planes of 33
+__host__ __device__ constexpr int patch_bytes(int rw, int stride = 1) { return patch_rows(rw, stride) * patch_cols(stride) * PPX; }    // 27 200 / 16 320 (stride 1: 8 / 4 rows), 47 520 (stride 2, 4 rows)
 
-template <int COT, int RW>
+template <int COT, int RW, int STRIDE = 1>
 __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvArgs a) {
-    constexpr int TH = tile_rows(RW), PH = TH + 2, PATCH_BYTES = patch_bytes(RW), PT = RW;     // (PT shadows the direct kernel's pixel-tile count)
+    constexpr int TH = tile_rows(RW), PH = patch_rows(RW, STRIDE), PATCH_BYTES = patch_bytes(RW, STRIDE), PT = RW;     // (PT shadows the direct kernel's pixel-tile count)
+    constexpr int PCOLS = STRIDE == 1 ? PW : 65;             // patch columns actually staged
+    // LDS position of patch pixel (row, col)
+    auto ppos = [](int row, int col) { return STRIDE == 1 ? row * PW + col : (row * 2 + (col & 1)) * 33 + (col >> 1); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const patch0 = smem;                     // [2][PATCH_BYTES]
     float* const itab = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);      // [3][Cin] when a.in_tab
@@ -435,8 +443,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
     // instructions (the f16 MFMA leaves the issue port free) -- while block cb + 2's loads fill the other set.  (Measured per
     // 256-channel 32x32 convolution, graph-timed: 30.7 us with the whole conversion behind the MFMAs, of which 15.1 us matrix work
     // + LDS reads, 7.6 us conversion + LDS writes, 1.4 us issuing loads, 1.7 us barriers; tools/probes/conv_layer_time.py.)
-    constexpr int PITEMS = PH * PW * 4, PPASS = (PITEMS + WAVES * 64 - 1) / (WAVES * 64);
-    static_assert(PPASS <= 9, "one patch item per tap");
+    constexpr int PITEMS = PH * PCOLS * 4, PPASS = (PITEMS + WAVES * 64 - 1) / (WAVES * 64);
+    static_assert(PPASS <= 18, "at most two patch items per tap");
     f32x4 preg[2][PPASS];
     auto fetch = [&](int cb, auto SET) {
         constexpr int S = decltype(SET)::value;
@@ -445,7 +453,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             const int item = s * (WAVES * 64) + (int)threadIdx.x;
             if (item < PITEMS) {
                 const int pp = item >> 2, qd = item & 3;
-                const int iy = reflect(ty0 + pp / PW - 1, a.H), ix = reflect(tx0 + pp % PW - 1, a.W);
+                const int iy = reflect(STRIDE * ty0 + pp / PCOLS - 1, a.H), ix = reflect(STRIDE * tx0 + pp % PCOLS - 1, a.W);
                 // tiles may hang far over the image, where the reflection itself leaves it: clamp (those outputs are never written)
                 const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
                 preg[S][s] = *reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + cy) * a.W + cx) * a.Cin + 16 * cb + 4 * qd);
@@ -472,7 +480,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             }
             v *= X_SCALE;
             const unsigned h0 = pk_hi(v[0], v[1]), h1 = pk_hi(v[2], v[3]);
-            unsigned* d = reinterpret_cast<unsigned*>(pb + pp * PPX + qd * 8);
+            unsigned* d = reinterpret_cast<unsigned*>(pb + ppos(pp / PCOLS, pp % PCOLS) * PPX + qd * 8);
             d[0] = h0; d[1] = h1;
             d[8] = lo_pair(h0, v[0], v[1]); d[9] = lo_pair(h1, v[2], v[3]);           // lo block starts 32 bytes in
         }
@@ -487,7 +495,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
-                const unsigned char* q = pb + ((RW * wave + t + ky) * PW + px + kx) * PPX + half * 16;
+                const unsigned char* q = pb + ppos(STRIDE * (RW * wave + t) + ky, STRIDE * px + kx) * PPX + half * 16;
                 b[slot][t].hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q));
                 b[slot][t].lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q + 32));
             }
@@ -521,6 +529,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
             if (cb_next >= 0) {
                 wload(tap, cb_next);
                 if (tap < PPASS) park_item(tap, buf ^ 1, cb_next, SET);
+                if (9 + tap < PPASS) park_item(9 + tap, buf ^ 1, cb_next, SET);
             }
         }
     };
@@ -745,16 +754,16 @@ int conv3x3_rows(int ho, int wo) {
     return ((ho + 7) / 8) * ((wo + TW - 1) / TW) <= f_max && ho > 4 ? 1 : 2;
 }
 
-template <int COT, int RW>
+template <int COT, int RW, int STRIDE = 1>
 int launch_conv3x3_as(const ConvArgs& a, int N, int tiles, void* stream) {
     // two patch buffers (+ the input norm's table); never less than what the epilogue's reductions use (tile sums, finalize)
-    size_t lds = 2 * (size_t)patch_bytes(RW) + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
+    size_t lds = 2 * (size_t)patch_bytes(RW, STRIDE) + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
     if (lds < 16384) lds = 16384;
-    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW>);
+    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW, STRIDE>);
     // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
     const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / COT));
-    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW>), grid, dim3(WAVES * 64), lds, S_(stream), a);
+    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW, STRIDE>), grid, dim3(WAVES * 64), lds, S_(stream), a);
     return status();
 }
 
@@ -772,6 +781,12 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     const int cot = (f_cot == 2 && a.CT % 2 == 0) ? 2 : 1;
     if (rw == 1) return cot == 2 ? launch_conv3x3_as<2, 1>(a, N, tiles, stream) : launch_conv3x3_as<1, 1>(a, N, tiles, stream);
     return cot == 2 ? launch_conv3x3_as<2, 2>(a, N, tiles, stream) : launch_conv3x3_as<1, 2>(a, N, tiles, stream);
+}
+
+// 3x3 stride 2 (the entry of every residual stage): the same kernel on 4-row output tiles, whose input patch is 9 x 65 pixels
+int launch_conv3x3_s2(const ConvArgs& a, int N, void* stream) {
+    const int tiles = ((a.Ho + 3) / 4) * ((a.Wo + TW - 1) / TW);
+    return launch_conv3x3_as<1, 1, 2>(a, N, tiles, stream);
 }
 
 }  // namespace
@@ -799,6 +814,7 @@ int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int
     if (h < 1 || w < 1 || (ks != 1 && ks != 3 && ks != 7) || (stride != 1 && stride != 2)) return 0;
     const int pad = ks / 2, ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
     if (ks == 3 && stride == 1 && cin >= 8) { const int th = tile_rows(conv3x3_rows(ho, wo)); return ((ho + th - 1) / th) * ((wo + TW - 1) / TW); }
+    if (ks == 3 && stride == 2 && cin >= 8) return ((ho + 3) / 4) * ((wo + TW - 1) / TW);
     return (ho * wo + WAVES * PT * 32 - 1) / (WAVES * PT * 32);
 }
 
@@ -812,7 +828,7 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
     if (h <= pad || w <= pad) return GPNERF_E_ARG;                       // reflection needs pad < size
     const bool narrow = cin < 8;
     if (!narrow && (cin & 15)) return GPNERF_E_ARG;                       // full 16-channel chunks, 32-byte aligned loads
-    if (in_table && !(ks == 3 && stride == 1 && !narrow)) return GPNERF_E_ARG;      // the staged form is the 3x3 stride-1 kernel's
+    if (in_table && !(ks == 3 && !narrow)) return GPNERF_E_ARG;                     // the staged form is the 3x3 kernel's
     if (in_table && (in_act < 0 || in_act > 1 || cin > 1024)) return GPNERF_E_ARG;
     if (out_table && (!tile_stats || !gamma || !beta || !counters)) return GPNERF_E_ARG;
     ConvArgs a;
@@ -827,7 +843,7 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
         return GPNERF_E_ARG;
     }
     if (ks == 3 && stride == 1) return launch_conv3x3(a, n, stream);
-    if (ks == 3 && stride == 2) return launch_conv<3, 2, false>(a, n, stream);
+    if (ks == 3 && stride == 2) return launch_conv3x3_s2(a, n, stream);
     if (ks == 1 && stride == 1) return launch_conv<1, 1, false>(a, n, stream);
     if (ks == 1 && stride == 2) return launch_conv<1, 2, false>(a, n, stream);
     return GPNERF_E_ARG;
