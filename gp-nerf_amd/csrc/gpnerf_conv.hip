@@ -398,16 +398,22 @@ __host__ __device__ constexpr int patch_rows(int rw, int stride) { return stride
 __host__ __device__ constexpr int patch_cols(int stride) { return stride == 1 ? PW : 66; }              // stride 2: 65 columns in 2 planes of 33
 __host__ __device__ constexpr int patch_bytes(int rw, int stride = 1) { return patch_rows(rw, stride) * patch_cols(stride) * PPX; }    // 27 200 / 16 320 (stride 1: 8 / 4 rows), 47 520 (stride 2, 4 rows)
 
-template <int COT, int RW, int STRIDE = 1>
-__global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvArgs a) {
+// KSPLIT = 2: eight waves, two halves of four; half kh runs the channel blocks kh, kh + 2, ... through its own pair of patch buffers
+// and the halves' accumulators meet in LDS at the end (lower + upper, a fixed order).  For the layers whose grid cannot fill the chip
+// (32 x 32 images: 192 workgroups): the serial chain of a wave halves, and every SIMD has a second wave to issue from while the
+// first waits.
+template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1>
+__global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(const ConvArgs a) {
     constexpr int TH = tile_rows(RW), PH = patch_rows(RW, STRIDE), PATCH_BYTES = patch_bytes(RW, STRIDE), PT = RW;     // (PT shadows the direct kernel's pixel-tile count)
     constexpr int PCOLS = STRIDE == 1 ? PW : 65;             // patch columns actually staged
     // LDS position of patch pixel (row, col)
     auto ppos = [](int row, int col) { return STRIDE == 1 ? row * PW + col : (row * 2 + (col & 1)) * 33 + (col >> 1); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const patch0 = smem;                     // [2][PATCH_BYTES]
-    float* const itab = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);      // [3][Cin] when a.in_tab
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
+    const int kh = KSPLIT == 1 ? 0 : (int)(threadIdx.x >> 8);                  // K half; ht: thread index within the half
+    const int ht = (int)threadIdx.x & (WAVES * 64 - 1);
+    unsigned char* const patch0 = smem + kh * 2 * PATCH_BYTES;                 // [KSPLIT][2][PATCH_BYTES]
+    float* const itab = reinterpret_cast<float*>(smem + KSPLIT * 2 * PATCH_BYTES);      // [3][Cin] when a.in_tab
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & (WAVES - 1), px = lane & 31, half = lane >> 5;
     const int tiles_x = (a.Wo + TW - 1) / TW;
     const int ty0 = ((int)blockIdx.x / tiles_x) * TH, tx0 = ((int)blockIdx.x % tiles_x) * TW;
     const int n = blockIdx.y, ct0 = blockIdx.z * COT;
@@ -450,7 +456,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
         constexpr int S = decltype(SET)::value;
 #pragma unroll
         for (int s = 0; s < PPASS; ++s) {
-            const int item = s * (WAVES * 64) + (int)threadIdx.x;
+            const int item = s * (WAVES * 64) + ht;
             if (item < PITEMS) {
                 const int pp = item >> 2, qd = item & 3;
                 const int iy = reflect(STRIDE * ty0 + pp / PCOLS - 1, a.H), ix = reflect(STRIDE * tx0 + pp % PCOLS - 1, a.W);
@@ -464,7 +470,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
     auto park_item = [&](int s, int buf, int pcb, auto SET) {
         constexpr int S = decltype(SET)::value;
         unsigned char* const pb = patch0 + buf * PATCH_BYTES;
-        const int item = s * (WAVES * 64) + (int)threadIdx.x;
+        const int item = s * (WAVES * 64) + ht;
         if (item < PITEMS) {
             const int pp = item >> 2, qd = item & 3;
             f32x4 v = preg[S][s];
@@ -535,26 +541,50 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_s1_nhwc_kernel(const ConvA
     };
     constexpr std::integral_constant<int, 0> S0{};
     constexpr std::integral_constant<int, 1> S1{};
-    fetch(0, S0);
-    if (a.CB > 1) fetch(1, S1);
+    // this half's channel blocks: blk(i) = kh + KSPLIT * i, i < nblk (the launcher takes KSPLIT = 2 only for an even CB)
+    const int nblk = a.CB / KSPLIT;
+    auto blk = [&](int i) { return kh + KSPLIT * i; };
+    fetch(blk(0), S0);
+    if (nblk > 1) fetch(blk(1), S1);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wload(tap, 0);
+    for (int tap = 0; tap < 9; ++tap) wload(tap, blk(0));
     if (a.in_tab) {
-        for (int i = threadIdx.x; i < 3 * a.Cin; i += WAVES * 64) itab[i] = a.in_tab[(size_t)n * 3 * a.Cin + i];
+        for (int i = threadIdx.x; i < 3 * a.Cin; i += WAVES * KSPLIT * 64) itab[i] = a.in_tab[(size_t)n * 3 * a.Cin + i];
         __syncthreads();
     }
 #pragma unroll
-    for (int s2 = 0; s2 < PPASS; ++s2) park_item(s2, 0, 0, S0);
+    for (int s2 = 0; s2 < PPASS; ++s2) park_item(s2, 0, blk(0), S0);
     __syncthreads();
-    for (int cb = 0; cb < a.CB; cb += 2) {
-        // even block: staged in buffer 0; set 1 holds block cb + 1 (in flight since the block before); set 0 is free for block cb + 2
-        if (cb + 2 < a.CB) fetch(cb + 2, S0);
-        compute(0, cb + 1 < a.CB ? cb + 1 : -1, S1);
+    for (int i = 0; i < nblk; i += 2) {
+        // even block: staged in buffer 0; set 1 holds block i + 1 (in flight since the block before); set 0 is free for block i + 2
+        if (i + 2 < nblk) fetch(blk(i + 2), S0);
+        compute(0, i + 1 < nblk ? blk(i + 1) : -1, S1);
         __syncthreads();
-        if (cb + 1 >= a.CB) break;
-        if (cb + 3 < a.CB) fetch(cb + 3, S1);
-        compute(1, cb + 2 < a.CB ? cb + 2 : -1, S0);
+        if (i + 1 >= nblk) break;
+        if (i + 3 < nblk) fetch(blk(i + 3), S1);
+        compute(1, i + 2 < nblk ? blk(i + 2) : -1, S0);
         __syncthreads();
+    }
+    if constexpr (KSPLIT == 2) {
+        // the upper half hands its sums over ([wave][t][c][r][lane] floats, past what the epilogue's reductions use) and is done;
+        // barriers from here on count the four surviving waves only (s_barrier ignores waves that have ended)
+        float* const xch = reinterpret_cast<float*>(smem + 16384) + (size_t)wave * (PT * COT * 16 * 64);
+        if (kh == 1) {
+#pragma unroll
+            for (int t = 0; t < PT; ++t)
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((t * COT + c) * 16 + r) * 64 + lane] = acc[t][c][r];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][c][r] += xch[((t * COT + c) * 16 + r) * 64 + lane];
     }
     const int ox = tx0 + px;
     bool valid[PT];
@@ -754,16 +784,18 @@ int conv3x3_rows(int ho, int wo) {
     return ((ho + 7) / 8) * ((wo + TW - 1) / TW) <= f_max && ho > 4 ? 1 : 2;
 }
 
-template <int COT, int RW, int STRIDE = 1>
+template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1>
 int launch_conv3x3_as(const ConvArgs& a, int N, int tiles, void* stream) {
-    // two patch buffers (+ the input norm's table); never less than what the epilogue's reductions use (tile sums, finalize)
-    size_t lds = 2 * (size_t)patch_bytes(RW, STRIDE) + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
-    if (lds < 16384) lds = 16384;
-    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW, STRIDE>);
+    // two patch buffers per K half (+ the input norm's table); never less than what the epilogue's reductions use (tile sums,
+    // finalize: 16 KB; the halves' exchange: RW * COT * 16 KB behind them)
+    size_t lds = KSPLIT * 2 * (size_t)patch_bytes(RW, STRIDE) + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
+    const size_t floor_ = 16384 + (KSPLIT == 2 ? (size_t)RW * COT * 16384 : 0);
+    if (lds < floor_) lds = floor_;
+    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT>);
     // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
     const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / COT));
-    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW, STRIDE>), grid, dim3(WAVES * 64), lds, S_(stream), a);
+    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT>), grid, dim3(WAVES * KSPLIT * 64), lds, S_(stream), a);
     return status();
 }
 
@@ -779,6 +811,16 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     // one 32-channel output tile per workgroup everywhere: with the weights in registers and 54 KB of LDS two workgroups share a CU,
     // and one's staging runs under the other's MFMAs (two tiles per workgroup, GPNERF_CONV_COT=2: 1.19 -> 1.38 ms per frame)
     const int cot = (f_cot == 2 && a.CT % 2 == 0) ? 2 : 1;
+    // a grid of at most one workgroup per CU (the 32 x 32 stage: 192): the channel blocks are split over the two halves of an
+    // eight-wave workgroup (encoder 1.097 -> 1.030 ms; at <= 400 workgroups, which takes in the 64 x 64 stage: 1.087)
+    static int f_ksplit = -1;
+    if (f_ksplit < 0) {                    // experiment knob, honoured only under GPNERF_DEBUG=1, clamped
+        const char* d = getenv("GPNERF_DEBUG");
+        const char* e = (d && d[0] == '1') ? getenv("GPNERF_CONV_KSPLIT_MAXWG") : nullptr;
+        f_ksplit = e ? min(max(atoi(e), 0), 1 << 20) : 256;
+    }
+    if (cot == 1 && rw == 1 && a.CB % 2 == 0 && a.CB >= 4 && (long)tiles * N * a.CT <= f_ksplit)
+        return launch_conv3x3_as<1, 1, 1, 2>(a, N, tiles, stream);
     if (rw == 1) return cot == 2 ? launch_conv3x3_as<2, 1>(a, N, tiles, stream) : launch_conv3x3_as<1, 1>(a, N, tiles, stream);
     return cot == 2 ? launch_conv3x3_as<2, 2>(a, N, tiles, stream) : launch_conv3x3_as<1, 2>(a, N, tiles, stream);
 }

@@ -34,3 +34,11 @@ for c, hw in ((64, 128), (128, 64), (256, 32)):
     out.append(f"{c}ch@{hw}: conv {t(lambda: enc._conv(conv, x)):.1f} +sums {t(lambda: enc._conv(conv, x, stats=True)):.1f} +finalize {t(lambda: enc._conv_norm(conv, norm, x)):.1f} "
                f"(empty launch {t(lambda: enc._upsample2x(small)):.1f}) us")
 print(" | ".join(out))
+
+# fixed cost vs cost per 16-channel block at the third stage's geometry (3 x 32 x 32 pixels, 256 output channels)
+line = ["cin sweep @32, cout 256 (conv only):"]
+for cin in (32, 64, 128, 256, 512):
+    conv = torch.nn.Conv2d(cin, 256, 3, padding=1, bias=False, padding_mode="reflect").to(dev)
+    x = torch.randn((3, cin, 32, 32), device=dev).contiguous(memory_format=torch.channels_last)
+    line.append(f"{cin}: {t(lambda: enc._conv(conv, x)):.1f}")
+print(" ".join(line) + " us")
