@@ -43,6 +43,11 @@ def check(rows, name):
             continue
         op = t.split()[0]
         ws = 1
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            # nothing falls through an unconditional jump: what follows is another block's start, reached only by jumps (the walk
+            # is linear; the inline-asm consumers this check is for sit in straight-line code behind their MFMAs)
+            recent = []
+            continue
         if op == "s_nop":
             ws = int(t.split()[1], 0) + 1
         if op.startswith("v_mfma") or op.startswith("v_smfma"):
