@@ -116,6 +116,10 @@ SYMBOLS = {
                                       C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_sparse_conv3_mfma": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_sparse_conv3_mfma16": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
+                                             C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_sparse_packed_weight16_bytes": (C.c_int64, [C.c_int32]),
+    "gpnerf_sparse_pack_weight16": (C.c_int, [FP, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_sparse_packed_weight_floats": (C.c_int64, [C.c_int32]),
     "gpnerf_sparse_pack_weight": (C.c_int, [FP, C.c_int32, C.c_int32, FP]),
     "gpnerf_sparse_merge_duplicates": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),

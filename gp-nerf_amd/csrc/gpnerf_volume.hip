@@ -150,6 +150,140 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const float* __restrict_
     }
 }
 
+
+// ---- the same convolution in the encoder's split-precision arithmetic (cin = 16 or 32) --------------------------------------
+// v_mfma_f32_32x32x2_f32 runs on the vector ALUs at 1/16 of the f16 rate: a 32-channel tap above is 16 of them, 1 024 cycles,
+// and a level of ~5 x 10^4 sites 30-39 us.  Here every fp32 operand is f16 hi + lo (gpnerf_conv.hip: hi rounded to nearest, lo the
+// rest, operands scaled by exact powers of two so that lo stays a normal number; three v_mfma_f32_32x32x16_f16 per 16 channels,
+// lo x lo dropped, f32 accumulation): 6 matrix instructions of 32 cycles per 32-channel tap, the conversion of the gathered rows
+// (16 values per lane and tap) in their shadow.  Weights: gpnerf_sparse_pack_weight16 -- per (tap, 16-channel chunk) 2 KB of f16
+// [hi | lo][lane = co + 32 half][8: channels 16 chunk + 8 half ..] followed by 2 KB of the SAME values in fp32 (scaled alike).
+// The f16 range (|16 x| < 65 504) is not given by construction here (BatchNorm + ReLU outputs of trained weights, the code the
+// caller hands in): a wavefront that meets a larger value in a tap runs THAT tap on the fp32 instructions with the fp32 copy
+// of the weights -- same scale, same accumulator, no host round trip, results within the split's 2^-22 of each other.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+constexpr float W16_SCALE = 4096.f, X16_SCALE = 16.f, ACC16_UNSCALE = 1.f / (4096.f * 16.f);
+constexpr int STEP16_BYTES = 4096;                             // one (tap, chunk): 2 KB f16 hi | lo + 2 KB fp32
+__device__ __forceinline__ unsigned pk_hi16(float a, float b) { const h2v r = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, r); }
+__device__ __forceinline__ unsigned lo_pair16(unsigned w, float x0, float x1) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(w), "v"(x1));
+    return r;
+}
+
+template <bool STRIDED, int NC>                                // NC = cin / 16
+__global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restrict__ in, const int32_t* __restrict__ in_grid,
+                                                          const Dims in_dims, const int32_t* __restrict__ out_coords,
+                                                          const int* __restrict__ m_ptr, const int m_cap,
+                                                          const unsigned char* __restrict__ Wp, const int cout,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ out) {
+    __shared__ float red[4][16][64];
+    constexpr int cin = 16 * NC;
+    const int lane = threadIdx.x & 63, s = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int m = m_ptr ? min(*m_ptr, m_cap) : m_cap;
+    const int site = (int)blockIdx.x * 32 + s;
+    if (site - s >= m) return;                                  // whole tile past the end (uniform over the workgroup)
+    const bool valid = site < m;
+    const int od = valid ? out_coords[3 * site] : 0, oh = valid ? out_coords[3 * site + 1] : 0, ow = valid ? out_coords[3 * site + 2] : 0;
+    f32x16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int TAPS = (KV + 3) / 4;                          // taps per wavefront (the last wavefront has one fewer)
+    int nbr[TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+        const int k = wave + 4 * j;
+        const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
+        const int d = (STRIDED ? 2 * od : od) - 1 + kd, h = (STRIDED ? 2 * oh : oh) - 1 + kh, w = (STRIDED ? 2 * ow : ow) - 1 + kw;
+        const bool inb = valid && k < KV && d >= 0 && d < in_dims.d && h >= 0 && h < in_dims.h && w >= 0 && w < in_dims.w;
+        nbr[j] = inb ? in_grid[cell_of(in_dims, d, h, w)] : -1;
+    }
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    // a tap's neighbour row: this lane's 8 channels of every 16-channel chunk (absent neighbours and the fourth wavefront's missing
+    // tap contribute zeros: the MFMA chain is branch-free)
+    auto load_tap = [&](int j, f32x4v (&b)[NC][2]) {
+        const int jj = nbr[j];
+        const float* x = in + (size_t)(jj < 0 ? 0 : jj) * cin + 8 * half;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            b[c][0] = jj >= 0 ? *reinterpret_cast<const f32x4v*>(x + 16 * c) : zero4;
+            b[c][1] = jj >= 0 ? *reinterpret_cast<const f32x4v*>(x + 16 * c + 4) : zero4;
+        }
+    };
+    auto load_w = [&](int j, u32x4v (&a)[NC][2]) {
+        const int k = min(wave + 4 * j, KV - 1);
+        const unsigned char* wk = Wp + (size_t)k * NC * STEP16_BYTES + lane * 16;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            a[c][0] = *reinterpret_cast<const u32x4v*>(wk + c * STEP16_BYTES);
+            a[c][1] = *reinterpret_cast<const u32x4v*>(wk + c * STEP16_BYTES + 1024);
+        }
+    };
+    constexpr int DEPTH = 3;
+    f32x4v buf[DEPTH][NC][2];
+    u32x4v wbuf[DEPTH][NC][2];
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; ++j) { load_tap(j, buf[j]); load_w(j, wbuf[j]); }
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+        if (j + DEPTH - 1 < TAPS) { load_tap(j + DEPTH - 1, buf[(j + DEPTH - 1) % DEPTH]); load_w(j + DEPTH - 1, wbuf[(j + DEPTH - 1) % DEPTH]); }
+        f32x4v xs[NC][2];
+        float big = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                xs[c][q] = buf[j % DEPTH][c][q] * X16_SCALE;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) big = fmaxf(big, fabsf(xs[c][q][i]));
+            }
+        // (a NaN compares false and takes the f16 path, where it stays a NaN)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(big >= 65504.f) != 0, 0)) {
+            const int k = min(wave + 4 * j, KV - 1);
+            const float* w32 = reinterpret_cast<const float*>(Wp + (size_t)k * NC * STEP16_BYTES + 2048) + lane * 8;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4v a0 = *reinterpret_cast<const f32x4v*>(w32 + c * (STEP16_BYTES / 4)),
+                             a1 = *reinterpret_cast<const f32x4v*>(w32 + c * (STEP16_BYTES / 4) + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], xs[c][0][i], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], xs[c][1][i], acc, 0, 0, 0);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            unsigned H[4], Lo[4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                H[2 * q] = pk_hi16(xs[c][q][0], xs[c][q][1]); Lo[2 * q] = lo_pair16(H[2 * q], xs[c][q][0], xs[c][q][1]);
+                H[2 * q + 1] = pk_hi16(xs[c][q][2], xs[c][q][3]); Lo[2 * q + 1] = lo_pair16(H[2 * q + 1], xs[c][q][2], xs[c][q][3]);
+            }
+            const h8v xh = __builtin_bit_cast(h8v, H), xl = __builtin_bit_cast(h8v, Lo);
+            const h8v wh = __builtin_bit_cast(h8v, wbuf[j % DEPTH][c][0]), wl = __builtin_bit_cast(h8v, wbuf[j % DEPTH][c][1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (!valid) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * wave + i;
+        const float v = (((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane]) * ACC16_UNSCALE;
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < cout) out[(size_t)site * cout + co] = fmaxf(fmaf(v, scale[co], shift[co]), 0.f);
+    }
+}
+
 // spconv's strided rulebook takes EVERY input row, so two vertices rounded into one voxel both contribute, while its
 // submanifold lookups find one row per voxel.  Fold the former into the grid formulation: add the features of the other
 // rows of a voxel onto the indexed row (only the vertex level can hold duplicates).
@@ -425,6 +559,52 @@ int gpnerf_sparse_pack_weight(const float* weight, int32_t cin, int32_t cout, fl
                     packed[(((size_t)k * ng + g) * 64 + lane) * 4 + i] = co < cout ? weight[((size_t)k * cin + ci) * cout + co] : 0.f;
                 }
     return GPNERF_OK;
+}
+
+
+int64_t gpnerf_sparse_packed_weight16_bytes(int32_t cin) { return (cin == 16 || cin == 32) ? (int64_t)KV * (cin / 16) * STEP16_BYTES : 0; }
+
+int gpnerf_sparse_pack_weight16(const float* weight, int32_t cin, int32_t cout, void* packed) {
+    if (!weight || !packed || (cin != 16 && cin != 32) || cout < 1 || cout > 32) return GPNERF_E_ARG;
+    const int nc = cin / 16;
+    unsigned char* const p = static_cast<unsigned char*>(packed);
+    for (int k = 0; k < KV; ++k)
+        for (int c = 0; c < nc; ++c) {
+            unsigned char* blk = p + ((size_t)k * nc + c) * STEP16_BYTES;
+            _Float16* hi = reinterpret_cast<_Float16*>(blk);
+            _Float16* lo = reinterpret_cast<_Float16*>(blk + 1024);
+            float* f32 = reinterpret_cast<float*>(blk + 2048);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const int co = lane & 31, ci = 16 * c + 8 * (lane >> 5) + i;
+                    const float w = co < cout ? weight[((size_t)k * cin + ci) * cout + co] : 0.f;
+                    if (!(fabsf(w) < 15.99f)) return GPNERF_E_ARG;          // the packed range (also refuses NaN)
+                    const float ws = w * W16_SCALE;
+                    const _Float16 h = (_Float16)ws;
+                    hi[lane * 8 + i] = h;
+                    lo[lane * 8 + i] = (_Float16)(ws - (float)h);
+                    f32[lane * 8 + i] = ws;
+                }
+        }
+    return GPNERF_OK;
+}
+
+int gpnerf_sparse_conv3_mfma16(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
+                               const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const void* packed_weight16, int32_t cout,
+                               const float* bn_scale, const float* bn_shift, float* out, void* stream) {
+    if (!in || !in_grid || bad(in_dims) || !out_coords || !packed_weight16 || !bn_scale || !bn_shift || !out) return GPNERF_E_ARG;
+    if ((cin != 16 && cin != 32) || cout < 1 || cout > 32 || m_cap < 0) return GPNERF_E_ARG;
+    if (m_cap == 0) return GPNERF_OK;
+    const Dims s{in_dims[0], in_dims[1], in_dims[2]};
+    const dim3 grid((unsigned)((m_cap + 31) / 32)), block(256);         // one workgroup (4 wavefronts, taps dealt out) per 32 sites
+    const unsigned char* wp = static_cast<const unsigned char*>(packed_weight16);
+#define GPNERF_LAUNCH16(ST, NC_)                                                                                                  \
+    hipLaunchKernelGGL((conv_mfma16_kernel<ST, NC_>), grid, block, 0, S_(stream), in, in_grid, s, out_coords, (const int*)m_dev, (int)m_cap, \
+                       wp, (int)cout, bn_scale, bn_shift, out)
+    if (strided) { if (cin == 32) GPNERF_LAUNCH16(true, 2); else GPNERF_LAUNCH16(true, 1); }
+    else { if (cin == 32) GPNERF_LAUNCH16(false, 2); else GPNERF_LAUNCH16(false, 1); }
+#undef GPNERF_LAUNCH16
+    return status();
 }
 
 int gpnerf_sparse_conv3_mfma(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,

@@ -140,12 +140,28 @@ class SparseConvNet(nn.Module):
         if hit is None or hit[0] != key:
             lib = L.lib()
             w = np.ascontiguousarray(mod.weight.detach().float().cpu().numpy().reshape(27, mod.cin, mod.cout))
+            if self._split16(mod):
+                # split-precision image (f16 hi | lo + an fp32 copy); weights beyond its range (|w| >= 15.99) keep the fp32 form
+                packed = np.zeros(int(lib.gpnerf_sparse_packed_weight16_bytes(mod.cin)), np.uint8)
+                rc = lib.gpnerf_sparse_pack_weight16(w.ctypes.data_as(L.FP), mod.cin, mod.cout, packed.ctypes.data_as(C.c_void_p))
+                if rc == 0:
+                    hit = (key, torch.from_numpy(packed).to(dev), True)
+                    cache[id(mod)] = hit
+                    return hit[1], True
             packed = np.zeros(int(lib.gpnerf_sparse_packed_weight_floats(mod.cin)), np.float32)
             L.check(lib.gpnerf_sparse_pack_weight(w.ctypes.data_as(L.FP), mod.cin, mod.cout, packed.ctypes.data_as(L.FP)),
                     "gpnerf_sparse_pack_weight")
-            hit = (key, torch.from_numpy(packed).to(dev))
+            hit = (key, torch.from_numpy(packed).to(dev), False)
             cache[id(mod)] = hit
-        return hit[1]
+        return hit[1], hit[2]
+
+    @staticmethod
+    def _split16(mod):
+        """the split-precision kernel's shapes (gpnerf_sparse_conv3_mfma16); GPNERF_SPARSE_FP32=1 under GPNERF_DEBUG=1 keeps the fp32 form"""
+        import os
+        if os.environ.get("GPNERF_DEBUG") == "1" and os.environ.get("GPNERF_SPARSE_FP32") == "1":
+            return False
+        return mod.cin in (16, 32) and mod.cout <= 32
 
     def plan_levels(self, coord, out_sh, channels=None):
         """The STRUCTURE of a frame's pyramid, which depends on the vertices' voxel coordinates only: the full-resolution index
@@ -210,10 +226,11 @@ class SparseConvNet(nn.Module):
             out = torch.empty((m_cap, mod.cout), device=dev, dtype=torch.float32)
             mp = m_dev.data_ptr() if m_dev is not None else None
             if mod.cin % 8 == 0 and mod.cin <= 32 and mod.cout <= 32:          # matrix-core form
-                wp = self._packed_weight(mod, dev)
-                L.check(lib.gpnerf_sparse_conv3_mfma(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims),
-                                                     coords.data_ptr(), mp, m_cap, wp.data_ptr(), mod.cout, scale.data_ptr(),
-                                                     shift.data_ptr(), out.data_ptr(), st), "gpnerf_sparse_conv3_mfma")
+                wp, split16 = self._packed_weight(mod, dev)
+                fn = lib.gpnerf_sparse_conv3_mfma16 if split16 else lib.gpnerf_sparse_conv3_mfma
+                L.check(fn(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims), coords.data_ptr(), mp, m_cap,
+                           wp.data_ptr(), mod.cout, scale.data_ptr(), shift.data_ptr(), out.data_ptr(), st),
+                        "gpnerf_sparse_conv3_mfma16" if split16 else "gpnerf_sparse_conv3_mfma")
             else:
                 w = mod.weight.detach().float().contiguous()
                 L.check(lib.gpnerf_sparse_conv3(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims), coords.data_ptr(),

@@ -274,6 +274,17 @@ int gpnerf_sparse_pack_weight(const float* weight_host, int32_t cin, int32_t cou
 int gpnerf_sparse_conv3_mfma(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
                              const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const float* packed_weight,
                              int32_t cout, const float* bn_scale, const float* bn_shift, float* out, void* stream);
+/* The same convolution in the encoder's split-precision arithmetic (cin = 16 or 32, cout <= 32): every fp32 operand as f16 hi + lo,
+ * three v_mfma_f32_32x32x16_f16 per 16 input channels, f32 accumulation -- the fp32 matrix instruction above runs at 1/16 of the
+ * f16 rate.  packed_weight16: device copy of gpnerf_sparse_pack_weight16()'s image (host side, model-load time;
+ * gpnerf_sparse_packed_weight16_bytes(cin) bytes; refuses |w| >= 15.99): per (tap, 16-channel chunk) the scaled weights as f16
+ * hi | lo and once more in fp32.  A wavefront that gathers a value beyond the f16 range (|x| >= 4 094) runs that tap on the fp32
+ * instructions with the fp32 copy.  Within 2^-21 (relative to the sum of |terms|) of gpnerf_sparse_conv3_mfma. */
+int64_t gpnerf_sparse_packed_weight16_bytes(int32_t cin);
+int gpnerf_sparse_pack_weight16(const float* weight_host, int32_t cin, int32_t cout, void* packed_host);
+int gpnerf_sparse_conv3_mfma16(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
+                               const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const void* packed_weight16,
+                               int32_t cout, const float* bn_scale, const float* bn_shift, float* out, void* stream);
 /* Before the first strided conv: feat[owner] += feat[i] for every row i whose voxel is indexed by another row (two
  * vertices rounded into one voxel).  spconv's strided rulebook takes every input row; its submanifold lookups one.
  * The rows of a voxel are added in ascending row order (deterministic); scratch: device int32[9 * m], overwritten (a count
