@@ -11,6 +11,7 @@
 // channels-last, the layout the render kernel samples.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/gpnerf_hip.h"
 
@@ -680,7 +681,14 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* wq, co
         return GPNERF_E_ARG;
     const int d_k = d_model / n_head;
     if (d_k & (d_k - 1)) return GPNERF_E_ARG;          // the per-head reduction is a butterfly
-    const int blocks = n < 4096 ? (n + 3) / 4 : 1024;
+    // two workgroups per CU: a wavefront reads its 4 x 32 weight rows once and walks ~3 vertices (6 890 vertices: 128 / 256 / 512 /
+    // 768 / 1 024 / 1 723 workgroups: 52 / 32 / 30 / 37 / 40 / 57 us, tools/probes/attention_time.py)
+    int blocks = n < 2048 ? (n + 3) / 4 : 512;
+    {
+        const char* d = getenv("GPNERF_DEBUG");
+        const char* e = (d && d[0] == '1') ? getenv("GPNERF_ATT_BLOCKS") : nullptr;
+        if (e) blocks = atoi(e) < 1 ? 1 : (atoi(e) > 4096 ? 4096 : atoi(e));
+    }
     if (d_model <= 32 && kv_dim <= 32)
         hipLaunchKernelGGL(vertex_attention_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q,
                            kv, wq, wk, wv, wfc, (int)n, (int)d_model, (int)kv_dim, (int)n_head, (int)views, out);

@@ -5,7 +5,7 @@ python3 - <<'PY'
 import csv, glob
 f = sorted(glob.glob("gpurun_out/sva2/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-fused = [i for i, r in enumerate(rows) if "render_fused_kernel<4, false, false>" in r["Kernel_Name"]]
+fused = [i for i, r in enumerate(rows) if "render_fused_kernel<4" in r["Kernel_Name"]]
 lo = max(i for i, r in enumerate(rows[:fused[-1]]) if "conv2d_nhwc_kernel<1, 1, 1" in r["Kernel_Name"])    # last encoder kernel of the last frame
 t0 = int(rows[lo]["End_Timestamp"]); prev = t0
 for r in rows[lo + 1:fused[-1] + 1]:
