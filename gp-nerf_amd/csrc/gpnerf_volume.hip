@@ -224,7 +224,10 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
             a[c][1] = *reinterpret_cast<const u32x4v*>(wk + c * STEP16_BYTES + 1024);
         }
     };
-    constexpr int DEPTH = 3;
+#ifndef GPNERF_SPARSE16_DEPTH
+#define GPNERF_SPARSE16_DEPTH 2   // 100 registers, 4 waves per SIMD: frame phase 0.300 -> 0.279 ms (3: 130 registers, 4: 162; tools/probes/sparse16_depth.sh)
+#endif
+    constexpr int DEPTH = GPNERF_SPARSE16_DEPTH;
     f32x4v buf[DEPTH][NC][2];
     u32x4v wbuf[DEPTH][NC][2];
 #pragma unroll
