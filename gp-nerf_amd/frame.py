@@ -75,7 +75,7 @@ class Frame:
     re-laid out channels-last on the device.  Built once per target view."""
 
     def __init__(self, src_imgs, featmaps, volumes, src_Ks, src_poses, Rh, Th, bounds_min, voxel_size, out_sh,
-                 head_blob, consts=None):
+                 head_blob, consts=None, imgs4=None):
         """
         src_imgs   [V,3,H,W] in [-1,1] (batch['src_imgs'][0]); de-normalised here (BaseRender.py:231)
         featmaps   [V,32,h,w]           encoder output (BaseRender.py:222)
@@ -85,6 +85,7 @@ class Frame:
         consts     optional: what fetch_host(src_Ks, src_poses, Rh, Th, bounds_min, voxel_size, out_sh) returned earlier, so that
                    building the frame does not synchronise with the device (Renderer.render fetches them before it enqueues
                    the encoder, while the queue is still empty)
+        imgs4      optional: relayout_images(src_imgs) done earlier (Renderer.render does it beside the encoder)
         """
         lib = L.lib()
         dev = src_imgs.device
@@ -100,8 +101,9 @@ class Frame:
         f = L.GpnerfFrame()
         V, _, H, W = src_imgs.shape
         src = src_imgs.contiguous().float()
-        self.imgs = torch.empty((V, H, W, 4), device=dev, dtype=torch.float32)
-        L.check(lib.gpnerf_relayout_images(src.data_ptr(), self.imgs.data_ptr(), V, H, W, st), "gpnerf_relayout_images")
+        if imgs4 is not None and (tuple(imgs4.shape) != (V, H, W, 4) or imgs4.dtype != torch.float32 or imgs4.device != dev or not imgs4.is_contiguous()):
+            raise L.GpnerfError(f"imgs4 must be relayout_images(src_imgs): float32 [{V},{H},{W},4] on {dev}")
+        self.imgs = imgs4 if imgs4 is not None else relayout_images(src)
         fh, fw = featmaps.shape[-2:]
         if (featmaps.dtype == torch.float32 and not featmaps.is_contiguous()
                 and featmaps.is_contiguous(memory_format=torch.channels_last)):
@@ -222,10 +224,21 @@ class Frame:
                           batch["out_sh"][0])
 
     @classmethod
-    def from_batch(cls, batch, featmaps, volumes, voxel_size, head_blob, consts=None):
+    def from_batch(cls, batch, featmaps, volumes, voxel_size, head_blob, consts=None, imgs4=None):
         """batch: the reference's batch dict (leading dim 1) with device tensors."""
         return cls(batch["src_imgs"][0], featmaps, volumes, batch["src_Ks"][0], batch["src_poses"][0], batch["Rh"][0],
-                   batch["Th"][0], batch["bounds"][0, 0], voxel_size, batch["out_sh"][0], head_blob, consts=consts)
+                   batch["Th"][0], batch["bounds"][0, 0], voxel_size, batch["out_sh"][0], head_blob, consts=consts, imgs4=imgs4)
+
+
+def relayout_images(src_imgs):
+    """[V,3,H,W] in [-1,1] -> the frame's [V,H,W,4] image (de-normalised, channels-last, one padding channel: a pixel is one
+    16-byte load), on the current stream (gpnerf_relayout_images)."""
+    _require_gpu(src_imgs, "src_imgs")
+    src = src_imgs.contiguous().float()
+    V, _, H, W = src.shape
+    out = torch.empty((V, H, W, 4), device=src.device, dtype=torch.float32)
+    L.check(L.lib().gpnerf_relayout_images(src.data_ptr(), out.data_ptr(), V, H, W, _stream_ptr(src.device)), "gpnerf_relayout_images")
+    return out
 
 
 def patch_order(mask_at_box, H, W, patch_w=32, patch_h=8):

@@ -139,7 +139,7 @@ class Renderer(nn.Module):
             cache[str(dev)] = vols
         return cache[str(dev)]
 
-    def build_frame(self, batch, featmaps=None, consts=None, prepared=None):
+    def build_frame(self, batch, featmaps=None, consts=None, prepared=None, imgs4=None):
         """Per-frame work after the encoder: volume pyramid, channels-last re-layout, weight image.  consts: Frame.consts_of_batch()
         fetched earlier; with it nothing below synchronises with the device (a batch of one frame: out_sh[0] is the maximum).
         prepared: prepare_builder_inputs() done earlier."""
@@ -148,11 +148,11 @@ class Renderer(nn.Module):
             featmaps = self.encode(batch)
         blob = self.nerfhead.head_blob(dev)
         if "volumes" in batch:
-            return F_.Frame.from_batch(batch, featmaps, batch["volumes"], self.voxel_size, blob, consts=consts)
+            return F_.Frame.from_batch(batch, featmaps, batch["volumes"], self.voxel_size, blob, consts=consts, imgs4=imgs4)
         # No pre-built pyramid: gather the SMPL vertices' per-view features with the image half of the frame
         # (BaseRender.py:128-131,344-347), run the per-frame volume builder (trainhead.py:48-56), then attach it.
         sp_input, smpl_xyz = prepared if prepared is not None else self.prepare_builder_inputs(batch, consts)
-        frame = F_.Frame.from_batch(batch, featmaps, self._placeholder_volumes(dev), self.voxel_size, blob, consts=consts)
+        frame = F_.Frame.from_batch(batch, featmaps, self._placeholder_volumes(dev), self.voxel_size, blob, consts=consts, imgs4=imgs4)
         feat, _ = F_.project_gather(frame, smpl_xyz[0], neg_ray=False)
         smpl_feat = feat[:, :, 3:].unsqueeze(0)                     # [1,6890,V,32]
         volumes = self.nerfhead.sigmahead.build_volumes(sp_input, smpl_feat)
@@ -294,9 +294,10 @@ class Renderer(nn.Module):
                     # order, decided on the device (reading the count on the host would be a synchronisation)
                     order = torch.where(mb.sum() == n, order, torch.arange(n, device=dev, dtype=order.dtype))
             prepared = self.prepare_builder_inputs(batch, consts)      # what the builder needs that does not depend on the encoder
+            imgs4 = F_.relayout_images(batch["src_imgs"][0])           # the frame's channels-last source images
         main.wait_stream(side)
         neg = self._neg_ray(batch)
-        frame = self.build_frame(batch, featmaps, consts, prepared)
+        frame = self.build_frame(batch, featmaps, consts, prepared, imgs4=imgs4)
 
         def fn(r):
             # sharded: `r` is this rank's share, already in patch-major order
