@@ -108,6 +108,26 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const int C
     dst[512 + lane * 8 + j] = __builtin_bit_cast(uint16_t, lo);
 }
 
+// The 7x7 stride-2 stem on <= 4 input channels (conv7x7_s2_stem_kernel): K = (ky, kx, c) with every kernel row padded to
+// 8 columns x 4 channels, 14 chunks of 16: chunk (ky, p), lane half h, j -> kx = 4 p + 2 h + (j >> 2), c = j & 3 -- so that a
+// lane's 8 values of a chunk are two NEIGHBOURING patch pixels x 4 channels, one aligned 16-byte LDS read.  [chunk][ct][hi | lo].
+constexpr int STEM_CHUNKS = 14;
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, const int Cout, const int Cin, const int CT, uint16_t* __restrict__ packed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one (step, lane, j)
+    if (i >= (long)STEM_CHUNKS * CT * 512) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long step = i >> 9;
+    const int ct = (int)(step % CT), ch = (int)(step / CT);
+    const int ky = ch >> 1, pq = ch & 1, kx = 4 * pq + 2 * (lane >> 5) + (j >> 2), c = j & 3;
+    const int co = 32 * ct + (lane & 31);
+    const float v = W_SCALE * ((co < Cout && kx < 7 && c < Cin) ? w[((long)co * Cin + c) * 49 + ky * 7 + kx] : 0.f);
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    uint16_t* dst = packed + step * (STEP_BYTES / 2);
+    dst[lane * 8 + j] = __builtin_bit_cast(uint16_t, hi);
+    dst[512 + lane * 8 + j] = __builtin_bit_cast(uint16_t, lo);
+}
+
 // ---- the convolution ----------------------------------------------------------------------------------------------------
 struct ConvArgs {
     const float* x;           // [N][H][W][Cin]
@@ -625,6 +645,134 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
     }
 }
 
+// ---- 7x7, stride 2, <= 4 input channels: the stem ------------------------------------------------------------------------
+// The direct kernel gathers this layer's operands with eight 4-byte loads per lane and chunk from pixels 24 bytes apart (72 us at
+// 3 x 512 x 512 for 5 us of matrix work).  Here a workgroup owns an 8 x 32 output tile x COT x 32 output channels: its
+// (2*8+5) x (2*32+5)-pixel input patch is loaded once, pixel by pixel (coalesced), scaled and split into hi / lo planes of 8 bytes
+// per pixel (4 channels, the 4th zero); the whole packed weight image of its output tiles (14 chunks, 28 KB per tile) is copied
+// into LDS beside it; then 14 chunks x 3 MFMAs per (pixel tile, output tile), every operand one aligned ds_read_b128
+// (pack_stem_weight_kernel's K order).  No loop over channel blocks, one barrier.
+constexpr int STEM_TH = 8, STEM_PH = 2 * STEM_TH + 5, STEM_PCOLS = 2 * TW + 5, STEM_PITCH = 72;     // patch: 21 rows x 69 (+3 zero) columns
+constexpr int STEM_PLANE = STEM_PH * STEM_PITCH * 8;                                                 // bytes of one plane (hi or lo)
+template <int COT>
+__global__ void __launch_bounds__(WAVES * 64) conv7x7_s2_stem_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const phi = smem;                               // [21][72] x 8 bytes: hi halves of (c0, c1, c2, 0)
+    unsigned char* const plo = smem + STEM_PLANE;
+    unsigned char* const wl = smem + 2 * STEM_PLANE;               // [14][COT][2048]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
+    const int tiles_x = (a.Wo + TW - 1) / TW;
+    const int ty0 = ((int)blockIdx.x / tiles_x) * STEM_TH, tx0 = ((int)blockIdx.x % tiles_x) * TW;
+    const int n = blockIdx.y, ct0 = blockIdx.z * COT;
+    // weights: the chunks of this workgroup's output tiles, 16 bytes per thread and pass
+    constexpr int WITEMS = STEM_CHUNKS * COT * (STEP_BYTES / 16);
+    for (int i = threadIdx.x; i < WITEMS; i += WAVES * 64) {
+        const int within = i & 127, c = (i >> 7) % COT, ch = (i >> 7) / COT;
+        *reinterpret_cast<u32x4*>(wl + i * 16) = *reinterpret_cast<const u32x4*>(
+            reinterpret_cast<const unsigned char*>(a.packed) + ((size_t)ch * a.CT + ct0 + c) * STEP_BYTES + within * 16);
+    }
+    // patch: one pixel per thread and pass; the columns past the patch are zero (they meet zero weights, but must be finite)
+    for (int i = threadIdx.x; i < STEM_PH * STEM_PITCH; i += WAVES * 64) {
+        const int row = i / STEM_PITCH, col = i % STEM_PITCH;
+        unsigned h0 = 0u, h1 = 0u, l0 = 0u, l1 = 0u;
+        if (col < STEM_PCOLS) {
+            const int iy = reflect(2 * ty0 + row - 3, a.H), ix = reflect(2 * tx0 + col - 3, a.W);
+            // tiles may hang far over the image, where the reflection itself leaves it: clamp (those outputs are never written)
+            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+            const float* q = a.x + (((size_t)n * a.H + cy) * a.W + cx) * a.Cin;
+            const float v0 = X_SCALE * q[0], v1 = a.Cin > 1 ? X_SCALE * q[1] : 0.f, v2 = a.Cin > 2 ? X_SCALE * q[2] : 0.f,
+                        v3 = a.Cin > 3 ? X_SCALE * q[3] : 0.f;
+            h0 = pk_hi(v0, v1); h1 = pk_hi(v2, v3);
+            l0 = lo_pair(h0, v0, v1); l1 = lo_pair(h1, v2, v3);
+        }
+        unsigned* dh = reinterpret_cast<unsigned*>(phi + i * 8);
+        unsigned* dl = reinterpret_cast<unsigned*>(plo + i * 8);
+        dh[0] = h0; dh[1] = h1; dl[0] = l0; dl[1] = l1;
+    }
+    __syncthreads();
+
+    f32x16 acc[PT][COT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+    // lane (px, half) of chunk (ky, p): patch pixels (2 oy + ky, 2 ox + 4 p + 2 half) and its right neighbour
+    Frag b[2][PT], w[2][COT];
+    auto read_chunk = [&](int ch, int slot) {
+        const int ky = ch >> 1, pq = ch & 1;
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+            const unsigned char* q = wl + (ch * COT + c) * STEP_BYTES + lane * 16;
+            w[slot][c].hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q));
+            w[slot][c].lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q + 1024));
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int off = ((2 * (PT * wave + t) + ky) * STEM_PITCH + 2 * px + 4 * pq + 2 * half) * 8;
+            b[slot][t].hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(phi + off));
+            b[slot][t].lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(plo + off));
+        }
+    };
+    read_chunk(0, 0);
+#pragma unroll
+    for (int ch = 0; ch < STEM_CHUNKS; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < STEM_CHUNKS) read_chunk(ch + 1, cur ^ 1);
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].lo, b[cur][t].hi, acc[t][c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].hi, b[cur][t].lo, acc[t][c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].hi, b[cur][t].hi, acc[t][c], 0, 0, 0);
+    }
+    __syncthreads();                                             // the epilogue's reductions reuse the LDS
+    const int ox = tx0 + px;
+    bool valid[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) valid[t] = (ty0 + PT * wave + t) < a.Ho && ox < a.Wo;
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * (ct0 + c) + ft(r, half);
+                const float bv = co < a.Cout ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t][c][r] += bv;
+            }
+    }
+    if (a.stats) tile_stats<COT, PT>(acc, valid, reinterpret_cast<float*>(smem), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
+    if (a.out_tab) finalize_if_last<COT>(a, n, ct0, (int)gridDim.x, reinterpret_cast<double*>(smem + 8192));
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        if (!valid[t]) continue;
+        float* yp = a.y + (((size_t)n * a.Ho + ty0 + PT * wave + t) * a.Wo + ox) * a.Cout;
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+            const int co0 = 32 * (ct0 + c);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + 8 * g + 4 * half;
+                if (co + 4 > a.Cout) continue;
+                const f32x4 v = {acc[t][c][4 * g + 0], acc[t][c][4 * g + 1], acc[t][c][4 * g + 2], acc[t][c][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(yp + co) = v;
+            }
+        }
+    }
+}
+
 // ---- InstanceNorm + residual + activation on NHWC -------------------------------------------------------------------------
 // three launches: (1) per (image, 256-pixel chunk, channel) sum and sum of squares in double; (2) per (image, channel) the
 // chunks added in a fixed order (deterministic) -> scale = gamma * rstd, shift = beta - mean * scale; (3) elementwise
@@ -831,18 +979,38 @@ int launch_conv3x3_s2(const ConvArgs& a, int N, void* stream) {
     return launch_conv3x3_as<1, 1, 2>(a, N, tiles, stream);
 }
 
+template <int COT>
+int launch_stem_as(const ConvArgs& a, int N, void* stream) {
+    const int tiles = ((a.Ho + STEM_TH - 1) / STEM_TH) * ((a.Wo + TW - 1) / TW);
+    const size_t lds = 2 * (size_t)STEM_PLANE + (size_t)STEM_CHUNKS * COT * STEP_BYTES;
+    const void* fn = reinterpret_cast<const void*>(&conv7x7_s2_stem_kernel<COT>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
+    const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / COT));
+    hipLaunchKernelGGL((conv7x7_s2_stem_kernel<COT>), grid, dim3(WAVES * 64), lds, S_(stream), a);
+    return status();
+}
+int launch_stem(const ConvArgs& a, int N, void* stream) { return a.CT % 2 == 0 ? launch_stem_as<2>(a, N, stream) : launch_stem_as<1>(a, N, stream); }
+
 }  // namespace
 
 extern "C" {
 
 int64_t gpnerf_conv_packed_bytes(int32_t cout, int32_t cin, int32_t ks) {
     if (cout < 1 || cin < 1 || ks < 1) return 0;
+    if (ks == 7 && cin <= 4) return (int64_t)STEM_CHUNKS * ((cout + 31) / 32) * STEP_BYTES;          // the stem's K order
     const int64_t chunks = cin < 8 ? (ks * ks * cin + 15) / 16 : (int64_t)ks * ks * ((cin + 15) / 16);     // narrow inputs: flat K
     return chunks * ((cout + 31) / 32) * STEP_BYTES;
 }
 
 int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, void* packed, void* stream) {
     if (!weight || !packed || cout < 1 || cin < 1 || (ks != 1 && ks != 3 && ks != 7)) return GPNERF_E_ARG;
+    if (ks == 7 && cin <= 4) {
+        const int CT = (cout + 31) / 32;
+        const long total = (long)STEM_CHUNKS * CT * 512;
+        hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_(stream), weight, (int)cout, (int)cin, CT,
+                           reinterpret_cast<uint16_t*>(packed));
+        return status();
+    }
     const int flat = cin < 8;
     const int CB = flat ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16, CT = (cout + 31) / 32;
     const long total = (flat ? (long)CB : (long)ks * ks * CB) * CT * 512;
@@ -857,6 +1025,7 @@ int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int
     const int pad = ks / 2, ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
     if (ks == 3 && stride == 1 && cin >= 8) { const int th = tile_rows(conv3x3_rows(ho, wo)); return ((ho + th - 1) / th) * ((wo + TW - 1) / TW); }
     if (ks == 3 && stride == 2 && cin >= 8) return ((ho + 3) / 4) * ((wo + TW - 1) / TW);
+    if (ks == 7 && stride == 2 && cin <= 4) return ((ho + STEM_TH - 1) / STEM_TH) * ((wo + TW - 1) / TW);
     return (ho * wo + WAVES * PT * 32 - 1) / (WAVES * PT * 32);
 }
 
@@ -880,7 +1049,8 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
     a.CB = narrow ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16; a.CT = (cout + 31) / 32;
     a.in_tab = in_table; a.in_act = in_act; a.out_tab = out_table; a.gamma = gamma; a.beta = beta; a.eps = eps; a.counters = counters;
     if (narrow) {
-        if (ks == 7 && stride == 2) return launch_conv<7, 2, true>(a, n, stream);
+        if (ks == 7 && stride == 2 && cin <= 4) return launch_stem(a, n, stream);
+        if (ks == 7) return GPNERF_E_ARG;                                  // (7x7 on 5 .. 7 channels: not built)
         if (ks == 3 && stride == 1) return launch_conv<3, 1, true>(a, n, stream);
         return GPNERF_E_ARG;
     }

@@ -101,7 +101,7 @@ def test_conv_entry_point_rejects_unsupported_shapes():
     assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 16, p, None, 30, 3, 1, p, None, None) == -1      # cout not a multiple of 4
     assert lib.gpnerf_conv2d_nhwc(None, 0, 8, 8, 16, p, None, 32, 3, 1, p, None, None) == 0     # nothing to do
     assert lib.gpnerf_conv_out_tiles(128, 128, 64, 3, 1) == 16 * 4 and lib.gpnerf_conv_out_tiles(32, 32, 256, 3, 1) == 8 and lib.gpnerf_conv_out_tiles(64, 64, 128, 3, 1) == 32 and lib.gpnerf_conv_out_tiles(128, 128, 64, 3, 2) == 32
-    assert lib.gpnerf_conv_packed_bytes(64, 3, 7) == 10 * 2 * 2048      # the 3-channel stem: K = 147 flattened into 10 chunks of 16
+    assert lib.gpnerf_conv_packed_bytes(64, 3, 7) == 14 * 2 * 2048      # the 3-channel stem: 7 kernel rows x 2 chunks of (2 x 2 columns x 4 channels)
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 33, 47), (128, 128, 16, 20), (256, 256, 9, 7), (64, 96, 40, 40)])
