@@ -311,6 +311,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
     constexpr int WPASS = (PIECES + WAVES * 64 - 1) / (WAVES * 64);
     u32x4 wreg[WPASS];
     f32x4 xin[PT][2];
+    // an InstanceNorm (+ ReLU) in FRONT of the convolution (a.in_tab; wide inputs only): the chunk's 8 channels of mean / scale / beta
+    // travel with its pixels and are applied where the pixels are split, as nhwc_norm_apply_kernel computes it
+    f32x4 tin[3][2];
+    const float act_floor = (a.in_tab && a.in_act == 1) ? 0.f : -__builtin_inff();
     auto fetch = [&](int q) {
 #pragma unroll
         for (int s = 0; s < WPASS; ++s) {
@@ -326,6 +330,14 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
 #pragma unroll
             for (int t = 0; t < PT; ++t)
                 load_px(a, n, reflect(oy[t] * STRIDE + ky - PAD, a.H), reflect(ox[t] * STRIDE + kx - PAD, a.W), cb, half, xin[t][0], xin[t][1]);
+            if (a.in_tab) {
+                const float* tb = a.in_tab + (size_t)n * 3 * a.Cin + 16 * cb + 8 * half;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    tin[j][0] = *reinterpret_cast<const f32x4*>(tb + (size_t)j * a.Cin);
+                    tin[j][1] = *reinterpret_cast<const f32x4*>(tb + (size_t)j * a.Cin + 4);
+                }
+            }
         }
     };
     auto park = [&](int buf) {
@@ -341,6 +353,17 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
     for (int q = 0; q < nchunk; ++q) {
         const int buf = q & 1;
         Frag b[PT];
+        if constexpr (!NARROW) {
+            if (a.in_tab) {
+#pragma unroll
+                for (int t = 0; t < PT; ++t)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            xin[t][h2][k] = fmaxf(fmaf(xin[t][h2][k] - tin[0][h2][k], tin[1][h2][k], tin[2][h2][k]), act_floor);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < PT; ++t) b[t] = make_frag(xin[t][0], xin[t][1]);
         if (q + 1 < nchunk) fetch(q + 1);                 // next chunk's loads fly while this chunk's MFMAs run
@@ -1039,7 +1062,7 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
     if (h <= pad || w <= pad) return GPNERF_E_ARG;                       // reflection needs pad < size
     const bool narrow = cin < 8;
     if (!narrow && (cin & 15)) return GPNERF_E_ARG;                       // full 16-channel chunks, 32-byte aligned loads
-    if (in_table && !(ks == 3 && !narrow)) return GPNERF_E_ARG;                     // the staged form is the 3x3 kernel's
+    if (in_table && (narrow || ks == 7)) return GPNERF_E_ARG;                       // wide 3x3 (while staging) and 1x1 (while splitting) only
     if (in_table && (in_act < 0 || in_act > 1 || cin > 1024)) return GPNERF_E_ARG;
     if (out_table && (!tile_stats || !gamma || !beta || !counters)) return GPNERF_E_ARG;
     ConvArgs a;

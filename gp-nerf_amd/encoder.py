@@ -152,8 +152,9 @@ def _conv_norm(conv, norm, x, in_tab=None, in_act=0):
 
 
 def _fusable_input_norm(conv):
-    """the staged form of the input norm is the 3x3 stride-1 kernel's"""
-    return conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.in_channels % 16 == 0
+    """convolutions that can apply an InstanceNorm (+ ReLU) to their input while they read it: 3x3 (staging) and 1x1 (splitting)
+    on whole 16-channel blocks"""
+    return conv.kernel_size in ((3, 3), (1, 1)) and conv.in_channels % 16 == 0
 
 
 def _apply(x, tab, act, residual=None, res_tab=None):
@@ -186,17 +187,26 @@ class ResidualUnit(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(_mk_conv(cin, cout, 1, stride), _inorm(cout))
 
-    def forward(self, x):
+    def forward(self, x, x_tab=None):
         # conv1 -> [bn1 + ReLU applied while conv2 stages its input] -> conv2 -> one pass: relu(bn2(.) + shortcut), the projected
-        # shortcut's own InstanceNorm applied on the fly: 4 launches per unit (5 with a projection) instead of 7 (10)
-        y1, t1 = _conv_norm(self.conv1, self.bn1, x)
+        # shortcut's own InstanceNorm applied on the fly: 4 launches per unit (5 with a projection) instead of 7 (10).
+        # x_tab: x is a convolution's raw output whose InstanceNorm + ReLU is still pending (its table).  A unit with a projected
+        # shortcut reads x twice, through two convolutions that can both apply the table as they read -- x is then never written
+        # normalised; any other unit needs the tensor itself (the identity shortcut adds it).
+        act0 = 0
+        if x_tab is not None:
+            if self.downsample is not None and _fusable_input_norm(self.conv1) and _fusable_input_norm(self.downsample[0]):
+                act0 = 1
+            else:
+                x, x_tab = _apply(x, x_tab, 1), None
+        y1, t1 = _conv_norm(self.conv1, self.bn1, x, in_tab=x_tab, in_act=act0)
         if _fusable_input_norm(self.conv2):
             y2, t2 = _conv_norm(self.conv2, self.bn2, y1, in_tab=t1, in_act=1)
         else:
             y2, t2 = _conv_norm(self.conv2, self.bn2, _apply(y1, t1, 1))
         if self.downsample is None:
             return _apply(y2, t2, 1, residual=x)
-        d, td = _conv_norm(self.downsample[0], self.downsample[1], x)
+        d, td = _conv_norm(self.downsample[0], self.downsample[1], x, in_tab=x_tab, in_act=act0)
         return _apply(y2, t2, 1, residual=d, res_tab=td)
 
 
@@ -334,8 +344,10 @@ class ResUNet(nn.Module):
         recognises (no re-layout launch)."""
         _require_gpu_inference(x, self.training)
         self.check_operand_range(x.shape[-2], x.shape[-1])
-        x = _apply(*_conv_norm(self.conv1, self.bn1, x.float()), 1)
-        x1 = self.layer1(x)
+        y0, t0 = _conv_norm(self.conv1, self.bn1, x.float())      # bn1 + ReLU: applied by the two convolutions that read y0
+        x1 = self.layer1[0](y0, t0)
+        for unit in list(self.layer1)[1:]:
+            x1 = unit(x1)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
         x = self.iconv3(_concat_skip(x2, self.upconv3(x3)))

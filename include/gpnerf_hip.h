@@ -329,7 +329,7 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
  *   conv - norm, UNet.py:38-53):
  *     in_table  NULL, or [N][3][cin] floats (mean, gamma * rstd, beta per channel, what out_table below produces): the
  *               convolution then reads act((x - mean) * scale + beta) instead of x while it stages its input, act = ReLU for
- *               in_act 1, identity for 0 -- the normalised tensor is never written.  3x3 stride-1 convolutions with cin % 16 == 0.
+ *               in_act 1, identity for 0 -- the normalised tensor is never written.  3x3 and 1x1 convolutions with cin % 16 == 0.
  *     out_table NULL, or [N][3][cout] floats that receive mean / gamma * rstd / beta of InstanceNorm2d(y; gamma, beta, eps): the
  *               last workgroup to finish an (image, 32..64-channel group) adds that group's tile_stats rows in double, in tile
  *               order (deterministic), so no separate reduction launch follows the convolution.  Needs tile_stats, gamma, beta and

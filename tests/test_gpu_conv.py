@@ -133,3 +133,27 @@ def test_fused_norms_around_a_convolution_match_the_separate_launches(cin, cout,
         if cin == cout:
             out = enc._apply(y_fus, t_fus, 1, residual=y0, res_tab=t0)                # shortcut normalised on the fly
             assert float((out.double() - F.relu(ref + n0(c0(x.double())))).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("ks,stride", [(1, 2), (1, 1), (3, 2)])
+def test_input_norm_is_applied_by_every_convolution_that_can_read_through_it(ks, stride, enc):
+    """A pending InstanceNorm + ReLU in front of a 1x1 convolution (applied where the direct kernel splits its pixels) and of the
+    stride-2 3x3 (applied while it stages its patch): bit for bit the convolution of the materialised tensor -- the stem's output is
+    read this way by the first residual unit's two convolutions and never written normalised."""
+    g = torch.Generator().manual_seed(10 * ks + stride)
+    dev = "cuda:0"
+    cin, cout = 64, 96
+    c0 = torch.nn.Conv2d(cin, cin, 3, padding=1, bias=False, padding_mode="reflect").to(dev)
+    n0 = torch.nn.InstanceNorm2d(cin, track_running_stats=False, affine=True).to(dev)
+    c1 = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False, padding_mode="reflect").to(dev)
+    n1 = torch.nn.InstanceNorm2d(cout, track_running_stats=False, affine=True).to(dev)
+    with torch.no_grad():
+        n0.weight.copy_(1 + 0.2 * torch.randn(n0.weight.shape, generator=g)); n0.bias.copy_(0.2 * torch.randn(n0.bias.shape, generator=g))
+        x = (torch.randn((3, cin, 37, 45), generator=g) * 2 + 0.5).to(dev)
+        y0, t0 = enc._conv_norm(c0, n0, x)
+        assert enc._fusable_input_norm(c1)
+        y_mat, t_mat = enc._conv_norm(c1, n1, enc._apply(y0, t0, 1))
+        y_fus, t_fus = enc._conv_norm(c1, n1, y0, in_tab=t0, in_act=1)
+        assert torch.equal(y_mat, y_fus) and torch.equal(t_mat, t_fus)
+        ref = c1.double()(F.relu(n0.double()(c0.double()(x.double()))))
+        assert float((y_fus.double() - ref).abs().max()) < 5e-5 * max(1.0, float(ref.abs().max()))
