@@ -145,6 +145,10 @@ struct ConvArgs {
     const float* beta;
     float eps;
     unsigned* counters;       // [N][gridDim.z], zero before the launch, left zero
+    // a channel concatenation read in place (3x3 stride-1 kernel only): channels 0 .. CinA of x ([N][H][W][CinA]), the rest of x2
+    // ([N][H][W][Cin - CinA]); x2 nullptr: CinA = Cin
+    const float* x2;
+    int CinA;
 };
 
 // Last-arriving workgroup of (image n, channel group ct0 .. ct0 + COT): every workgroup has written its tile sums; the one whose
@@ -445,7 +449,7 @@ __host__ __device__ constexpr int patch_bytes(int rw, int stride = 1) { return p
 // and the halves' accumulators meet in LDS at the end (lower + upper, a fixed order).  For the layers whose grid cannot fill the chip
 // (32 x 32 images: 192 workgroups): the serial chain of a wave halves, and every SIMD has a second wave to issue from while the
 // first waits.
-template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1>
+template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1, bool CAT = false>
 __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(const ConvArgs a) {
     constexpr int TH = tile_rows(RW), PH = patch_rows(RW, STRIDE), PATCH_BYTES = patch_bytes(RW, STRIDE), PT = RW;     // (PT shadows the direct kernel's pixel-tile count)
     constexpr int PCOLS = STRIDE == 1 ? PW : 65;             // patch columns actually staged
@@ -505,7 +509,17 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
                 const int iy = reflect(STRIDE * ty0 + pp / PCOLS - 1, a.H), ix = reflect(STRIDE * tx0 + pp % PCOLS - 1, a.W);
                 // tiles may hang far over the image, where the reflection itself leaves it: clamp (those outputs are never written)
                 const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+                if constexpr (CAT) {
+                // the decoder's [up, skip] concatenations are never materialised: a block's channels come from one tensor or the
+                // other (an instantiation of its own: the pixel stride changes with the block, which costs the other layers' loops
+                // an address multiplication per item)
+                const bool second = 16 * cb >= a.CinA;
+                const float* const src = second ? a.x2 : a.x;
+                const int cs = second ? a.Cin - a.CinA : a.CinA, c0 = 16 * cb - (second ? a.CinA : 0);
+                preg[S][s] = *reinterpret_cast<const f32x4*>(src + (((size_t)n * a.H + cy) * a.W + cx) * cs + c0 + 4 * qd);
+            } else {
                 preg[S][s] = *reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + cy) * a.W + cx) * a.Cin + 16 * cb + 4 * qd);
+            }
             }
         }
     };
@@ -955,18 +969,18 @@ int conv3x3_rows(int ho, int wo) {
     return ((ho + 7) / 8) * ((wo + TW - 1) / TW) <= f_max && ho > 4 ? 1 : 2;
 }
 
-template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1>
+template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1, bool CAT = false>
 int launch_conv3x3_as(const ConvArgs& a, int N, int tiles, void* stream) {
     // two patch buffers per K half (+ the input norm's table); never less than what the epilogue's reductions use (tile sums,
     // finalize: 16 KB; the halves' exchange: RW * COT * 16 KB behind them)
     size_t lds = KSPLIT * 2 * (size_t)patch_bytes(RW, STRIDE) + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
     const size_t floor_ = 16384 + (KSPLIT == 2 ? (size_t)RW * COT * 16384 : 0);
     if (lds < floor_) lds = floor_;
-    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT>);
+    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT, CAT>);
     // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
     const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / COT));
-    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT>), grid, dim3(WAVES * KSPLIT * 64), lds, S_(stream), a);
+    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT, CAT>), grid, dim3(WAVES * KSPLIT * 64), lds, S_(stream), a);
     return status();
 }
 
@@ -982,6 +996,7 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     // one 32-channel output tile per workgroup everywhere: with the weights in registers and 54 KB of LDS two workgroups share a CU,
     // and one's staging runs under the other's MFMAs (two tiles per workgroup, GPNERF_CONV_COT=2: 1.19 -> 1.38 ms per frame)
     const int cot = (f_cot == 2 && a.CT % 2 == 0) ? 2 : 1;
+    if (a.x2) return rw == 1 ? launch_conv3x3_as<1, 1, 1, 1, true>(a, N, tiles, stream) : launch_conv3x3_as<1, 2, 1, 1, true>(a, N, tiles, stream);
     // a grid of at most one workgroup per CU (the 32 x 32 stage: 192): the channel blocks are split over the two halves of an
     // eight-wave workgroup (encoder 1.097 -> 1.030 ms; at <= 400 workgroups, which takes in the 64 x 64 stage: 1.087)
     static int f_ksplit = -1;
@@ -1052,6 +1067,21 @@ int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int
     return (ho * wo + WAVES * PT * 32 - 1) / (WAVES * PT * 32);
 }
 
+int gpnerf_conv2d_norm_cat_nhwc(const float* x, int32_t cin_a, const float* x_b, int32_t cin_b, int32_t n, int32_t h, int32_t w,
+                                const void* packed, const float* bias, int32_t cout, float* y, float* tile_stats, const float* gamma,
+                                const float* beta, float eps, float* out_table, uint32_t* counters, void* stream) {
+    if (n == 0) return GPNERF_OK;
+    if (!x || !x_b || !packed || !y || n < 0 || h < 2 || w < 2 || cin_a < 16 || (cin_a & 15) || cin_b < 16 || (cin_b & 15) || cout < 4 || (cout & 3))
+        return GPNERF_E_ARG;
+    if (out_table && (!tile_stats || !gamma || !beta || !counters)) return GPNERF_E_ARG;
+    ConvArgs a;
+    a.x = x; a.x2 = x_b; a.CinA = cin_a; a.packed = reinterpret_cast<const uint16_t*>(packed); a.bias = bias; a.y = y; a.stats = tile_stats;
+    a.H = h; a.W = w; a.Cin = cin_a + cin_b; a.Cout = cout; a.Ho = h; a.Wo = w;
+    a.CB = a.Cin / 16; a.CT = (cout + 31) / 32;
+    a.in_tab = nullptr; a.in_act = 0; a.out_tab = out_table; a.gamma = gamma; a.beta = beta; a.eps = eps; a.counters = counters;
+    return launch_conv3x3(a, n, stream);
+}
+
 int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* in_table, int32_t in_act,
                             const void* packed, const float* bias, int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats,
                             const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, void* stream) {
@@ -1066,7 +1096,7 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
     if (in_table && (in_act < 0 || in_act > 1 || cin > 1024)) return GPNERF_E_ARG;
     if (out_table && (!tile_stats || !gamma || !beta || !counters)) return GPNERF_E_ARG;
     ConvArgs a;
-    a.x = x; a.packed = reinterpret_cast<const uint16_t*>(packed); a.bias = bias; a.y = y; a.stats = tile_stats;
+    a.x = x; a.x2 = nullptr; a.CinA = cin; a.packed = reinterpret_cast<const uint16_t*>(packed); a.bias = bias; a.y = y; a.stats = tile_stats;
     a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
     a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
     a.CB = narrow ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16; a.CT = (cout + 31) / 32;

@@ -151,6 +151,28 @@ def _conv_norm(conv, norm, x, in_tab=None, in_act=0):
     return out, tab
 
 
+def _conv_norm_cat(conv, norm, xa, xb):
+    """_conv_norm on torch.cat([xa, xb], 1) without writing the concatenation (gpnerf_conv2d_norm_cat_nhwc: a 3x3 stride-1 convolution
+    whose channel blocks come from one tensor or the other).  Returns (y, table)."""
+    xa, xb = _nhwc(xa), _nhwc(xb)
+    n, ca, h, w = xa.shape
+    cb = xb.shape[1]
+    cout = conv.weight.shape[0]
+    lib = L.lib()
+    out = torch.empty((n, cout, h, w), device=xa.device, dtype=torch.float32, memory_format=torch.channels_last)
+    bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+    ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, ca + cb, 3, 1)), cout, 2), device=xa.device, dtype=torch.float32)
+    tab = torch.empty((n, 3, cout), device=xa.device, dtype=torch.float32)
+    tick = _ticket_words(xa.device)
+    if n * ((cout + 31) // 32) > tick.numel():
+        raise L.GpnerfError("too many (image, channel group) pairs for the ticket words")
+    L.check(lib.gpnerf_conv2d_norm_cat_nhwc(xa.data_ptr(), ca, xb.data_ptr(), cb, n, h, w, _packed_weight(conv).data_ptr(),
+                                            bias.data_ptr() if bias is not None else None, cout, out.data_ptr(), ts.data_ptr(),
+                                            norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), tab.data_ptr(), tick.data_ptr(),
+                                            _st(xa)), "gpnerf_conv2d_norm_cat_nhwc")
+    return out, tab
+
+
 def _fusable_input_norm(conv):
     """convolutions that can apply an InstanceNorm (+ ReLU) to their input while they read it: 3x3 (staging) and 1x1 (splitting)
     on whole 16-channel blocks"""
@@ -218,6 +240,8 @@ class ConvNormELU(nn.Module):
         self.conv, self.bn = _mk_conv(cin, cout, k, bias=True), _inorm(cout)
 
     def forward(self, x):
+        if isinstance(x, tuple):                     # (a, b): the concatenation [a, b] on channels, read in place
+            return _apply(*_conv_norm_cat(self.conv, self.bn, *x), 2)
         return _apply(*_conv_norm(self.conv, self.bn, x), 2)
 
 
@@ -245,6 +269,9 @@ def _concat_skip(skip, up):
     dy, dx = up.shape[2] - skip.shape[2], up.shape[3] - skip.shape[3]
     if dy or dx:
         skip = F.pad(skip, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+    if (up.is_cuda and up.shape[1] % 16 == 0 and skip.shape[1] % 16 == 0 and up.dtype == torch.float32 and skip.dtype == torch.float32
+            and not (os.environ.get("GPNERF_DEBUG") == "1" and os.environ.get("GPNERF_ENC_CAT") == "0")):
+        return up, skip                              # the convolution behind reads the two tensors in place (ConvNormELU.forward)
     return torch.cat([up, skip], dim=1)
 
 

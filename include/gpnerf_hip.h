@@ -334,6 +334,9 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
  *               last workgroup to finish an (image, 32..64-channel group) adds that group's tile_stats rows in double, in tile
  *               order (deterministic), so no separate reduction launch follows the convolution.  Needs tile_stats, gamma, beta and
  *               `counters`: at least N * ceil(cout / 32) uint32 words that are zero before the call; they are zero again after it.
+ * conv2d_norm_cat_nhwc = the 3x3 stride-1 convolution of conv2d_norm_nhwc on the channel concatenation [x (cin_a channels), x_b (cin_b)]
+ *   of two NHWC tensors of one size (UNet.py:199-211's torch.cat([up, skip], 1) in front of iconv3 / iconv2), read in place: the
+ *   concatenated tensor is never written.  cin_a, cin_b multiples of 16; `packed` is the image of the [cout][cin_a + cin_b][3][3] weight.
  * norm_apply_nhwc = act((x - mean) * scale + beta [+ residual]) from such a table; with res_table the residual is itself
  *   normalised on the fly ((residual - rmean) * rscale + rbeta: the projected shortcut's InstanceNorm, UNet.py:48-51).
  * upsample2x_nhwc = F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (UNet.py:129). */
@@ -342,6 +345,9 @@ int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int3
 int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t stride);
 int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
                        int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, void* stream);
+int gpnerf_conv2d_norm_cat_nhwc(const float* x, int32_t cin_a, const float* x_b, int32_t cin_b, int32_t n, int32_t h, int32_t w,
+                                const void* packed, const float* bias, int32_t cout, float* y, float* tile_stats, const float* gamma,
+                                const float* beta, float eps, float* out_table, uint32_t* counters, void* stream);
 int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* in_table, int32_t in_act,
                             const void* packed, const float* bias, int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats,
                             const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, void* stream);
