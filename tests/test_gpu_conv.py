@@ -17,6 +17,13 @@ def enc():
 
 CONVS = [  # cin, cout, ks, stride, H, W, bias
     (3, 64, 7, 2, 40, 56, False),        # stem (narrow input)
+    (3, 64, 7, 2, 37, 45, False),        # stem: ragged tiles, odd sizes
+    (3, 64, 7, 2, 130, 70, True),        # stem: several tiles, bias
+    (3, 32, 7, 2, 8, 8, False),          # stem: one output tile, one 32-channel tile
+    (3, 96, 7, 2, 21, 90, False),        # stem: three output tiles (one per workgroup)
+    (4, 64, 7, 2, 24, 24, False),        # stem: four input channels
+    (64, 128, 3, 2, 33, 47, False),      # stride-2 3x3: ragged tiles, odd sizes
+    (128, 64, 3, 2, 70, 130, True),      # stride-2 3x3: several tiles
     (64, 64, 3, 1, 33, 47, False),       # ragged pixel tiles
     (64, 128, 3, 2, 32, 32, False),
     (64, 128, 1, 2, 32, 32, False),      # projected shortcut
@@ -157,3 +164,26 @@ def test_input_norm_is_applied_by_every_convolution_that_can_read_through_it(ks,
         assert torch.equal(y_mat, y_fus) and torch.equal(t_mat, t_fus)
         ref = c1.double()(F.relu(n0.double()(c0.double()(x.double()))))
         assert float((y_fus.double() - ref).abs().max()) < 5e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("ca,cb,cout,H,W", [(128, 128, 128, 64, 64), (64, 64, 32, 72, 40), (32, 16, 64, 9, 33), (128, 128, 128, 24, 40)])
+def test_concatenation_read_in_place_equals_the_convolution_of_the_concatenated_tensor(ca, cb, cout, H, W, enc):
+    """gpnerf_conv2d_norm_cat_nhwc (4-row and 8-row tile forms): bit for bit `_conv_norm` on torch.cat([a, b], 1), table included."""
+    g = torch.Generator().manual_seed(ca + cb + H)
+    dev = "cuda:0"
+    conv = torch.nn.Conv2d(ca + cb, cout, 3, padding=1, bias=True, padding_mode="reflect").to(dev)
+    norm = torch.nn.InstanceNorm2d(cout, track_running_stats=False, affine=True).to(dev)
+    a = (torch.randn((3, ca, H, W), generator=g) * 2 + 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    b = (torch.randn((3, cb, H, W), generator=g) - 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y_cat, t_cat = enc._conv_norm(conv, norm, torch.cat([a, b], 1))
+        y_inp, t_inp = enc._conv_norm_cat(conv, norm, a, b)
+        if (H, W) == (24, 40):
+            # 144 workgroups: the materialised tensor takes the K-split form (two halves' sums added at the end), the in-place
+            # read does not -- the same terms in another order
+            assert float((y_cat - y_inp).abs().max()) < 2e-5 and float((t_cat - t_inp).abs().max()) < 2e-5
+        else:
+            assert torch.equal(y_cat, y_inp) and torch.equal(t_cat, t_inp)
+        assert int(enc._ticket_words(a.device).abs().sum()) == 0
+        ref = conv.double()(torch.cat([a, b], 1).double())
+        assert float((y_inp.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
