@@ -102,6 +102,25 @@ def test_encoder_on_gpu_feeds_frame_without_relayout(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(100, 140), (136, 72), (200, 264), (52, 60)])
+def test_encoder_at_sizes_that_pad_the_skips_and_leave_ragged_tiles(H, W):
+    """Sizes that are not multiples of 8: the decoder pads its skip tensors (UNet.py:199-211), every layer has ragged workgroup
+    tiles (stem and stride-2 patches hanging over the image, reflection at both borders), and the concatenations are read in
+    place.  Checked against the float64 run of the torch-operator restatement (which the golden vectors pin to the reference)."""
+    from oracle import producers_ref as ref
+    net, _ = _net(H + W)
+    imgs = torch.from_numpy(syn.make_encoder_images(H, W, H * W))
+    with torch.no_grad():
+        want = ref.encoder(__import__("copy").deepcopy(net).double(), imgs.double()).float().numpy()
+        got = net.to("cuda:0")(imgs.to("cuda:0"))
+        again = net(imgs.to("cuda:0"))
+    assert torch.equal(got, again)
+    assert got.shape == want.shape
+    err = float(np.abs(got.cpu().numpy() - want).max())
+    assert err < 5e-5, err
+
+
+@pytest.mark.gpu
 def test_encoder_is_bit_deterministic_at_full_size():
     """Three forwards of a 3x512x512 frame give the same bits (every reduction of the kernels has a fixed order, and no result
     may depend on how the wavefronts of a CU interleave): a timing-dependent difference would mean an MFMA result is being read
