@@ -273,8 +273,18 @@ class Renderer(nn.Module):
             side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
         group = P_.resolve_group(self.shard_group)
         sharded = group is not None
+        # The host enqueues in the order the DEVICE needs things: first what the builder needs (it runs right behind the encoder),
+        # then the builder and the frame, and only then the ray list and its patch order, which nobody reads before the per-ray
+        # kernel -- with the encoder at 1.0 ms the host's ~1.4 ms of enqueueing had caught up with the device, and those 0.2 ms of
+        # small tensor operations sat in front of the builder's launches.
         with torch.cuda.stream(side):              # the batch's tensors are complete: render() synchronised at its top
             consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
+            prepared = self.prepare_builder_inputs(batch, consts)      # what the builder needs that does not depend on the encoder
+            imgs4 = F_.relayout_images(batch["src_imgs"][0])           # the frame's channels-last source images
+        main.wait_stream(side)
+        neg = self._neg_ray(batch)
+        frame = self.build_frame(batch, featmaps, consts, prepared, imgs4=imgs4)
+        with torch.cuda.stream(side):
             rays = torch.cat([batch["ray_o"], batch["ray_d"], batch["near"].unsqueeze(-1), batch["far"].unsqueeze(-1)], dim=-1)[0]
             n = rays.shape[0]
             # Which 32 rays share a wavefront is the launch's choice (results do not depend on it): when the batch says which
@@ -293,11 +303,7 @@ class Renderer(nn.Module):
                     # a mask that does not keep exactly the n pixels the rays belong to cannot order them: fall back to list
                     # order, decided on the device (reading the count on the host would be a synchronisation)
                     order = torch.where(mb.sum() == n, order, torch.arange(n, device=dev, dtype=order.dtype))
-            prepared = self.prepare_builder_inputs(batch, consts)      # what the builder needs that does not depend on the encoder
-            imgs4 = F_.relayout_images(batch["src_imgs"][0])           # the frame's channels-last source images
         main.wait_stream(side)
-        neg = self._neg_ray(batch)
-        frame = self.build_frame(batch, featmaps, consts, prepared, imgs4=imgs4)
 
         def fn(r):
             # sharded: `r` is this rank's share, already in patch-major order
