@@ -701,30 +701,47 @@ __global__ void __launch_bounds__(WAVES * 64) conv7x7_s2_stem_kernel(const ConvA
     const int tiles_x = (a.Wo + TW - 1) / TW;
     const int ty0 = ((int)blockIdx.x / tiles_x) * STEM_TH, tx0 = ((int)blockIdx.x % tiles_x) * TW;
     const int n = blockIdx.y, ct0 = blockIdx.z * COT;
+    // Both staging loops are unrolled with every load issued before the first use: left as loops, each of their 14 + 6 passes waited
+    // out a memory round trip (the kernel ran 51 us against 5 us of matrix work).
     // weights: the chunks of this workgroup's output tiles, 16 bytes per thread and pass
-    constexpr int WITEMS = STEM_CHUNKS * COT * (STEP_BYTES / 16);
-    for (int i = threadIdx.x; i < WITEMS; i += WAVES * 64) {
+    constexpr int WITEMS = STEM_CHUNKS * COT * (STEP_BYTES / 16), WPASS = (WITEMS + WAVES * 64 - 1) / (WAVES * 64);
+    u32x4 wv[WPASS];
+#pragma unroll
+    for (int s = 0; s < WPASS; ++s) {
+        const int i = min(s * (WAVES * 64) + (int)threadIdx.x, WITEMS - 1);
         const int within = i & 127, c = (i >> 7) % COT, ch = (i >> 7) / COT;
-        *reinterpret_cast<u32x4*>(wl + i * 16) = *reinterpret_cast<const u32x4*>(
-            reinterpret_cast<const unsigned char*>(a.packed) + ((size_t)ch * a.CT + ct0 + c) * STEP_BYTES + within * 16);
+        wv[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(a.packed) + ((size_t)ch * a.CT + ct0 + c) * STEP_BYTES + within * 16);
     }
     // patch: one pixel per thread and pass; the columns past the patch are zero (they meet zero weights, but must be finite)
-    for (int i = threadIdx.x; i < STEM_PH * STEM_PITCH; i += WAVES * 64) {
-        const int row = i / STEM_PITCH, col = i % STEM_PITCH;
-        unsigned h0 = 0u, h1 = 0u, l0 = 0u, l1 = 0u;
-        if (col < STEM_PCOLS) {
-            const int iy = reflect(2 * ty0 + row - 3, a.H), ix = reflect(2 * tx0 + col - 3, a.W);
-            // tiles may hang far over the image, where the reflection itself leaves it: clamp (those outputs are never written)
-            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-            const float* q = a.x + (((size_t)n * a.H + cy) * a.W + cx) * a.Cin;
-            const float v0 = X_SCALE * q[0], v1 = a.Cin > 1 ? X_SCALE * q[1] : 0.f, v2 = a.Cin > 2 ? X_SCALE * q[2] : 0.f,
-                        v3 = a.Cin > 3 ? X_SCALE * q[3] : 0.f;
-            h0 = pk_hi(v0, v1); h1 = pk_hi(v2, v3);
-            l0 = lo_pair(h0, v0, v1); l1 = lo_pair(h1, v2, v3);
-        }
+    constexpr int PPASS = (STEM_PH * STEM_PITCH + WAVES * 64 - 1) / (WAVES * 64);
+    float pv[PPASS][4];
+#pragma unroll
+    for (int s = 0; s < PPASS; ++s) {
+        const int i = min(s * (WAVES * 64) + (int)threadIdx.x, STEM_PH * STEM_PITCH - 1);
+        const int row = i / STEM_PITCH, col = min(i % STEM_PITCH, STEM_PCOLS - 1);
+        const int iy = reflect(2 * ty0 + row - 3, a.H), ix = reflect(2 * tx0 + col - 3, a.W);
+        // tiles may hang far over the image, where the reflection itself leaves it: clamp (those outputs are never written)
+        const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
+        const float* q = a.x + (((size_t)n * a.H + cy) * a.W + cx) * a.Cin;
+        // (a channel the input does not have repeats the last one: it meets zero weights, and a conditional load would put a
+        // branch and a full wait behind every one of the 18 loads)
+        pv[s][0] = q[0]; pv[s][1] = q[min(1, a.Cin - 1)]; pv[s][2] = q[min(2, a.Cin - 1)]; pv[s][3] = q[min(3, a.Cin - 1)];
+    }
+#pragma unroll
+    for (int s = 0; s < WPASS; ++s) {
+        const int i = min(s * (WAVES * 64) + (int)threadIdx.x, WITEMS - 1);
+        *reinterpret_cast<u32x4*>(wl + i * 16) = wv[s];
+    }
+#pragma unroll
+    for (int s = 0; s < PPASS; ++s) {
+        const int i = min(s * (WAVES * 64) + (int)threadIdx.x, STEM_PH * STEM_PITCH - 1);
+        const bool real = i % STEM_PITCH < STEM_PCOLS;
+        const float v0 = real ? X_SCALE * pv[s][0] : 0.f, v1 = real ? X_SCALE * pv[s][1] : 0.f, v2 = real ? X_SCALE * pv[s][2] : 0.f,
+                    v3 = real ? X_SCALE * pv[s][3] : 0.f;
+        const unsigned h0 = pk_hi(v0, v1), h1 = pk_hi(v2, v3);
         unsigned* dh = reinterpret_cast<unsigned*>(phi + i * 8);
         unsigned* dl = reinterpret_cast<unsigned*>(plo + i * 8);
-        dh[0] = h0; dh[1] = h1; dl[0] = l0; dl[1] = l1;
+        dh[0] = h0; dh[1] = h1; dl[0] = lo_pair(h0, v0, v1); dl[1] = lo_pair(h1, v2, v3);
     }
     __syncthreads();
 
