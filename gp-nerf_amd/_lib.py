@@ -136,6 +136,8 @@ SYMBOLS = {
     "gpnerf_relayout_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_featmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_relayout_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gpnerf_patch_order_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gpnerf_patch_order": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_head_layout": (C.c_int, [C.POINTER(C.c_int32)]),
     "gpnerf_strerror": (C.c_char_p, [C.c_int]),
     "gpnerf_rays_per_tile": (C.c_int32, []),

@@ -2390,6 +2390,130 @@ int launch_head(const float* head_blob, const float* a, const float* rgb_feat, c
                        head_blob, a, rgb_feat, mask, (long)n_points, out, out2);
     return launch_status();
 }
+
+// ---- patch-major order of a frame's kept pixels (frame.patch_order on the device, three launches) --------------------------------
+// order[q] = raster rank (among the kept pixels) of the q-th kept pixel when the image is walked patch by patch (patch_w x patch_h
+// pixels, patches in raster order, pixels inside a patch in raster order).  A workgroup owns a band of patch_h image rows, one
+// wavefront walks a row 64 pixels at a time with ballots (prefix inside the row = popcount below the lane + the row's running sum):
+//   1. po_count_kernel: kept pixels per image row and per patch;
+//   2. po_scan_kernel (one workgroup): both count arrays -> exclusive prefixes; the grand total is compared with the caller's n;
+//   3. po_scatter_kernel: rank = row base + prefix in the row; position = patch base + kept pixels of the patch's earlier rows +
+//      prefix in the patch's row; order[position] = rank.  A mask that does not keep exactly n pixels: order = 0 .. n - 1.
+// scratch (int32): rows[H] | patches[npy * npx] | flag[1]
+constexpr int PO_MAX_PH = 32;
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) po_band_kernel(const uint8_t* __restrict__ mask, const int H, const int W, const int pw, const int ph,
+                                                      int* __restrict__ rows, int* __restrict__ patches, const int n, int* __restrict__ order) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, band = blockIdx.x, npx = (W + pw - 1) / pw;
+    const int* const flag = patches + (size_t)gridDim.x * npx;
+    if (SCATTER && *flag != n) {                         // uniform: the mask does not match the ray list
+        for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < n; i += (int)gridDim.x * 256) order[i] = i;
+        return;
+    }
+    if (!SCATTER) {
+        // rows of the band dealt to the four wavefronts; a row's total, and its patches' totals added up by atomics in LDS-free form:
+        // every patch of the band is touched by ph rows, so the patch counts go through global atomics on zeroed words (integer adds
+        // commute: deterministic)
+        for (int yy = wave; yy < ph; yy += 4) {
+            const int y = band * ph + yy;
+            if (y >= H) break;
+            int run = 0;
+            for (int x0 = 0; x0 < W; x0 += 64) {
+                const int x = x0 + lane;
+                const bool m = x < W && mask[(size_t)y * W + x] != 0;
+                const unsigned long long b = __ballot(m);
+                // the 64 pixels span at most 64 / pw + 1 patches: lanes that START a patch segment add that segment's count
+                const int k = x / pw, xe = min(min((k + 1) * pw, W), x0 + 64);          // end of this lane's segment inside the window
+                if (x < W && (x % pw == 0 || lane == 0)) {
+                    const unsigned long long seg = (xe - x >= 64 ? ~0ull : ((1ull << (xe - x)) - 1ull)) << lane;
+                    const int c = __popcll(b & seg);
+                    if (c) atomicAdd(patches + (size_t)band * npx + k, c);
+                }
+                run += __popcll(b);
+            }
+            if (lane == 0) rows[y] = run;
+        }
+        return;
+    } else {
+        // patch by patch would leave most lanes idle for narrow patches; instead row by row, with the earlier rows' counts of every
+        // patch kept in LDS: pass A counts (patch, row) pairs, pass B scatters
+        extern __shared__ int pr[];                      // [ph][npx] kept pixels of patch k in band row yy
+        for (int i = threadIdx.x; i < ph * npx; i += 256) pr[i] = 0;
+        __syncthreads();
+        for (int yy = wave; yy < ph; yy += 4) {
+            const int y = band * ph + yy;
+            if (y >= H) break;
+            for (int x0 = 0; x0 < W; x0 += 64) {
+                const int x = x0 + lane;
+                const bool m = x < W && mask[(size_t)y * W + x] != 0;
+                const unsigned long long b = __ballot(m);
+                const int k = x / pw, xe = min(min((k + 1) * pw, W), x0 + 64);
+                if (x < W && (x % pw == 0 || lane == 0)) {
+                    const unsigned long long seg = (xe - x >= 64 ? ~0ull : ((1ull << (xe - x)) - 1ull)) << lane;
+                    const int c = __popcll(b & seg);
+                    if (c) atomicAdd(pr + yy * npx + k, c);
+                }
+            }
+        }
+        __syncthreads();
+        for (int yy = wave; yy < ph; yy += 4) {
+            const int y = band * ph + yy;
+            if (y >= H) break;
+            int run = rows[y];                           // raster rank of the row's first kept pixel
+            for (int x0 = 0; x0 < W; x0 += 64) {
+                const int x = x0 + lane;
+                const bool m = x < W && mask[(size_t)y * W + x] != 0;
+                const unsigned long long b = __ballot(m);
+                if (m) {
+                    const int k = x / pw;
+                    int pos = patches[(size_t)band * npx + k];                        // kept pixels in earlier patches
+                    for (int r = 0; r < yy; ++r) pos += pr[r * npx + k];              // ... in this patch's earlier rows
+                    // ... in this row of the patch before x: pixels of the patch's row segment left of x, counted in this window and,
+                    // when the segment started in an earlier window, in those (pw <= 64 keeps that to one earlier window at most)
+                    const int xs = k * pw;
+                    int before;
+                    if (xs >= x0) before = __popcll(b & (((1ull << lane) - 1ull) & ~((1ull << (xs - x0)) - 1ull)));
+                    else {
+                        before = __popcll(b & ((1ull << lane) - 1ull));
+                        for (int xx = xs; xx < x0; ++xx) before += mask[(size_t)y * W + xx] != 0;
+                    }
+                    order[pos + before] = run + __popcll(b & ((1ull << lane) - 1ull));
+                }
+                run += __popcll(b);
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(1024) po_scan_kernel(int* __restrict__ rows, const int H, int* __restrict__ patches, const int NP) {
+    // exclusive prefixes of both arrays in place, one after the other; patches[NP] receives the grand total
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int pass = 0; pass < 2; ++pass) {
+        int* a = pass ? patches : rows;
+        const int n = pass ? NP : H;
+        if (threadIdx.x == 0) carry = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + (int)threadIdx.x;
+            const int v = i < n ? a[i] : 0;
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            int woff = carry;
+            for (int w = 0; w < wave; ++w) woff += wsum[w];
+            if (i < n) a[i] = woff + inc - v;
+            __syncthreads();
+            if (threadIdx.x == 1023) carry = woff + inc;
+            __syncthreads();
+        }
+        if (pass && threadIdx.x == 0) patches[NP] = carry;
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -2949,6 +3073,27 @@ int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t 
     const long P = (long)H * W;
     hipLaunchKernelGGL(cfirst_to_clast32_kernel, dim3((unsigned)((P + 63) / 64), (unsigned)V), dim3(256), 0, S_(stream), nchw,
                        nhwc, P, 32 * P, 32 * P);
+    return launch_status();
+}
+
+int64_t gpnerf_patch_order_scratch_bytes(int32_t H, int32_t W, int32_t patch_w, int32_t patch_h) {
+    if (H < 1 || W < 1 || patch_w < 1 || patch_h < 1) return 0;
+    return (int64_t)sizeof(int32_t) * ((int64_t)H + (int64_t)((H + patch_h - 1) / patch_h) * ((W + patch_w - 1) / patch_w) + 1);
+}
+
+int gpnerf_patch_order(const uint8_t* mask, int32_t H, int32_t W, int32_t patch_w, int32_t patch_h, int32_t n, int32_t* scratch,
+                       int32_t* order, void* stream) {
+    if (n == 0) return GPNERF_OK;
+    if (!mask || !scratch || !order || H < 1 || W < 1 || patch_w < 1 || patch_w > 64 || patch_h < 1 || patch_h > PO_MAX_PH || n < 0) return GPNERF_E_ARG;
+    const int npy = (H + patch_h - 1) / patch_h, npx = (W + patch_w - 1) / patch_w;
+    int* const rows = scratch;
+    int* const patches = scratch + H;
+    if (!zero_async(patches, sizeof(int) * ((size_t)npy * npx + 1), stream)) return GPNERF_E_LAUNCH;
+    hipLaunchKernelGGL((po_band_kernel<false>), dim3((unsigned)npy), dim3(256), 0, S_(stream), mask, (int)H, (int)W, (int)patch_w, (int)patch_h, rows,
+                       patches, (int)n, order);
+    hipLaunchKernelGGL(po_scan_kernel, dim3(1), dim3(1024), 0, S_(stream), rows, (int)H, patches, npy * npx);
+    hipLaunchKernelGGL((po_band_kernel<true>), dim3((unsigned)npy), dim3(256), sizeof(int) * (size_t)patch_h * npx, S_(stream), mask, (int)H, (int)W,
+                       (int)patch_w, (int)patch_h, rows, patches, (int)n, order);
     return launch_status();
 }
 

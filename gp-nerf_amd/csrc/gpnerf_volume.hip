@@ -189,7 +189,11 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
     const int site = (int)blockIdx.x * 32 + s;
     if (site - s >= m) return;                                  // whole tile past the end (uniform over the workgroup)
     const bool valid = site < m;
-    const int od = valid ? out_coords[3 * site] : 0, oh = valid ? out_coords[3 * site + 1] : 0, ow = valid ? out_coords[3 * site + 2] : 0;
+    // Every load below is UNCONDITIONAL (clamped index, the value dropped afterwards where it does not apply): a load under a lane
+    // condition becomes a branch around it with a full wait behind it, and the taps' gathers -- meant to be DEPTH taps ahead --
+    // each waited out their own round trip (a level of ~5 x 10^4 sites: 20 -> see DESIGN.md 4.2)
+    const int site_c = min(site, m - 1);                       // (m >= 1 here: the tile holds a site)
+    const int od = out_coords[3 * site_c], oh = out_coords[3 * site_c + 1], ow = out_coords[3 * site_c + 2];
     f32x16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -201,18 +205,19 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
         const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
         const int d = (STRIDED ? 2 * od : od) - 1 + kd, h = (STRIDED ? 2 * oh : oh) - 1 + kh, w = (STRIDED ? 2 * ow : ow) - 1 + kw;
         const bool inb = valid && k < KV && d >= 0 && d < in_dims.d && h >= 0 && h < in_dims.h && w >= 0 && w < in_dims.w;
-        nbr[j] = inb ? in_grid[cell_of(in_dims, d, h, w)] : -1;
+        const int g = in_grid[cell_of(in_dims, min(max(d, 0), in_dims.d - 1), min(max(h, 0), in_dims.h - 1), min(max(w, 0), in_dims.w - 1))];
+        nbr[j] = inb ? g : -1;
     }
     const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
     // a tap's neighbour row: this lane's 8 channels of every 16-channel chunk (absent neighbours and the fourth wavefront's missing
     // tap contribute zeros: the MFMA chain is branch-free)
     auto load_tap = [&](int j, f32x4v (&b)[NC][2]) {
         const int jj = nbr[j];
-        const float* x = in + (size_t)(jj < 0 ? 0 : jj) * cin + 8 * half;
+        const float* x = in + (size_t)(jj < 0 ? 0 : jj) * cin + 8 * half;      // (row 0 exists: m >= 1; its values are dropped below)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            b[c][0] = jj >= 0 ? *reinterpret_cast<const f32x4v*>(x + 16 * c) : zero4;
-            b[c][1] = jj >= 0 ? *reinterpret_cast<const f32x4v*>(x + 16 * c + 4) : zero4;
+            b[c][0] = *reinterpret_cast<const f32x4v*>(x + 16 * c);
+            b[c][1] = *reinterpret_cast<const f32x4v*>(x + 16 * c + 4);
         }
     };
     auto load_w = [&](int j, u32x4v (&a)[NC][2]) {
@@ -241,7 +246,7 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                xs[c][q] = buf[j % DEPTH][c][q] * X16_SCALE;
+                xs[c][q] = nbr[j] >= 0 ? buf[j % DEPTH][c][q] * X16_SCALE : zero4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) big = fmaxf(big, fabsf(xs[c][q][i]));
             }

@@ -274,6 +274,22 @@ def patch_order_device(mask, H, W, patch_w=4, patch_h=8, n_kept=None):
     return t[t >= 0].contiguous()
 
 
+def patch_order_rays(mask, H, W, n, patch_w=32, patch_h=8):
+    """patch_order() for the n rays of a frame whose kept pixels are `mask` (bool / uint8 device tensor [H*W]): three launches, no
+    host round trip (gpnerf_patch_order); the identity when the mask does not keep exactly n pixels."""
+    _require_gpu(mask, "mask_at_box")
+    m = mask.reshape(-1)
+    m = (m if m.dtype in (torch.uint8, torch.bool) else (m != 0)).contiguous()
+    if m.numel() != H * W:
+        raise L.GpnerfError(f"mask has {m.numel()} entries for a {H}x{W} image")
+    lib = L.lib()
+    scratch = torch.empty((int(lib.gpnerf_patch_order_scratch_bytes(H, W, patch_w, patch_h)) // 4,), device=m.device, dtype=torch.int32)
+    order = torch.empty((int(n),), device=m.device, dtype=torch.int32)
+    L.check(lib.gpnerf_patch_order(m.data_ptr(), H, W, patch_w, patch_h, int(n), scratch.data_ptr(), order.data_ptr(), _stream_ptr(m.device)),
+            "gpnerf_patch_order")
+    return order
+
+
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-5,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
                  split_f16=False, flip=None, subset=False, guard=None, fold=None):

@@ -298,11 +298,14 @@ class Renderer(nn.Module):
                     # with early termination a wavefront's 32 rays are a compact 8x4-pixel block rather than a 32-pixel row: the
                     # rays of a block become opaque together far more often (bench frame: 43 % -> 35 % of the samples evaluated)
                     pw, ph = (8, 4) if self.early_term else (32, 8)
-                    mb = m.bool()
-                    order = F_.patch_order_device(mb, Hs, Ws, patch_w=pw, patch_h=ph, n_kept=n)
-                    # a mask that does not keep exactly the n pixels the rays belong to cannot order them: fall back to list
-                    # order, decided on the device (reading the count on the host would be a synchronisation)
-                    order = torch.where(mb.sum() == n, order, torch.arange(n, device=dev, dtype=order.dtype))
+                    # (a mask that does not keep exactly the n pixels the rays belong to cannot order them: the kernels then leave
+                    # list order -- decided on the device, reading the count on the host would be a synchronisation)
+                    if os.environ.get("GPNERF_DEBUG") == "1" and os.environ.get("GPNERF_PATCH_ORDER_TORCH") == "1":
+                        mb = m.bool()          # the same list from ~25 small library launches (the A/B of tools/time_survey_api.py)
+                        order = F_.patch_order_device(mb, Hs, Ws, patch_w=pw, patch_h=ph, n_kept=n)
+                        order = torch.where(mb.sum() == n, order, torch.arange(n, device=dev, dtype=order.dtype))
+                    else:
+                        order = F_.patch_order_rays(m, Hs, Ws, n, patch_w=pw, patch_h=ph)
         main.wait_stream(side)
 
         def fn(r):

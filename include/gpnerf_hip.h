@@ -364,6 +364,15 @@ int gpnerf_relayout_volume(const float* ncdhw, float* ndhwc, int32_t D, int32_t 
 int gpnerf_relayout_featmaps(const float* nchw, float* nhwc, int32_t V, int32_t H, int32_t W, void* stream);
 /* src_imgs [V][3][H][W] in [-1,1] -> [V][H][W][4] = x*0.5+0.5 (BaseRender.py:231), 4th lane 0 */
 int gpnerf_relayout_images(const float* nchw, float* nhwc4, int32_t V, int32_t H, int32_t W, void* stream);
+/* Launch order of a frame's rays: order[q] = row (in the caller's ray list, which follows the raster order of the kept pixels of
+ * `mask`, as ZjumocapDataset.py:505's mask_at_box does) of the q-th ray when the H x W image is walked in patches of
+ * patch_w x patch_h pixels (patch_w <= 64, patch_h <= 32), patches and the pixels inside a patch in raster order -- the 32 rays of
+ * a wavefront then cover a compact block (gpnerf_render_fused's ray_order).  mask: H*W bytes, non-zero = kept; n: the caller's ray
+ * count; scratch: gpnerf_patch_order_scratch_bytes() bytes, overwritten.  Three launches, no host round trip; a mask that does not
+ * keep exactly n pixels yields the identity 0 .. n-1.  Results of a render do not depend on the order; it is a locality choice. */
+int64_t gpnerf_patch_order_scratch_bytes(int32_t H, int32_t W, int32_t patch_w, int32_t patch_h);
+int gpnerf_patch_order(const uint8_t* mask, int32_t H, int32_t W, int32_t patch_w, int32_t patch_h, int32_t n, int32_t* scratch,
+                       int32_t* order, void* stream);
 
 /* Layout of the head image, for tools and tests: table[4*l + {0,1,2,3}] = k-steps, 32-row output tiles,
  * weight offset, bias offset (in floats) of MFMA layer l = GEO,D1,D2,D3,BS,BV,B2,V1,V2,R1,R2 (11 layers),

@@ -366,3 +366,26 @@ def test_a_frame_that_gets_new_volumes_drops_what_it_derived_from_the_old_ones(f
     want = fm.render_fused(build_frame(fm, fresh_scene), rays, 32)
     assert torch.equal(got["rgb_map"], want["rgb_map"]) and torch.equal(got["depth_map"], want["depth_map"])
     assert not torch.equal(got["rgb_map"], first["rgb_map"])
+
+
+@pytest.mark.parametrize("H,W,pw,ph,fill", [(512, 512, 32, 8, 0.3), (512, 512, 8, 4, 0.28), (64, 48, 8, 4, 0.5), (37, 45, 32, 8, 0.7),
+                                            (128, 96, 4, 8, 1.0), (40, 40, 32, 8, 0.0), (70, 200, 24, 5, 0.6), (1024, 1024, 32, 8, 0.2)])
+def test_patch_order_kernels_equal_the_host_function(H, W, pw, ph, fill):
+    """gpnerf_patch_order (three launches, no host round trip) gives frame.patch_order()'s permutation for any mask -- ragged bands
+    and patches, patch widths that do not divide the 64-pixel window, empty and full masks -- and the identity when the mask does not
+    keep exactly the caller's n pixels."""
+    fm = importlib.import_module("gp-nerf_amd.frame")
+    g = np.random.default_rng(H * W + pw)
+    mask = g.random(H * W) < fill
+    if fill == 0.3:                       # a body-shaped blob rather than noise: whole empty rows and patches
+        yy, xx = np.mgrid[0:H, 0:W]
+        mask = (((yy - H / 2) / (0.4 * H)) ** 2 + ((xx - W / 2) / (0.2 * W)) ** 2 < 1).reshape(-1)
+    n = int(mask.sum())
+    want = fm.patch_order(mask, H, W, patch_w=pw, patch_h=ph)
+    md = torch.from_numpy(mask).to("cuda:0")
+    got = fm.patch_order_rays(md, H, W, n, patch_w=pw, patch_h=ph)
+    assert got.dtype == torch.int32 and np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(fm.patch_order_rays(md.to(torch.uint8), H, W, n, patch_w=pw, patch_h=ph).cpu().numpy(), want)
+    if n > 3:
+        wrong = fm.patch_order_rays(md, H, W, n - 3, patch_w=pw, patch_h=ph)
+        assert np.array_equal(wrong.cpu().numpy(), np.arange(n - 3))
