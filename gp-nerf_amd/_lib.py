@@ -38,6 +38,25 @@ class GpnerfFrame(C.Structure):
     ]
 
 
+PYRAMID_MAX_LEVELS = 4
+
+
+class GpnerfSparseConv(C.Structure):
+    """include/gpnerf_hip.h: one convolution of the sparse pyramid (gpnerf_sparse_pyramid_run)"""
+    _fields_ = [("strided", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("form", C.c_int32),
+                ("weight", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
+
+
+class GpnerfPyramid(C.Structure):
+    """include/gpnerf_hip.h: the buffers of one frame's pyramid (gpnerf_sparse_pyramid_plan / _run)"""
+    _fields_ = [("n_levels", C.c_int32), ("m0", C.c_int32), ("dims0", C.c_int32 * 3),
+                ("dims", (C.c_int32 * 3) * PYRAMID_MAX_LEVELS), ("cap", C.c_int32 * PYRAMID_MAX_LEVELS), ("ch", C.c_int32 * PYRAMID_MAX_LEVELS),
+                ("coords0", C.c_void_p), ("grid0", C.c_void_p), ("dup_scratch", C.c_void_p),
+                ("grid", C.c_void_p * PYRAMID_MAX_LEVELS), ("coords", C.c_void_p * PYRAMID_MAX_LEVELS), ("m", C.c_void_p * PYRAMID_MAX_LEVELS),
+                ("vol", C.c_void_p * PYRAMID_MAX_LEVELS), ("feat_a", C.c_void_p), ("feat_b", C.c_void_p)]
+
+
+
 HEAD_FIELDS = [
     ("geo", "sigmahead.out_geometry_fc.0"), ("b1", "rgbhead.base_fc.0"), ("b2", "rgbhead.base_fc.2"),
     ("v1", "rgbhead.vis_fc.0"), ("v2", "rgbhead.vis_fc.2"), ("r1", "rgbhead.rgb_fc.0"),
@@ -124,6 +143,8 @@ SYMBOLS = {
     "gpnerf_sparse_pack_weight16": (C.c_int, [FP, C.c_int32, C.c_int32, C.c_void_p]),
     "gpnerf_sparse_packed_weight_floats": (C.c_int64, [C.c_int32]),
     "gpnerf_sparse_pack_weight": (C.c_int, [FP, C.c_int32, C.c_int32, FP]),
+    "gpnerf_sparse_pyramid_plan": (C.c_int, [C.POINTER(GpnerfPyramid), C.c_void_p]),
+    "gpnerf_sparse_pyramid_run": (C.c_int, [C.POINTER(GpnerfPyramid), C.c_void_p, C.c_int32, C.POINTER(GpnerfSparseConv), C.c_int32, C.c_void_p]),
     "gpnerf_sparse_merge_duplicates": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                                  C.c_void_p, C.c_void_p]),
     "gpnerf_sparse_down_sites": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,

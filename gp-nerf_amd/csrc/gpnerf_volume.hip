@@ -681,6 +681,69 @@ int gpnerf_sparse_scatter_dense(const float* feat, int32_t channels, const int32
     return status();
 }
 
+int gpnerf_sparse_pyramid_plan(const GpnerfPyramid* p, void* stream) {
+    if (!p || p->n_levels < 1 || p->n_levels > GPNERF_PYRAMID_MAX_LEVELS || p->m0 < 0 || !p->coords0 || !p->grid0) return GPNERF_E_ARG;
+    int rc = gpnerf_sparse_index(p->coords0, nullptr, p->m0, p->dims0, p->grid0, stream);
+    if (rc != GPNERF_OK) return rc;
+    const int32_t* coords = p->coords0;
+    const int32_t* m_dev = nullptr;
+    int32_t m_cap = p->m0;
+    for (int i = 0; i < p->n_levels; ++i) {
+        if (!p->grid[i] || !p->coords[i] || !p->m[i] || !p->vol[i]) return GPNERF_E_ARG;
+        rc = gpnerf_sparse_down_sites(coords, m_dev, m_cap, p->dims[i], p->grid[i], p->coords[i], p->m[i], p->cap[i], stream);
+        if (rc != GPNERF_OK) return rc;
+        rc = gpnerf_zero_volume(p->vol[i], p->ch[i], p->dims[i], stream);
+        if (rc != GPNERF_OK) return rc;
+        coords = p->coords[i]; m_dev = p->m[i]; m_cap = p->cap[i];
+    }
+    return GPNERF_OK;
+}
+
+int gpnerf_sparse_pyramid_run(const GpnerfPyramid* p, const float* code, int32_t code_ch, const GpnerfSparseConv* convs, int32_t n_convs,
+                              void* stream) {
+    if (!p || !code || !convs || p->n_levels < 1 || p->n_levels > GPNERF_PYRAMID_MAX_LEVELS || n_convs != 2 + 3 * p->n_levels || !p->feat_a ||
+        !p->feat_b || !p->dup_scratch)
+        return GPNERF_E_ARG;
+    auto conv = [&](const GpnerfSparseConv& c, const float* in, const int32_t* in_grid, const int32_t* in_dims, const int32_t* coords,
+                    const int32_t* m_dev, int32_t m_cap, float* out) -> int {
+        if (c.form == 2)
+            return gpnerf_sparse_conv3_mfma16(c.strided, in, c.cin, in_grid, in_dims, coords, m_dev, m_cap, c.weight, c.cout, c.bn_scale, c.bn_shift,
+                                              out, stream);
+        if (c.form == 1)
+            return gpnerf_sparse_conv3_mfma(c.strided, in, c.cin, in_grid, in_dims, coords, m_dev, m_cap, static_cast<const float*>(c.weight), c.cout,
+                                            c.bn_scale, c.bn_shift, out, stream);
+        return gpnerf_sparse_conv3(c.strided, in, c.cin, in_grid, in_dims, coords, m_dev, m_cap, static_cast<const float*>(c.weight), c.cout,
+                                   c.bn_scale, c.bn_shift, out, stream);
+    };
+    if (convs[0].cin != code_ch || convs[0].strided || convs[1].strided) return GPNERF_E_ARG;
+    float* cur = p->feat_a;
+    float* other = p->feat_b;
+    int rc = conv(convs[0], code, p->grid0, p->dims0, p->coords0, nullptr, p->m0, cur);
+    if (rc != GPNERF_OK) return rc;
+    rc = conv(convs[1], cur, p->grid0, p->dims0, p->coords0, nullptr, p->m0, other);
+    if (rc != GPNERF_OK) return rc;
+    { float* t = cur; cur = other; other = t; }
+    rc = gpnerf_sparse_merge_duplicates(cur, convs[1].cout, p->coords0, p->grid0, p->m0, p->dims0, p->dup_scratch, stream);
+    if (rc != GPNERF_OK) return rc;
+    const int32_t* grid = p->grid0;
+    const int32_t* dims = p->dims0;
+    for (int i = 0; i < p->n_levels; ++i) {
+        const GpnerfSparseConv* c = convs + 2 + 3 * i;
+        if (!c[0].strided || c[1].strided || c[2].strided || c[2].cout != p->ch[i]) return GPNERF_E_ARG;
+        rc = conv(c[0], cur, grid, dims, p->coords[i], p->m[i], p->cap[i], other);               // reads the finer level at the coarser sites
+        if (rc != GPNERF_OK) return rc;
+        grid = p->grid[i]; dims = p->dims[i];
+        rc = conv(c[1], other, grid, dims, p->coords[i], p->m[i], p->cap[i], cur);
+        if (rc != GPNERF_OK) return rc;
+        rc = conv(c[2], cur, grid, dims, p->coords[i], p->m[i], p->cap[i], other);
+        if (rc != GPNERF_OK) return rc;
+        { float* t = cur; cur = other; other = t; }
+        rc = gpnerf_sparse_scatter_dense(cur, c[2].cout, p->coords[i], grid, p->m[i], p->cap[i], dims, p->vol[i], 1, stream);
+        if (rc != GPNERF_OK) return rc;
+    }
+    return GPNERF_OK;
+}
+
 int gpnerf_vertex_attention(const float* q, const float* kv, const float* wq, const float* wk, const float* wv, const float* wfc,
                             int32_t n, int32_t d_model, int32_t kv_dim, int32_t n_head, int32_t views, float* out, void* stream) {
     if (n == 0) return GPNERF_OK;

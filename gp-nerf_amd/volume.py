@@ -102,6 +102,20 @@ def stride_conv(cin, cout):      # SparseConvNet.py:78-87: k3 s2 p1
     return _SparseSequential(_SparseConv3d(cin, cout, 3, stride=2, padding=1), _bn(cout), nn.ReLU())
 
 
+class _NotCopied:
+    """holder of a per-module cache that copy.deepcopy / pickle leave behind (ctypes arrays of pointers cannot be copied, and a copy
+    of the module has to build its own anyway)"""
+
+    def __init__(self, v):
+        self.v = v
+
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
+
 class SparseConvNet(nn.Module):
     """Same module tree / state_dict keys as SparseConvNet.py:90-103 (`net.{0..8}`)."""
 
@@ -177,29 +191,36 @@ class SparseConvNet(nn.Module):
         lib = L.lib()
         dev = coord.device
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        I3 = C.c_int32 * 3
         dims = tuple(int(v) for v in out_sh)
         coords = coord[:, 1:].to(torch.int32).contiguous()
-        m_cap, m_dev = coords.shape[0], None
-        grid = torch.empty(dims, device=dev, dtype=torch.int32)
-        L.check(lib.gpnerf_sparse_index(coords.data_ptr(), None, m_cap, I3(*dims), grid.data_ptr(), st), "gpnerf_sparse_index")
-        plan = {"level0": (grid, dims, coords, m_dev, m_cap), "dup": torch.empty((9 * m_cap,), device=dev, dtype=torch.int32), "levels": []}
+        m0 = coords.shape[0]
         ch = [int(c) for c in (channels or [self.net[2 * i + 2][3].cout for i in range(self.n_layers)])]
+        if self.n_layers > L.PYRAMID_MAX_LEVELS:
+            raise L.GpnerfError(f"the pyramid runner is built for at most {L.PYRAMID_MAX_LEVELS} levels")
+        # every buffer of the frame's pyramid, and ONE native call that lays its structure out (gpnerf_sparse_pyramid_plan: the
+        # full-resolution index, per level the coarse sites + their grid + the zeroed dense volume: ~30 launches)
+        p = L.GpnerfPyramid()
+        p.n_levels, p.m0 = self.n_layers, m0
+        p.dims0[:] = dims
+        keep = {"coords0": coords, "grid0": torch.empty(dims, device=dev, dtype=torch.int32),
+                "dup": torch.empty((9 * max(m0, 1),), device=dev, dtype=torch.int32), "levels": []}
+        p.coords0, p.grid0, p.dup_scratch = coords.data_ptr(), keep["grid0"].data_ptr(), keep["dup"].data_ptr()
+        m_cap, d = m0, dims
         for i in range(self.n_layers):
-            odims = tuple(n // 2 for n in dims)
-            cells = odims[0] * odims[1] * odims[2]
-            ocap = int(min(cells, 8 * m_cap))                       # a fine site reaches at most 2^3 coarse sites
-            ogrid = torch.empty(odims, device=dev, dtype=torch.int32)
-            ocoords = torch.empty((ocap, 3), device=dev, dtype=torch.int32)
+            d = tuple(n // 2 for n in d)
+            cap = int(min(d[0] * d[1] * d[2], 8 * m_cap))           # a fine site reaches at most 2^3 coarse sites
+            grid = torch.empty(d, device=dev, dtype=torch.int32)
+            oc = torch.empty((max(cap, 1), 3), device=dev, dtype=torch.int32)
             om = torch.empty((1,), device=dev, dtype=torch.int32)
-            L.check(lib.gpnerf_sparse_down_sites(coords.data_ptr(), m_dev.data_ptr() if m_dev is not None else None, m_cap,
-                                                 I3(*odims), ogrid.data_ptr(), ocoords.data_ptr(), om.data_ptr(), ocap, st),
-                    "gpnerf_sparse_down_sites")
-            vol = torch.empty(odims + (ch[i],), device=dev, dtype=torch.float32)
-            L.check(lib.gpnerf_zero_volume(vol.data_ptr(), ch[i], I3(*odims), st), "gpnerf_zero_volume")
-            plan["levels"].append((ogrid, odims, ocoords, om, ocap, vol))
-            grid, dims, coords, m_dev, m_cap = ogrid, odims, ocoords, om, ocap
-        return plan
+            vol = torch.empty(d + (ch[i],), device=dev, dtype=torch.float32)
+            p.dims[i][:] = d
+            p.cap[i], p.ch[i] = cap, ch[i]
+            p.grid[i], p.coords[i], p.m[i], p.vol[i] = grid.data_ptr(), oc.data_ptr(), om.data_ptr(), vol.data_ptr()
+            keep["levels"].append((grid, d, oc, om, cap, vol))
+            m_cap = cap
+        L.check(lib.gpnerf_sparse_pyramid_plan(C.byref(p), st), "gpnerf_sparse_pyramid_plan")
+        keep["pyramid"], keep["dims0"], keep["max_rows"] = p, dims, max([m0] + [lv[4] for lv in keep["levels"]])
+        return keep
 
     def dense_levels_hip(self, code, coord, out_sh, batch_size=1, plan=None):
         """code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) -> the 4 dense levels of
@@ -219,48 +240,53 @@ class SparseConvNet(nn.Module):
         lib = L.lib()
         dev = code.device
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        I3 = C.c_int32 * 3
-
-        def conv(strided, mod, bn, x, in_grid, in_dims, coords, m_dev, m_cap):
-            scale, shift = self._folded_bn(bn)
-            out = torch.empty((m_cap, mod.cout), device=dev, dtype=torch.float32)
-            mp = m_dev.data_ptr() if m_dev is not None else None
-            if mod.cin % 8 == 0 and mod.cin <= 32 and mod.cout <= 32:          # matrix-core form
-                wp, split16 = self._packed_weight(mod, dev)
-                fn = lib.gpnerf_sparse_conv3_mfma16 if split16 else lib.gpnerf_sparse_conv3_mfma
-                L.check(fn(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims), coords.data_ptr(), mp, m_cap,
-                           wp.data_ptr(), mod.cout, scale.data_ptr(), shift.data_ptr(), out.data_ptr(), st),
-                        "gpnerf_sparse_conv3_mfma16" if split16 else "gpnerf_sparse_conv3_mfma")
-            else:
-                w = mod.weight.detach().float().contiguous()
-                L.check(lib.gpnerf_sparse_conv3(int(strided), x.data_ptr(), mod.cin, in_grid.data_ptr(), I3(*in_dims), coords.data_ptr(),
-                                                mp, m_cap, w.data_ptr(), mod.cout, scale.data_ptr(), shift.data_ptr(),
-                                                out.data_ptr(), st), "gpnerf_sparse_conv3")
-            return out
-
-        grid, dims, coords, m_dev, m_cap = plan["level0"]
+        convs = self._conv_table(dev)
+        p = plan["pyramid"]
+        if [lv[5].shape[-1] for lv in plan["levels"]] != [int(convs[4 + 3 * i].cout) for i in range(self.n_layers)]:
+            raise L.GpnerfError("plan_levels: channel count of the planned volume does not match the network")
         x = code.detach().float().contiguous()
-        with torch.no_grad():
-            dc = self.net[0]                                            # double_conv at full resolution
-            x = conv(False, dc[0], dc[1], x, grid, dims, coords, m_dev, m_cap)
-            x = conv(False, dc[3], dc[4], x, grid, dims, coords, m_dev, m_cap)
-            L.check(lib.gpnerf_sparse_merge_duplicates(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_cap,
-                                                       I3(*dims), plan["dup"].data_ptr(), st), "gpnerf_sparse_merge_duplicates")
-            levels = []
-            for i in range(self.n_layers):
-                sc, dc = self.net[2 * i + 1], self.net[2 * i + 2]
-                ogrid, odims, ocoords, om, ocap, vol = plan["levels"][i]
-                x = conv(True, sc[0], sc[1], x, grid, dims, ocoords, om, ocap)
-                grid, dims, coords, m_dev, m_cap = ogrid, odims, ocoords, om, ocap
-                x = conv(False, dc[0], dc[1], x, grid, dims, coords, m_dev, m_cap)
-                x = conv(False, dc[3], dc[4], x, grid, dims, coords, m_dev, m_cap)
-                if vol.shape[-1] != x.shape[1]:
-                    raise L.GpnerfError("plan_levels: channel count of the planned volume does not match the network")
-                L.check(lib.gpnerf_sparse_scatter_dense(x.data_ptr(), x.shape[1], coords.data_ptr(), grid.data_ptr(), m_dev.data_ptr(),
-                                                        m_cap, I3(*dims), vol.data_ptr(), 1, st), "gpnerf_sparse_scatter_dense")
-                vol._gpnerf_ndhwc = True
-                levels.append(vol)
+        if x.shape[0] != p.m0 or x.shape[1] != convs[0].cin:
+            raise L.GpnerfError(f"code {tuple(x.shape)} does not match the plan's {p.m0} rows / the network's {convs[0].cin} input channels")
+        # two feature buffers the convolutions alternate between, then ONE native call for the ~30 launches of the pyramid
+        feat = torch.empty((2, max(plan["max_rows"], 1), 32), device=dev, dtype=torch.float32)
+        p.feat_a, p.feat_b = feat[0].data_ptr(), feat[1].data_ptr()
+        L.check(lib.gpnerf_sparse_pyramid_run(C.byref(p), x.data_ptr(), int(x.shape[1]), convs, len(convs), st), "gpnerf_sparse_pyramid_run")
+        levels = []
+        for lv in plan["levels"]:
+            lv[5]._gpnerf_ndhwc = True
+            levels.append(lv[5])
+        plan["feat"] = feat                                   # alive until the plan goes (stream order covers the rest)
         return levels
+
+    def _conv_table(self, dev):
+        """GpnerfSparseConv[2 + 3 * n_layers] in network order (weights packed / BatchNorm folded on a parameter change only); the
+        tensors it points to are kept alive with it."""
+        mods = [(False, self.net[0][0], self.net[0][1]), (False, self.net[0][3], self.net[0][4])]
+        for i in range(self.n_layers):
+            sc, dc = self.net[2 * i + 1], self.net[2 * i + 2]
+            mods += [(True, sc[0], sc[1]), (False, dc[0], dc[1]), (False, dc[3], dc[4])]
+        key = (str(dev),) + tuple((m.weight.data_ptr(), m.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+                                   bn.running_var._version, bn.running_mean.data_ptr()) for _, m, bn in mods)
+        hit = self.__dict__.get("_conv_table_cache")
+        hit = hit.v if hit is not None else None
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        table = (L.GpnerfSparseConv * len(mods))()
+        alive = []
+        for t, (strided, mod, bn) in zip(table, mods):
+            if mod.cout > 32:
+                raise L.GpnerfError("the sparse convolutions are built for at most 32 output channels")
+            scale, shift = self._folded_bn(bn)
+            if mod.cin % 8 == 0 and mod.cin <= 32:
+                w, split16 = self._packed_weight(mod, dev)
+                form = 2 if split16 else 1
+            else:
+                w, form = mod.weight.detach().float().contiguous(), 0
+            t.strided, t.cin, t.cout, t.form = int(strided), mod.cin, mod.cout, form
+            t.weight, t.bn_scale, t.bn_shift = w.data_ptr(), scale.data_ptr(), shift.data_ptr()
+            alive += [w, scale, shift]
+        self.__dict__["_conv_table_cache"] = _NotCopied((key, table, alive))
+        return table
 
     # ---- the reference's two calls (SparseConvNet.py:105-143) --------------------------------------------------------
     def _levels_of(self, x):

@@ -285,6 +285,41 @@ int gpnerf_sparse_pack_weight16(const float* weight_host, int32_t cin, int32_t c
 int gpnerf_sparse_conv3_mfma16(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
                                const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const void* packed_weight16,
                                int32_t cout, const float* bn_scale, const float* bn_shift, float* out, void* stream);
+/* The whole pyramid of SparseConvNet.py:90-111 behind two calls (the entries above, in the reference's order, enqueued from
+ * native code: ~60 launches without a trip through the host language between them).  The caller owns every buffer.
+ *   gpnerf_sparse_pyramid_plan: everything that depends on the vertices' voxel coordinates only -- the full-resolution index grid,
+ *     every coarse level's site list + grid (gpnerf_sparse_down_sites) and the zeroed dense volumes; may run on another stream
+ *     beside the image encoder.
+ *   gpnerf_sparse_pyramid_run: double_conv at full resolution, the duplicate merge, then per level strided conv + double_conv +
+ *     scatter into vol[i] (channels-last [D_i][H_i][W_i][ch_i]).  convs: 2 + 3 * n_levels entries in network order.
+ * feat_a / feat_b: two float buffers of max(m0, cap[i]) * 32 each (ping-pong).  code: [m0][code_ch] per-vertex features. */
+#define GPNERF_PYRAMID_MAX_LEVELS 4
+typedef struct GpnerfSparseConv {
+    int32_t strided, cin, cout;
+    int32_t form;                 /* 2: gpnerf_sparse_conv3_mfma16 (weight = its packed image), 1: _mfma, 0: gpnerf_sparse_conv3 (raw [27][cin][cout]) */
+    const void* weight;
+    const float* bn_scale;
+    const float* bn_shift;
+} GpnerfSparseConv;
+typedef struct GpnerfPyramid {
+    int32_t n_levels, m0;
+    int32_t dims0[3];
+    int32_t dims[GPNERF_PYRAMID_MAX_LEVELS][3];
+    int32_t cap[GPNERF_PYRAMID_MAX_LEVELS];
+    int32_t ch[GPNERF_PYRAMID_MAX_LEVELS];
+    const int32_t* coords0;       /* [m0][3] (d, h, w) */
+    int32_t* grid0;               /* dims0 cells */
+    int32_t* dup_scratch;         /* 9 * m0 */
+    int32_t* grid[GPNERF_PYRAMID_MAX_LEVELS];
+    int32_t* coords[GPNERF_PYRAMID_MAX_LEVELS];     /* [cap][3] */
+    int32_t* m[GPNERF_PYRAMID_MAX_LEVELS];          /* device row counts */
+    float* vol[GPNERF_PYRAMID_MAX_LEVELS];
+    float* feat_a;
+    float* feat_b;
+} GpnerfPyramid;
+int gpnerf_sparse_pyramid_plan(const GpnerfPyramid* p, void* stream);
+int gpnerf_sparse_pyramid_run(const GpnerfPyramid* p, const float* code, int32_t code_ch, const GpnerfSparseConv* convs, int32_t n_convs,
+                              void* stream);
 /* Before the first strided conv: feat[owner] += feat[i] for every row i whose voxel is indexed by another row (two
  * vertices rounded into one voxel).  spconv's strided rulebook takes every input row; its submanifold lookups one.
  * The rows of a voxel are added in ascending row order (deterministic); scratch: device int32[9 * m], overwritten (a count
