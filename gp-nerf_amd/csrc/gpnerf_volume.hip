@@ -523,6 +523,93 @@ __global__ void __launch_bounds__(256, 1) vertex_attention_kernel(const float* _
         if (lane < d_model) out[v * d_model + lane] = y;
     }
 }
+
+// The same attention on the matrix cores for d_model = kv_dim = 32 (the reference's sizes): one wavefront = 32 vertices, transposed
+// like everything else here -- out[channel][vertex] += W[channel][k] . x[k][vertex] on v_mfma_f32_32x32x2_f32, 16 per projection, eight
+// projections per tile (q, k and v of up to four views, fc).  In the accumulator layout a lane holds 16 channels of its vertex, four
+// runs of 4 (register group g = channels 8 g + 4 half ..): the per-head dot products are sums over register groups (+ one exchange
+// between the lane halves for heads of 8 channels and more), the softmax over the views is per lane, and the attention output goes
+// through LDS once to become the B operand of the last projection.  The shuffle form above spends ~1 us per vertex and wavefront.
+template <int VIEWS>
+__global__ void __launch_bounds__(64) vertex_attention_mfma_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                                   const float* __restrict__ wq, const float* __restrict__ wk,
+                                                                   const float* __restrict__ wv, const float* __restrict__ wfc, const int n,
+                                                                   const int n_head, float* __restrict__ out) {
+    __shared__ float stage[32][33];
+    const int lane = threadIdx.x, nn = lane & 31, half = lane >> 5;
+    const int v = (int)blockIdx.x * 32 + nn, vc = min(v, n - 1);
+    const int d_k = 32 / n_head;
+    const float inv_t = 1.f / sqrtf((float)d_k);
+    // operand of k-step s from a row of 32 values held as 8 x float4: element 2 s + half
+    auto pick = [&](const f32x4v (&row)[8], int s) { const f32x4v t = row[s >> 1]; return half ? t[2 * (s & 1) + 1] : t[2 * (s & 1)]; };
+    auto load_row = [&](const float* p, f32x4v (&row)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[i] = reinterpret_cast<const f32x4v*>(p)[i];
+    };
+    // D = W . X for one 32 x 32 weight matrix (row m = this lane's output channel as A operand) and the tile's 32 input rows
+    auto project = [&](const float* __restrict__ W, const f32x4v (&x)[8]) {
+        f32x4v wr[8];
+        load_row(W + nn * 32, wr);
+        f32x16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pick(wr, s), pick(x, s), acc, 0, 0, 0);
+        return acc;
+    };
+    f32x4v xq[8];
+    load_row(q + (size_t)vc * 32, xq);
+    f32x16v qh = project(wq, xq);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qh[r] *= inv_t;
+    float score[VIEWS][4];
+    f32x16v val[VIEWS];
+#pragma unroll
+    for (int s = 0; s < VIEWS; ++s) {
+        f32x4v xf[8];
+        load_row(kv + ((size_t)vc * VIEWS + s) * 32, xf);
+        const f32x16v kh = project(wk, xf);
+        val[s] = project(wv, xf);
+        float sg[4];                                    // register group g: channels 8 g + 4 half .. + 3 of this lane's vertex
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sg[g] = ((qh[4 * g] * kh[4 * g] + qh[4 * g + 1] * kh[4 * g + 1]) + qh[4 * g + 2] * kh[4 * g + 2]) + qh[4 * g + 3] * kh[4 * g + 3];
+        if (d_k >= 8) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sg[g] += __shfl_xor(sg[g], 32);
+        }
+        if (d_k == 16) { const float a = sg[0] + sg[1], b = sg[2] + sg[3]; sg[0] = sg[1] = a; sg[2] = sg[3] = b; }
+        if (d_k == 32) { const float a = (sg[0] + sg[1]) + (sg[2] + sg[3]); sg[0] = sg[1] = sg[2] = sg[3] = a; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) score[s][g] = sg[g];
+    }
+    // softmax over the views per head, and the heads' weighted values: this lane's 16 channels of the attention output
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float m = score[0][g];
+#pragma unroll
+        for (int s = 1; s < VIEWS; ++s) m = fmaxf(m, score[s][g]);
+        float den = 0.f, e[VIEWS];
+#pragma unroll
+        for (int s = 0; s < VIEWS; ++s) { e[s] = __expf(score[s][g] - m); den += e[s]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < VIEWS; ++s) acc = fmaf(e[s], val[s][4 * g + i], acc);
+            stage[nn][8 * g + 4 * half + i] = acc / den;
+        }
+    }
+    __syncthreads();
+    f32x4v xo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xo[i] = f32x4v{stage[nn][4 * i], stage[nn][4 * i + 1], stage[nn][4 * i + 2], stage[nn][4 * i + 3]};
+    const f32x16v y = project(wfc, xo);
+    if (v < n) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4v*>(out + (size_t)v * 32 + 8 * g + 4 * half) = f32x4v{y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -754,6 +841,24 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* wq, co
     if (d_k & (d_k - 1)) return GPNERF_E_ARG;          // the per-head reduction is a butterfly
     // two workgroups per CU: a wavefront reads its 4 x 32 weight rows once and walks ~3 vertices (6 890 vertices: 128 / 256 / 512 /
     // 768 / 1 024 / 1 723 workgroups: 52 / 32 / 30 / 37 / 40 / 57 us, tools/probes/attention_time.py)
+    // the reference's shape: the matrix-core form (GPNERF_ATT_SHUFFLE=1 under GPNERF_DEBUG=1 keeps the shuffle form for comparison)
+    if (d_model == 32 && kv_dim == 32 && d_k >= 4) {
+        static int f_shuffle = -1;
+        if (f_shuffle < 0) {
+            const char* d = getenv("GPNERF_DEBUG");
+            const char* e = (d && d[0] == '1') ? getenv("GPNERF_ATT_SHUFFLE") : nullptr;
+            f_shuffle = (e && e[0] == '1') ? 1 : 0;
+        }
+        if (!f_shuffle) {
+            const dim3 grid((unsigned)((n + 31) / 32)), block(64);
+            hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+            if (views == 1) hipLaunchKernelGGL(vertex_attention_mfma_kernel<1>, grid, block, 0, st, q, kv, wq, wk, wv, wfc, (int)n, (int)n_head, out);
+            else if (views == 2) hipLaunchKernelGGL(vertex_attention_mfma_kernel<2>, grid, block, 0, st, q, kv, wq, wk, wv, wfc, (int)n, (int)n_head, out);
+            else if (views == 3) hipLaunchKernelGGL(vertex_attention_mfma_kernel<3>, grid, block, 0, st, q, kv, wq, wk, wv, wfc, (int)n, (int)n_head, out);
+            else hipLaunchKernelGGL(vertex_attention_mfma_kernel<4>, grid, block, 0, st, q, kv, wq, wk, wv, wfc, (int)n, (int)n_head, out);
+            return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH;
+        }
+    }
     int blocks = n < 2048 ? (n + 3) / 4 : 512;
     {
         const char* d = getenv("GPNERF_DEBUG");

@@ -57,3 +57,31 @@ def test_fused_attention_rejects_unsupported_shapes():
     assert lib.gpnerf_vertex_attention(p, p, p, p, p, p, 8, 128, 32, 4, 3, p, None) == -1    # d_model > 64
     assert lib.gpnerf_vertex_attention(p, p, p, p, p, p, 8, 32, 32, 4, 5, p, None) == -1     # views > 4
     assert lib.gpnerf_vertex_attention(None, p, p, p, p, p, 0, 32, 32, 4, 3, p, None) == 0    # nothing to do
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_head,views,n", [(4, 3, 6890), (8, 3, 100), (2, 4, 33), (1, 2, 64), (4, 1, 31)])
+def test_matrix_core_attention_for_every_head_size_and_view_count(n_head, views, n):
+    """gpnerf_vertex_attention at d_model = kv_dim = 32 (the matrix-core form): heads of 4, 8, 16 and 32 channels, 1-4 views, a last
+    tile that is not full -- against the formula in float64 (MultiHeadAttention.py:61-98, sum=False, one query per vertex)."""
+    L = importlib.import_module("gp-nerf_amd._lib")
+    lib = L.lib()
+    g = torch.Generator().manual_seed(n_head * 100 + views)
+    d = 32
+    q = torch.randn((n, d), generator=g)
+    kv = torch.randn((n, views, d), generator=g)
+    w = [torch.randn((d, d), generator=g) * 0.25 for _ in range(4)]
+    qd, kd = q.double(), kv.double()
+    d_k = d // n_head
+    qh = (qd @ w[0].double().T).view(n, n_head, d_k) / d_k ** 0.5
+    kh = (kd @ w[1].double().T).view(n, views, n_head, d_k)
+    vh = (kd @ w[2].double().T).view(n, views, n_head, d_k)
+    att = torch.softmax(torch.einsum("nhd,nvhd->nhv", qh, kh), dim=-1)
+    ref = (torch.einsum("nhv,nvhd->nhd", att, vh).reshape(n, d) @ w[3].double().T).float()
+    dev = "cuda:0"
+    qg, kg, wg = q.to(dev), kv.to(dev), [t.to(dev).contiguous() for t in w]
+    out = torch.empty((n, d), device=dev)
+    L.check(lib.gpnerf_vertex_attention(qg.data_ptr(), kg.data_ptr(), wg[0].data_ptr(), wg[1].data_ptr(), wg[2].data_ptr(), wg[3].data_ptr(),
+                                        n, d, d, n_head, views, out.data_ptr(), None), "gpnerf_vertex_attention")
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
