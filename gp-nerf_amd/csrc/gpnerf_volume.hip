@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
                                                           const int* __restrict__ m_ptr, const int m_cap,
                                                           const unsigned char* __restrict__ Wp, const int cout,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, float* __restrict__ vol) {
+    // vol (or nullptr): the level's zeroed dense volume [D][H][W][cout] of the OUTPUT sites' grid -- the rows are also written at
+    // their sites' cells (SparseConvTensor.dense() for a level without duplicate sites: every level but the vertices')
     __shared__ float red[4][16][64];
     constexpr int cin = 16 * NC;
     const int lane = threadIdx.x & 63, s = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
@@ -289,7 +291,15 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
         const int r = 4 * wave + i;
         const float v = (((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane]) * ACC16_UNSCALE;
         const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < cout) out[(size_t)site * cout + co] = fmaxf(fmaf(v, scale[co], shift[co]), 0.f);
+        if (co < cout) {
+            const float y = fmaxf(fmaf(v, scale[co], shift[co]), 0.f);
+            out[(size_t)site * cout + co] = y;
+            if (vol) {
+                // (submanifold: the output grid is the input grid; strided: the coarse grid has half the input's size, rounded down)
+                const Dims vd = STRIDED ? Dims{in_dims.d / 2, in_dims.h / 2, in_dims.w / 2} : in_dims;
+                vol[(size_t)cell_of(vd, od, oh, ow) * cout + co] = y;
+            }
+        }
     }
 }
 
@@ -685,9 +695,19 @@ int gpnerf_sparse_pack_weight16(const float* weight, int32_t cin, int32_t cout, 
     return GPNERF_OK;
 }
 
+static int sparse_conv16(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
+                         const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const void* packed_weight16, int32_t cout,
+                         const float* bn_scale, const float* bn_shift, float* out, float* vol, void* stream);
+
 int gpnerf_sparse_conv3_mfma16(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
                                const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const void* packed_weight16, int32_t cout,
                                const float* bn_scale, const float* bn_shift, float* out, void* stream) {
+    return sparse_conv16(strided, in, cin, in_grid, in_dims, out_coords, m_dev, m_cap, packed_weight16, cout, bn_scale, bn_shift, out, nullptr, stream);
+}
+
+static int sparse_conv16(int32_t strided, const float* in, int32_t cin, const int32_t* in_grid, const int32_t* in_dims,
+                         const int32_t* out_coords, const int32_t* m_dev, int32_t m_cap, const void* packed_weight16, int32_t cout,
+                         const float* bn_scale, const float* bn_shift, float* out, float* vol, void* stream) {
     if (!in || !in_grid || bad(in_dims) || !out_coords || !packed_weight16 || !bn_scale || !bn_shift || !out) return GPNERF_E_ARG;
     if ((cin != 16 && cin != 32) || cout < 1 || cout > 32 || m_cap < 0) return GPNERF_E_ARG;
     if (m_cap == 0) return GPNERF_OK;
@@ -696,7 +716,7 @@ int gpnerf_sparse_conv3_mfma16(int32_t strided, const float* in, int32_t cin, co
     const unsigned char* wp = static_cast<const unsigned char*>(packed_weight16);
 #define GPNERF_LAUNCH16(ST, NC_)                                                                                                  \
     hipLaunchKernelGGL((conv_mfma16_kernel<ST, NC_>), grid, block, 0, S_(stream), in, in_grid, s, out_coords, (const int*)m_dev, (int)m_cap, \
-                       wp, (int)cout, bn_scale, bn_shift, out)
+                       wp, (int)cout, bn_scale, bn_shift, out, vol)
     if (strided) { if (cin == 32) GPNERF_LAUNCH16(true, 2); else GPNERF_LAUNCH16(true, 1); }
     else { if (cin == 32) GPNERF_LAUNCH16(false, 2); else GPNERF_LAUNCH16(false, 1); }
 #undef GPNERF_LAUNCH16
@@ -822,11 +842,19 @@ int gpnerf_sparse_pyramid_run(const GpnerfPyramid* p, const float* code, int32_t
         grid = p->grid[i]; dims = p->dims[i];
         rc = conv(c[1], other, grid, dims, p->coords[i], p->m[i], p->cap[i], cur);
         if (rc != GPNERF_OK) return rc;
-        rc = conv(c[2], cur, grid, dims, p->coords[i], p->m[i], p->cap[i], other);
-        if (rc != GPNERF_OK) return rc;
-        { float* t = cur; cur = other; other = t; }
-        rc = gpnerf_sparse_scatter_dense(cur, c[2].cout, p->coords[i], grid, p->m[i], p->cap[i], dims, p->vol[i], 1, stream);
-        if (rc != GPNERF_OK) return rc;
+        if (c[2].form == 2) {
+            // the level's last convolution also writes its rows at their sites' cells of the (zeroed) dense volume: no scatter launch
+            rc = sparse_conv16(0, cur, c[2].cin, grid, dims, p->coords[i], p->m[i], p->cap[i], c[2].weight, c[2].cout, c[2].bn_scale, c[2].bn_shift,
+                               other, p->vol[i], stream);
+            if (rc != GPNERF_OK) return rc;
+            { float* t = cur; cur = other; other = t; }
+        } else {
+            rc = conv(c[2], cur, grid, dims, p->coords[i], p->m[i], p->cap[i], other);
+            if (rc != GPNERF_OK) return rc;
+            { float* t = cur; cur = other; other = t; }
+            rc = gpnerf_sparse_scatter_dense(cur, c[2].cout, p->coords[i], grid, p->m[i], p->cap[i], dims, p->vol[i], 1, stream);
+            if (rc != GPNERF_OK) return rc;
+        }
     }
     return GPNERF_OK;
 }
