@@ -282,6 +282,14 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
         }
     }
+    // the four channels this wavefront finishes (8 wave + 4 half ..): their BatchNorm factors are fetched before the exchange, all at
+    // once and unconditionally (clamped index) -- under `co < cout` each pair was a branch with a full wait behind it
+    float bsc[4], bsh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = min(i + 8 * wave + 4 * half, cout - 1);
+        bsc[i] = scale[co]; bsh[i] = shift[co];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
@@ -292,7 +300,7 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
         const float v = (((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane]) * ACC16_UNSCALE;
         const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < cout) {
-            const float y = fmaxf(fmaf(v, scale[co], shift[co]), 0.f);
+            const float y = fmaxf(fmaf(v, bsc[i], bsh[i]), 0.f);
             out[(size_t)site * cout + co] = y;
             if (vol) {
                 // (submanifold: the output grid is the input grid; strided: the coarse grid has half the input's size, rounded down)
