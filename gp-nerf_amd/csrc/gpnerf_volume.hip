@@ -564,10 +564,15 @@ __global__ void __launch_bounds__(64) vertex_attention_mfma_kernel(const float* 
 #pragma unroll
         for (int i = 0; i < 8; ++i) row[i] = reinterpret_cast<const f32x4v*>(p)[i];
     };
+    // every row the tile needs -- four weight rows, the vertex's code, its features in the views -- is requested before the first
+    // MFMA (a 64-thread workgroup has the whole register file): loaded per projection, each of the eight waited out its own round trip
+    f32x4v wrq[8], wrk[8], wrv[8], wrf[8], xq[8], xf[VIEWS][8];
+    load_row(wq + nn * 32, wrq); load_row(wk + nn * 32, wrk); load_row(wv + nn * 32, wrv); load_row(wfc + nn * 32, wrf);
+    load_row(q + (size_t)vc * 32, xq);
+#pragma unroll
+    for (int s = 0; s < VIEWS; ++s) load_row(kv + ((size_t)vc * VIEWS + s) * 32, xf[s]);
     // D = W . X for one 32 x 32 weight matrix (row m = this lane's output channel as A operand) and the tile's 32 input rows
-    auto project = [&](const float* __restrict__ W, const f32x4v (&x)[8]) {
-        f32x4v wr[8];
-        load_row(W + nn * 32, wr);
+    auto project = [&](const f32x4v (&wr)[8], const f32x4v (&x)[8]) {
         f32x16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -575,19 +580,15 @@ __global__ void __launch_bounds__(64) vertex_attention_mfma_kernel(const float* 
         for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pick(wr, s), pick(x, s), acc, 0, 0, 0);
         return acc;
     };
-    f32x4v xq[8];
-    load_row(q + (size_t)vc * 32, xq);
-    f32x16v qh = project(wq, xq);
+    f32x16v qh = project(wrq, xq);
 #pragma unroll
     for (int r = 0; r < 16; ++r) qh[r] *= inv_t;
     float score[VIEWS][4];
     f32x16v val[VIEWS];
 #pragma unroll
     for (int s = 0; s < VIEWS; ++s) {
-        f32x4v xf[8];
-        load_row(kv + ((size_t)vc * VIEWS + s) * 32, xf);
-        const f32x16v kh = project(wk, xf);
-        val[s] = project(wv, xf);
+        const f32x16v kh = project(wrk, xf[s]);
+        val[s] = project(wrv, xf[s]);
         float sg[4];                                    // register group g: channels 8 g + 4 half .. + 3 of this lane's vertex
 #pragma unroll
         for (int g = 0; g < 4; ++g) sg[g] = ((qh[4 * g] * kh[4 * g] + qh[4 * g + 1] * kh[4 * g + 1]) + qh[4 * g + 2] * kh[4 * g + 2]) + qh[4 * g + 3] * kh[4 * g + 3];
@@ -621,7 +622,7 @@ __global__ void __launch_bounds__(64) vertex_attention_mfma_kernel(const float* 
     f32x4v xo[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) xo[i] = f32x4v{stage[nn][4 * i], stage[nn][4 * i + 1], stage[nn][4 * i + 2], stage[nn][4 * i + 3]};
-    const f32x16v y = project(wfc, xo);
+    const f32x16v y = project(wrf, xo);
     if (v < n) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
