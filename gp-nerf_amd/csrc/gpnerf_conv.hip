@@ -571,6 +571,13 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
             h8 wh[COT], wlo[COT];
 #pragma unroll
             for (int c = 0; c < COT; ++c) { wh[c] = __builtin_bit_cast(h8, wreg[tap][c][0]); wlo[c] = __builtin_bit_cast(h8, wreg[tap][c][1]); }
+            // (GPNERF_X_CONV_*: diagnostic builds of tools/probes/conv_ablate.sh, results wrong on purpose: the loop without one of its parts)
+#ifdef GPNERF_X_CONV_NOMFMA
+#pragma unroll
+            for (int c = 0; c < COT; ++c) asm volatile("" :: "v"(wh[c]), "v"(wlo[c]));
+#pragma unroll
+            for (int t = 0; t < PT; ++t) asm volatile("" :: "v"(b[cur][t].hi), "v"(b[cur][t].lo));
+#else
 #ifdef GPNERF_X_LOLO
 #pragma unroll
             for (int c = 0; c < COT; ++c)
@@ -589,10 +596,13 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
             for (int c = 0; c < COT; ++c)
 #pragma unroll
                 for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+#endif
             if (cb_next >= 0) {
                 wload(tap, cb_next);
+#ifndef GPNERF_X_CONV_NOPARK
                 if (tap < PPASS) park_item(tap, buf ^ 1, cb_next, SET);
                 if (9 + tap < PPASS) park_item(9 + tap, buf ^ 1, cb_next, SET);
+#endif
             }
         }
     };
@@ -614,13 +624,23 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
     __syncthreads();
     for (int i = 0; i < nblk; i += 2) {
         // even block: staged in buffer 0; set 1 holds block i + 1 (in flight since the block before); set 0 is free for block i + 2
-        if (i + 2 < nblk) fetch(blk(i + 2), S0);
+#ifdef GPNERF_X_CONV_NOFETCH
+#define GPNERF_FETCH_(cb, S) ((void)0)
+#else
+#define GPNERF_FETCH_(cb, S) fetch(cb, S)
+#endif
+#ifdef GPNERF_X_CONV_NOSYNC
+#define GPNERF_SYNC_() ((void)0)
+#else
+#define GPNERF_SYNC_() __syncthreads()
+#endif
+        if (i + 2 < nblk) GPNERF_FETCH_(blk(i + 2), S0);
         compute(0, i + 1 < nblk ? blk(i + 1) : -1, S1);
-        __syncthreads();
+        GPNERF_SYNC_();
         if (i + 1 >= nblk) break;
-        if (i + 3 < nblk) fetch(blk(i + 3), S1);
+        if (i + 3 < nblk) GPNERF_FETCH_(blk(i + 3), S1);
         compute(1, i + 2 < nblk ? blk(i + 2) : -1, S0);
-        __syncthreads();
+        GPNERF_SYNC_();
     }
     if constexpr (KSPLIT == 2) {
         // the upper half hands its sums over ([wave][t][c][r][lane] floats, past what the epilogue's reductions use) and is done;

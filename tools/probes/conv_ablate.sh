@@ -6,8 +6,7 @@ build() { # name, flags
   hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function $2 -c -o /tmp/ab/conv_$1.o $C/gpnerf_conv.hip &&
   hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/ab/lib_$1.so $C/gpnerf_kernels.o $C/gpnerf_volume.o /tmp/ab/conv_$1.o; }
 run() { echo "== $1"; GPNERF_DEBUG=1 GPNERF_LIB_PATH=/tmp/ab/lib_$1.so GPNERF_CONV_KSPLIT_MAXWG=${KS:-256} python tools/probes/conv_layer_time.py 2>&1 | tail -2; }
-build product "" & build nomfma "-DGPNERF_X_CONV_NOMFMA" & build nopark "-DGPNERF_X_CONV_NOPARK" & build nowpark "-DGPNERF_X_CONV_NOWPARK" & wait
-build noread "-DGPNERF_X_CONV_NOREAD" & build nofetch "-DGPNERF_X_CONV_NOFETCH -DGPNERF_X_CONV_NOPARK" & build nosync "-DGPNERF_X_CONV_NOSYNC" &
-build mfmaonly "-DGPNERF_X_CONV_NOFETCH -DGPNERF_X_CONV_NOPARK -DGPNERF_X_CONV_NOWPARK -DGPNERF_X_CONV_NOREAD -DGPNERF_X_CONV_NOSYNC" & wait
-for v in product nomfma nopark nowpark noread nofetch nosync mfmaonly; do KS=0 run $v; done
+build product "" & build nomfma "-DGPNERF_X_CONV_NOMFMA" & build nopark "-DGPNERF_X_CONV_NOPARK" & build nofetch "-DGPNERF_X_CONV_NOFETCH -DGPNERF_X_CONV_NOPARK" & wait
+build nosync "-DGPNERF_X_CONV_NOSYNC" & build mfmaonly "-DGPNERF_X_CONV_NOFETCH -DGPNERF_X_CONV_NOPARK -DGPNERF_X_CONV_NOSYNC" & wait
+for v in product nomfma nopark nofetch nosync mfmaonly; do KS=0 run $v; done
 echo "---- with the K split"; for v in product nomfma mfmaonly; do run $v; done
