@@ -2,7 +2,9 @@
 """Headline benchmark: rays/s of the fused per-ray render path on synthetic 512x512x64 frames.
 
     python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by torch.distributed.run, one rank per GPU over RCCL.)
+(N > 1: one rank per GPU over RCCL.  Under torch.distributed.run -- WORLD_SIZE / RANK / LOCAL_RANK in the environment -- this
+process IS a rank; started plainly, it launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+before touching any GPU, relays rank 0's JSON line and exits with the child's status.)
 
 A "step" renders ONE frame through gpnerf_render_fused (sample -> gather -> MLP -> composite) with every output
 `Renderer.render` returns (rgb, depth, acc, disp, weights, z_vals, rgb_in), in the 32x8-pixel patch order `Renderer.render`
@@ -116,8 +118,44 @@ def time_launches(fn, steps, warmup):
     return float(np.mean([a.elapsed_time(b) for a, b in ev])), out
 
 
+def launch_command(gpus, port, argv):
+    """The command a plain `python bench.py --gpus N ...` runs as a child: the driver's own N > 1 launch line."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(args):
+    """`--gpus N` with no WORLD_SIZE in the environment: start the N ranks as a CHILD process (this one has not touched a GPU and
+    never does -- it only counts devices, which does not initialise HIP on this image --, and it does not exec), pass rank 0's
+    JSON line through on stdout and return the child's exit status."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if env.get("GPNERF_BENCH_BACKEND", "nccl") == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but {have} device(s) visible; a measured run needs one GPU per rank "
+                  f"(GPNERF_BENCH_BACKEND=gloo is the dry run with ranks sharing devices)", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = subprocess.Popen(launch_command(args.gpus, port, sys.argv[1:]), stdout=subprocess.PIPE, text=True, env=env)
+    for line in p.stdout:                             # the ranks' stderr goes straight through; stdout carries rank 0's one line
+        if line.lstrip().startswith("{"):
+            print(line.rstrip("\n"), flush=True)
+        else:
+            sys.stderr.write(line)
+    return p.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -217,11 +255,12 @@ def main():
         # BASELINE.json configs[3]: one 1024x1024x64 frame over the same ranks, same flow
         wl4 = Workload(args, 1024, 64, dev, 0.0)
         f4 = Flow(wl4)
-        dt4, k4, _ = f4.timed(max(3, args.steps // 2), 2)
+        dt4, k4, out4 = f4.timed(max(3, args.steps // 2), 2)
         st4 = max(3, args.steps // 2)
         extras["config4_1024"] = {"workload": "1024x1024 frame, 64 samples/ray, rays in round-robin bands over the ranks + pixel all-gather "
                                               "(BASELINE.json configs[3])", "value": wl4.n * st4 / dt4, "unit": "rays/s", "ms_per_frame": dt4 / st4 * 1e3,
-                                  "kernel_ms_rank0": k4, "rays_per_rank": int(f4.n_local), "rays_total": int(wl4.n)}
+                                  "kernel_ms_rank0": k4, "rays_per_rank": int(f4.n_local), "rays_total": int(wl4.n),
+                                  "maps_finite": bool(all(torch.isfinite(out4[k]).all() for k in par.PIXEL_KEYS))}
         del wl4, f4
 
     if rank == 0:
@@ -288,6 +327,7 @@ def main():
             line["vs_cpu_scalar_oracle"] = value / line["cpu_baseline"]["scalar_oracle"]["value"]
         # sanity on the product's own output (not a parity check; tests/ do that)
         assert bool(torch.isfinite(out["rgb_map"]).all()), "non-finite rgb"
+        line["maps_finite"] = bool(torch.isfinite(out["rgb_map"]).all() and torch.isfinite(out["depth_map"]).all())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -157,10 +157,16 @@ struct ConvArgs {
 template <int COT>
 DEV void finalize_if_last(const ConvArgs& a, const int n, const int ct0, const int ntiles, double* red /* [2][256] doubles of LDS */) {
     // No agent-scope fence here: a release fence would write back this XCD's whole L2 (the convolution's output has just
-    // dirtied it; measured: the encoder 1.35 -> 1.9 ms).  The tile sums were stored with agent-scope atomics (write-through);
-    // the workgroup-scope release below is an s_waitcnt on those stores' acknowledgements, the ticket is a relaxed agent-scope
-    // atomic issued after it, and the last workgroup reads the sums back with agent-scope atomic loads (past its own L2).
+    // dirtied it; measured: the encoder 1.35 -> 1.9 ms).  The tile sums were stored with agent-scope atomic stores (sc1:
+    // written through to the device's coherence point).  What orders them before the ticket is an EXPLICIT s_waitcnt vmcnt(0)
+    // in every wave, in front of the barrier: on gfx9 a workgroup-scope release fence only waits on lgkmcnt (round 3 relied on
+    // it and the built code had its first vmcnt(0) behind the ticket atomic, so the ticket could become visible while another
+    // wave's write-through stores were still in flight to their L2 channel).  With the wait, every wave's stores are
+    // acknowledged before it enters the barrier, the ticket (a relaxed agent-scope atomic) is issued behind the barrier, and
+    // the last workgroup reads the sums back with agent-scope atomic loads (past its own L2).  tools/isa_ticket_release.py
+    // checks the built ISA for exactly this order (tests/test_abi.py).
     __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -183,3 +183,38 @@ def test_the_hazard_checker_flags_an_opaque_consumer(tmp_path):
     by_mode = {m: next(b for n, b in res.items() if f"ILi{m}E" in n) for m in (0, 1, 2)}
     assert not by_mode[0] and not by_mode[2]
     assert len(by_mode[1]) == 1 and by_mode[1][0][5] is True and "v_add_f32" in by_mode[1][0][1]
+
+
+def _ticket_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_ticket_release", os.path.join(ROOT, "tools", "isa_ticket_release.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_every_waves_tile_sums_are_acknowledged_before_the_norm_ticket():
+    """The fused InstanceNorm table (gpnerf_conv.hip finalize_if_last): the last workgroup of an (image, channel group) reads
+    every other workgroup's write-through tile sums, so each wave must `s_waitcnt vmcnt(0)` before the barrier in front of the
+    ticket atomic -- a workgroup-scope release fence does not emit that wait on gfx9 (round 3's build had it BEHIND the ticket:
+    a timing-dependent stale read no golden vector can catch).  tools/isa_ticket_release.py walks the ISA the compiler emitted."""
+    import shutil
+    if not (shutil.which("llvm-objdump") or os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    res = _ticket_tool().scan(os.path.join(ROOT, "gp-nerf_amd", "csrc", "libgpnerf_hip.so"))
+    assert len(res) >= 15, "the disassembly did not find the convolution kernels with a norm ticket"
+    bad = [(name, b) for name, _, b in res if b]
+    assert not bad, bad
+
+
+def test_the_ticket_checker_flags_an_unwaited_store():
+    tool = _ticket_tool()
+    good = ["global_store_dword v[20:21], v22, off sc1", "s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_barrier",
+            "global_atomic_add v20, v20, v21, s[12:13] sc0"]
+    late = ["global_store_dword v[20:21], v22, off sc1", "s_waitcnt lgkmcnt(0)", "s_barrier",
+            "global_atomic_add v20, v20, v21, s[12:13] sc0", "s_waitcnt vmcnt(0)"]
+    none = ["global_store_dword v[20:21], v22, off sc1", "s_waitcnt vmcnt(0)", "global_atomic_add v20, v20, v21, s[12:13] sc0"]
+    rows = lambda ls: list(enumerate(ls, 1))
+    assert tool.check(rows(good)) == (1, [])
+    assert len(tool.check(rows(late))[1]) == 1 and "not waited for" in tool.check(rows(late))[1][0][2]
+    assert len(tool.check(rows(none))[1]) == 1 and "no s_barrier" in tool.check(rows(none))[1][0][2]

@@ -43,7 +43,52 @@ def test_bench_early_termination_line():
     assert j["roofline"]["samples_evaluated_frac"] == j["early_term"]["samples_evaluated_frac"]
 
 
+def _env_without_ranks(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how a driver might issue the SCALE run) launches its two
+    ranks itself -- RCCL when two devices are visible, the gloo dry run with both ranks on cuda:0 otherwise -- and relays rank 0's
+    single line: the strong-scaling flow of one frame (libs/renders/BaseRender.py:160-184 as N ranks x one launch) plus the
+    1024x1024 frame of BASELINE.json configs[3]."""
+    import torch
+    extra = {} if torch.cuda.device_count() >= 2 else {"GPNERF_BENCH_BACKEND": "gloo"}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128"],
+                         capture_output=True, text=True, timeout=900, env=_env_without_ranks(**extra))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 2
+    assert j["config"]["rays_total"] == 128 * 128 and 0 < j["config"]["rays_per_gpu"] < j["config"]["rays_total"]
+    assert j["value"] > 0 and abs(j["value"] - j["config"]["rays_total"] / (j["ms_per_step"] * 1e-3)) < 1e-3 * j["value"]
+    c4 = j["config4_1024"]
+    assert c4["rays_total"] == 1024 * 1024 and c4["rays_per_rank"] * 2 >= c4["rays_total"] and c4["value"] > 0
+    assert j["maps_finite"] is True and c4["maps_finite"] is True
+
+
+def test_bench_launch_line_is_the_drivers():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(4, 29511, ["--gpus", "4", "--steps", "3"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+
+
 def test_bench_refuses_a_world_size_mismatch():
+    """Under a launcher (WORLD_SIZE set) the process is a rank and must not start ranks of its own; a mismatch is an error."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
-                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+                         env=_env_without_ranks(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_bench_self_launch_needs_a_gpu_per_rank_and_says_so():
+    """No GPU here: the parent counts devices before starting anything and refuses a measured (nccl) run with fewer GPUs than ranks."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                         env=_env_without_ranks(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    assert out.returncode == 2 and "device(s) visible" in out.stderr and not out.stdout.strip()
