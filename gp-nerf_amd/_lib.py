@@ -118,12 +118,15 @@ SYMBOLS = {
     "gpnerf_conv_pack_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_conv_out_tiles": (C.c_int32, [C.c_int32] * 5),
     "gpnerf_conv2d_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpnerf_conv2d_nhwc_exact": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_conv2d_norm_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
-                                          C.c_void_p, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_conv2d_norm_cat_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
     "gpnerf_norm_apply_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                          C.c_void_p]),
     "gpnerf_instance_norm_nhwc_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int64, C.c_int32]),

@@ -149,6 +149,14 @@ struct ConvArgs {
     // ([N][H][W][Cin - CinA]); x2 nullptr: CinA = Cin
     const float* x2;
     int CinA;
+    // Range flag of the split-f16 form, or nullptr: ONE word that is set to 1 when an operand left the f16 range.  An activation
+    // with |16 x| >= 65520 (or a weight with |4096 w| >= 65520) becomes an f16 infinity when it is split, its lo half the opposite
+    // infinity, and every accumulator it meets ends up NaN -- nothing is silently wrong, the result is loudly non-finite.  That is
+    // looked for where it costs nothing: the InstanceNorm table's sums (finalize_if_last: a non-finite sum or sum of squares of any
+    // channel), and the accumulators themselves in a convolution with no norm behind it.  The host then runs the layer chain
+    // again in the exact fp32 form (gpnerf_conv2d_nhwc_exact).  A non-finite INPUT sets the flag too (the exact form then returns
+    // what fp32 arithmetic makes of it).  The word is only ever written with 1; the caller zeroes it.
+    unsigned* flag;
 };
 
 // Last-arriving workgroup of (image n, channel group ct0 .. ct0 + COT): every workgroup has written its tile sums; the one whose
@@ -207,6 +215,8 @@ DEV void finalize_if_last(const ConvArgs& a, const int n, const int ct0, const i
         a.out_tab[((size_t)n * 3 + 0) * a.Cout + co] = (float)mean;
         a.out_tab[((size_t)n * 3 + 1) * a.Cout + co] = g;
         a.out_tab[((size_t)n * 3 + 2) * a.Cout + co] = a.beta[co];
+        // an operand beyond the f16 range (ConvArgs::flag): the channel's sums are non-finite
+        if (a.flag && !(fabs(ts) < __builtin_inf() && fabs(tq) < __builtin_inf())) __hip_atomic_store(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (threadIdx.x == 0) __hip_atomic_store(&a.counters[(size_t)n * gridDim.z + blockIdx.z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
@@ -259,6 +269,21 @@ DEV void tile_stats(const f32x16 (&acc)[NP][COT], const bool (&valid)[NP], float
             __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+// A convolution with no InstanceNorm behind it (the encoder's output convolution): the range flag (ConvArgs::flag) is raised
+// from the accumulators themselves -- 0 * v is NaN exactly when v is not finite.  Pixels beyond the image are copies of real
+// ones (clamped positions), so they raise no false flag.
+template <int COT, int NP>
+DEV void flag_nonfinite(const f32x16 (&acc)[NP][COT], const ConvArgs& a) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t = fmaf(acc[p][c][r], 0.f, t);
+    if (t != t) __hip_atomic_store(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // this lane's 8 input channels (16 cb + 8 half ..) of pixel (iy, ix)
@@ -414,7 +439,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
     if (a.out_tab) {
         __shared__ double fin_red[512];
         finalize_if_last<COT>(a, n, ct0, (int)gridDim.x, fin_red);
-    }
+    } else if (a.flag) flag_nonfinite<COT, PT>(acc, a);
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (!valid[t]) continue;
@@ -690,6 +715,7 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
     }
     if (a.stats) tile_stats<COT, RW>(acc, valid, reinterpret_cast<float*>(smem), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
     if (a.out_tab) finalize_if_last<COT>(a, n, ct0, (int)gridDim.x, reinterpret_cast<double*>(smem + 8192));
+    else if (a.flag) flag_nonfinite<COT, PT>(acc, a);
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (!valid[t]) continue;
@@ -835,6 +861,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv7x7_s2_stem_kernel(const ConvA
     }
     if (a.stats) tile_stats<COT, PT>(acc, valid, reinterpret_cast<float*>(smem), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
     if (a.out_tab) finalize_if_last<COT>(a, n, ct0, (int)gridDim.x, reinterpret_cast<double*>(smem + 8192));
+    else if (a.flag) flag_nonfinite<COT, PT>(acc, a);
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (!valid[t]) continue;
@@ -980,6 +1007,53 @@ __global__ void upsample2x_nhwc_kernel(const float* __restrict__ x, const int N,
     *reinterpret_cast<f32x4*>(out + (size_t)p * C + 4 * g) = o;
 }
 
+// ---- the exact form: fp32 operands on v_mfma_f32_32x32x2_f32 -----------------------------------------------------------------
+// What the encoder falls back to when the split-f16 form raised its range flag (an activation of 4 095 or more in magnitude, a
+// weight of 16 or more): the same implicit GEMM with the operands as they are, every dot product an fp32 FMA chain over
+// (tap, input channel) -- the reference's own arithmetic up to the order of the sum, no range to respect.  Reads the PyTorch
+// weight [Cout][Cin][KS][KS] directly (nothing is packed) and any KS / stride / channel count.  A wave owns 32 output pixels x
+// 32 output channels and issues one MFMA per two input channels with two scalar loads per lane in front of it: ~20x the time of
+// the split form, which does not matter on a path that exists so that no checkpoint is refused.
+struct ExactArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    int H, W, Cin, Ho, Wo, Cout, KS, stride;
+};
+
+__global__ void __launch_bounds__(WAVES * 64) conv2d_exact_kernel(const ExactArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y, ct = blockIdx.z;
+    const int howo = a.Ho * a.Wo, pad = a.KS / 2, kk = a.KS * a.KS;
+    const int p = ((int)blockIdx.x * WAVES + wave) * 32 + px;
+    const bool valid = p < howo;
+    const int pc = valid ? p : howo - 1;
+    const int oy = pc / a.Wo, ox = pc % a.Wo;
+    const int co_a = 32 * ct + px;                                  // the A operand's row of this lane: lane (row, k = half)
+    const bool row_ok = co_a < a.Cout;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ky = 0; ky < a.KS; ++ky)
+        for (int kx = 0; kx < a.KS; ++kx) {
+            const int iy = reflect(oy * a.stride + ky - pad, a.H), ix = reflect(ox * a.stride + kx - pad, a.W);
+            const float* xp = a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.Cin;
+            const float* wp = a.w + (size_t)(row_ok ? co_a : 0) * a.Cin * kk + ky * a.KS + kx;
+            for (int ci = 0; ci < a.Cin; ci += 2) {
+                const int k = ci + half;
+                const bool k_ok = k < a.Cin;
+                const float bv = k_ok ? xp[k] : 0.f;
+                const float av = (k_ok && row_ok) ? wp[(size_t)k * kk] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+        }
+    if (!valid) return;
+    float* yp = a.y + ((size_t)n * howo + p) * a.Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * ct + ft(r, half);
+        if (co < a.Cout) yp[co] = acc[r] + (a.bias ? a.bias[co] : 0.f);
+    }
+}
+
 hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 int status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
 
@@ -1112,7 +1186,7 @@ int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int
 
 int gpnerf_conv2d_norm_cat_nhwc(const float* x, int32_t cin_a, const float* x_b, int32_t cin_b, int32_t n, int32_t h, int32_t w,
                                 const void* packed, const float* bias, int32_t cout, float* y, float* tile_stats, const float* gamma,
-                                const float* beta, float eps, float* out_table, uint32_t* counters, void* stream) {
+                                const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag, void* stream) {
     if (n == 0) return GPNERF_OK;
     if (!x || !x_b || !packed || !y || n < 0 || h < 2 || w < 2 || cin_a < 16 || (cin_a & 15) || cin_b < 16 || (cin_b & 15) || cout < 4 || (cout & 3))
         return GPNERF_E_ARG;
@@ -1122,12 +1196,14 @@ int gpnerf_conv2d_norm_cat_nhwc(const float* x, int32_t cin_a, const float* x_b,
     a.H = h; a.W = w; a.Cin = cin_a + cin_b; a.Cout = cout; a.Ho = h; a.Wo = w;
     a.CB = a.Cin / 16; a.CT = (cout + 31) / 32;
     a.in_tab = nullptr; a.in_act = 0; a.out_tab = out_table; a.gamma = gamma; a.beta = beta; a.eps = eps; a.counters = counters;
+    a.flag = range_flag;
     return launch_conv3x3(a, n, stream);
 }
 
 int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* in_table, int32_t in_act,
                             const void* packed, const float* bias, int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats,
-                            const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, void* stream) {
+                            const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag,
+                            void* stream) {
     if (n == 0) return GPNERF_OK;
     if (!x || !packed || !y || n < 0 || h < 1 || w < 1 || cin < 1 || cout < 4 || (cout & 3)) return GPNERF_E_ARG;
     if ((ks != 1 && ks != 3 && ks != 7) || (stride != 1 && stride != 2)) return GPNERF_E_ARG;
@@ -1144,6 +1220,7 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
     a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
     a.CB = narrow ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16; a.CT = (cout + 31) / 32;
     a.in_tab = in_table; a.in_act = in_act; a.out_tab = out_table; a.gamma = gamma; a.beta = beta; a.eps = eps; a.counters = counters;
+    a.flag = range_flag;
     if (narrow) {
         if (ks == 7 && stride == 2 && cin <= 4) return launch_stem(a, n, stream);
         if (ks == 7) return GPNERF_E_ARG;                                  // (7x7 on 5 .. 7 channels: not built)
@@ -1158,9 +1235,23 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
 }
 
 int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
-                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, void* stream) {
+                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, uint32_t* range_flag, void* stream) {
     return gpnerf_conv2d_norm_nhwc(x, n, h, w, cin, nullptr, 0, packed, bias, cout, ks, stride, y, tile_stats, nullptr, nullptr, 0.f, nullptr,
-                                   nullptr, stream);
+                                   nullptr, range_flag, stream);
+}
+
+int gpnerf_conv2d_nhwc_exact(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* weight, const float* bias,
+                             int32_t cout, int32_t ks, int32_t stride, float* y, void* stream) {
+    if (n == 0) return GPNERF_OK;
+    if (!x || !weight || !y || n < 0 || h < 1 || w < 1 || cin < 1 || cout < 1 || ks < 1 || !(ks & 1) || stride < 1) return GPNERF_E_ARG;
+    const int pad = ks / 2;
+    if (h <= pad || w <= pad) return GPNERF_E_ARG;                       // reflection needs pad < size
+    ExactArgs a;
+    a.x = x; a.w = weight; a.bias = bias; a.y = y; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.KS = ks; a.stride = stride;
+    a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
+    const int tiles = (a.Ho * a.Wo + WAVES * 32 - 1) / (WAVES * 32);
+    hipLaunchKernelGGL(conv2d_exact_kernel, dim3((unsigned)tiles, (unsigned)n, (unsigned)((cout + 31) / 32)), dim3(WAVES * 64), 0, S_(stream), a);
+    return status();
 }
 
 int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c) {

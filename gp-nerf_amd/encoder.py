@@ -10,12 +10,20 @@ is the layout the render kernel gathers from, so `Frame` takes it as is, without
 nn.InstanceNorm2d sub-modules are parameter containers under the reference's names; there is no torch-operator path (the
 one the tests check against is oracle/producers_ref.py `encoder`).
 
+Operand range.  The split-f16 convolutions hold |w| < 16 and |x| < 4 095.  No checkpoint is refused for that: an operand beyond
+the range splits into f16 infinities, the outputs it meets are NaN, and the convolutions raise a flag word when they see a
+non-finite sum in their InstanceNorm table (`_Run.flag`, include/gpnerf_hip.h `range_flag`) -- a DATA-dependent guard that costs
+the kernels nothing.  A flagged pass is discarded and the frame encoded again by `forward_exact` (fp32 operands on
+v_mfma_f32_32x32x2_f32, every norm from a double-precision pass).  `check_operand_range` is the fast accept in front of it: when
+the parameters alone bound every activation (sqrt(h w) |gamma| + |beta| ...) the flag cannot be raised and is never looked at.
+
 Network (UNet.py:154-234): 7x7/2 stem -> three residual stages of [3,4,6] two-conv units at 64/128/256 channels, every stage
 entered with stride 2 (there is no max-pool), all 3x3 / 7x7 convolutions reflect-padded, every normalisation an affine
 InstanceNorm without running statistics -> two (bilinear x2, align_corners) + conv + concat-skip decoder steps with
 InstanceNorm + ELU -> 1x1 output convolution.
 """
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -91,8 +99,27 @@ def _conv(conv, x, stats=False):
     ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, cin, ks, stride)), cout, 2), device=x.device, dtype=torch.float32) if stats else None
     L.check(lib.gpnerf_conv2d_nhwc(x.data_ptr(), n, h, w, cin, _packed_weight(conv).data_ptr(),
                                    bias.data_ptr() if bias is not None else None, cout, ks, stride, out.data_ptr(),
-                                   ts.data_ptr() if ts is not None else None, _st(x)), "gpnerf_conv2d_nhwc")
+                                   ts.data_ptr() if ts is not None else None, _run_of(x).flag_ptr, _st(x)), "gpnerf_conv2d_nhwc")
     return (out, ts) if stats else out
+
+
+def _conv_exact(conv, x):
+    """The same nn.Conv2d on fp32 operands (gpnerf_conv2d_nhwc_exact: an fp32 FMA chain per output on v_mfma_f32_32x32x2_f32,
+    straight from the PyTorch weight): what a frame is encoded with after the split-f16 form raised its range flag."""
+    if not x.is_cuda:
+        raise L.GpnerfError("the HIP image encoder runs on GPU tensors only (no CPU fallback)")
+    x = _nhwc(x.float())
+    n, cin, h, w = x.shape
+    cout, _, ks, _ = conv.weight.shape
+    stride = conv.stride[0]
+    pad = ks // 2
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    out = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    wt = conv.weight.detach().float().contiguous()
+    bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+    L.check(L.lib().gpnerf_conv2d_nhwc_exact(x.data_ptr(), n, h, w, cin, wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                             cout, ks, stride, out.data_ptr(), _st(x)), "gpnerf_conv2d_nhwc_exact")
+    return out
 
 
 def _norm_act(norm, x, act, residual=None, stats=None):
@@ -113,14 +140,66 @@ def _norm_act(norm, x, act, residual=None, stats=None):
     return out
 
 
-_tickets = {}     # device -> zeroed uint32 words the fused convolutions count their finished workgroups in (left zero by every launch)
+class _Run:
+    """The words one pass of the encoder's fused convolutions shares on the device: the ticket words in which the workgroups of an
+    (image, channel group) count themselves (zero before a launch, left zero by it) and the range flag (module docstring).  Two
+    passes that may overlap in time must not share them -- counts would mix -- so there is one _Run per (device, stream) for eager
+    calls and one per captured graph (a graph bakes the pointers in and may be replayed on any stream).
+    The flag lives in pinned host memory: the device writes it (only ever a 1, and only when something is out of range), the
+    host reads it after a stream synchronisation without a copy."""
+
+    def __init__(self, dev):
+        self.tickets = torch.zeros((4096,), dtype=torch.int32, device=dev)
+        if L._DEBUG and os.environ.get("GPNERF_ENC_FLAG_DEVICE") == "1":      # diagnostic: the flag in device memory, read with a copy
+            self.flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        else:
+            self.flag = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self.flag_ptr = self.flag.data_ptr()
+
+    def raised(self):
+        """True when a convolution of the passes since the last clear() saw an operand beyond the f16 range.  The caller has
+        synchronised with the stream the pass ran on."""
+        return bool(int(self.flag[0]) != 0)
+
+    def clear(self):
+        self.flag.zero_()
+
+
+_runs = {}                       # (device, stream handle) -> _Run of the eager calls on that stream
+_current = threading.local()     # .run: the _Run a capture / replay pins for the calls it makes
+
+
+def _run_of(x):
+    run = getattr(_current, "run", None)
+    if run is not None:
+        return run
+    key = (str(x.device), _st(x))
+    run = _runs.get(key)
+    if run is None:
+        if len(_runs) > 64:
+            _runs.clear()
+        run = _runs[key] = _Run(x.device)
+    return run
+
+
+class _pinned_run:
+    """with _pinned_run(run): every fused convolution called inside uses `run`'s words"""
+
+    def __init__(self, run):
+        self.run = run
+
+    def __enter__(self):
+        self.prev = getattr(_current, "run", None)
+        _current.run = self.run
+        return self.run
+
+    def __exit__(self, *exc):
+        _current.run = self.prev
 
 
 def _ticket_words(dev):
-    t = _tickets.get(str(dev))
-    if t is None:
-        t = _tickets[str(dev)] = torch.zeros((4096,), dtype=torch.int32, device=dev)
-    return t
+    """the ticket words of the current stream's eager calls on `dev` (tests look at them: a launch must leave them zero)"""
+    return _run_of(torch.empty((0,), device=dev)).tickets
 
 
 def _conv_norm(conv, norm, x, in_tab=None, in_act=0):
@@ -141,13 +220,14 @@ def _conv_norm(conv, norm, x, in_tab=None, in_act=0):
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
     ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, cin, ks, stride)), cout, 2), device=x.device, dtype=torch.float32)
     tab = torch.empty((n, 3, cout), device=x.device, dtype=torch.float32)
-    tick = _ticket_words(x.device)
+    run = _run_of(x)
+    tick = run.tickets
     if n * ((cout + 31) // 32) > tick.numel():
         raise L.GpnerfError("too many (image, channel group) pairs for the ticket words")
     L.check(lib.gpnerf_conv2d_norm_nhwc(x.data_ptr(), n, h, w, cin, in_tab.data_ptr() if in_tab is not None else None, int(in_act),
                                         _packed_weight(conv).data_ptr(), bias.data_ptr() if bias is not None else None, cout, ks, stride,
                                         out.data_ptr(), ts.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
-                                        tab.data_ptr(), tick.data_ptr(), _st(x)), "gpnerf_conv2d_norm_nhwc")
+                                        tab.data_ptr(), tick.data_ptr(), run.flag_ptr, _st(x)), "gpnerf_conv2d_norm_nhwc")
     return out, tab
 
 
@@ -163,13 +243,14 @@ def _conv_norm_cat(conv, norm, xa, xb):
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
     ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, ca + cb, 3, 1)), cout, 2), device=xa.device, dtype=torch.float32)
     tab = torch.empty((n, 3, cout), device=xa.device, dtype=torch.float32)
-    tick = _ticket_words(xa.device)
+    run = _run_of(xa)
+    tick = run.tickets
     if n * ((cout + 31) // 32) > tick.numel():
         raise L.GpnerfError("too many (image, channel group) pairs for the ticket words")
     L.check(lib.gpnerf_conv2d_norm_cat_nhwc(xa.data_ptr(), ca, xb.data_ptr(), cb, n, h, w, _packed_weight(conv).data_ptr(),
                                             bias.data_ptr() if bias is not None else None, cout, out.data_ptr(), ts.data_ptr(),
                                             norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), tab.data_ptr(), tick.data_ptr(),
-                                            _st(xa)), "gpnerf_conv2d_norm_cat_nhwc")
+                                            run.flag_ptr, _st(xa)), "gpnerf_conv2d_norm_cat_nhwc")
     return out, tab
 
 
@@ -231,6 +312,13 @@ class ResidualUnit(nn.Module):
         d, td = _conv_norm(self.downsample[0], self.downsample[1], x, in_tab=x_tab, in_act=act0)
         return _apply(y2, t2, 1, residual=d, res_tab=td)
 
+    def forward_exact(self, x):
+        """UNet.py:38-53 on the exact kernels, one launch chain per operator (conv / statistics pass / normalise)."""
+        out = _norm_act(self.bn1, _conv_exact(self.conv1, x), 1)
+        out = _conv_exact(self.conv2, out)
+        idn = x if self.downsample is None else _norm_act(self.downsample[1], _conv_exact(self.downsample[0], x), 0)
+        return _norm_act(self.bn2, out, 1, residual=idn)
+
 
 class ConvNormELU(nn.Module):
     """conv (with bias, reflect pad) -> InstanceNorm -> ELU (UNet.py:107-120); sub-modules `conv`, `bn`."""
@@ -243,6 +331,11 @@ class ConvNormELU(nn.Module):
         if isinstance(x, tuple):                     # (a, b): the concatenation [a, b] on channels, read in place
             return _apply(*_conv_norm_cat(self.conv, self.bn, *x), 2)
         return _apply(*_conv_norm(self.conv, self.bn, x), 2)
+
+    def forward_exact(self, x):
+        if isinstance(x, tuple):
+            x = torch.cat([_nhwc(x[0]), _nhwc(x[1])], dim=1)
+        return _norm_act(self.bn, _conv_exact(self.conv, x), 2)
 
 
 class UpsampleConv(nn.Module):
@@ -257,6 +350,11 @@ class UpsampleConv(nn.Module):
         if self.scale != 2 or x.dtype != torch.float32:
             raise L.GpnerfError("the upsampling kernel is built for the reference's x2 bilinear steps on fp32 (UNet.py:185-188)")
         return self.conv(_upsample2x(x))
+
+    def forward_exact(self, x):
+        if self.scale != 2 or x.dtype != torch.float32:
+            raise L.GpnerfError("the upsampling kernel is built for the reference's x2 bilinear steps on fp32 (UNet.py:185-188)")
+        return self.conv.forward_exact(_upsample2x(x))
 
 
 def _stage(cin, cout, n):
@@ -296,34 +394,49 @@ class ResUNet(nn.Module):
     W_LIMIT, X_LIMIT = 15.99, 4094.0
 
     def check_operand_range(self, H, W):
-        """The convolutions' f16 hi/lo operands hold |w| < 16 and |x| < 4 094.  Weights are checked directly; activations through
-        the bound InstanceNorm gives them: a normalised value is at most sqrt(h w - 1) in magnitude, so a norm's output is bounded by
-        sqrt(h w) max|gamma| + max|beta| whatever the data, a residual unit's by that plus its shortcut's bound, and bilinear
-        upsampling / concatenation / ReLU / ELU do not raise a bound.  Raises GpnerfError naming the first layer whose input could
-        leave the range (for the reference's initialisation and any InstanceNorm scale below ~10 it cannot); cached per (H, W,
-        parameter versions): ONE device-to-host copy per parameter change.  The images themselves must stay below 255 in
-        magnitude (the dataset hands over values in [-1, 1])."""
+        """Which guard a frame of H x W images needs, from the PARAMETERS alone (cached per (H, W, parameter versions): one
+        device-to-host copy per parameter change).  Never refuses finite parameters:
+          "static"   every convolution's operands are inside the split-f16 range whatever the images: weights |w| < 16 directly,
+                     activations through the bound InstanceNorm gives them -- a normalised value is at most sqrt(h w - 1) in
+                     magnitude, so a norm's output is bounded by sqrt(h w) max|gamma| + max|beta|, a residual unit's by that plus
+                     its shortcut's bound, and upsampling / concatenation / ReLU / ELU do not raise a bound.  The range flag cannot
+                     be raised and nobody waits for it (the reference's initialisation; any InstanceNorm scale below ~10 at 512^2);
+          "dynamic"  the bound does not hold (it grows with the image size and is attained by a one-hot image only): the split form
+                     runs and its range flag says whether THIS frame left the range -- if so the frame is encoded again by
+                     forward_exact;
+          "exact"    a weight is 16 or more in magnitude (or a parameter is not finite): every frame goes through forward_exact.
+        `self.range_report` names the first layer that decided a "dynamic" / "exact" answer."""
         key = (int(H), int(W), _graph_key(self, next(self.parameters()))[3])
-        hit = self.__dict__.get("_gpnerf_range_ok")
-        if hit == key:
-            return
+        hit = self.__dict__.get("_gpnerf_range_class")
+        if hit is not None and hit[0] == key:
+            return hit[1]
         names, tensors = zip(*[(n, p) for n, p in self.named_parameters()])
         mx = dict(zip(names, torch.stack([t.detach().abs().max().float() for t in tensors]).cpu().tolist()))
+        verdict, report = "static", None
+
+        def settle(v, why):
+            nonlocal verdict, report
+            if report is None or (v == "exact" and verdict != "exact"):
+                report = why
+            if v == "exact" or verdict == "static":
+                verdict = v
+
         for n, v in mx.items():
             if n.endswith("weight") and n.rsplit(".", 1)[0] in self._conv_names() and not v < self.W_LIMIT:
-                raise L.GpnerfError(f"encoder: |{n}| reaches {v:.3g}; the split-f16 convolution holds weights below 16")
+                settle("exact", f"|{n}| reaches {v:.3g}; the split-f16 convolution holds weights below 16")
+            elif not v < float("inf"):
+                settle("exact", f"{n} is not finite")
 
         def norm_bound(prefix, hw):
             return (hw ** 0.5) * mx[prefix + ".weight"] + mx[prefix + ".bias"]
 
         def need(name, bound):
             if not bound < self.X_LIMIT:
-                raise L.GpnerfError(f"encoder: the input of {name} can reach {bound:.4g} (InstanceNorm scales too large for this image "
-                                    f"size); the split-f16 convolution holds activations below {self.X_LIMIT:.0f}")
+                settle("dynamic", f"the input of {name} can reach {bound:.4g} on a one-hot image (InstanceNorm scales x sqrt(h w)); the "
+                                  f"split-f16 convolution holds activations below {self.X_LIMIT:.0f}")
 
         half = lambda n: (n - 1) // 2 + 1
         h, w = half(int(H)), half(int(W))
-        need("conv1", 255.0)
         b = norm_bound("bn1", h * w)
         sizes, bounds = {}, {}
         for stage, units in (("layer1", 3), ("layer2", 4), ("layer3", 6)):
@@ -350,7 +463,9 @@ class ResUNet(nn.Module):
         b = max(norm_bound("upconv2.conv.bn", h * w), bounds["layer1"])
         need("iconv2.conv", b)
         need("out_conv", norm_bound("iconv2.bn", h * w))
-        self.__dict__["_gpnerf_range_ok"] = key
+        self.__dict__["_gpnerf_range_class"] = (key, verdict)
+        self.__dict__["range_report"] = report
+        return verdict
 
     def _conv_names(self):
         names = self.__dict__.get("_gpnerf_conv_names")
@@ -368,9 +483,24 @@ class ResUNet(nn.Module):
 
     def forward(self, x):
         """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the result leaves with channels-last strides, which `Frame`
-        recognises (no re-layout launch)."""
+        recognises (no re-layout launch).  The split-f16 form; a frame that leaves its operand range (check_operand_range: only
+        looked at when the parameters do not exclude it -- the host then waits for the stream once) is encoded again by
+        forward_exact.  `self.exact_frames` counts those."""
         _require_gpu_inference(x, self.training)
-        self.check_operand_range(x.shape[-2], x.shape[-1])
+        cls = self.check_operand_range(x.shape[-2], x.shape[-1])
+        if cls == "exact":
+            return self.forward_exact(x)
+        run = _run_of(x)
+        y = self.forward_fast(x)
+        if cls == "dynamic":
+            torch.cuda.current_stream(x.device).synchronize()
+            if run.raised():
+                run.clear()
+                return self.forward_exact(x)
+        return y
+
+    def forward_fast(self, x):
+        """The split-f16 launch chain alone (what a HIP graph captures): the caller looks at the range flag."""
         y0, t0 = _conv_norm(self.conv1, self.bn1, x.float())      # bn1 + ReLU: applied by the two convolutions that read y0
         x1 = self.layer1[0](y0, t0)
         for unit in list(self.layer1)[1:]:
@@ -380,6 +510,25 @@ class ResUNet(nn.Module):
         x = self.iconv3(_concat_skip(x2, self.upconv3(x3)))
         x = self.iconv2(_concat_skip(x1, self.upconv2(x)))
         return _conv(self.out_conv, x)
+
+    def forward_exact(self, x):
+        """The same network (UNet.py:154-234) with fp32 operands everywhere: gpnerf_conv2d_nhwc_exact for the convolutions, every
+        InstanceNorm from a double-precision pass over its input.  No operand range; ~20x the split form's time."""
+        _require_gpu_inference(x, self.training)
+        self.__dict__["exact_frames"] = self.__dict__.get("exact_frames", 0) + 1
+        x = _norm_act(self.bn1, _conv_exact(self.conv1, x.float()), 1)
+        x1 = x
+        for unit in self.layer1:
+            x1 = unit.forward_exact(x1)
+        x2 = x1
+        for unit in self.layer2:
+            x2 = unit.forward_exact(x2)
+        x3 = x2
+        for unit in self.layer3:
+            x3 = unit.forward_exact(x3)
+        x = self.iconv3.forward_exact(_concat_skip(x2, self.upconv3.forward_exact(x3)))
+        x = self.iconv2.forward_exact(_concat_skip(x1, self.upconv2.forward_exact(x)))
+        return _conv_exact(self.out_conv, x)
 
 
 class _EncoderGraph:
@@ -391,18 +540,22 @@ class _EncoderGraph:
 
     def __init__(self, net, x):
         dev = x.device
+        self.run = _Run(dev)                          # the graph's own ticket words and range flag (baked into its nodes)
         self.static_in = torch.empty(tuple(x.shape), device=dev, dtype=torch.float32)
         self.static_in.copy_(x)
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):                 # eager warm-up: packs the weights, sets the kernels' LDS attributes
-            net.forward(self.static_in)
-            net.forward(self.static_in)
-        cur.wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = net.forward(self.static_in)
+        with _pinned_run(self.run):
+            with torch.cuda.stream(side):             # eager warm-up: packs the weights, sets the kernels' LDS attributes
+                net.forward_fast(self.static_in)
+                net.forward_fast(self.static_in)
+            cur.wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = net.forward_fast(self.static_in)
+        torch.cuda.current_stream(dev).synchronize()
+        self.run.clear()                              # (the warm-up ran on this frame's data; the first replay decides for itself)
 
     def __call__(self, x):
         self.static_in.copy_(x)
@@ -419,18 +572,44 @@ def _graph_key(net, x):
     return (tuple(x.shape), x.device.index, x.dtype, tuple([(p.data_ptr(), p._version) for p in plist]))
 
 
-def forward_graphed(net, x):
+def forward_graphed(net, x, defer_range_check=False):
     """net(x) through a cached HIP graph (re-captured when the input shape, the device or any parameter changes).  Same bits as
     the eager call (tests/test_encoder.py).  "Any parameter changes" = the storage pointer or the version counter of one of the
     module's Parameter OBJECTS (load_state_dict, optimiser steps, .to(), in-place edits); the list of those objects is looked up
-    once -- after REPLACING a Parameter object (`net.conv1.weight = nn.Parameter(...)`) call `forget_graph(net)`."""
+    once -- after REPLACING a Parameter object (`net.conv1.weight = nn.Parameter(...)`) call `forget_graph(net)`.
+    Operand range (ResUNet.check_operand_range): "exact" parameters skip the graph; for "dynamic" ones the replay's range flag
+    decides -- here, after waiting for the stream, or, with defer_range_check=True, whenever the caller next synchronises anyway:
+    it then calls `range_check_pending(net)` and, on True, discards what it computed from the result and encodes again with
+    `net.forward_exact` (Renderer.render does this at the end of the call, so an in-range frame never waits for the encoder)."""
     _require_gpu_inference(x, net.training)
+    cls = net.check_operand_range(x.shape[-2], x.shape[-1])
+    if cls == "exact":
+        return net.forward_exact(x)
     key = _graph_key(net, x)
     hit = net.__dict__.get("_gpnerf_graph")
     if hit is None or hit[0] != key:
         hit = (key, _EncoderGraph(net, x.float()))
         net.__dict__["_gpnerf_graph"] = hit
-    return hit[1](x)
+    y = hit[1](x)
+    if cls == "dynamic":
+        if defer_range_check:
+            net.__dict__["_gpnerf_pending_run"] = hit[1].run
+        else:
+            torch.cuda.current_stream(x.device).synchronize()
+            if hit[1].run.raised():
+                hit[1].run.clear()
+                return net.forward_exact(x)
+    return y
+
+
+def range_check_pending(net):
+    """After forward_graphed(..., defer_range_check=True) and a synchronisation with its stream: True when that replay left the
+    split-f16 operand range (its result is NaN-ridden and must be replaced by net.forward_exact's).  Clears the flag."""
+    run = net.__dict__.pop("_gpnerf_pending_run", None)
+    if run is None or not run.raised():
+        return False
+    run.clear()
+    return True
 
 
 def forget_graph(net):

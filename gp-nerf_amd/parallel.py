@@ -171,28 +171,32 @@ def view_owner(v, V, world):
     return v if world >= V else v % world
 
 
-def encode_views_sharded(encoder, src_imgs, group=None, out_shape=None):
+def encode_views_sharded(encoder, src_imgs, group=None, out_shape=None, encode_fn=None):
     """The per-frame image encoder with the source views dealt out over the ranks (views are independent: the encoder
     normalises per image, libs/encoders/UNet.py:40-53).  Every view is encoded by exactly one rank (`view_owner`) and handed
     to the others by a broadcast from its owner into one [V,h,w,C] buffer -- the PHYSICAL layout of the encoder's
     channels-last result, so nothing is re-laid out on either side and `Frame` takes the returned tensor by pointer.  Ranks
     beyond the V-th encode nothing.  Every rank of `group` must hold the same `src_imgs`.
     group=None: the plain call.  out_shape: (C, h, w) of the encoder's result when the caller knows it; otherwise
-    `encoder.out_shape(H, W)` is asked, and an encoder without it makes every rank encode its own copy (no collective)."""
+    `encoder.out_shape(H, W)` is asked, and an encoder without it makes every rank encode its own copy (no collective).
+    encode_fn: how to call the encoder on a [v,3,H,W] subset (default `encoder(...)`; Renderer.render passes the HIP-graph replay
+    `encoder.forward_graphed`, the same bits with one host call instead of ~20 launches per view)."""
     group = resolve_group(group)
+    if encode_fn is None:
+        encode_fn = encoder
     if group is None:
-        return encoder(src_imgs)
+        return encode_fn(src_imgs)
     V = src_imgs.shape[0]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if out_shape is None and hasattr(encoder, "out_shape"):
         out_shape = encoder.out_shape(int(src_imgs.shape[-2]), int(src_imgs.shape[-1]))
     if out_shape is None:
-        return encoder(src_imgs)
+        return encode_fn(src_imgs)
     C, h, w = (int(x) for x in out_shape)
     mine = [v for v in range(V) if view_owner(v, V, world) == rank]
     allv = torch.empty((V, h, w, C), dtype=torch.float32, device=src_imgs.device)
     if mine:
-        out = encoder(src_imgs[mine])
+        out = encode_fn(src_imgs[mine])
         phys = out.permute(0, 2, 3, 1)                       # the channels-last result viewed in its physical order: no copy
         if tuple(phys.shape[1:]) != (h, w, C):
             raise RuntimeError(f"encoder.out_shape promised {(C, h, w)}, the encoder returned {tuple(out.shape[1:])}")

@@ -11,9 +11,10 @@ Drop-in contract:
   * sampling is deterministic (is_train=False, as libs/renders/demo_render.py:661 forces for inference;
     SURVEY.md §0-6 explains why the dense renderer's `is_train` latch is not reproduced).
 
-The per-ray work never touches torch ops; per-frame producers (encoder, volume builder) are ordinary
-PyTorch-ROCm modules and can be bypassed by putting their products into the batch
-(`batch['featmaps']`, `batch['volumes']`).
+The per-ray work never touches torch ops; the per-frame producers (`encoder.py`: the image encoder, `volume.py`: vertex
+attention + sparse volume builder) are nn.Modules under the reference's parameter names whose forward passes are hand-written
+HIP kernels as well (csrc/gpnerf_conv.hip, gpnerf_volume.hip; no torch operator computes anything), and can be bypassed by
+putting their products into the batch (`batch['featmaps']`, `batch['volumes']`).
 """
 import os
 import time
@@ -82,19 +83,24 @@ class Renderer(nn.Module):
             return self.neg_ray_val
         return self.neg_ray_train
 
-    def encode(self, batch):
+    def encode(self, batch, defer_range_check=False):
         """`featmaps = self.encoder(src_imgs.squeeze(0))` (BaseRender.py:222, demo_render.py:441): the part of a frame the
-        reference's demo renderer reports as `etime`."""
+        reference's demo renderer reports as `etime`.  defer_range_check: see encoder.forward_graphed -- render() looks at the
+        encoder's range flag at the end of the call, where it synchronises anyway."""
         src_imgs = batch["src_imgs"]
         if src_imgs.shape[0] != 1:
             raise L.GpnerfError("only batch_size=1 is supported (as BaseRender.py:336 asserts)")
-        # with a shard_group: the source views dealt out over the ranks + a broadcast of each feature map (parallel.py)
+        graphed = self.encoder_graph and src_imgs.is_cuda and isinstance(self.encoder, E_.ResUNet)
         if "featmaps" in batch:
             featmaps = batch["featmaps"]
-        elif self.encoder_graph and P_.resolve_group(self.shard_group) is None and src_imgs.is_cuda and isinstance(self.encoder, E_.ResUNet):
-            featmaps = E_.forward_graphed(self.encoder, src_imgs.squeeze(0))
+        elif graphed and P_.resolve_group(self.shard_group) is None:
+            featmaps = E_.forward_graphed(self.encoder, src_imgs.squeeze(0), defer_range_check=defer_range_check)
         else:
-            featmaps = P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0), group=self.shard_group)
+            # with a shard_group: the source views dealt out over the ranks + a broadcast of each feature map (parallel.py); a
+            # rank replays its own views as ONE graph too (per view count: the graph's key holds the input shape) -- enqueued
+            # launch by launch through Python the owner of a view was host-bound (~1.4 ms for ~0.4 ms of device time)
+            fn = (lambda t: E_.forward_graphed(self.encoder, t)) if graphed else None
+            featmaps = P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0), group=self.shard_group, encode_fn=fn)
         return featmaps[0] if featmaps.dim() == 5 else featmaps
 
     def prepare_sp_input(self, batch, out_sh=None):
@@ -264,7 +270,7 @@ class Renderer(nn.Module):
         # the encoder's time comes from two events on the stream instead of two host synchronisations around it
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        featmaps = self.encode(batch)
+        featmaps = self.encode(batch, defer_range_check=True)
         ev1.record()
         self.nerfhead.head_blob(dev)                                   # (cached; packs on a parameter change)
         main = torch.cuda.current_stream(dev)
@@ -277,11 +283,17 @@ class Renderer(nn.Module):
         # then the builder and the frame, and only then the ray list and its patch order, which nobody reads before the per-ray
         # kernel -- with the encoder at 1.0 ms the host's ~1.4 ms of enqueueing had caught up with the device, and those 0.2 ms of
         # small tensor operations sat in front of the builder's launches.
+        # INVARIANT for everything allocated under `side` and consumed on `main` (consts' device copies, the pyramid plan's buffers,
+        # imgs4, rays, order): the caching allocator knows them as `side`'s blocks, and `main.wait_stream(side)` orders the USE, not
+        # the FREE -- a block dropped early could be handed to side's next allocation while main's kernels still read it.  They are
+        # therefore recorded on `main` below (record_stream), on top of every one of them staying referenced until the
+        # torch.cuda.synchronize at the end of the call.
         with torch.cuda.stream(side):              # the batch's tensors are complete: render() synchronised at its top
             consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
             prepared = self.prepare_builder_inputs(batch, consts)      # what the builder needs that does not depend on the encoder
             imgs4 = F_.relayout_images(batch["src_imgs"][0])           # the frame's channels-last source images
         main.wait_stream(side)
+        _record_on(main, consts, prepared, imgs4)
         neg = self._neg_ray(batch)
         frame = self.build_frame(batch, featmaps, consts, prepared, imgs4=imgs4)
         with torch.cuda.stream(side):
@@ -307,6 +319,7 @@ class Renderer(nn.Module):
                     else:
                         order = F_.patch_order_rays(m, Hs, Ws, n, patch_w=pw, patch_h=ph)
         main.wait_stream(side)
+        _record_on(main, rays, order)
 
         def fn(r):
             # sharded: `r` is this rank's share, already in patch-major order
@@ -324,6 +337,17 @@ class Renderer(nn.Module):
         # BaseTrainer.py:276 sums rtime): the encoder's share is its device time between the two events
         etime = ev0.elapsed_time(ev1) * 1e-3
         rtime = max(0.0, (t2 - te) - etime)
+        if "featmaps" not in batch and isinstance(self.encoder, E_.ResUNet) and E_.range_check_pending(self.encoder):
+            # this frame drove the split-f16 encoder out of its operand range (its feature maps are NaN-ridden): encode it in the
+            # exact form and render again from those maps; the wasted pass stays in rtime, the exact encoder's time goes to etime
+            t3 = time.time()
+            fm = self.encoder.forward_exact(batch["src_imgs"].squeeze(0))
+            torch.cuda.synchronize(dev)
+            t_exact = time.time() - t3
+            ret = self.render(dict(batch, featmaps=fm))
+            ret["etime"] = t_exact
+            ret["rtime"] = ret["rtime"] + (t2 - te)
+            return ret
         if keys is P_.PIXEL_KEYS:
             return {"rgb_map": o["rgb_map"].view(1, n, 3), "depth_map": o["depth_map"].view(1, n, 1), "etime": etime, "rtime": rtime}
         return {
@@ -335,6 +359,18 @@ class Renderer(nn.Module):
             # demo renderer provides: encoder time and everything after it, each on its own clock (demo_render.py:441-446,494-497)
             "etime": etime, "rtime": rtime,
         }
+
+
+def _record_on(stream, *items):
+    """tensor.record_stream(stream) for every CUDA tensor in `items` (tensors, or lists / tuples / dicts of them, nested)"""
+    for it in items:
+        if isinstance(it, torch.Tensor):
+            if it.is_cuda:
+                it.record_stream(stream)
+        elif isinstance(it, dict):
+            _record_on(stream, *it.values())
+        elif isinstance(it, (list, tuple)):
+            _record_on(stream, *it)
 
 
 def build_render(cfg, progressive=False):

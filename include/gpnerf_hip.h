@@ -374,18 +374,30 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
  *   concatenated tensor is never written.  cin_a, cin_b multiples of 16; `packed` is the image of the [cout][cin_a + cin_b][3][3] weight.
  * norm_apply_nhwc = act((x - mean) * scale + beta [+ residual]) from such a table; with res_table the residual is itself
  *   normalised on the fly ((residual - rmean) * rscale + rbeta: the projected shortcut's InstanceNorm, UNet.py:48-51).
- * upsample2x_nhwc = F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (UNet.py:129). */
+ * upsample2x_nhwc = F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (UNet.py:129).
+ * range_flag (the three split-f16 convolutions): NULL, or ONE uint32 word (device memory, or pinned host memory the device can
+ *   write) that the call sets to 1 -- it never clears it -- when an operand was beyond what the f16 hi/lo split holds (an
+ *   activation with |x| >= 4095, a weight with |w| >= 16, or a non-finite input): such an operand splits into f16 infinities and
+ *   the outputs it meets are NaN, which the call finds in the sums of the InstanceNorm table (out_table given) or in its
+ *   accumulators (no norm behind it).  A result produced with the flag raised must be discarded and the convolution chain run
+ *   again through conv2d_nhwc_exact, so that parameters of any size are served (a trained InstanceNorm scale times sqrt(h w) can
+ *   exceed the range on a one-hot image; ordinary images stay orders of magnitude below it).
+ * conv2d_nhwc_exact = the same nn.Conv2d on fp32 operands (v_mfma_f32_32x32x2_f32, an fp32 FMA chain per output, any odd ks,
+ *   any stride, any channel counts), from the PyTorch weight [cout][cin][ks][ks] as it is: the fall-back form, ~20x slower. */
 int64_t gpnerf_conv_packed_bytes(int32_t cout, int32_t cin, int32_t ks);
 int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, void* packed, void* stream);
 int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t stride);
 int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
-                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, void* stream);
+                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, uint32_t* range_flag, void* stream);
 int gpnerf_conv2d_norm_cat_nhwc(const float* x, int32_t cin_a, const float* x_b, int32_t cin_b, int32_t n, int32_t h, int32_t w,
                                 const void* packed, const float* bias, int32_t cout, float* y, float* tile_stats, const float* gamma,
-                                const float* beta, float eps, float* out_table, uint32_t* counters, void* stream);
+                                const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag, void* stream);
 int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* in_table, int32_t in_act,
                             const void* packed, const float* bias, int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats,
-                            const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, void* stream);
+                            const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag,
+                            void* stream);
+int gpnerf_conv2d_nhwc_exact(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* weight, const float* bias,
+                             int32_t cout, int32_t ks, int32_t stride, float* y, void* stream);
 int gpnerf_norm_apply_nhwc(const float* x, const float* table, const float* residual, const float* res_table, int32_t n, int64_t hw,
                            int32_t c, int32_t act, float* out, void* stream);
 int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c);

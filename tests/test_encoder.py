@@ -157,22 +157,124 @@ def test_encoder_through_a_hip_graph_gives_the_eager_bits_and_follows_its_parame
         assert torch.equal(ga, ea)                                         # earlier results untouched
 
 
-def test_operand_range_is_checked_by_construction():
-    """The split-f16 convolutions hold |w| < 16 and |x| < 4 094 (weights staged as 2^12 w, activations as 2^4 x).  There is no
-    per-operand guard in the encoder's kernels: instead the module refuses parameters for which InstanceNorm's bound
-    sqrt(h w) |gamma| + |beta| (+ the shortcut's) cannot keep a convolution's input inside the range -- on the host, from the
-    parameters alone, once per parameter version."""
-    L = importlib.import_module("gp-nerf_amd._lib")
+def test_operand_range_classes_come_from_the_parameters_and_never_refuse():
+    """The split-f16 convolutions hold |w| < 16 and |x| < 4 095 (weights staged as 2^12 w, activations as 2^4 x).  From the
+    parameters alone (once per parameter version, on the host) the module decides which guard a frame needs: "static" when
+    InstanceNorm's bound sqrt(h w) |gamma| + |beta| (+ the shortcut's) keeps every convolution's input inside the range whatever
+    the image -- nobody then looks at the range flag --, "dynamic" when only the data can tell (the kernels' range flag decides per
+    frame, forward_exact re-encodes a flagged one), "exact" for weights beyond 16.  Round 3 RAISED in the last two cases, which
+    turned an ordinary trained InstanceNorm scale (>= 8 at 512x512, >= 4 at 1024x1024) into an unloadable checkpoint."""
     net, _ = _net(3)
-    net.check_operand_range(512, 512)
-    net.check_operand_range(1024, 1024)                      # the reference's full-resolution images
+    assert net.check_operand_range(512, 512) == "static" and net.range_report is None
+    assert net.check_operand_range(1024, 1024) == "static"              # the reference's full-resolution images
     with torch.no_grad():
         net.layer3[2].bn1.weight.mul_(200.0)
-    with pytest.raises(L.GpnerfError, match="layer3.2.conv2"):
-        net.check_operand_range(512, 512)
+    assert net.check_operand_range(512, 512) == "dynamic" and "layer3.2.conv2" in net.range_report
     with torch.no_grad():
         net.layer3[2].bn1.weight.div_(200.0)
-        net.check_operand_range(512, 512)
+        assert net.check_operand_range(512, 512) == "static"
+        for m in net.modules():                                          # a trained-sized scale everywhere
+            if isinstance(m, torch.nn.InstanceNorm2d):
+                m.weight.fill_(12.0)
+        assert net.check_operand_range(512, 512) == "dynamic"
+        for m in net.modules():
+            if isinstance(m, torch.nn.InstanceNorm2d):
+                m.weight.fill_(1.0)
         net.layer2[0].conv1.weight[0, 0, 0, 0] = 17.0
-    with pytest.raises(L.GpnerfError, match="layer2.0.conv1.weight"):
-        net.check_operand_range(512, 512)
+    assert net.check_operand_range(512, 512) == "exact" and "layer2.0.conv1.weight" in net.range_report
+    with torch.no_grad():
+        net.layer2[0].conv1.weight[0, 0, 0, 0] = float("nan")
+    assert net.check_operand_range(512, 512) == "exact"
+
+
+def _float64_encoder(net, imgs):
+    from oracle import producers_ref as ref
+    twin = enc.ResUNet(encoder="resnet34", out_ch=32)                  # (the module may carry a HIP graph: not copyable)
+    twin.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    with torch.no_grad():
+        return ref.encoder(twin.double().eval(), imgs.cpu().double()).float().numpy()
+
+
+def _set_norm_scales(net, gamma, beta=0.0):
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.InstanceNorm2d):
+                m.weight.fill_(gamma)
+                m.bias.fill_(beta)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,gamma", [(512, 12.0), (1024, 5.0)])
+def test_trained_sized_norm_scales_are_served_not_refused(size, gamma):
+    """InstanceNorm scales of 12 at 512x512 / 5 at 1024x1024 put the parameter-only bound beyond the split
+    form's range ("dynamic"); on an ordinary image nothing leaves it: the split form's result stands (no exact pass, no flag) and
+    matches the float64 run of the restatement.  Tolerance: 1e-4 of the output's scale -- the LAST norm multiplies every absolute
+    error by its gamma, the reference's own float32 included."""
+    net, _ = _net(11)
+    _set_norm_scales(net, gamma, 0.1)
+    net = net.to("cuda:0")
+    imgs = torch.from_numpy(syn.make_encoder_images(size, size, 11))
+    assert net.check_operand_range(size, size) == "dynamic"
+    with torch.no_grad():
+        got = net(imgs.to("cuda:0"))
+        g2 = enc.forward_graphed(net, imgs.to("cuda:0"))
+    assert net.__dict__.get("exact_frames", 0) == 0 and torch.equal(got, g2)
+    want = _float64_encoder(net, imgs)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got.cpu().numpy() - want).max())
+    print(f"{size}x{size}, gamma {gamma}: max-abs {err:.3e} on an output range of {scale:.3g}")
+    assert err < 1e-4 * scale, (err, scale)
+
+
+@pytest.mark.gpu
+def test_a_frame_that_leaves_the_split_range_is_encoded_exactly():
+    """A one-hot image is what attains InstanceNorm's bound: one bright pixel in a black 256x256 image, scales of 60 -> the stem's
+    normalised output reaches ~60 * sqrt(128 * 128 / footprint) > 4 095 and splits into f16 infinities.  The convolution that stages
+    it raises the range flag (a NaN sum in its norm table), the pass is discarded and the frame encoded by forward_exact: eager
+    call, graph replay and the deferred check all end up with the float64 restatement's values; the next ordinary frame takes the
+    split form again.  Also: forward_exact on ordinary parameters agrees with the split form to 1e-4."""
+    net, _ = _net(4)
+    net = net.to("cuda:0")
+    ordinary = torch.from_numpy(syn.make_encoder_images(256, 256, 4)).to("cuda:0")
+    with torch.no_grad():
+        fast, exact = net(ordinary), net.forward_exact(ordinary)
+    assert float((fast - exact).abs().max()) < 1e-4 and net.exact_frames == 1
+    _set_norm_scales(net, 60.0)
+    hot = torch.full((3, 3, 256, 256), -1.0)
+    hot[:, :, 77, 131] = 1.0
+    assert net.check_operand_range(256, 256) == "dynamic"
+    want = _float64_encoder(net, hot)
+    scale = max(1.0, float(np.abs(want).max()))
+    with torch.no_grad():
+        n0 = net.exact_frames
+        got = net(hot.to("cuda:0"))
+        assert net.exact_frames == n0 + 1, "the one-hot frame did not raise the range flag"
+        g2 = enc.forward_graphed(net, hot.to("cuda:0"))
+        assert net.exact_frames == n0 + 2 and torch.equal(got, g2)
+        g3 = enc.forward_graphed(net, hot.to("cuda:0"), defer_range_check=True)
+        torch.cuda.synchronize()
+        # (the discarded pass itself may look finite: ReLU maps the NaNs of a poisoned channel to 0 -- the flag is the signal)
+        assert float((g3 - got).abs().max()) > 1e-2 * scale
+        assert enc.range_check_pending(net) and not enc.range_check_pending(net)
+        again = net(ordinary)                         # the flag does not stick: the next ordinary frame runs the split form
+        assert net.exact_frames == n0 + 2 and bool(torch.isfinite(again).all())
+    err = float(np.abs(got.cpu().numpy() - want).max())
+    print(f"one-hot frame through forward_exact: max-abs {err:.3e} on an output range of {scale:.3g}")
+    assert err < 1e-4 * scale, (err, scale)
+
+
+@pytest.mark.gpu
+def test_weights_beyond_the_split_range_take_the_exact_form():
+    net, _ = _net(6)
+    with torch.no_grad():
+        net.layer1[1].conv1.weight[3, 5, 1, 1] = 40.0
+    net = net.to("cuda:0")
+    imgs = torch.from_numpy(syn.make_encoder_images(96, 128, 6))
+    assert net.check_operand_range(96, 128) == "exact"
+    with torch.no_grad():
+        got = net(imgs.to("cuda:0"))
+        g2 = enc.forward_graphed(net, imgs.to("cuda:0"))
+    assert net.exact_frames == 2 and torch.equal(got, g2)
+    want = _float64_encoder(net, imgs)
+    err = float(np.abs(got.cpu().numpy() - want).max())
+    assert err < 1e-4 * max(1.0, float(np.abs(want).max())), err

@@ -102,11 +102,11 @@ def test_conv_entry_point_rejects_unsupported_shapes():
     L = importlib.import_module("gp-nerf_amd._lib")
     lib = L.lib()
     p = 0x1000
-    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 24, p, None, 32, 3, 1, p, None, None) == -1      # cin neither < 8 nor a multiple of 16
-    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 16, p, None, 32, 5, 1, p, None, None) == -1      # 5x5 is not built
-    assert lib.gpnerf_conv2d_nhwc(p, 1, 1, 8, 16, p, None, 32, 3, 1, p, None, None) == -1      # reflection needs pad < size
-    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 16, p, None, 30, 3, 1, p, None, None) == -1      # cout not a multiple of 4
-    assert lib.gpnerf_conv2d_nhwc(None, 0, 8, 8, 16, p, None, 32, 3, 1, p, None, None) == 0     # nothing to do
+    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 24, p, None, 32, 3, 1, p, None, None, None) == -1      # cin neither < 8 nor a multiple of 16
+    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 16, p, None, 32, 5, 1, p, None, None, None) == -1      # 5x5 is not built
+    assert lib.gpnerf_conv2d_nhwc(p, 1, 1, 8, 16, p, None, 32, 3, 1, p, None, None, None) == -1      # reflection needs pad < size
+    assert lib.gpnerf_conv2d_nhwc(p, 1, 8, 8, 16, p, None, 30, 3, 1, p, None, None, None) == -1      # cout not a multiple of 4
+    assert lib.gpnerf_conv2d_nhwc(None, 0, 8, 8, 16, p, None, 32, 3, 1, p, None, None, None) == 0     # nothing to do
     assert lib.gpnerf_conv_out_tiles(128, 128, 64, 3, 1) == 16 * 4 and lib.gpnerf_conv_out_tiles(32, 32, 256, 3, 1) == 8 and lib.gpnerf_conv_out_tiles(64, 64, 128, 3, 1) == 32 and lib.gpnerf_conv_out_tiles(128, 128, 64, 3, 2) == 32
     assert lib.gpnerf_conv_packed_bytes(64, 3, 7) == 14 * 2 * 2048      # the 3-channel stem: 7 kernel rows x 2 chunks of (2 x 2 columns x 4 channels)
 
