@@ -392,6 +392,7 @@ class ResUNet(nn.Module):
 
     # ---- operand range of the split-f16 convolutions (csrc/gpnerf_conv.hip: weights staged as 2^12 w, activations as 2^4 x) ----
     W_LIMIT, X_LIMIT = 15.99, 4094.0
+    exact_frames = 0             # frames this module has encoded through forward_exact (instances count in their __dict__)
 
     def check_operand_range(self, H, W):
         """Which guard a frame of H x W images needs, from the PARAMETERS alone (cached per (H, W, parameter versions): one
@@ -515,7 +516,7 @@ class ResUNet(nn.Module):
         """The same network (UNet.py:154-234) with fp32 operands everywhere: gpnerf_conv2d_nhwc_exact for the convolutions, every
         InstanceNorm from a double-precision pass over its input.  No operand range; ~20x the split form's time."""
         _require_gpu_inference(x, self.training)
-        self.__dict__["exact_frames"] = self.__dict__.get("exact_frames", 0) + 1
+        self.__dict__["exact_frames"] = self.exact_frames + 1
         x = _norm_act(self.bn1, _conv_exact(self.conv1, x.float()), 1)
         x1 = x
         for unit in self.layer1:

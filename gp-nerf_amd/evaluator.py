@@ -9,6 +9,10 @@ covariance (x 49/48), K1 = 0.01, K2 = 0.03, data range 2 (skimage's range for fl
 3 pixels and over channels.  scikit-image is not installed in this image, so that part is a restatement of the published
 algorithm: **parity unpinned** (tests check it against a scipy `uniform_filter` restatement).
 Image writing (cfg.test.save_imgs) is I/O and out of scope.
+
+`evaluate_loop` is the evaluation loop around it (libs/trainers/BaseTrainer.py:255-280 `Trainer.evaluate`): per frame
+`render.render(batch)` -> `Evaluator.evaluate`, the render time summed from `ret["rtime"]`, the means from `summarize()`;
+pinned to the reference's own loop over three frames (tests/golden/loop_demo_3frames.npz).
 """
 import math
 import os
@@ -100,3 +104,37 @@ class Evaluator:
             print(f"{k}: {metrics[k]}")
         self.mse, self.psnr, self.ssim = [], [], []
         return metrics
+
+
+def evaluate_loop(render, eval_loader, cfg, device=None, quiet=False):
+    """`Trainer.evaluate` (libs/trainers/BaseTrainer.py:255-280) without its image writing: for every batch of `eval_loader`
+    move it to `device` (`_read_inputs`, :89-97), `ret = render.render(batch)` (the reference calls `.module.render` on its
+    DataParallel wrapper; a wrapped model is unwrapped here too), `Evaluator.evaluate(ret, batch)`, `total_time += ret["rtime"]`;
+    then `summarize()` when the head renders colour.  Returns {"count", "total_time", "avg_time", "metrics" (summarize()'s dict or
+    None), "mse", "psnr", "ssim" (the per-frame lists)} -- the reference prints the average and returns nothing."""
+    model = getattr(render, "module", render)
+    model.eval()
+    evaluator = Evaluator(cfg, cfg.test.test_seq)
+    count, total_time = 0, 0.0
+
+    def move(v):
+        if device is None:
+            return v
+        if isinstance(v, (list, tuple)):
+            return [b.to(device) for b in v]
+        if isinstance(v, dict):
+            return {k: b.to(device) for k, b in v.items()}
+        return v.to(device)
+
+    for data in eval_loader:
+        with torch.no_grad():
+            val = {k: move(v) for k, v in data.items()}
+            ret = model.render(val)
+            evaluator.evaluate(ret, val)
+        total_time += ret["rtime"]                       # the dense renderer of the reference returns no "rtime": KeyError there
+        count += 1
+    per_frame = {"mse": list(evaluator.mse), "psnr": list(evaluator.psnr), "ssim": list(evaluator.ssim)}
+    metrics = evaluator.summarize() if cfg.head.rgb.use_rgbhead else None
+    if not quiet:
+        print(f"avg total render time: {total_time / max(count, 1)}s per sample")
+    return dict(count=count, total_time=total_time, avg_time=total_time / max(count, 1), metrics=metrics, **per_frame)

@@ -48,17 +48,21 @@ def _rng(seed, stream):
     return np.random.Generator(np.random.PCG64([int(seed), int(stream)]))
 
 
-def make_head_weights(seed=0, bias_std=0.0, sigma_bias=0.0):
+def make_head_weights(seed=0, bias_std=0.0, sigma_bias=0.0, head_scale=1.0):
     """kaiming-normal W (std = sqrt(2/fan_in)), zero b: trainhead.py:13-17.
 
     ``bias_std`` > 0 draws non-zero biases so tests exercise the bias path;
     ``sigma_bias`` shifts the last density bias so that a useful share of
-    samples has sigma > 0 (random-init nets otherwise sit near ReLU(0)).
+    samples has sigma > 0 (random-init nets otherwise sit near ReLU(0));
+    ``head_scale`` multiplies every weight matrix (a trained head is not at its initialisation's scale: the "trained-like"
+    golden cases use 2 - 3, where the ELU chains leave their linear range and sigmoid / exp(-sigma) saturate).
     """
     g = _rng(seed, 101)
     sd = OrderedDict()
     for name, n_out, n_in in HEAD_LAYERS:
         w = g.standard_normal((n_out, n_in), dtype=np.float32) * np.float32(math.sqrt(2.0 / n_in))
+        if head_scale != 1.0:
+            w = w * np.float32(head_scale)
         if bias_std > 0:
             b = g.standard_normal((n_out,), dtype=np.float32) * np.float32(bias_std)
         else:
@@ -93,19 +97,25 @@ def encoder_param_shapes(out_ch=32):
     return t
 
 
-def make_encoder_weights(seed=0, out_ch=32):
+def make_encoder_weights(seed=0, out_ch=32, gamma_range=None, beta_std=0.1, conv_scale=1.0):
     """Seeded encoder parameters: conv kernels ~ N(0, 2/fan_in), norm scales ~ 1 + 0.1 N, every bias ~ 0.1 N (so that the
-    affine and bias paths are exercised).  Drawn in `encoder_param_shapes()` order from PCG64([seed, 303])."""
+    affine and bias paths are exercised).  Drawn in `encoder_param_shapes()` order from PCG64([seed, 303]).
+    "Trained-like" variants: gamma_range (lo, hi) draws every InstanceNorm scale from U(lo, hi) (the standard normal draw mapped
+    through its CDF, so the stream stays aligned), beta_std widens the biases, conv_scale multiplies the kernels."""
     g = _rng(seed, 303)
     sd = OrderedDict()
     for key, shape in encoder_param_shapes(out_ch):
         x = g.standard_normal(shape, dtype=np.float32)
         if len(shape) == 4:
-            x *= np.float32(math.sqrt(2.0 / (shape[1] * shape[2] * shape[3])))
+            x *= np.float32(math.sqrt(2.0 / (shape[1] * shape[2] * shape[3])) * conv_scale)
         elif key.endswith("weight"):
-            x = np.float32(1.0) + np.float32(0.1) * x
+            if gamma_range is None:
+                x = np.float32(1.0) + np.float32(0.1) * x
+            else:
+                u = 0.5 * (1.0 + np.vectorize(math.erf)(x.astype(np.float64) / math.sqrt(2.0)))
+                x = (gamma_range[0] + (gamma_range[1] - gamma_range[0]) * u).astype(np.float32)
         else:
-            x *= np.float32(0.1)
+            x *= np.float32(beta_std)
         sd[key] = x.astype(np.float32)
     return sd
 
@@ -251,6 +261,10 @@ def make_scene(
     neg_cams=False,
     vol_occupancy=None,
     neg_target=False,
+    head_scale=1.0,
+    feat_scale=1.0,
+    feat_tail=0.0,
+    vol_relu=False,
 ):
     """Build one synthetic frame.
 
@@ -259,6 +273,10 @@ def make_scene(
     fill="survey": f = 1.05*W as written in §8d (about a fifth of the pixels hit).
     pose="identity": Rh=I, Th=0 (§8d); pose="random": a non-trivial Rh/Th so the
     world->SMPL transform (BaseRender.py:52-60) is exercised.
+    "Trained-like" knobs (the distributions a checkpoint has and an initialisation has not): head_scale (weights x this),
+    feat_scale (feature maps x this), feat_tail t > 0 (feature maps and volumes x exp(t N'): log-normal heavy tails),
+    vol_relu (the dense levels are max(., 0): the sparse conv net ends in ReLU, so about half of every level is exactly zero),
+    vol_scale (volumes x this).
     """
     g = _rng(seed, 7)
     hx, hy, hz = [float(a) for a in aabb_half]
@@ -323,6 +341,10 @@ def make_scene(
     src_imgs01 = g.random((N_VIEWS, 3, H, W), dtype=np.float32)
     src_imgs = (src_imgs01 - 0.5) / 0.5  # dataset normalisation (transform.py:349-373)
     featmaps = g.standard_normal((N_VIEWS, FEAT_CH, H // 4, W // 4), dtype=np.float32)
+    if feat_tail > 0.0:
+        featmaps = featmaps * np.exp(np.float32(feat_tail) * _rng(seed, 150).standard_normal(featmaps.shape, dtype=np.float32))
+    if feat_scale != 1.0:
+        featmaps = (featmaps * np.float32(feat_scale)).astype(np.float32)
 
     volumes = []
     if make_volumes:
@@ -336,6 +358,10 @@ def make_scene(
             d, h, w = [int(s) >> k for s in out_sh]
             gv = _rng(seed, 200 + k)
             v = gv.standard_normal((1, FEAT_CH, d, h, w), dtype=np.float32) * np.float32(vol_scale)
+            if feat_tail > 0.0:
+                v = v * np.exp(np.float32(feat_tail) * _rng(seed, 250 + k).standard_normal(v.shape, dtype=np.float32))
+            if vol_relu:
+                v = np.maximum(v, np.float32(0.0))
             if occ_coarse is not None:
                 r = 1 << (N_LEVELS - k)
                 m = np.repeat(np.repeat(np.repeat(occ_coarse, r, 0), r, 1), r, 2)
@@ -377,5 +403,5 @@ def make_scene(
         "H": H,
         "W": W,
     }
-    scene["head"] = make_head_weights(seed, bias_std=bias_std, sigma_bias=sigma_bias)
+    scene["head"] = make_head_weights(seed, bias_std=bias_std, sigma_bias=sigma_bias, head_scale=head_scale)
     return scene

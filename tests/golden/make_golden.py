@@ -155,13 +155,55 @@ def build_reference_renderer(scene, n_samples, neg_ray):
     return r, BaseRender, trainhead
 
 
+class _float_is_double:
+    """`Tensor.float()` -> `.double()` while the reference's head runs in float64 (trainhead.py:55 casts the grid with .float())."""
+
+    def __enter__(self):
+        self._f = torch.Tensor.float
+        torch.Tensor.float = lambda t, *a, **k: t.double()
+
+    def __exit__(self, *exc):
+        torch.Tensor.float = self._f
+
+
+class _Head64(nn.Module):
+    """The reference's NeRFHead evaluated in float64 on the float32 renderer's own inputs: sample positions, projections, masks
+    and gathered view features stay the float32 run's bit for bit (so no in-bounds test flips), the trilinear volume
+    interpolation, every dense layer and -- behind it -- raw2outputs run in double.  The distance between this run and the plain
+    float32 one is what the reference's OWN float32 rounding in the head does to each map on these parameters."""
+
+    def __init__(self, head):
+        super().__init__()
+        self.head = head.double()
+        for m in self.head.sigmahead.xyzc_net.net:
+            if hasattr(m, "vol"):
+                m.vol = m.vol.double()
+        self.use_rgbhead = head.use_rgbhead
+
+    def forward(self, sp_input, grid_coords, smpl_feat, rgb_feat, mask):
+        with _float_is_double():
+            return self.head(sp_input, grid_coords.double(), smpl_feat.double(), rgb_feat.double(), mask.double())
+
+
+def head_f64_spread(scene, n_samples, neg_ray, chunk, ret32):
+    """max |float32 run - float64-head run| per map over ALL rays (see _Head64), and the float64-head maps themselves"""
+    r, _, _ = build_reference_renderer(scene, n_samples, neg_ray)
+    r.chunk = chunk
+    r.nerfhead = _Head64(r.nerfhead)
+    with torch.no_grad():
+        ret64 = r.render(to_batch(scene))
+    assert ret64["rgb_map"].dtype == torch.float64
+    keys = ("rgb_map", "depth_map", "acc_map", "rgb_in_map")
+    return {k: float((ret32[k].double() - ret64[k]).abs().max()) for k in keys}, ret64
+
+
 def to_batch(scene):
     keys = ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "target_K", "target_pose",
             "feature", "coord", "out_sh", "bounds", "Rh", "R", "Th", "body_msk")
     return {k: torch.from_numpy(np.ascontiguousarray(scene[k])) for k in keys}
 
 
-def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays=32, outputs_only=False, ray_stride=None, chunk=400):
+def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays=32, outputs_only=False, ray_stride=None, chunk=400, spread=False):
     syn = importlib.import_module("gp-nerf_amd.synthetic")
     scene = syn.make_scene(**scene_kw)
     if stretch is not None:
@@ -182,6 +224,13 @@ def run_case(name, scene_kw, n_samples, neg_ray=False, stretch=None, stages_rays
         "disp_map": ret["disp_map"][0, :, 0].numpy(),
         "rgb_in_map": ret["rgb_in_map"][0].numpy(),
     }
+    if spread:
+        sp, ret64 = head_f64_spread(scene, n_samples, neg_ray, chunk, ret)
+        for k, v in sp.items():
+            out["spread_" + k] = np.float64(v)
+        for k in ("rgb_map", "depth_map", "acc_map"):
+            out[k + "_head64"] = ret64[k][0].numpy().reshape(out[k].shape)          # float64
+        print("   float32-vs-float64 head spread of the reference:", sp)
     if not outputs_only:
         out["weights"] = ret["alpha"][0].numpy()
         out["z_vals"] = ret["z_vals"][0].numpy()
@@ -361,7 +410,7 @@ def run_demo_case(name, scene_kw, n_samples, neg_ray=False, probe=96):
           f"rgb mean={out['rgb_map'].mean():.4f} max={out['rgb_map'].max():.4f} -> {os.path.getsize(path)} B")
 
 
-def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400, spread=False):
+def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400, spread=False, weights_kw=None):
     """The evaluation loop's per-frame chain with the reference's REAL image encoder (BASELINE.json configs[4] in miniature;
     the ZJU-MoCap data itself is not in the tree): libs/encoders/UNet.py ResUNet.forward -> libs/renders/BaseRender.py
     Renderer.render, then libs/evaluators/if_nerf.py Evaluator.psnr_metric on the result against a seeded ground truth.
@@ -385,7 +434,7 @@ def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400, sp
     r, BaseRender, trainhead = build_reference_renderer(scene, n_samples, False)
     r.chunk = chunk
     enc = UNet.ResUNet(encoder="resnet34", out_ch=32)
-    enc_state = syn.make_encoder_weights(seed)
+    enc_state = syn.make_encoder_weights(seed, **(weights_kw or {}))
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in enc_state.items()}, strict=True)
     r.encoder = enc.eval()
     batch = to_batch(scene)
@@ -407,6 +456,18 @@ def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400, sp
     out = {"rgb_map": rgb, "depth_map": ret["depth_map"][0, :, 0].numpy(), "acc_map": ret["acc_map"][0, :, 0].numpy(),
            "rgb_in_map": ret["rgb_in_map"][0].numpy(), "featmaps": featmaps.astype(np.float32), "rgb_gt": rgb_gt,
            "psnr": np.float64(psnr), "mse": np.float64(np.mean((rgb - rgb_gt) ** 2))}
+    if weights_kw:
+        # "trained-like" case: the head's own float32 noise on the reference's feature maps (the yardstick of the identical-inputs leg)
+        sc_h = dict(scene, featmaps=featmaps.astype(np.float32))
+        with torch.no_grad():
+            r.encoder = _FixedEncoder(torch.from_numpy(sc_h["featmaps"]))
+            ret_fixed = r.render(batch)
+        r.encoder = enc
+        assert torch.equal(ret_fixed["rgb_map"], ret["rgb_map"])
+        sp, _ = head_f64_spread(sc_h, n_samples, False, chunk, ret)
+        for k, v in sp.items():
+            out["spread_head_" + k] = np.float64(v)
+        print("   float32-vs-float64 head spread of the reference:", sp)
     if ray_stride is not None or spread:
         import copy
         rs = ray_stride or 1
@@ -434,10 +495,145 @@ def run_e2e_case(name, scene_kw, n_samples, seed, ray_stride=None, chunk=400, sp
                    featmaps_absmax=np.float64(np.abs(fm).max()), outputs_sha256=np.frombuffer(full.digest(), np.uint8))
     meta = {"scene_kw": scene_kw, "n_samples": n_samples, "seed": seed, "n_rays": int(rgb.shape[0]), "sha256_inputs": h.hexdigest(),
             "torch": torch.__version__, "reference": "UNet.ResUNet.forward -> BaseRender.Renderer.render -> if_nerf.Evaluator.psnr_metric, eval, CPU fp32"}
+    if weights_kw:
+        meta["weights_kw"] = weights_kw
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: N={meta['n_rays']} rgb mean={rgb.mean():.4f} acc mean={out['acc_map'].mean():.4f} psnr={psnr:.4f} -> {os.path.getsize(path)} B")
+
+
+def run_loop_case(name, frames, n_samples):
+    """The evaluation LOOP of BASELINE.json configs[4] (libs/trainers/BaseTrainer.py:255-280 Trainer.evaluate -> per frame
+    render.module.render(batch) -> libs/evaluators/if_nerf.py:49-66 Evaluator.evaluate, `total_time += ret["rtime"]`, then
+    Evaluator.summarize :68-83), run as the README's inference command runs it: with the progressive renderer
+    (`render.file demo_render` -- the dense BaseRender.Renderer returns no "rtime" and the loop would stop at its first frame),
+    over `frames` synthetic frames that share one head.  Two passes: the first renders each frame once to derive an 8-bit ground
+    truth (clip(pred + noise) rounded to 1/255, as a dataset would hold it) so that the PSNRs are informative; the second IS the
+    reference's loop.  Stored per frame: ground truth, dataset mask, MSE and PSNR as the reference's evaluator computed them
+    (captured from its lists inside summarize()), every 8th predicted pixel; plus the summary means, the frame count and the keys
+    of what render() returned.  Import-time stand-ins: tensorboardX / torchvision / termcolor (never called), cv2.boundingRect and
+    skimage's compare_ssim (inert: SSIM stays UNPINNED, its value is not stored)."""
+    import tempfile
+    from types import SimpleNamespace as NS
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    for mod, attrs in (("tensorboardX", dict(SummaryWriter=object)), ("torchvision", dict(__version__="0.15.0")),
+                       ("termcolor", dict(colored=lambda s, *a, **k: s))):
+        m = sys.modules.setdefault(mod, types.ModuleType(mod))
+        for k, v in attrs.items():
+            setattr(m, k, v)
+    sk = sys.modules.setdefault("skimage", types.ModuleType("skimage"))
+    skm = sys.modules.setdefault("skimage.measure", types.ModuleType("skimage.measure"))
+    skm.compare_ssim = lambda *a, **k: float("nan")
+    sk.measure = skm
+    cv2 = sys.modules["cv2"]
+    cv2.boundingRect = lambda m: (0, 0, int(m.shape[1]), int(m.shape[0]))
+    if_nerf = importlib.import_module("libs.evaluators.if_nerf")
+    if_nerf.compare_ssim = skm.compare_ssim
+    BaseTrainer = importlib.import_module("libs.trainers.BaseTrainer")
+    demo = importlib.import_module("demo_render")
+    trainhead = importlib.import_module("trainhead")
+    scenes = [syn.make_scene(**kw) for kw in frames]
+    head = trainhead.NeRFHead(in_feat_ch=32, n_smpl=6890, code_dim=32, attn_n_heads=4, spconv_n_layers=4, spconv_out_dim=[32, 32, 32, 32],
+                              use_rgbhead=True)
+    sd = head.state_dict()
+    for k, v in scenes[0]["head"].items():                      # ONE model for the whole loop: the first frame's head
+        sd[k] = torch.from_numpy(v.copy())
+    head.load_state_dict(sd, strict=True)
+    levels = [_Level(None) for _ in range(4)]
+    net = [_Pass()]
+    for lv in levels:
+        net += [_Pass(), lv]
+    head.sigmahead.xyzc_net.net = nn.ModuleList(net)
+    enc = _FixedEncoder(None)
+    r = demo.Renderer(enc, head, is_train=False, neg_ray_train=True, neg_ray_val=False, n_rays=1024, n_samples=n_samples,
+                      voxel_size=[float(x) for x in scenes[0]["voxel_size"]], chunk=400)
+    rets = []
+
+    class _Module:
+        """what `self.render.module` is to the loop; switches the per-frame products (feature maps, dense levels) by frame_index"""
+
+        def render(self, batch):
+            i = int(batch["frame_index"])
+            enc.featmaps = torch.from_numpy(scenes[i]["featmaps"])
+            for lv, v in zip(levels, scenes[i]["volumes"]):
+                lv.vol = torch.from_numpy(v)
+            with _device_shim():
+                ret = r.render(batch)
+            rets.append(ret)
+            return ret
+
+    model = NS(module=_Module(), eval=lambda: r.eval(), train=lambda: None)
+
+    def batch_of(i):
+        b = to_batch(scenes[i])
+        b["target_K_inv"] = torch.from_numpy(scenes[i]["target_K_inv"].copy())
+        b["body_msk"] = torch.ones((1, 2048))
+        b["mask_at_box"] = torch.from_numpy(scenes[i]["mask_at_box"].copy())
+        b["frame_index"] = torch.tensor([i])
+        return b
+
+    # pass 1: a ground truth per frame from the reference's own render
+    gts, masks = [], []
+    with torch.no_grad():
+        for i in range(len(scenes)):
+            b = batch_of(i)
+            ret = model.module.render(b)
+            m = scenes[i]["mask_at_box"][0].reshape(512, 512)
+            pred = ret["pred_img"][m]
+            g = np.random.Generator(np.random.PCG64([int(frames[i]["seed"]), 911]))
+            gts.append(np.round(np.clip(pred + 0.05 * g.standard_normal(pred.shape), 0, 1) * 255.0).astype(np.uint8))
+            masks.append(m)
+    first = rets[:]
+    del rets[:]
+    # pass 2: the reference's loop
+    cap = {}
+    summarize = if_nerf.Evaluator.summarize
+
+    def summarize_and_capture(self):
+        cap.update(mse=[float(v) for v in self.mse], psnr=[float(v) for v in self.psnr])
+        cap["summary"] = summarize(self)
+        return cap["summary"]
+
+    if_nerf.Evaluator.summarize = summarize_and_capture
+    BaseTrainer.Evaluator = if_nerf.Evaluator
+    tmp = tempfile.mkdtemp(prefix="gpnerf_loop_")
+    cfg = NS(dataset=NS(H=1024, W=1024, ratio=0.5), test=NS(test_seq="loop", save_imgs=False), head=NS(rgb=NS(use_rgbhead=True)),
+             result_dir=tmp, train=NS(max_epoch=1), render=NS(file="demo_render"), output_dir="")
+    loader = []
+    for i in range(len(scenes)):
+        b = batch_of(i)
+        b["rgb"] = torch.from_numpy(gts[i].astype(np.float32) / np.float32(255.0))[None]
+        loader.append(b)
+    try:
+        t = BaseTrainer.Trainer(cfg, model, criterion=None, optimizer=None, lr_scheduler=None, logger=None, log_dir=None,
+                                performance_indicator="psnr", last_iter=None, rank=0, device="cpu")
+        t.evaluate(loader, os.path.join(tmp, "loop"), is_vis=False)
+    finally:
+        if_nerf.Evaluator.summarize = summarize
+    assert len(rets) == len(scenes) and len(cap["psnr"]) == len(scenes)
+    saved = np.load(os.path.join(tmp, "loop", "metrics.npy"))             # if_nerf.py:72-80 keeps the per-frame MSE list
+    assert np.allclose(saved, cap["mse"])
+    out = {"count": np.int64(len(rets)), "mse": np.array(cap["mse"], np.float64), "psnr": np.array(cap["psnr"], np.float64),
+           "summary_mse": np.float64(cap["summary"]["mse"]), "summary_psnr": np.float64(cap["summary"]["psnr"]),
+           "ret_keys": np.frombuffer(json.dumps(sorted(rets[0])).encode(), dtype=np.uint8)}
+    h = hashlib.sha256()
+    for i, (ret, ret1) in enumerate(zip(rets, first)):
+        assert np.array_equal(ret["pred_img"], ret1["pred_img"]), "the reference's two passes differ"
+        assert isinstance(ret["rtime"], float) and isinstance(ret["etime"], float)
+        pred = ret["pred_img"][masks[i]].astype(np.float32)
+        out[f"gt_u8_{i}"] = gts[i]
+        out[f"mask_at_box_bits_{i}"] = np.packbits(masks[i])
+        out[f"pred_sub_{i}"] = np.ascontiguousarray(pred[::8])
+        out[f"sel_mask_bits_{i}"] = np.packbits(np.asarray(ret["mask_at_box"]).astype(bool))
+        h.update(sha_inputs(scenes[i]).encode())
+    meta = {"frames": frames, "n_samples": n_samples, "sha256_inputs": h.hexdigest(), "torch": torch.__version__,
+            "reference": "BaseTrainer.Trainer.evaluate -> demo_render.Renderer.render -> if_nerf.Evaluator.evaluate / summarize, eval, CPU fp32 "
+                         "via the device-name shim; SSIM not computed (scikit-image absent): unpinned"}
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(rets)} frames, psnr {cap['psnr']}, summary {cap['summary']['psnr']:.5f} -> {os.path.getsize(path)} B")
 
 
 DEMO_SMALL = dict(H=512, W=512, aabb_half=(0.12, 0.16, 0.05), voxel=0.005, bias_std=0.1, pose="random")
@@ -467,6 +663,18 @@ CASES = [
                                aabb_half=(0.25, 0.45, 0.125), voxel=0.005), 32, dict(outputs_only=True)),
 ]
 
+# "Trained-like" parameters and features (VERDICT r3 next #1a): every other fixture runs `weights_init` heads (kaiming-normal, zero
+# bias), N(0,1) features and InstanceNorm scales near 1 -- none of which a trained checkpoint has.  Here: head weights x 1.5 / 2 / 3
+# with non-zero biases, feature maps and volumes x 4 with log-normal tails, ReLU-sparse dense levels; >= 4 096 rays x 64 samples.
+TRAINED = dict(fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), voxel=0.005, feat_scale=4.0, feat_tail=0.5, vol_scale=4.0, vol_relu=True)
+TRAINED_CASES = [
+    ("trained_h1_s64", dict(H=64, W=64, seed=46, bias_std=0.1, sigma_bias=-10.0, head_scale=1.0, **TRAINED), 64, dict(outputs_only=True, spread=True)),
+    ("trained_h1p5_s64", dict(H=64, W=64, seed=50, bias_std=0.2, sigma_bias=-2.0, head_scale=1.5, **TRAINED), 64, dict(outputs_only=True, spread=True)),
+    ("trained_h2_s64", dict(H=64, W=64, seed=51, bias_std=0.3, sigma_bias=-4.0, head_scale=2.0, **TRAINED), 64, dict(spread=True)),
+    ("trained_h3_s64", dict(H=72, W=72, seed=52, bias_std=0.5, sigma_bias=-16.0, head_scale=3.0, **TRAINED), 64, dict(outputs_only=True, spread=True)),
+]
+TRAINED_ENC = dict(gamma_range=(0.5, 6.0), beta_std=0.5)
+
 # BASELINE.json configs[1..3] at FULL size, on the very scenes bench.py and tests/test_gpu_configs.py render: the reference's
 # Renderer.render over every ray (test chunk 2000), every 64th / 256th ray stored.  Slow (1 - 5 minutes each on 8 CPU threads).
 FULL_CASES = [
@@ -477,7 +685,7 @@ FULL_CASES = [
 ]
 
 
-def run_encoder_case(name, H, W, seed, stride=None):
+def run_encoder_case(name, H, W, seed, stride=None, weights_kw=None):
     """libs/encoders/UNet.py ResUNet.forward on seeded images with seeded parameters.  The parameters
     come from gp-nerf_amd/synthetic.py by state_dict key, and are loaded strict=True into the reference's module, so the
     vector also pins the key/shape map.  `stride` (the 512x512 case, the size BASELINE configs[4] encodes at): every
@@ -485,22 +693,31 @@ def run_encoder_case(name, H, W, seed, stride=None):
     float64 means and mean squares, and the per-channel max-abs."""
     syn = importlib.import_module("gp-nerf_amd.synthetic")
     UNet = importlib.import_module("UNet")
-    state = syn.make_encoder_weights(seed)
+    state = syn.make_encoder_weights(seed, **(weights_kw or {}))
     net = UNet.ResUNet(encoder="resnet34", out_ch=32)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
     net.eval()
     imgs = syn.make_encoder_images(H, W, seed)
     with torch.no_grad():
         out = net(torch.from_numpy(imgs)).numpy()
+        out64 = None
+        if weights_kw:           # the reference's own float32-vs-float64 distance on these parameters: the yardstick for a "trained-like" case
+            import copy
+            out64 = copy.deepcopy(net).double()(torch.from_numpy(imgs).double()).numpy()
     h = hashlib.sha256()
     h.update(np.ascontiguousarray(imgs).tobytes())
     for k in sorted(state):
         h.update(np.ascontiguousarray(state[k]).tobytes())
     meta = dict(name=name, H=H, W=W, seed=seed, inputs_sha256=h.hexdigest(), torch=torch.__version__,
                 reference="libs/encoders/UNet.py ResUNet(resnet34, out_ch=32).forward, eval, CPU fp32")
+    if weights_kw:
+        meta["weights_kw"] = weights_kw
     out = out.astype(np.float32)
     if stride is None:
         arrs = dict(featmaps=out)
+        if out64 is not None:
+            arrs["spread_f32_f64"] = np.float64(np.abs(out64 - out.astype(np.float64)).max())
+            arrs["featmaps_absmax"] = np.float64(np.abs(out).max())
     else:
         o64 = out.astype(np.float64)
         arrs = dict(featmaps_sub=np.ascontiguousarray(out[:, :, ::stride, ::stride]), featmaps_stride=np.int64(stride),
@@ -538,7 +755,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
-    for name, kw, S, extra in CASES + FULL_CASES:
+    for name, kw, S, extra in CASES + TRAINED_CASES + FULL_CASES:
         if only and name not in only:
             continue
         run_case(name, kw, S, **extra)
@@ -558,6 +775,15 @@ def main():
                                      ("encoder_512x512", 512, 512, 11, 4)):
         if not only or name in only:
             run_encoder_case(name, H, W, seed, stride)
+    if not only or "encoder_trained_96x128" in only:
+        run_encoder_case("encoder_trained_96x128", 96, 128, 12, None, weights_kw=TRAINED_ENC)
+    if not only or "e2e_trained_64x64_s32" in only:
+        run_e2e_case("e2e_trained_64x64_s32", dict(H=64, W=64, seed=35, bias_std=0.3, sigma_bias=-60.0, head_scale=2.0, **TRAINED), 32, 35,
+                     spread=True, weights_kw=TRAINED_ENC)
+    if not only or "loop_demo_3frames" in only:
+        run_loop_case("loop_demo_3frames", [dict(seed=61, focal_mul=1.6, vol_occupancy=0.3, sigma_bias=0.5, **DEMO_SMALL),
+                                            dict(seed=62, focal_mul=1.4, vol_occupancy=0.5, sigma_bias=0.5, **DEMO_SMALL),
+                                            dict(seed=63, focal_mul=1.8, vol_occupancy=0.4, sigma_bias=1.0, **DEMO_SMALL)], 32)
     if not only or "e2e_512_survey" in only:
         # the size BASELINE.json configs[4] runs at: 512x512 sources (1024 x ratio 0.5), full-size SMPL box, literal f = 1.05 W
         # camera of SURVEY.md 8d, 64 samples per ray (configs/trainzju_valzju.yaml train.n_samples), test chunk 2000

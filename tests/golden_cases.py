@@ -12,7 +12,14 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("rays_", "encoder_", "attention_", "demo_", "e2e_", "config2_", "config3_", "config4_")))
+                  if not os.path.basename(p).startswith(("rays_", "encoder_", "attention_", "demo_", "e2e_", "config2_", "config3_", "config4_",
+                                                         "trained_", "loop_")))
+
+
+def trained_case_names():
+    """"trained-like" dense-renderer cases (make_golden.py TRAINED_CASES): scaled heads with biases, heavy-tailed features,
+    ReLU-sparse levels; each carries the reference's own float32-vs-float64-head spread"""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "trained_*.npz")))
 
 
 def full_size_case_names():
@@ -32,8 +39,16 @@ def attention_case_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "attention_*.npz")))
 
 
+def trained_tolerance(z, key, floor=1e-4, k=8.0):
+    """Bound for a map of a trained_* fixture: north_star's 1e-4, or `k` x the reference's own float32-vs-float64-head distance on
+    that map where that is larger.  k = 8: the yardstick leaves out the float32 rounding of the GATHERS (sample coordinates,
+    interpolation weights), which the op-for-op C oracle shows to weigh 2 - 6 x the head's (tools/trained_like_report.py prints the
+    table; profiles/r04/j_trained_like.txt)."""
+    return max(floor, k * float(z["spread_" + key]))
+
+
 def encoder_case_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "encoder_*.npz")))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "encoder_*.npz")) if "trained" not in os.path.basename(p))
 
 
 def load(name):

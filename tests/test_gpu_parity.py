@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import assert_close, case_names, demo_case_names, load, rays_case_names, scene_of
+from golden_cases import assert_close, case_names, demo_case_names, load, rays_case_names, scene_of, trained_case_names, trained_tolerance
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +56,36 @@ def test_fused_matches_reference_golden(name, fm):
         idx = z["st_rays"]
         assert_close(got["raw"][idx], z["st_raw"], TOL, "raw")
         assert np.array_equal(got["ray_mask"][idx].astype(bool), z["st_ray_mask"])
+
+
+@pytest.mark.parametrize("form", ["fp32_folded", "fp32_per_sample", "split_f16"])
+@pytest.mark.parametrize("name", trained_case_names())
+def test_fused_on_trained_like_parameters(name, form, fm, oracle):
+    """VERDICT r3 next #1a: parity on something other than `weights_init` parameters -- head weights x 1 / 1.5 / 2 / 3 with non-zero
+    biases, feature maps and volumes x 4 with log-normal tails, ReLU-sparse levels, >= 4 096 rays x 64 samples, produced by the
+    reference's Renderer.render.  Every kernel form against (a) the reference's float32 maps and (b) the maps of its head evaluated in
+    float64, both within golden_cases.trained_tolerance -- 1e-4 where float32 can deliver it (x 1), the reference's own
+    rounding-noise yardstick beyond -- and (c) no further from the reference than 3 x the op-for-op C oracle (+ 1e-4): the
+    distance is float32 conditioning, not this kernel.  tools/trained_like_report.py prints how the error grows with the scale."""
+    z, meta = load(name)
+    sc = scene_of(meta)
+    S = meta["n_samples"]
+    fr = build_frame(fm, sc)
+    kw = {"fp32_folded": dict(fold=True), "fp32_per_sample": dict(fold=False), "split_f16": dict(split_f16=True)}[form]
+    got = cpu(fm.render_fused(fr, rays_of(sc), S, want=("weights", "z_vals", "rgb_in", "guard_tiles") if form == "split_f16" else ("weights", "z_vals", "rgb_in"), **kw))
+    ref = oracle.render(sc, S)
+    line = []
+    for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map"):
+        err = assert_close(got[k], z[k], trained_tolerance(z, k), f"{name} {k}")
+        err_o = float(np.abs(ref[k].astype(np.float64) - z[k]).max())
+        assert err <= 3.0 * err_o + 1e-4, (k, err, err_o)
+        line.append(f"{k} {err:.2e} (oracle {err_o:.2e}, reference's own {float(z['spread_' + k]):.2e})")
+    for k in ("rgb_map", "depth_map", "acc_map"):
+        assert_close(got[k].astype(np.float64), z[k + "_head64"], trained_tolerance(z, k), f"{name} {k} vs the float64 head")
+    if "weights" in z:
+        assert_close(got["weights"], z["weights"], trained_tolerance(z, "acc_map"), "weights")
+        assert_close(got["z_vals"], z["z_vals"], 1e-6, "z_vals")
+    print(f"{name} [{form}]: " + "; ".join(line) + (f"; guard tiles {int(got['guard_tiles'][0])}" if "guard_tiles" in got else ""))
 
 
 @pytest.mark.parametrize("split_f16", [False, True])

@@ -4,7 +4,8 @@ import os
 import numpy as np
 import pytest
 
-from golden_cases import GOLDEN_DIR, assert_close, case_names, demo_case_names, load, rays_case_names, scene_of, sha_inputs
+from golden_cases import (GOLDEN_DIR, assert_close, case_names, demo_case_names, load, rays_case_names, scene_of, sha_inputs, trained_case_names,
+                          trained_tolerance)
 
 # fp32 re-association only: the reference's own fp32-vs-fp64 spread is 6.5e-7
 TOL = 2e-5
@@ -36,6 +37,59 @@ def test_oracle_matches_reference_outputs(name, oracle):
         assert np.array_equal(res["st_mask"][idx], z["st_mask"]), "view masks"
         assert_close(res["st_raw"][idx], z["st_raw"], TOL, "raw")
         assert np.array_equal(res["ray_mask"][idx].astype(bool), z["st_ray_mask"]), "ray mask"
+
+
+@pytest.mark.parametrize("name", trained_case_names())
+def test_oracle_on_trained_like_parameters(name, oracle):
+    """Head weights x 1 / 1.5 / 2 / 3 with biases, feature maps and volumes x 4 with log-normal tails, ReLU-sparse levels (VERDICT r3
+    next #1a: every other fixture sits at `weights_init` scale).  At these scales 1e-4 is below what float32 delivers: the fixtures
+    carry the reference's OWN float32-vs-float64-head distance (`spread_*`, 4e-6 at x 1 ... 4.6e-4 at x 3 on rgb), and an op-for-op
+    restatement sits 2 - 6 x that from the reference (its gathers round their coordinates differently; a 1.7e-5 difference in one
+    interpolated feature becomes 2e-3 in a colour behind five layers of gain 3).  Bound: golden_cases.trained_tolerance."""
+    z, meta = load(name)
+    scene = scene_of(meta)
+    assert sha_inputs(scene) == meta["sha256_inputs"], "synthetic inputs are not byte-identical to the golden run"
+    res = oracle.render(scene, meta["n_samples"], stages="st_raw" in z)
+    for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map"):
+        assert_close(res[k], z[k], trained_tolerance(z, k), f"{name} {k}")
+    for k in ("rgb_map", "depth_map", "acc_map"):          # and as close to the float64-head result as to the float32 one
+        assert_close(res[k].astype(np.float64), z[k + "_head64"], trained_tolerance(z, k), f"{name} {k} vs the float64 head")
+    if "st_raw" in z:
+        idx = z["st_rays"]
+        assert np.array_equal(res["st_mask"][idx], z["st_mask"]), "view masks"
+        assert_close(res["st_grid"][idx].reshape(-1, 3), z["st_grid"], 2e-5, "grid_coords")
+
+
+def test_oracle_through_the_evaluation_loop(oracle):
+    """tests/golden/loop_demo_3frames.npz: the reference's Trainer.evaluate (BaseTrainer.py:255-280) over three frames with its
+    progressive renderer and Evaluator (if_nerf.py:49-83).  The oracle's progressive path per frame -> the per-frame MSE / PSNR the
+    reference's evaluator computed, and its summary means.  SSIM is not in the fixture (scikit-image absent): unpinned."""
+    z, meta = load("loop_demo_3frames")
+    assert int(z["count"]) == len(meta["frames"]) == 3
+    from golden_cases import scene_of as _scene
+    head = None
+    psnrs, mses = [], []
+    for i, kw in enumerate(meta["frames"]):
+        sc = _scene({"scene_kw": kw})
+        head = head or sc["head"]
+        sc["head"] = head                                   # ONE model for the loop: the first frame's head
+        occ = oracle.build_occupancy(sc)
+        ro, rd, near, far, sel = oracle.select_rays(occ, sc["voxel_size"], sc["bounds"][0, 0], sc["Rh"][0], sc["Th"][0],
+                                                    sc["target_pose"][0], sc["target_K"][0], 512, 512, neg_ray=False)
+        assert np.array_equal(sel, np.unpackbits(z[f"sel_mask_bits_{i}"]).astype(bool)), "selected pixels"
+        res = oracle.render(sc, meta["n_samples"], occ=occ, rays=np.concatenate([ro, rd, near[:, None], far[:, None]], 1))
+        img = np.zeros((512 * 512, 3))
+        img[sel] = res["rgb_map"]
+        m = np.unpackbits(z[f"mask_at_box_bits_{i}"]).astype(bool)
+        assert np.array_equal(m, sc["mask_at_box"][0])
+        pred = img[m].astype(np.float32)
+        assert_close(pred[::8], z[f"pred_sub_{i}"], TOL, f"frame {i} pred_img[mask]")
+        gt = z[f"gt_u8_{i}"].astype(np.float32) / np.float32(255.0)
+        mse = float(np.mean((pred - gt) ** 2))
+        mses.append(mse)
+        psnrs.append(-10.0 * np.log(mse) / np.log(10.0))
+    assert np.abs(np.array(psnrs) - z["psnr"]).max() < 1e-3 and np.abs(np.array(mses) / z["mse"] - 1).max() < 1e-4
+    assert abs(np.mean(psnrs) - float(z["summary_psnr"])) < 1e-3
 
 
 def check_rays_against_golden(z, ro, rd, near, far, mask):
