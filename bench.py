@@ -412,16 +412,18 @@ def renderer_api_wall(args, wl, survey=False):
             bb = dict(b, **extra)
             for _ in range(2):
                 r.render(bb)
-            ts, et = [], []
-            for _ in range(5):
+            ts, et, rt = [], [], []
+            for _ in range(9):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 ret = r.render(bb)
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) * 1e3)
                 et.append(ret["etime"] * 1e3)
-            res[name] = {"wall_ms": float(np.median(ts)), "etime_ms": float(np.median(et)), "rtime_ms": float(ret["rtime"] * 1e3),
-                         "rays": int(ret["rgb_map"].shape[1]), "returns": sorted(k for k in ret if k not in ("etime", "rtime"))}
+                rt.append(ret["rtime"] * 1e3)
+            res[name] = {"wall_ms": float(np.median(ts)), "wall_ms_min_max": [float(np.min(ts)), float(np.max(ts))],
+                         "etime_ms": float(np.median(et)), "rtime_ms": float(np.median(rt)), "rtime_ms_min_max": [float(np.min(rt)), float(np.max(rt))],
+                         "calls": len(ts), "rays": int(ret["rgb_map"].shape[1]), "returns": sorted(k for k in ret if k not in ("etime", "rtime"))}
     res["note"] = ("products_in_batch: batch carries featmaps + the 4 dense levels; with_producers: hip_encoder + vertex attention + sparse "
                    "volume builder run per frame (their volumes are sparse, the per-ray kernel's work is the same)")
     return res

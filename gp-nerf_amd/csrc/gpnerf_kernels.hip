@@ -371,8 +371,13 @@ template <int N> DEV void guard_n(Guard&, const float* v) {
 #pragma unroll
     for (int i = 2; i < N; i += 2) m = fmaxf(fmaxf(m, fabsf(v[i])), fabsf(v[i + 1]));
     // Branch-free on purpose: lanes in range write a dummy word.  With `if (__any(...))` here -- a branch in the middle of the
-    // layer chain, never taken -- this kernel's results came out 2e-5 off and different from run to run (measured; a minimal
-    // kernel does not reproduce it, tools/micro/mfma_branch_hazard.hip, so the cause is not established).
+    // layer chain, never taken -- round 2's build of this kernel gave results 2e-5 off and different from run to run.  What IS
+    // known (round 3): gfx950 does not interlock a consumer of an MFMA's destination registers inside the MFMA's shadow, LLVM
+    // pads only the consumers it can see, and this file's inline-asm conversions (lo_pair) are opaque to it -- demonstrated on
+    // hardware (tools/micro/mfma_asm_hazard.hip: 65 535 of 65 536 results stale) and gated by a static check of the shipped ISA
+    // (tools/isa_mfma_hazards.py, tests/test_abi.py).  What is NOT known: whether that was the failing pair in the round-2
+    // schedule -- that source variant was never committed, and the branch form re-created under -DGPNERF_X_BRANCHGUARD is
+    // deterministic and checker-clean.  The mechanism class is established, the instance is not.
 #ifdef GPNERF_X_BRANCHGUARD       // diagnostic build only (tools/probes/branch_guard.sh): the guard as first written, with a branch
     if (__any(!(m < F16_RANGE))) { if (!(m < F16_RANGE)) guard_slot()[0] = 1u; }
 #else
