@@ -394,7 +394,7 @@ class ResUNet(nn.Module):
     W_LIMIT, X_LIMIT = 15.99, 4094.0
     exact_frames = 0             # frames this module has encoded through forward_exact (instances count in their __dict__)
 
-    def check_operand_range(self, H, W):
+    def check_operand_range(self, H, W, params_key=None):
         """Which guard a frame of H x W images needs, from the PARAMETERS alone (cached per (H, W, parameter versions): one
         device-to-host copy per parameter change).  Never refuses finite parameters:
           "static"   every convolution's operands are inside the split-f16 range whatever the images: weights |w| < 16 directly,
@@ -407,7 +407,9 @@ class ResUNet(nn.Module):
                      forward_exact;
           "exact"    a weight is 16 or more in magnitude (or a parameter is not finite): every frame goes through forward_exact.
         `self.range_report` names the first layer that decided a "dynamic" / "exact" answer."""
-        key = (int(H), int(W), _graph_key(self, next(self.parameters()))[3])
+        # params_key: the (storage, version) tuple of the parameters when the caller has just computed it (forward_graphed: walking
+        # the 108 parameters costs the host ~0.1 ms, and this runs before the frame's first launch with the device idle)
+        key = (int(H), int(W), params_key if params_key is not None else _graph_key(self, None)[3])
         hit = self.__dict__.get("_gpnerf_range_class")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -570,7 +572,8 @@ def _graph_key(net, x):
     plist = net.__dict__.get("_gpnerf_params")
     if plist is None:
         plist = net.__dict__["_gpnerf_params"] = list(net.parameters())
-    return (tuple(x.shape), x.device.index, x.dtype, tuple([(p.data_ptr(), p._version) for p in plist]))
+    pk = tuple([(p.data_ptr(), p._version) for p in plist])
+    return (tuple(x.shape), x.device.index, x.dtype, pk) if x is not None else (None, None, None, pk)
 
 
 def forward_graphed(net, x, defer_range_check=False):
@@ -583,10 +586,10 @@ def forward_graphed(net, x, defer_range_check=False):
     it then calls `range_check_pending(net)` and, on True, discards what it computed from the result and encodes again with
     `net.forward_exact` (Renderer.render does this at the end of the call, so an in-range frame never waits for the encoder)."""
     _require_gpu_inference(x, net.training)
-    cls = net.check_operand_range(x.shape[-2], x.shape[-1])
+    key = _graph_key(net, x)
+    cls = net.check_operand_range(x.shape[-2], x.shape[-1], params_key=key[3])
     if cls == "exact":
         return net.forward_exact(x)
-    key = _graph_key(net, x)
     hit = net.__dict__.get("_gpnerf_graph")
     if hit is None or hit[0] != key:
         hit = (key, _EncoderGraph(net, x.float()))

@@ -23,6 +23,7 @@ def timed(obj, name, label=None):
     def w(*a, **k):
         t = time.perf_counter(); o = f(*a, **k); acc.setdefault(label or name, []).append((time.perf_counter() - t) * 1e3); return o
     setattr(obj, name, w)
+R_ = importlib.import_module("gp-nerf_amd.render"); timed(R_, "_record_on")
 timed(r, "encode"); timed(r, "build_frame"); timed(r, "prepare_builder_inputs"); timed(F_, "render_fused"); timed(F_, "patch_order_device")
 timed(F_.Frame, "consts_of_batch"); timed(F_, "relayout_images"); timed(F_, "project_gather"); timed(F_.Frame, "from_batch", "Frame()")
 net = r.nerfhead.sigmahead.xyzc_net

@@ -19,7 +19,7 @@ marks = []
 def mark(name):
     e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((name, time.perf_counter(), e))
 orig_encode, orig_build, orig_fused = r.encode, r.build_frame, F_.render_fused
-def encode(batch): mark("encode:start"); o = orig_encode(batch); mark("encode:end"); return o
+def encode(batch, **kw): mark("encode:start"); o = orig_encode(batch, **kw); mark("encode:end"); return o
 def build(*a, **k): mark("frame:start"); o = orig_build(*a, **k); mark("frame:end"); return o
 def fused(*a, **k): mark("fused:start"); o = orig_fused(*a, **k); mark("fused:end"); return o
 r.encode, r.build_frame, F_.render_fused = encode, build, fused
