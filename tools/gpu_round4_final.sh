@@ -1,7 +1,7 @@
-# round-3 measurements: GPU suite, benches, rocprofv3 kernel stats, PMC passes (separate runs, counters only), probes
+# round-4 measurements: GPU suite, benches, rocprofv3 kernel stats, PMC passes (separate runs, counters only), probes
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-o=gpurun_out/r3f; rm -rf $o; mkdir -p $o
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $o/gpu_tests.txt
+o=gpurun_out/r4f; rm -rf $o; mkdir -p $o
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $o/gpu_tests.txt
 timeout 500 python bench.py > $o/bench_default.json 2> $o/bench_default.err
 timeout 300 python bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras > $o/bench_c3.json 2> $o/bench_c3.err
 timeout 300 python bench.py --steps 10 --warmup 3 --split-f16 --no-cpu-baseline --no-extras > $o/bench_split_guarded.json 2> $o/bench_split.err
@@ -9,30 +9,39 @@ timeout 300 python bench.py --steps 10 --warmup 3 --size 1024 --no-cpu-baseline 
 timeout 300 python bench.py --steps 10 --warmup 3 --size 64 --samples 32 --no-cpu-baseline --no-extras > $o/bench_64.json 2> $o/bench_64.err
 timeout 300 python bench.py --steps 10 --warmup 3 --fill survey --no-cpu-baseline --no-extras > $o/bench_survey.json 2> $o/bench_survey.err
 timeout 300 python bench.py --steps 10 --warmup 3 --occ-cull --occupancy 0.1 --outputs light --no-cpu-baseline --no-extras > $o/bench_cull10.json 2> $o/bench_cull.err
+GPNERF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 > $o/bench_2ranks_gloo_dry_run.json 2> $o/bench_2ranks.err
 timeout 200 python tools/time_render_api.py > $o/render_api.txt 2>&1
 timeout 200 python tools/time_survey_api.py 20 > $o/render_api_survey.txt 2>&1
 timeout 200 python tools/probes/render_phases.py > $o/render_phases_survey.txt 2>&1
 timeout 200 python tools/probes/encoder_time.py > $o/encoder_time.txt 2>&1
+timeout 200 python tools/probes/encoder_views_time.py > $o/encoder_views_time.txt 2>&1
 timeout 200 python tools/probes/encoder_error.py > $o/encoder_error.txt 2>&1
 timeout 200 python tools/e2e512_probe.py > $o/e2e512_probe.txt 2>&1
+timeout 200 python tools/trained_like_report.py > $o/trained_like.txt 2>&1
 timeout 300 python tools/config_sweep.py > $o/config_sweep.txt 2>&1
-timeout 300 bash tools/probes/view_fold_proxy.sh > $o/view_fold_proxy.txt 2>&1
+timeout 600 python tools/parity_sweep.py 300 > $o/parity_sweep.txt 2>&1
+timeout 600 python tools/et_sweep.py 50 > $o/et_sweep.txt 2>&1
+timeout 600 python tools/producers_sweep.py 40 > $o/producers_sweep.txt 2>&1
+timeout 900 bash tools/probes/view_fold_proxy.sh > $o/view_fold_proxy.txt 2>&1
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r3f/bench_*.json")):
+for f in sorted(glob.glob("gpurun_out/r4f/bench_*.json")):
     try:
         j = json.load(open(f)); print(f.split("/")[-1], round(j["value"]), round(j["ms_per_step"], 3), round(j["roofline"]["frac"], 4), j.get("early_term", {}).get("samples_evaluated_frac"))
     except Exception as e:
         print(f, "ERR", e)
 PY
-tail -2 $o/render_api.txt; tail -1 $o/render_api_survey.txt; tail -1 $o/encoder_time.txt
+tail -2 $o/render_api.txt; tail -1 $o/render_api_survey.txt; tail -1 $o/encoder_time.txt; tail -4 $o/view_fold_proxy.txt
+# kernel stats: the headline ALONE (--no-extras: the fused kernel's average is then the timed launches' + their warm-up, nothing else), and the default line with everything beside it
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_headline -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $o/prof_bench_headline.json 2> $o/stats_headline.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_default -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $o/prof_bench_default.json 2> $o/stats_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c3 -- python3 bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras > $o/prof_bench_c3.json 2> $o/stats_c3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_encoder -- python3 tools/probes/encoder_time.py > $o/encoder.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_survey_api -- python3 tools/time_survey_api.py 6 > $o/survey_api_prof.log 2>&1
-for f in $(find $o -name "*kernel_stats.csv"); do echo "== $f"; head -5 $f | cut -c1-160; done
-rm -rf gpurun_out/pmc_r03_default gpurun_out/pmc_r03_c3 gpurun_out/pmc_r03_split
-bash tools/pmc_passes.sh r03_default --no-extras | tail -2
-bash tools/pmc_passes.sh r03_c3 --samples 128 --early-term --no-extras | tail -2
-bash tools/pmc_passes.sh r03_split --split-f16 --no-extras | tail -2
+for f in $(find $o -name "*kernel_stats.csv"); do echo "== $f"; head -4 $f | cut -c1-160; done
+rm -rf gpurun_out/pmc_r04_default gpurun_out/pmc_r04_c3 gpurun_out/pmc_r04_split gpurun_out/pmc_r04_survey
+bash tools/pmc_passes.sh r04_default --no-extras | tail -2
+bash tools/pmc_passes.sh r04_c3 --samples 128 --early-term --no-extras | tail -2
+bash tools/pmc_passes.sh r04_split --split-f16 --no-extras | tail -2
+bash tools/pmc_passes.sh r04_survey --fill survey --no-extras | tail -2
 bash tools/gpu_c3_fetch_per_level.sh > $o/c3_traffic_per_level.txt 2>&1; tail -9 $o/c3_traffic_per_level.txt
