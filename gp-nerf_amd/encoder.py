@@ -156,15 +156,6 @@ class _Run:
             self.flag = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self.flag_ptr = self.flag.data_ptr()
 
-    def branch(self):
-        """The words of a launch chain that runs BESIDE this one on another stream (a residual unit's projected shortcut next to its
-        two 3x3 convolutions): ticket words of its own -- two convolutions in flight count in different words -- and the SAME flag."""
-        b = self.__dict__.get("_branch")
-        if b is None:
-            b = self.__dict__["_branch"] = object.__new__(_Run)
-            b.tickets, b.flag, b.flag_ptr = torch.zeros_like(self.tickets), self.flag, self.flag_ptr
-        return b
-
     def raised(self):
         """True when a convolution of the passes since the last clear() saw an operand beyond the f16 range.  The caller has
         synchronised with the stream the pass ran on."""
@@ -263,24 +254,6 @@ def _conv_norm_cat(conv, norm, xa, xb):
     return out, tab
 
 
-# GPNERF_ENC_BRANCH=0 (under GPNERF_DEBUG=1): the projected shortcuts behind their units' convolutions, as in round 3 (A/B knob)
-_BRANCH = not (L._DEBUG and os.environ.get("GPNERF_ENC_BRANCH") == "0")
-_branch_streams = {}
-
-
-def _branch_stream(dev):
-    s = _branch_streams.get(str(dev))
-    if s is None:
-        s = _branch_streams[str(dev)] = torch.cuda.Stream(device=dev)
-    return s
-
-
-def _record(stream, *tensors):
-    for t in tensors:
-        if t is not None:
-            t.record_stream(stream)
-
-
 def _fusable_input_norm(conv):
     """convolutions that can apply an InstanceNorm (+ ReLU) to their input while they read it: 3x3 (staging) and 1x1 (splitting)
     on whole 16-channel blocks"""
@@ -329,18 +302,6 @@ class ResidualUnit(nn.Module):
                 act0 = 1
             else:
                 x, x_tab = _apply(x, x_tab, 1), None
-        side = None
-        if self.downsample is not None and _BRANCH:
-            # the projected shortcut (a 1x1 stride-2 convolution + its norm table, ~13 us) depends on nothing the two 3x3
-            # convolutions produce: it runs BESIDE them on a second stream (a parallel branch of the captured graph) instead of
-            # behind them -- these layers are latency-bound and leave most of the chip idle.  Its launches count in ticket words of
-            # their own (_Run.branch); the tensors that cross streams are recorded on the stream that did not allocate them.
-            main, run = torch.cuda.current_stream(x.device), _run_of(x)
-            side = _branch_stream(x.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side), _pinned_run(run.branch()):
-                d, td = _conv_norm(self.downsample[0], self.downsample[1], x, in_tab=x_tab, in_act=act0)
-            _record(side, x, x_tab)
         y1, t1 = _conv_norm(self.conv1, self.bn1, x, in_tab=x_tab, in_act=act0)
         if _fusable_input_norm(self.conv2):
             y2, t2 = _conv_norm(self.conv2, self.bn2, y1, in_tab=t1, in_act=1)
@@ -348,11 +309,7 @@ class ResidualUnit(nn.Module):
             y2, t2 = _conv_norm(self.conv2, self.bn2, _apply(y1, t1, 1))
         if self.downsample is None:
             return _apply(y2, t2, 1, residual=x)
-        if side is None:
-            d, td = _conv_norm(self.downsample[0], self.downsample[1], x, in_tab=x_tab, in_act=act0)
-        else:
-            main.wait_stream(side)
-            _record(main, d, td)
+        d, td = _conv_norm(self.downsample[0], self.downsample[1], x, in_tab=x_tab, in_act=act0)
         return _apply(y2, t2, 1, residual=d, res_tab=td)
 
     def forward_exact(self, x):
