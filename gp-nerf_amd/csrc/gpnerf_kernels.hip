@@ -2196,7 +2196,24 @@ int chain_len(int S) {
     const int least = (S + CHAIN_MAX_SEGS - 1) / CHAIN_MAX_SEGS;
     return f_seg > least ? f_seg : least;
 }
-int chain_segs(int S) { const int len = chain_len(S); return (S + len - 1) / len; }      // upper bound (workspace sizing)
+// GPNERF_CHAIN_SCHEDULE="16,8,8,8,16" (experiment knob, under GPNERF_DEBUG=1): the launches' segment lengths, the last one repeated
+// to the end of the ray; at most CHAIN_MAX_SEGS entries.  Empty (default): equal segments.
+const int* chain_custom(int* n) {
+    static int f_n = -1, f_len[CHAIN_MAX_SEGS];
+    if (f_n < 0) {
+        f_n = 0;
+        const char* e = dbg_env("GPNERF_CHAIN_SCHEDULE");
+        while (e && *e && f_n < CHAIN_MAX_SEGS) {
+            const int v = atoi(e);
+            if (v < 1) break;
+            f_len[f_n++] = v > 256 ? 256 : v;
+            while (*e && *e != ',') ++e;
+            if (*e == ',') ++e;
+        }
+    }
+    *n = f_n;
+    return f_len;
+}
 // The launches' sample ranges.  Default: equal segments of chain_len().  GPNERF_CHAIN_MERGE_AFTER=k (experiment knob, under
 // GPNERF_DEBUG=1): from sample k on every segment is as long as all the samples before it ([0,16) .. [48,64), [64,128), ...).
 // Measured on the 512x512x128 bench frame, where 5 % of the rays are alive after 64 samples: 8.82 ms with equal segments,
@@ -2206,15 +2223,25 @@ int chain_segs(int S) { const int len = chain_len(S); return (S + len - 1) / len
 int chain_schedule(int S, int* begins) {
     static int f_merge = -1;
     if (f_merge < 0) f_merge = dbg_int("GPNERF_CHAIN_MERGE_AFTER", 0, 0, 1 << 20);       // 0 (default): equal segments throughout
+    int nc = 0;
+    const int* custom = chain_custom(&nc);
     const int len = chain_len(S);
     int n = 0, k = 0, cur = len;
-    while (k < S) {
-        begins[n++] = k;
-        if (f_merge > 0 && k >= f_merge) { cur = k; }                 // from here on every segment is as long as all before it
+    while (k < S && n < CHAIN_MAX_SEGS) {
+        begins[n] = k;
+        if (nc > 0) cur = custom[n < nc ? n : nc - 1];
+        else if (f_merge > 0 && k >= f_merge) { cur = k; }            // from here on every segment is as long as all before it
+        ++n;
         k += cur;
+        if (n == CHAIN_MAX_SEGS - 1 && k < S) { begins[n++] = k; k = S; }     // (the schedule ran out of launches: one last segment to the end)
     }
     begins[n] = S;
     return n;
+}
+int chain_segs(int S) {               // upper bound on the launches (workspace sizing)
+    int begins[CHAIN_MAX_SEGS + 2];
+    const int n = chain_schedule(S, begins), len = chain_len(S), eq = (S + len - 1) / len;
+    return n > eq ? n : eq;
 }
 size_t chain_chunks(int64_t n_rays) { return (size_t)((n_rays + 2047) / 2048); }       // LIST_CHUNK entries each
 // control block: per segment 8 queue counters, the length of its output list, and one survivor counter per LIST_CHUNK input entries
