@@ -746,9 +746,13 @@ template <bool BATCH = false, class MP>
 DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
                            const float* __restrict__ fm, int fh, int fw, float px, float py, float pz, bool neg,
                            int half, float* f, const float* __restrict__ ftab = nullptr) {
-    const float hx = ((M[0] * px + M[1] * py) + M[2] * pz) + M[3];
-    const float hy = ((M[4] * px + M[5] * py) + M[6] * pz) + M[7];
-    const float hz = ((M[8] * px + M[9] * py) + M[10] * pz) + M[11];
+    // (K4 P4) bmm [p, 1] (BaseRender.py:314): on the reference's CPU path an sgemm whose micro-kernel accumulates over k = 0..3 with
+    // FMAs, k ascending, the last term (x 1) a plain add -- checked bit for bit against torch.bmm; with this order the pixel
+    // coordinates, the in-bounds masks and the gathered view features are the reference's own bits (round 3 summed left to
+    // right with separate multiplies and adds: one ulp of a pixel coordinate, 1.7e-5 in a trained-like feature)
+    const float hx = fmaf(M[2], pz, fmaf(M[1], py, M[0] * px)) + M[3];
+    const float hy = fmaf(M[6], pz, fmaf(M[5], py, M[4] * px)) + M[7];
+    const float hz = fmaf(M[10], pz, fmaf(M[9], py, M[8] * px)) + M[11];
     float u = hx / hz, w = hy / hz;
     u = fminf(fmaxf(u, -1e6f), 1e6f);        // torch.clamp; a NaN lands out of bounds here as it does there
     w = fminf(fmaxf(w, -1e6f), 1e6f);
@@ -942,9 +946,10 @@ DEV float linspace01(int k, int S, float step) {
 template <class FR>
 DEV void grid_coords(const FR& fr, float px, float py, float pz, float& gx, float& gy, float& gz) {
     const float qx0 = px - fr.Th[0], qy0 = py - fr.Th[1], qz0 = pz - fr.Th[2];
-    const float qx = (qx0 * fr.Rh[0] + qy0 * fr.Rh[3]) + qz0 * fr.Rh[6];
-    const float qy = (qx0 * fr.Rh[1] + qy0 * fr.Rh[4]) + qz0 * fr.Rh[7];
-    const float qz = (qx0 * fr.Rh[2] + qy0 * fr.Rh[5]) + qz0 * fr.Rh[8];
+    // torch.matmul([n,3], Rh) (:57): the same sgemm FMA chain over k = 0..2 -- the grid coordinates are then the reference's bits
+    const float qx = fmaf(qz0, fr.Rh[6], fmaf(qy0, fr.Rh[3], qx0 * fr.Rh[0]));
+    const float qy = fmaf(qz0, fr.Rh[7], fmaf(qy0, fr.Rh[4], qx0 * fr.Rh[1]));
+    const float qz = fmaf(qz0, fr.Rh[8], fmaf(qy0, fr.Rh[5], qx0 * fr.Rh[2]));
     gx = ((qx - fr.bounds_min[0]) / fr.voxel[2]) / fr.out_sh[2] * 2.f - 1.f;
     gy = ((qy - fr.bounds_min[1]) / fr.voxel[1]) / fr.out_sh[1] * 2.f - 1.f;
     gz = ((qz - fr.bounds_min[2]) / fr.voxel[0]) / fr.out_sh[0] * 2.f - 1.f;

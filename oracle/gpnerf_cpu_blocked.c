@@ -203,7 +203,7 @@ static void render_block(const BlockedFrame *f, const float *rays, int64_t r0, i
         const float p[3] = {ray[0] + ray[3] * z, ray[1] + ray[4] * z, ray[2] + ray[5] * z};
         const float q0[3] = {p[0] - f->Th[0], p[1] - f->Th[1], p[2] - f->Th[2]};
         float q[3], gc[3];
-        for (int j = 0; j < 3; ++j) q[j] = q0[0] * f->Rh[j] + q0[1] * f->Rh[3 + j] + q0[2] * f->Rh[6 + j];
+        for (int j = 0; j < 3; ++j) q[j] = fmaf(q0[2], f->Rh[6 + j], fmaf(q0[1], f->Rh[3 + j], q0[0] * f->Rh[j]));
         for (int a = 0; a < 3; ++a) gc[2 - a] = (q[2 - a] - f->bounds_min[2 - a]) / f->voxel[a] / (float)f->out_sh[a] * 2.f - 1.f;
         for (int l = 0; l < NL; ++l) {
             const int D = f->vol_dhw[l][0], H = f->vol_dhw[l][1], W = f->vol_dhw[l][2];
@@ -229,7 +229,7 @@ static void render_block(const BlockedFrame *f, const float *rays, int64_t r0, i
         for (int v = 0; v < NV; ++v) {
             const float *M = f->K4P4[v];
             float h[3];
-            for (int a = 0; a < 3; ++a) h[a] = M[a * 4 + 0] * p[0] + M[a * 4 + 1] * p[1] + M[a * 4 + 2] * p[2] + M[a * 4 + 3];
+            for (int a = 0; a < 3; ++a) h[a] = fmaf(M[a * 4 + 2], p[2], fmaf(M[a * 4 + 1], p[1], M[a * 4 + 0] * p[0])) + M[a * 4 + 3];   /* the reference's sgemm order (gpnerf_oracle.c) */
             float u = h[0] / h[2], w = h[1] / h[2];
             u = fminf(fmaxf(u, -1e6f), 1e6f);
             w = fminf(fmaxf(w, -1e6f), 1e6f);

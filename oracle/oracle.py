@@ -88,7 +88,9 @@ def _p(a):
 
 
 def k4p4(src_Ks, src_poses):
-    """train_intrinsics.bmm(train_poses) on the 4x4 embeddings, fp32 (BaseRender.py:233-247,314)."""
+    """train_intrinsics.bmm(train_poses) on the 4x4 embeddings, fp32 (BaseRender.py:233-247,314).  For matrices this small
+    torch.bmm runs its native loop: every element a float32 multiply-add chain over k = 0..3, NO fused multiply-adds (checked
+    bit for bit on 6 000 elements; numpy's `@` goes through a BLAS whose FMAs differ in the last bit of most products)."""
     V = src_Ks.shape[0]
     out = np.zeros((V, 4, 4), np.float32)
     for v in range(V):
@@ -96,7 +98,10 @@ def k4p4(src_Ks, src_poses):
         K4[:3, :3] = src_Ks[v].astype(np.float32)
         P4 = np.eye(4, dtype=np.float32)
         P4[:3, :4] = src_poses[v].astype(np.float32)
-        out[v] = (K4 @ P4).astype(np.float32)
+        acc = np.zeros((4, 4), np.float32)
+        for k in range(4):
+            acc = (acc + (K4[:, k:k + 1] * P4[k:k + 1, :]).astype(np.float32)).astype(np.float32)
+        out[v] = acc
     return out
 
 

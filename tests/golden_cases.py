@@ -39,10 +39,11 @@ def attention_case_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "attention_*.npz")))
 
 
-def trained_tolerance(z, key, floor=1e-4, k=8.0):
+def trained_tolerance(z, key, floor=1e-4, k=4.0):
     """Bound for a map of a trained_* fixture: north_star's 1e-4, or `k` x the reference's own float32-vs-float64-head distance on
-    that map where that is larger.  k = 8: the yardstick leaves out the float32 rounding of the GATHERS (sample coordinates,
-    interpolation weights), which the op-for-op C oracle shows to weigh 2 - 6 x the head's (tools/trained_like_report.py prints the
+    that map where that is larger (x 2 and x 3 heads: 1.3e-4 ... 4.6e-4 on rgb -- 1e-4 is below the reference's own rounding noise
+    there).  k = 4: with the geometry in the reference's summation order (round 4) the gathers are the reference's bits and the
+    HIP forms sit at 0.5 - 2 x that yardstick, 3 x at most against the float64-head maps (tools/trained_like_report.py prints the
     table; profiles/r04/j_trained_like.txt)."""
     return max(floor, k * float(z["spread_" + key]))
 

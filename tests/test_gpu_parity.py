@@ -64,9 +64,10 @@ def test_fused_on_trained_like_parameters(name, form, fm, oracle):
     """VERDICT r3 next #1a: parity on something other than `weights_init` parameters -- head weights x 1 / 1.5 / 2 / 3 with non-zero
     biases, feature maps and volumes x 4 with log-normal tails, ReLU-sparse levels, >= 4 096 rays x 64 samples, produced by the
     reference's Renderer.render.  Every kernel form against (a) the reference's float32 maps and (b) the maps of its head evaluated in
-    float64, both within golden_cases.trained_tolerance -- 1e-4 where float32 can deliver it (x 1), the reference's own
-    rounding-noise yardstick beyond -- and (c) no further from the reference than 3 x the op-for-op C oracle (+ 1e-4): the
-    distance is float32 conditioning, not this kernel.  tools/trained_like_report.py prints how the error grows with the scale."""
+    float64, both within golden_cases.trained_tolerance -- 1e-4 where float32 can deliver it (x 1, x 1.5), the reference's own
+    rounding-noise yardstick beyond.  Printed beside each: the C oracle's distance (it follows the reference's summation order
+    bit for bit through the gathers, so it shows what is left to exp / sigmoid and the layers' blocking) and the yardstick.
+    tools/trained_like_report.py prints how the error grows with the scale."""
     z, meta = load(name)
     sc = scene_of(meta)
     S = meta["n_samples"]
@@ -78,12 +79,11 @@ def test_fused_on_trained_like_parameters(name, form, fm, oracle):
     for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map"):
         err = assert_close(got[k], z[k], trained_tolerance(z, k), f"{name} {k}")
         err_o = float(np.abs(ref[k].astype(np.float64) - z[k]).max())
-        assert err <= 3.0 * err_o + 1e-4, (k, err, err_o)
         line.append(f"{k} {err:.2e} (oracle {err_o:.2e}, reference's own {float(z['spread_' + k]):.2e})")
     for k in ("rgb_map", "depth_map", "acc_map"):
         assert_close(got[k].astype(np.float64), z[k + "_head64"], trained_tolerance(z, k), f"{name} {k} vs the float64 head")
     if "weights" in z:
-        assert_close(got["weights"], z["weights"], trained_tolerance(z, "acc_map"), "weights")
+        assert_close(got["weights"], z["weights"], max(trained_tolerance(z, k) for k in ("rgb_map", "acc_map")), "weights")
         assert_close(got["z_vals"], z["z_vals"], 1e-6, "z_vals")
     print(f"{name} [{form}]: " + "; ".join(line) + (f"; guard tiles {int(got['guard_tiles'][0])}" if "guard_tiles" in got else ""))
 
@@ -175,13 +175,20 @@ def test_stage_entry_points_match_reference_golden(name, fm):
     fr = build_frame(fm, sc)
     rays = rays_of(sc)[torch.from_numpy(idx).to("cuda:0")]
     pts, zv, grid = fm.sample_points(fr, rays, S)
-    assert_close(pts.cpu().numpy(), z["st_pts"], 1e-6, "pts")
-    assert_close(zv.cpu().numpy(), z["st_z"], 1e-6, "z_vals")
-    assert_close(grid.cpu().numpy().reshape(-1, 3), z["st_grid"], 2e-5, "grid_coords")
+    # Geometry: the reference's bits.  Sample positions and grid coordinates are unfused IEEE operations in the reference's order, the
+    # two small matrix products (world -> SMPL, K4 P4 [p, 1]) FMA chains over k as the reference's sgemm runs them (round 4), the
+    # bilinear taps an FMA chain from the north-west tap as ATen's vectorised 2-D kernel sums them.
+    assert np.array_equal(pts.cpu().numpy(), z["st_pts"]), "pts"
+    assert np.array_equal(zv.cpu().numpy(), z["st_z"]), "z_vals"
+    assert np.array_equal(grid.cpu().numpy().reshape(-1, 3), z["st_grid"]), "grid_coords"
     vf = fm.sample_volume(fr, grid)
-    assert_close(vf.cpu().numpy().reshape(k, S, 128)[hv].reshape(-1, 128), z["st_vol_feat"], 2e-4, "volume features")
+    # (the trilinear taps are accumulated with FMAs here, with multiply-adds in ATen's scalar 3-D kernel: an ulp or two)
+    e_vol = assert_close(vf.cpu().numpy().reshape(k, S, 128)[hv].reshape(-1, 128), z["st_vol_feat"], 2e-6, "volume features")
     feat, mask = fm.project_gather(fr, pts, neg_ray=neg)
-    assert_close(feat.cpu().numpy().reshape(k, S, 3, 35)[hv], z["st_rgb_feat"], 2e-4, "rgb_feat")
+    got_feat = feat.cpu().numpy().reshape(k, S, 3, 35)[hv]
+    print(f"{name}: volume features max-abs {e_vol:.2e}; view features bit-equal on {float((got_feat == z['st_rgb_feat']).mean()):.4f} of the values, "
+          f"max-abs {float(np.abs(got_feat - z['st_rgb_feat']).max()):.2e}")
+    assert np.array_equal(got_feat, z["st_rgb_feat"]), "rgb_feat"
     assert np.array_equal(mask.cpu().numpy().reshape(k, S, 3), z["st_mask"])
     raw = fm.head_forward(fr.head_blob, vf, feat, mask)
     assert_close(raw.cpu().numpy().reshape(k, S, 4), z["st_raw"], TOL, "raw")

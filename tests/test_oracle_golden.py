@@ -7,8 +7,10 @@ import pytest
 from golden_cases import (GOLDEN_DIR, assert_close, case_names, demo_case_names, load, rays_case_names, scene_of, sha_inputs, trained_case_names,
                           trained_tolerance)
 
-# fp32 re-association only: the reference's own fp32-vs-fp64 spread is 6.5e-7
-TOL = 2e-5
+# The oracle follows the reference's summation ORDER where that could be established bit for bit (gpnerf_oracle.c header): grid
+# coordinates, masks and gathered features are the reference's bits; what is left is exp / sigmoid and the dense layers' blocking:
+# measured <= 3e-7 on rgb, 2.3e-6 on depth (values ~3) over the small cases (round 3's order: up to 2e-5)
+TOL = 5e-6
 
 
 @pytest.mark.parametrize("name", case_names())
@@ -31,9 +33,10 @@ def test_oracle_matches_reference_outputs(name, oracle):
     if stages:
         idx, heavy = z["st_rays"], z["st_heavy"]          # stage vectors: 32 rays spread over the list, the wide arrays for 8 of them
         assert idx.size >= min(32, meta["n_rays"]) and heavy.size >= idx.size // 4
-        assert_close(res["st_grid"][idx].reshape(-1, 3), z["st_grid"], 2e-5, "grid_coords")
-        assert_close(res["st_vol_feat"][heavy].reshape(-1, 128), z["st_vol_feat"], 2e-4, "volume features")
-        assert_close(res["st_rgb_feat"][heavy], z["st_rgb_feat"], 2e-4, "rgb_feat")
+        # geometry and gathers: the reference's bits (index work AND arithmetic, since the order is the reference's)
+        assert np.array_equal(res["st_grid"][idx].reshape(-1, 3), z["st_grid"]), "grid_coords"
+        assert np.array_equal(res["st_vol_feat"][heavy].reshape(-1, 128), z["st_vol_feat"]), "volume features"
+        assert np.array_equal(res["st_rgb_feat"][heavy], z["st_rgb_feat"]), "rgb_feat"
         assert np.array_equal(res["st_mask"][idx], z["st_mask"]), "view masks"
         assert_close(res["st_raw"][idx], z["st_raw"], TOL, "raw")
         assert np.array_equal(res["ray_mask"][idx].astype(bool), z["st_ray_mask"]), "ray mask"
@@ -42,10 +45,11 @@ def test_oracle_matches_reference_outputs(name, oracle):
 @pytest.mark.parametrize("name", trained_case_names())
 def test_oracle_on_trained_like_parameters(name, oracle):
     """Head weights x 1 / 1.5 / 2 / 3 with biases, feature maps and volumes x 4 with log-normal tails, ReLU-sparse levels (VERDICT r3
-    next #1a: every other fixture sits at `weights_init` scale).  At these scales 1e-4 is below what float32 delivers: the fixtures
-    carry the reference's OWN float32-vs-float64-head distance (`spread_*`, 4e-6 at x 1 ... 4.6e-4 at x 3 on rgb), and an op-for-op
-    restatement sits 2 - 6 x that from the reference (its gathers round their coordinates differently; a 1.7e-5 difference in one
-    interpolated feature becomes 2e-3 in a colour behind five layers of gain 3).  Bound: golden_cases.trained_tolerance."""
+    next #1a: every other fixture sits at `weights_init` scale).  The fixtures carry the reference's OWN float32-vs-float64-head
+    distance (`spread_*`, 4e-6 at x 1 ... 4.6e-4 at x 3 on rgb).  These cases are what exposed the summation ORDER of the geometry:
+    with multiply-adds summed left to right the oracle sat 2 - 6 x that yardstick from the reference (one ulp of a pixel coordinate
+    = 1.7e-5 in an interpolated feature = 2e-3 in a colour behind five layers of gain 3); in the reference's sgemm order it sits
+    at 0.2 x.  Bound: golden_cases.trained_tolerance."""
     z, meta = load(name)
     scene = scene_of(meta)
     assert sha_inputs(scene) == meta["sha256_inputs"], "synthetic inputs are not byte-identical to the golden run"
@@ -57,7 +61,8 @@ def test_oracle_on_trained_like_parameters(name, oracle):
     if "st_raw" in z:
         idx = z["st_rays"]
         assert np.array_equal(res["st_mask"][idx], z["st_mask"]), "view masks"
-        assert_close(res["st_grid"][idx].reshape(-1, 3), z["st_grid"], 2e-5, "grid_coords")
+        assert np.array_equal(res["st_grid"][idx].reshape(-1, 3), z["st_grid"]), "grid_coords"
+        assert np.array_equal(res["st_rgb_feat"][z["st_heavy"]], z["st_rgb_feat"]), "rgb_feat"
 
 
 def test_oracle_through_the_evaluation_loop(oracle):
