@@ -11,6 +11,9 @@ pytestmark = pytest.mark.gpu
 
 # north_star: within 1e-4 max-abs of the reference on RGB / depth
 TOL = 1e-4
+# what the kernels actually deliver on the initialisation-scale golden cases since the geometry runs in the reference's summation
+# order (round 4): rgb <= 1.6e-6, depth <= 8e-6 (tools/parity_report.py); a regression bound well inside north_star's
+TIGHT = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -44,10 +47,10 @@ def test_fused_matches_reference_golden(name, fm):
     S = meta["n_samples"]
     fr = build_frame(fm, sc)
     got = cpu(fm.render_fused(fr, rays_of(sc), S, neg_ray=meta["neg_ray"], want=("weights", "z_vals", "rgb_in", "ray_mask", "raw")))
-    assert_close(got["rgb_map"], z["rgb_map"], TOL, "rgb_map")
-    assert_close(got["depth_map"], z["depth_map"], TOL, "depth_map")
-    assert_close(got["acc_map"], z["acc_map"], TOL, "acc_map")
-    assert_close(got["rgb_in_map"], z["rgb_in_map"], TOL, "rgb_in_map")
+    assert_close(got["rgb_map"], z["rgb_map"], TIGHT, "rgb_map")
+    assert_close(got["depth_map"], z["depth_map"], TIGHT, "depth_map")
+    assert_close(got["acc_map"], z["acc_map"], TIGHT, "acc_map")
+    assert_close(got["rgb_in_map"], z["rgb_in_map"], TIGHT, "rgb_in_map")
     assert_close(got["disp_map"], z["disp_map"], 5e-4, "disp_map")
     if "weights" in z:
         assert_close(got["weights"], z["weights"], TOL, "weights")
