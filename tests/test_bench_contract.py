@@ -92,3 +92,20 @@ def test_bench_self_launch_needs_a_gpu_per_rank_and_says_so():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
                          env=_env_without_ranks(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
     assert out.returncode == 2 and "device(s) visible" in out.stderr and not out.stdout.strip()
+
+
+def test_bench_self_launch_relays_one_line_and_the_childs_status(tmp_path, monkeypatch, capsys):
+    """The parent half of `python bench.py --gpus N` without a launcher (no GPU needed): whatever it starts as its ranks, it passes
+    rank 0's JSON line through on stdout, everything else to stderr, and returns the child's exit status."""
+    sys.path.insert(0, ROOT)
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text("import sys\nprint('NOTE: some launcher chatter')\nprint('{\"metric\": \"rays_per_sec\", \"n_gpus\": 2}')\nsys.exit(7)\n")
+    monkeypatch.setattr(bench, "launch_command", lambda gpus, port, argv: [sys.executable, str(child)])
+    monkeypatch.setenv("GPNERF_BENCH_BACKEND", "gloo")          # (skips the device count: this is the dry-run backend)
+    from types import SimpleNamespace as NS
+    rc = bench.self_launch(NS(gpus=2))
+    out = capsys.readouterr()
+    assert rc == 7
+    assert [l for l in out.out.splitlines() if l.strip()] == ['{"metric": "rays_per_sec", "n_gpus": 2}']
+    assert "launcher chatter" in out.err
