@@ -260,6 +260,16 @@ def test_trained_sized_norm_scales_are_served_not_refused(size, gamma):
     err = float(np.abs(got.cpu().numpy() - want).max())
     print(f"{size}x{size}, gamma {gamma}: max-abs {err:.3e} on an output range of {scale:.3g}")
     assert err < 1e-4 * scale, (err, scale)
+    # ... and in absolute terms once the LAST norm (iconv2.bn, whose gamma only scales the output and every error in it) is back at
+    # 1: all 34 other norms still at `gamma`, the feature maps in their usual range -> within north_star's 1e-4 of float64
+    with torch.no_grad():
+        net.iconv2.bn.weight.fill_(1.0)
+        got1 = net(imgs.to("cuda:0"))
+    assert net.check_operand_range(size, size) == "dynamic" and net.exact_frames == 0
+    want1 = _float64_encoder(net, imgs)
+    err1 = float(np.abs(got1.cpu().numpy() - want1).max())
+    print(f"{size}x{size}, gamma {gamma} on every norm but the last: max-abs {err1:.3e} on an output range of {float(np.abs(want1).max()):.3g}")
+    assert err1 < 1e-4, err1
 
 
 @pytest.mark.gpu
