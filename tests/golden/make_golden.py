@@ -642,6 +642,10 @@ DEMO_CASES = [
     ("demo_neg_s96", dict(seed=22, focal_mul=1.3, vol_occupancy=0.6, sigma_bias=0.5, neg_cams=True, neg_target=True, **DEMO_SMALL), 96,
      dict(neg_ray=True)),
     ("demo_dense_s16", dict(seed=23, focal_mul=1.0, vol_occupancy=0.9, sigma_bias=2.0, **DEMO_SMALL), 16, {}),
+    # the progressive renderer on "trained-like" parameters (round 4): head x 2 with biases, sparse non-negative levels and feature
+    # maps x 4 with log-normal tails -- the distribution of trained_h2_s64, whose float32-vs-float64 yardstick the tests borrow
+    ("demo_trained_s32", dict(seed=24, focal_mul=1.5, vol_occupancy=0.4, sigma_bias=-4.0, head_scale=2.0, feat_scale=4.0, feat_tail=0.5,
+                              vol_scale=4.0, **dict(DEMO_SMALL, bias_std=0.3)), 32, {}),
 ]
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import assert_close, demo_case_names, load, scene_of
+from golden_cases import assert_close, demo_case_names, demo_tolerances, load, scene_of
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -141,7 +141,8 @@ def test_head_surface_of_the_progressive_renderer(name, plugins):
                                 dense_levels=[torch.from_numpy(v).to(dev) for v in sc["volumes"]])
     net = head.sigmahead.xyzc_net
     net.encode(xyzc, threshold=0.1)                                   # demo_render.py:155
-    assert_close(net.masks3d.cpu().numpy(), z["masks3d"], 1e-4, "masks3d")
+    tol_rgb, tol_occ = demo_tolerances(name, TOL)
+    assert_close(net.masks3d.cpu().numpy(), z["masks3d"], tol_occ, "masks3d")
     assert net.mask_xyz.shape == (int(z["n_mask_xyz"]), 3) and net.mask_xyz.dtype == torch.float32
     assert np.array_equal(net.mask_xyz[:64].cpu().numpy(), z["mask_xyz_head"]), "mask_xyz order / values"
     assert [tuple(f.shape) for f in net.features] == [tuple(v.shape) for v in sc["volumes"]]
@@ -151,18 +152,20 @@ def test_head_surface_of_the_progressive_renderer(name, plugins):
     sigma_feat, globalfeat = head.sigmahead.test_forward({"xyzc": xyzc}, grid, rgb_feat, mask)       # :295
     P = grid.shape[1]
     assert sigma_feat.shape == (P, 1, 64) and globalfeat.shape == (P, 1, 1, 134)
-    assert_close(sigma_feat[:, 0].cpu().numpy(), z["tf_sigma_feat"], TOL, "sigma_feat")
-    assert_close(globalfeat[:, 0, 0].cpu().numpy(), z["tf_globalfeat"], TOL, "globalfeat")
+    assert_close(sigma_feat[:, 0].cpu().numpy(), z["tf_sigma_feat"], tol_rgb, "sigma_feat")
+    assert_close(globalfeat[:, 0, 0].cpu().numpy(), z["tf_globalfeat"], tol_rgb, "globalfeat")
     # the density MLP as demo_render.py:300 runs it (stock nn.Sequential on the module's own parameters) and the colour head
     # as :326 calls it agree with the fused head on the same points
     sigma = head.rgbhead.out_geometry_fc(globalfeat.squeeze(2))
     rgb_in, rgb_out, sigma_out = head.rgbhead(rgb_feat, sigma_feat, mask)
     assert rgb_in.shape == (P, 1, 3, 3) and rgb_out.shape == (P, 1, 3) and sigma_out.shape == (P, 1, 1)
     raw, _ = head({"volumes": xyzc.dense_levels}, grid, None, rgb_feat.view(P, 1, 3, 35), mask)
+    # (densities are unbounded: on the trained-like case they reach the hundreds, so these self-consistency bounds are relative to them)
+    s_max = max(1.0, float(raw[..., 3:].abs().max()))
     assert_close(rgb_out.cpu().numpy(), raw[..., :3].cpu().numpy(), 1e-6, "rgb_out")
-    assert_close(sigma_out.cpu().numpy(), raw[..., 3:].cpu().numpy(), 1e-6, "sigma_out")
+    assert_close(sigma_out.cpu().numpy(), raw[..., 3:].cpu().numpy(), 1e-6 * s_max, "sigma_out")
     nvalid = mask.sum(dim=2)
-    assert_close(sigma.masked_fill(nvalid < 1, 0.0).detach().cpu().numpy(), sigma_out.cpu().numpy(), 2e-5, "sigma (nn.Sequential vs HIP)")
+    assert_close(sigma.masked_fill(nvalid < 1, 0.0).detach().cpu().numpy(), sigma_out.cpu().numpy(), 2e-5 * s_max, "sigma (nn.Sequential vs HIP)")
     # NeRFSigmaHead.forward's view (trainhead.py:58) of the same features
     sf = head.sigmahead({"xyzc": xyzc}, grid, None, torch.zeros((P // 8, 8, 3, 1), device=dev))
     assert sf.shape == (P * 64 // 8, 8, 1) and torch.equal(sf.reshape(P, 64), sigma_feat[:, 0])
@@ -259,10 +262,12 @@ def test_progressive_renderer_matches_reference_fixtures(name, split_f16, plugin
     assert set(json.loads(bytes(z["time_slot_keys"]).decode())) <= set(ret["time_slots"])
     mask_ref = np.unpackbits(z["mask_at_box_bits"]).astype(bool)
     assert np.array_equal(ret["mask_at_box"], mask_ref), "mask_at_box must be bit-exact"
-    assert_close(ret["rgb_map"], z["rgb_map"], TOL, "progressive rgb_map")
+    tol_rgb, _ = demo_tolerances(name, TOL)
+    err = assert_close(ret["rgb_map"], z["rgb_map"], tol_rgb, "progressive rgb_map")
+    print(f"{name} [{'split' if split_f16 else 'fp32'}]: progressive rgb_map max-abs {err:.2e} (bound {tol_rgb:.1e})")
     pred = np.zeros((512, 512, 3))
     pred[mask_ref.reshape(512, 512)] = z["rgb_map"]
-    assert ret["pred_img"].dtype == np.float64 and np.abs(ret["pred_img"] - pred).max() <= TOL
+    assert ret["pred_img"].dtype == np.float64 and np.abs(ret["pred_img"] - pred).max() <= tol_rgb
     assert ret["etime"] >= 0 and ret["rtime"] > 0
     # without body_msk the rule falls back to neg_ray_train (False here): a different image in the neg case
     if neg:

@@ -4,8 +4,8 @@ import os
 import numpy as np
 import pytest
 
-from golden_cases import (GOLDEN_DIR, assert_close, case_names, demo_case_names, load, rays_case_names, scene_of, sha_inputs, trained_case_names,
-                          trained_tolerance)
+from golden_cases import (GOLDEN_DIR, assert_close, case_names, demo_case_names, demo_tolerances, load, rays_case_names, scene_of, sha_inputs,
+                          trained_case_names, trained_tolerance)
 
 # The oracle follows the reference's summation ORDER where that could be established bit for bit (gpnerf_oracle.c header): grid
 # coordinates, masks and gathered features are the reference's bits; what is left is exp / sigmoid and the dense layers' blocking:
@@ -137,8 +137,9 @@ def test_oracle_matches_the_progressive_renderer(name, oracle):
     assert sha_inputs(sc) == meta["sha256_inputs"], "synthetic inputs are not byte-identical to the golden run"
     assert np.array_equal(sc["target_K_inv"], z["target_K_inv"]), "np.linalg.inv(float32 K) differs on this host"
     # SparseConvNet.encode: masks3d and the occupied-voxel list (SparseConvNet.py:135-141)
+    tol_rgb, tol_occ = demo_tolerances(name, TOL)
     occ = oracle.build_occupancy(sc)
-    assert_close(occ, z["masks3d"], 1e-4, "masks3d")          # sums of ~128 values of magnitude ~1: fp32 order only
+    assert_close(occ, z["masks3d"], tol_occ, "masks3d")          # sums of ~128 values of magnitude ~1: fp32 order only
     assert int((occ > 0.1).sum()) == int(z["n_mask_xyz"])
     # ray selection + near/far (demo_render.py:166-239): index work, bit-exact
     mask_ref = np.unpackbits(z["mask_at_box_bits"]).astype(bool)
@@ -150,7 +151,7 @@ def test_oracle_matches_the_progressive_renderer(name, oracle):
     # culled render + the un-flipped integral (:270-344), on the oracle's own rays
     res = oracle.render(sc, meta["n_samples"], neg_ray=meta["neg_ray"], occ=occ,
                         rays=np.concatenate([ro, rd, near[:, None], far[:, None]], 1))
-    assert_close(res["rgb_map"], z["rgb_map"], TOL, "rgb_map")
+    assert_close(res["rgb_map"], z["rgb_map"], tol_rgb, "rgb_map")
     if meta["neg_ray"]:      # the fixture discriminates the two readings of neg_ray: flipping the samples is far off
         bad = oracle.render(sc, meta["n_samples"], neg_ray=True, flip=True, occ=occ, rays=np.concatenate([ro, rd, near[:, None], far[:, None]], 1))
         assert np.abs(bad["rgb_map"] - z["rgb_map"]).max() > 1e-2
