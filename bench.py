@@ -62,7 +62,10 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--split-f16", action="store_true",
                     help="dense layers on f16 MFMA with fp32 operands split into hi+lo (GPNERF_FLAG_SPLIT_F16)")
-    ap.add_argument("--no-fold", action="store_true", help="fp32 form without the folded volumes (gpnerf_fold_volumes): the sigma feature layer per sample")
+    ap.add_argument("--fold", action="store_true",
+                    help="the fast fp32 form of round 4 (coarse levels folded per frame, log2e-scaled layers; `render.file hip_render_fold`) "
+                         "instead of the default reference-order form")
+    ap.add_argument("--no-fold", action="store_true", help="(default since round 5; accepted for old command lines)")
     ap.add_argument("--no-guard", action="store_true", help="with --split-f16: without the range guard (GPNERF_FLAG_SPLIT_GUARD)")
     ap.add_argument("--occ-cull", action="store_true",
                     help="progressive sample culling (demo_render.py semantics) on a sparse synthetic pyramid")
@@ -207,7 +210,7 @@ def main():
                 self.rays_per_step = wl.n * world
             self.n_local = self.rays.shape[0]
             # the fold is per-frame work and the bench re-uses one Frame: True = fold again in every step, inside the timed region
-            self.fold = bool(not args.no_fold and not args.split_f16 and not args.occ_cull)
+            self.fold = bool(args.fold and not args.split_f16 and not args.occ_cull)
 
         def render(self):
             return fm.render_fused(self.wl.frame, self.rays, self.wl.S, want=self.want, ray_order=self.order, fold=self.fold, **kw)
@@ -296,6 +299,7 @@ def main():
                        "ray_order": args.ray_order, "patch": args.patch if args.ray_order == "patch" else None, "outputs": "rgb+depth (the all-gather payload)" if strong else
                        ("rgb,depth,acc,disp,weights,z_vals,rgb_in (Renderer.render's dict)" if args.outputs == "api" else "rgb,depth,acc,disp"),
                        "early_term": bool(args.early_term), "term_eps": args.term_eps if args.early_term else None, "sigma_bias": sigma_bias,
+                       "form": "split-f16" if args.split_f16 else ("fp32, folded coarse levels (round 4)" if flow.fold else "fp32, reference summation order"),
                        "folded_volumes": bool(flow.fold), "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "split_guard": bool(args.split_f16 and not args.no_guard), "vol_occupancy": args.occupancy,
                        "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -348,6 +352,7 @@ def beside_headline(args, fm, wl, kw, flow):
     head_ms = None
     for name, want, order, extra in (("api_outputs_patch_order", API_OUTPUTS, wl.patch, {}), ("light_outputs_patch_order", (), wl.patch, {}),
                                      ("api_outputs_raster_order", API_OUTPUTS, None, {}),
+                                     ("fp32_folded_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"fold": True}),
                                      ("split_f16_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True}),
                                      ("split_f16_unguarded_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True, "guard": False})):
         k2 = dict(kw, fold=flow.fold and not extra.get("split_f16", False))
@@ -359,7 +364,9 @@ def beside_headline(args, fm, wl, kw, flow):
         if extra:
             res[name]["max_abs_vs_f32_form"] = {"rgb": float((o["rgb_map"] - head_out["rgb_map"]).abs().max()),
                                                 "depth": float((o["depth_map"] - head_out["depth_map"]).abs().max())}
-            res[name]["note"] = ("dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation; " +
+            res[name]["note"] = ("round 4's fast fp32 form (`render.file hip_render_fold`): coarse levels folded into the sigma feature layer per frame "
+                                 "(the fold is inside the timed step), log2e-scaled layers; not in the reference's summation order") if extra.get("fold") else \
+                                ("dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation; " +
                                  ("no range check (operands must stay below 65504)" if extra.get("guard") is False else
                                   "range guard on: tiles with an operand at the f16 range are rendered again in the fp32 form"))
     try:

@@ -35,6 +35,7 @@ class GpnerfFrame(C.Structure):
         ("head_blob_split", C.c_void_p),
         ("occ", C.c_void_p),
         ("vol_folded", C.c_void_p * LEVELS),
+        ("head_blob_ref", C.c_void_p),
     ]
 
 
@@ -87,12 +88,14 @@ FLAG_OCC_CULL = 4
 FLAG_SPLIT_F16 = 8
 FLAG_FLIP_SAMPLES = 16
 FLAG_SPLIT_GUARD = 32
+FLAG_REF_ORDER = 64
 FOLD_FIRST_LEVEL = 2
 
 # every symbol include/gpnerf_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "gpnerf_head_blob_floats": (C.c_int64, []),
     "gpnerf_pack_head": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
+    "gpnerf_pack_head_ref": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
     "gpnerf_head_blob_split_floats": (C.c_int64, []),
     "gpnerf_pack_head_split": (C.c_int, [C.POINTER(GpnerfHeadParams), FP]),
     "gpnerf_render_fused": (C.c_int, [C.POINTER(GpnerfFrame), C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float,

@@ -188,6 +188,47 @@ DEV f32x16 mfma_tile_from(const float* __restrict__ w, int lane, const float (&b
     return acc;
 }
 
+// The reference-order chain: as mfma_tile_from, and the tile's 16 biases (this half's) are fetched from LDS while the chain's
+// LAST group of MFMAs runs -- they are added after the chain (sgemm's beta = 1 step), and read at their first use they
+// cost an exposed LDS round trip per tile.
+template <int NT>
+DEV f32x16 mfma_tile_bias(const float* __restrict__ w, int lane, const float (&b)[NT], const f32x16& cin,
+                          const float* __restrict__ bias, f32x4 (&bq)[4]) {
+    static_assert(NT % 4 == 2 || NT % 4 == 0, "");
+    typedef const __attribute__((address_space(3))) float* lds_ptr;
+    typedef const __attribute__((address_space(3))) f32x4* lds_ptr4;
+    lds_ptr p = (lds_ptr)w + lane * 4;
+    lds_ptr bp = (lds_ptr)bias;
+    f32x4 a = *reinterpret_cast<lds_ptr4>(p);
+    constexpr int NG = NT / 4;
+    f32x4 an = a;
+    f32x2 at = {0.f, 0.f};
+    f32x16 acc = cin;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        an = a;
+        if (g + 1 < NG) an = *reinterpret_cast<lds_ptr4>(p + (g + 1) * 256);
+        else {
+            if constexpr (NT % 4 == 2) at = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>((lds_ptr)w + NG * 256 + lane * 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<lds_ptr4>(bp + 4 * q);
+            asm volatile("" : "+v"(bp));
+        }
+        if (g == 0) asm volatile("" : "+v"(p));
+        else asm volatile("" : "+v"(p), "+v"(acc));
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * g + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[4 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[4 * g + 3], acc, 0, 0, 0);
+        a = an;
+    }
+    if constexpr (NT % 4 == 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[0], b[4 * NG + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[1], b[4 * NG + 1], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 // accumulator initialised with the bias of tile m of layer L (image: [half][16 regs])
 template <int L>
 DEV f32x16 bias_tile(const float* __restrict__ lds, int m, int half) {
@@ -314,6 +355,213 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
         mfma_tile<16>(wtile<gpl::R2>(lds, 0), lane, h1, c2);
         float e[8];
         elus_n<8>(c2, e);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float* w3 = lds + gpl::R3_W + o * 16 + half * 8;
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) part = fmaf(w3[r], e[r], part);
+            const float s = part + __shfl_xor(part, 32) + lds[gpl::R3_B + o];
+            rgb[o] = 1.f / (1.f + fast_exp(-s));        // .sigmoid()
+        }
+    }
+    STAMP(st, 5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference-order MLP core (FORM_F32: the fp32 form without folded volumes; head_layout.h gpr, gpnerf_pack_head_ref)
+// ---------------------------------------------------------------------------------------------
+// On trained parameters (head weights x 1.5 ... x 3) every layer amplifies what the layers before it rounded differently from
+// the reference, so a kernel that is "fp32 with another summation order" sits 5-10 x further from the reference's maps than
+// an order-faithful one -- and EACH deviation alone (bias first, k in register order, the log2(e)-scaled domain, x * (1/3) for
+// x / 3, FMA-accumulated trilinear taps, folded levels) costs most of that, because one early layer out of step decorrelates
+// everything behind it (oracle/kernel_order.inc reproduces the round-4 kernel's distances to two digits on the CPU and
+// switches the deviations one at a time; profiles/r05/a_kernel_order_attribution.txt).  This form therefore follows the
+// reference's order everywhere it matters: each dense layer is sgemm's chain -- k ascending from ZERO, one FMA per k -- then
+// the bias, then ELU on the unscaled value; mean / variance and vis_fc's input divide by 3 with IEEE rounding; the trilinear
+// taps multiply, then add.  What is left: exp through v_exp_f32 (ELU's negative branch as 2^(x log2 e) - 1, sigmoid, alpha),
+// and the two small output layers as two half sums -- measured harmless (same file).
+
+// x / 3, correctly rounded (torch.mean divides): q = RN(x / 3) for every finite x whose quotient is normal -- c = RN(1/3), one
+// Newton step on the residual, which fma(-3, q0, x) delivers exactly (checked against IEEE division on 2^32 samples by
+// tests/test_kernel_order.py's C twin).  Three full-rate instructions against ~10 for v_rcp + refinement + v_div_fixup.
+DEV f32x2 div3(f32x2 x) {
+    const f32x2 c = {1.f / 3.f, 1.f / 3.f};
+    const f32x2 q = x * c;
+    const f32x2 r = __builtin_elementwise_fma(f32x2{-3.f, -3.f}, q, x);
+    return __builtin_elementwise_fma(r, c, q);
+}
+
+// bias, then nn.ELU on N accumulator registers: x = s + b;  x > 0 ? x : 2^(x log2 e) - 1  as med3(x, e - 1, 0)
+// (e - 1 is exact by Sterbenz for e in [1/2, 1]; where expm1 would return -|tiny| this returns 0: 6e-8 absolute at most).
+// `b`: this half's 16 biases of the tile (mfma_tile_bias fetched them).  Staged like elus_n: all the adds, then the exps, then the medians.
+template <int N>
+DEV void elur_n(f32x16& a, const f32x4 (&b)[4], float* out) {
+    asm volatile("" : "+v"(a));
+    float x[N], e[N];
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+        const f32x4 bv = b[q];
+        const f32x2 s0 = f32x2{a[4 * q], a[4 * q + 1]} + f32x2{bv[0], bv[1]};
+        const f32x2 s1 = f32x2{a[4 * q + 2], a[4 * q + 3]} + f32x2{bv[2], bv[3]};
+        x[4 * q] = s0[0]; x[4 * q + 1] = s0[1]; x[4 * q + 2] = s1[0]; x[4 * q + 3] = s1[1];
+    }
+#pragma unroll
+    for (int r = 0; r < N; r += 2) {
+        const f32x2 t = f32x2{x[r], x[r + 1]} * f32x2{LOG2E, LOG2E};
+        e[r] = t[0]; e[r + 1] = t[1];
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) e[r] = __builtin_amdgcn_exp2f(e[r]);
+#pragma unroll
+    for (int r = 0; r < N; r += 2) {
+        const f32x2 m = f32x2{e[r], e[r + 1]} - f32x2{1.f, 1.f};
+        e[r] = m[0]; e[r + 1] = m[1];
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) out[r] = __builtin_amdgcn_fmed3f(x[r], e[r], 0.f);
+    static_assert(N == 8 || N == 16, "");
+    asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]), "+v"(out[4]), "+v"(out[5]), "+v"(out[6]), "+v"(out[7]));
+    if constexpr (N == 16)
+        asm volatile("" : "+v"(out[8]), "+v"(out[9]), "+v"(out[10]), "+v"(out[11]), "+v"(out[12]), "+v"(out[13]), "+v"(out[14]), "+v"(out[15]));
+}
+
+template <int L>
+DEV const float* bias_ptr(const float* __restrict__ lds, int m, int half) { return lds + gpl::b_off(L) + m * 32 + half * 16; }
+
+DEV f32x16 zero_tile() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// 16 gathered channels per half (register c: channel c in half 0, 16 + c in half 1) -> k order: out[i] = channels (2i, 2i+1),
+// out[8 + i] = (16 + 2i, 17 + 2i).  v_permlane32_swap exchanges the upper half of its first operand with the lower half of its
+// second: ([a.lo, a.hi], [b.lo, b.hi]) -> ([a.lo, b.lo], [a.hi, b.hi]) (tools/micro/permlane32_swap.hip).
+// Written as inline assembly: with __builtin_amdgcn_permlane32_swap this compiler (ROCm 7.2 clang) emitted the instruction but
+// wired every user of the SECOND result to the first (the sigma layer then saw channels 0..15 twice; found with a register
+// dump against the oracle's stage vectors).  The s_nop covers the one hazard LLVM pads for this instruction (a VALU write of an
+// operand needs two wait states before the swap reads it; GCNHazardRecognizer::checkPermlaneHazards) -- inside an asm statement
+// nobody else would.
+DEV void interleave16(const float* __restrict__ in, float* __restrict__ out) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float a = in[2 * i], b = in[2 * i + 1];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        out[i] = a;
+        out[8 + i] = b;
+    }
+}
+
+// sigma feature layer, reference order.  fv[64]: k-step t of the layer = level t >> 4, channels 2 (t & 15) + half
+DEV void geo_eval_ref(const float* __restrict__ lds, int lane, const float (&fv)[64], float (&sf)[32]) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    f32x4 bq_g0[4], bq_g1[4];
+    f32x16 g0 = mfma_tile_bias<64>(wtile<gpl::GEO>(lds, 0), lane, fv, zero_tile(), bias_ptr<gpl::GEO>(lds, 0, half), bq_g0);
+    f32x16 g1 = mfma_tile_bias<64>(wtile<gpl::GEO>(lds, 1), lane, fv, zero_tile(), bias_ptr<gpl::GEO>(lds, 1, half), bq_g1);
+    elur_n<16>(g0, bq_g0, sf);
+    elur_n<16>(g1, bq_g1, sf + 16);
+}
+
+// The rest of NeRFHead.forward in the reference's order.  x[v][18]: slot t of half h = element gpr::ref35(t, h) of view v's
+// [r, g, b, f0..f31] (slot 1 of half 1 is the zero pad).
+DEV void mlp_eval_ref(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
+                      float nvalid, float& sigma, float (&rgb)[3], Stamps& st) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    float d1in[68];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) d1in[r] = sf[r];
+
+    // ---- fused_mean_variance (trainhead.py:20-24): x.mean(-2) = sum / 3, then mean((x - mean)^2) = sum / 3 ----
+    float mv[36];
+#pragma unroll
+    for (int t = 0; t < 18; t += 2) {
+        const f32x2 x0 = {x[0][t], x[0][t + 1]}, x1 = {x[1][t], x[1][t + 1]}, x2 = {x[2][t], x[2][t + 1]};
+        const f32x2 m = div3((x0 + x1) + x2);
+        const f32x2 a = x0 - m, b = x1 - m, c = x2 - m;
+        const f32x2 v = div3((a * a + b * b) + c * c);
+        mv[t] = m[0]; mv[t + 1] = m[1];
+        mv[18 + t] = v[0]; mv[18 + t + 1] = v[1];
+    }
+#pragma unroll
+    for (int t = 0; t < 36; ++t) d1in[32 + t] = mv[t];
+
+    // ---- density branch 134 -> 64 -> 32 -> 16 -> 1 (trainhead.py:102-110,133-137) ----
+    {
+        f32x4 bq_a0[4];
+        f32x16 a0 = mfma_tile_bias<68>(wtile<gpl::D1>(lds, 0), lane, d1in, zero_tile(), bias_ptr<gpl::D1>(lds, 0, half), bq_a0);
+        f32x4 bq_a1[4];
+        f32x16 a1 = mfma_tile_bias<68>(wtile<gpl::D1>(lds, 1), lane, d1in, zero_tile(), bias_ptr<gpl::D1>(lds, 1, half), bq_a1);
+        float h1[32];
+        elur_n<16>(a0, bq_a0, h1);
+        elur_n<16>(a1, bq_a1, h1 + 16);
+        f32x4 bq_a2[4];
+        f32x16 a2 = mfma_tile_bias<32>(wtile<gpl::D2>(lds, 0), lane, h1, zero_tile(), bias_ptr<gpl::D2>(lds, 0, half), bq_a2);
+        float h2[16];
+        elur_n<16>(a2, bq_a2, h2);
+        f32x4 bq_a3[4];
+        f32x16 a3 = mfma_tile_bias<16>(wtile<gpl::D3>(lds, 0), lane, h2, zero_tile(), bias_ptr<gpl::D3>(lds, 0, half), bq_a3);
+        float h3[8];
+        elur_n<8>(a3, bq_a3, h3);
+        // 16 -> 1 on the VALU: this half holds features 2r + half, r < 8; two half sums, then the bias
+        const float* w4 = lds + gpl::D4_W + half * 8;
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part = fmaf(w4[r], h3[r], part);
+        float s = part + __shfl_xor(part, 32) + lds[gpl::D4_B];
+        s = fmaxf(s, 0.f);                              // nn.ReLU
+        sigma = (nvalid < 1.f) ? 0.f : s;               // masked_fill(num_valid_obs < 1, 0)
+    }
+
+    STAMP(st, 3);
+    // ---- colour branch (trainhead.py:85-100,131,139-143) ----
+    // base_fc.0 on [mean, var, x_v]: k = 0..69 ([mean, var]) is the same for the three views, computed once; each view's chain
+    // goes on from there over its own 35 columns, then the bias
+    f32x16 s0 = mfma_tile_from<36>(wtile<gpl::BS>(lds, 0), lane, mv, zero_tile());
+    f32x16 s1 = mfma_tile_from<36>(wtile<gpl::BS>(lds, 1), lane, mv, zero_tile());
+    float y[48];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        asm volatile("" : "+v"(lane));
+        f32x4 bq_a0[4];
+        f32x16 a0 = mfma_tile_bias<18>(wtile<gpl::BV>(lds, 0), lane, x[v], s0, bias_ptr<gpl::BS>(lds, 0, half), bq_a0);
+        f32x4 bq_a1[4];
+        f32x16 a1 = mfma_tile_bias<18>(wtile<gpl::BV>(lds, 1), lane, x[v], s1, bias_ptr<gpl::BS>(lds, 1, half), bq_a1);
+        float h1[32];
+        elur_n<16>(a0, bq_a0, h1);
+        elur_n<16>(a1, bq_a1, h1 + 16);
+        f32x4 bq_a2[4];
+        f32x16 a2 = mfma_tile_bias<32>(wtile<gpl::B2>(lds, 0), lane, h1, zero_tile(), bias_ptr<gpl::B2>(lds, 0, half), bq_a2);
+        float xb[16], xs[16];
+        elur_n<16>(a2, bq_a2, xb);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {                                                   // x * 1.0 / num_views (:140)
+            const f32x2 q = div3(f32x2{xb[r], xb[r + 1]});
+            xs[r] = q[0]; xs[r + 1] = q[1];
+        }
+        f32x4 bq_t1[4];
+        f32x16 t1 = mfma_tile_bias<16>(wtile<gpl::V1>(lds, 0), lane, xs, zero_tile(), bias_ptr<gpl::V1>(lds, 0, half), bq_t1);
+        float u1[16];
+        elur_n<16>(t1, bq_t1, u1);
+        f32x4 bq_t2[4];
+        f32x16 t2 = mfma_tile_bias<16>(wtile<gpl::V2>(lds, 0), lane, u1, zero_tile(), bias_ptr<gpl::V2>(lds, 0, half), bq_t2);
+        elur_n<16>(t2, bq_t2, y + 16 * v);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[16 * v + r] = xb[r] + y[16 * v + r];                 // x = x + x_vis
+    }
+    STAMP(st, 4);
+    {
+        f32x4 bq_c1[4];
+        f32x16 c1 = mfma_tile_bias<48>(wtile<gpl::R1>(lds, 0), lane, y, zero_tile(), bias_ptr<gpl::R1>(lds, 0, half), bq_c1);
+        float h1[16];
+        elur_n<16>(c1, bq_c1, h1);
+        f32x4 bq_c2[4];
+        f32x16 c2 = mfma_tile_bias<16>(wtile<gpl::R2>(lds, 0), lane, h1, zero_tile(), bias_ptr<gpl::R2>(lds, 0, half), bq_c2);
+        float e[8];
+        elur_n<8>(c2, bq_c2, e);
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const float* w3 = lds + gpl::R3_W + o * 16 + half * 8;
@@ -637,8 +885,24 @@ DEV void fma16(const float* __restrict__ p, float w, float* f) {
     }
 }
 
+// the same, multiply THEN add (two roundings): ATen's scalar 3-D grid_sample kernel accumulates `out += val * weight` without
+// contraction, and the reference-order form follows it -- one ulp of a volume feature is 3 x the oracle's distance on the
+// trained-like fixtures once the head has amplified it (oracle/kernel_order.inc TRIFMA)
+DEV void muladd16(const float* __restrict__ p, float w, float* f) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(p);
+    const f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    const f32x2 w2 = {w, w};
+    const f32x2 src[8] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}, {c[0], c[1]}, {c[2], c[3]}, {d[0], d[1]}, {d[2], d[3]}};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x2 r = f32x2{f[2 * i], f[2 * i + 1]} + src[i] * w2;
+        f[2 * i] = r[0]; f[2 * i + 1] = r[1];
+    }
+}
+
 // trilinear sample of one level [D][H][W][32] at normalised (gx,gy,gz) -> this half's 16 channels
-// (libs/nerfheads/networks/SparseConvNet.py:113-116)
+// (libs/nerfheads/networks/SparseConvNet.py:113-116).  UNFUSED: the reference-order form's multiply-then-add taps.
+template <bool UNFUSED = false>
 DEV void gather_volume(const float* __restrict__ vol, int D, int H, int W, float gx, float gy, float gz, int half,
                        float* f) {
     const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
@@ -654,7 +918,10 @@ DEV void gather_volume(const float* __restrict__ vol, int D, int H, int W, float
         for (int b = 0; b < 2; ++b) {
             const unsigned rowb = __umul24(mad24(zi[a], (unsigned)H, yi[b]), row_bytes);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) fma16(at_byte(vol, rowb + xb[e]), (xw[e] * yw[b]) * zw[a], f);
+            for (int e = 0; e < 2; ++e) {
+                if constexpr (UNFUSED) muladd16(at_byte(vol, rowb + xb[e]), (xw[e] * yw[b]) * zw[a], f);
+                else fma16(at_byte(vol, rowb + xb[e]), (xw[e] * yw[b]) * zw[a], f);
+            }
         }
 }
 
@@ -867,6 +1134,7 @@ struct FrameK {           // GpnerfFrame by value (kernel argument; lands in SGP
     float out_sh[3];      // as float
     const float* head_blob;
     const float* head_blob_split;   // f16 hi/lo image (GPNERF_FLAG_SPLIT_F16) or nullptr
+    const float* head_blob_ref;     // reference-order image (FORM_F32) or nullptr
     const float* occ;     // level-1-sized occupancy volume or nullptr
     const float* vol_fold[GPNERF_LEVELS];    // folded volumes (gpnerf_fold_volumes) or nullptr: FORM_F32_FOLD
 };
@@ -1213,6 +1481,9 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         if constexpr (P == 1) n_done += dead ? 0 : 1;
         float sf[32];
         Frag sff[4];
+#ifdef GPNERF_X_DUMP
+        float dbg[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
         if constexpr (FORM == FORM_F32_FOLD) {
             // the sigma feature layer's pre-activation: levels FOLD_FROM.. interpolated from the folded volumes (see gather_folded),
             // the finer levels' features through the layer's first 16 FOLD_FROM k-steps as before
@@ -1243,13 +1514,22 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 #pragma unroll
             for (int l = 0; l < GPNERF_LEVELS; ++l)
             {
-                gather_volume(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
+                gather_volume<!SPLIT>(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
                 if (l & 1) __builtin_amdgcn_sched_barrier(0);    // at most two levels' 64 loads in flight (register pressure)
 
             }
             STAMP(st, (k == k_begin ? 10 : (k == k_begin + P ? 11 : 0)));
             if constexpr (SPLIT) geo_eval_s(gmax, lw, lane, fv, sff);
-            else geo_eval(lds, lane, fv, sf);
+            else {
+                // reference order: k-step t of the layer = channels (2i, 2i + 1) of level t >> 4
+                float fk[64];
+#pragma unroll
+                for (int l = 0; l < GPNERF_LEVELS; ++l) interleave16(fv + 16 * l, fk + 16 * l);
+#ifdef GPNERF_X_DUMP
+                dbg[0] = fk[0]; dbg[1] = fk[1]; dbg[2] = fk[8]; dbg[3] = fk[16];
+#endif
+                geo_eval_ref(lds, lane, fk, sf);
+            }
         }
         STAMP(st, 1);
 
@@ -1266,8 +1546,18 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                                              , fr.vol_fold[0] ? fr.vol_fold[0] + (size_t)v * fr.feat_h * fr.feat_w * 64 : nullptr
 #endif
                                              );
-            x[v][16] = half ? s.rgb[1] : s.rgb[0];
-            x[v][17] = half ? 0.f : s.rgb[2];
+            if constexpr (FORM == FORM_F32) {
+                // reference order (gpr::ref35): (r, g) (b, 0) (f0, f1) ... (f30, f31)
+                float fk[16];
+                interleave16(x[v], fk);
+                x[v][0] = half ? s.rgb[1] : s.rgb[0];
+                x[v][1] = half ? 0.f : s.rgb[2];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[v][2 + c] = fk[c];
+            } else {
+                x[v][16] = half ? s.rgb[1] : s.rgb[0];
+                x[v][17] = half ? 0.f : s.rgb[2];
+            }
             vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
             nvalid += s.valid;
         }
@@ -1277,6 +1567,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         STAMP(st, 2);
         float sigma, rgb[3];
         if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
+        else if constexpr (FORM == FORM_F32) mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st);
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
         if (CULL || cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
@@ -1285,6 +1576,9 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 
         if (out.raw && active && half == 0 && in_seg) {
             f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
+#ifdef GPNERF_X_DUMP          // diagnostic build only: intermediate registers of half 0 instead of (rgb, sigma)
+            if constexpr (FORM == FORM_F32) { rw[0] = dbg[0]; rw[1] = dbg[1]; rw[2] = dbg[2]; rw[3] = dbg[3]; }
+#endif
             *reinterpret_cast<f32x4*>(out.raw + ((size_t)ray * S + ks) * 4) = rw;
         }
 
@@ -1458,7 +1752,8 @@ render_fused_kernel(const KArgs ka) {
         if (ka.list_in && *ka.count_in == 0u) return;               // no ray is left for this segment
     }
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : ka.fr.head_blob);
+        constexpr bool REF = FORM == FORM_F32 || FORM == FORM_F32_FIXUP;
+        const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : (REF ? ka.fr.head_blob_ref : ka.fr.head_blob));
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         for (int i = threadIdx.x; i < (SPLIT ? gph::BLOB_WORDS : gpl::BLOB_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
         if constexpr (FORM == FORM_SPLIT_GUARD) {
@@ -1722,58 +2017,61 @@ head_forward_kernel(const float* __restrict__ blob, const float* __restrict__ vo
     for (long tile = (long)blockIdx.x * NWAVES + wave; tile < ntile; tile += (long)gridDim.x * NWAVES) {
         const bool active = tile * 32 + n < P;
         const long p = active ? tile * 32 + n : P - 1;
+        // reference order (head_layout.h gpr): slot t of half h = element ref35(t, h) of [r, g, b, f0 .. f31]; read straight in k order
         float x[NV][18];
         float nvalid = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float* xv = rgb_feat + (p * NV + v) * 35;
+            x[v][0] = half ? xv[1] : xv[0];
+            x[v][1] = half ? 0.f : xv[2];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) x[v][c] = xv[3 + 16 * half + c];
-            x[v][16] = half ? xv[1] : xv[0];
-            x[v][17] = half ? 0.f : xv[2];
+            for (int i = 0; i < 16; ++i) x[v][2 + i] = xv[3 + 2 * i + half];
             if (MODE != 1) nvalid += mask[p * NV + v];
         }
         float sf[32];
         if constexpr (MODE == 2) {
-            // the accumulator layout of geo_eval's output, in the scaled domain: feature 32 m + ft(r, half) in sf[16 m + r]
+            // the accumulator layout of geo_eval_ref's output: feature 32 m + 2 r + half in sf[16 m + r]
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sf[16 * m + r] = vol_feat[p * 64 + 32 * m + gpl::ft(r, half)] * LOG2E;
+                for (int r = 0; r < 16; ++r) sf[16 * m + r] = vol_feat[p * 64 + 32 * m + 2 * r + half];
         } else {
             float fv[64];
 #pragma unroll
-            for (int l = 0; l < 4; ++l)
-#pragma unroll
-                for (int c = 0; c < 16; ++c) fv[16 * l + c] = vol_feat[p * 128 + 32 * l + 16 * half + c];
-            geo_eval(lds, lane, fv, sf);
+            for (int t = 0; t < 64; ++t) fv[t] = vol_feat[p * 128 + 2 * t + half];
+            geo_eval_ref(lds, lane, fv, sf);
         }
         if constexpr (MODE == 1) {
             if (active) {
-                constexpr float LN2 = 0.69314718055994530942f;
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = sf[16 * m + r] * LN2;
-                        raw[p * 64 + 32 * m + gpl::ft(r, half)] = v;
-                        globalfeat[p * 134 + 32 * m + gpl::ft(r, half)] = v;
+                        const float v = sf[16 * m + r];
+                        raw[p * 64 + 32 * m + 2 * r + half] = v;
+                        globalfeat[p * 134 + 32 * m + 2 * r + half] = v;
                     }
 #pragma unroll
-                for (int t = 0; t < 18; ++t) {       // fused_mean_variance (trainhead.py:20-24), as mlp_eval computes it
-                    const int c = half ? gpl::idx35(t, 1) : gpl::idx35(t, 0);      // this lane's slot of the 35-vector, -1 = pad
-                    const float m_ = ((x[0][t] + x[1][t]) + x[2][t]) * (1.f / 3.f);
-                    const float a = x[0][t] - m_, b = x[1][t] - m_, cc = x[2][t] - m_;
-                    if (c >= 0) {
-                        globalfeat[p * 134 + 64 + c] = m_;
-                        globalfeat[p * 134 + 99 + c] = ((a * a + b * b) + cc * cc) * (1.f / 3.f);
+                for (int t = 0; t < 18; t += 2) {       // fused_mean_variance (trainhead.py:20-24), as mlp_eval_ref computes it
+                    const f32x2 x0 = {x[0][t], x[0][t + 1]}, x1 = {x[1][t], x[1][t + 1]}, x2 = {x[2][t], x[2][t + 1]};
+                    const f32x2 m_ = div3((x0 + x1) + x2);
+                    const f32x2 a = x0 - m_, b = x1 - m_, cc = x2 - m_;
+                    const f32x2 vr = div3((a * a + b * b) + cc * cc);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int c = half ? gpr::ref35(t + j, 1) : gpr::ref35(t + j, 0);      // this lane's slot of the 35-vector, -1 = pad
+                        if (c >= 0) {
+                            globalfeat[p * 134 + 64 + c] = m_[j];
+                            globalfeat[p * 134 + 99 + c] = vr[j];
+                        }
                     }
                 }
             }
         } else {
             float sigma, rgb[3];
             Stamps st;
-            mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
+            mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st);
             if (active && half == 0) {
                 f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
                 *reinterpret_cast<f32x4*>(raw + p * 4) = rw;
@@ -2169,6 +2467,30 @@ void pack_layer(int L, const float* W, const float* b, int n_out, int n_in, floa
     }
 }
 
+// reference-order image (head_layout.h gpr): tile row i carries output feature gpr::feat_of_row(i), k-step t the columns
+// (2t, 2t+1) (gpr::col_of), nothing is scaled, the bias tile holds feature 2r + h at [h][r]
+void pack_layer_ref(int L, const float* W, const float* b, int n_out, int n_in, float* blob) {
+    for (int m = 0; m < gpl::MT[L]; ++m) {
+        float* wt = blob + gpl::w_off(L) + m * gpl::NT[L] * 64;
+        const int NT = gpl::NT[L], NG = NT / 4;
+        for (int t = 0; t < NT; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = 32 * m + gpr::feat_of_row(lane & 31), h = lane >> 5;
+                const int c = gpr::col_of(L, t, h);
+                const float v = (row < n_out && col_ok(c, n_in)) ? W[(size_t)row * n_in + c] : 0.f;
+                const int g = t / 4;
+                if (g < NG) wt[(g * 64 + lane) * 4 + (t & 3)] = v;
+                else wt[NG * 256 + lane * 2 + (t - 4 * NG)] = v;
+            }
+        float* bt = blob + gpl::b_off(L) + m * 32;
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + 2 * r + h;
+                bt[h * 16 + r] = (b && row < n_out) ? b[row] : 0.f;
+            }
+    }
+}
+
 // Launch geometry of the fused kernel.  One workgroup is resident per CU (LDS), a wave's step time depends on how many
 // waves share its SIMD (measured: ~86k cycles per 32-sample step with one wave per SIMD, ~134k with two), and a work unit
 // (32 rays x S samples) is long, so a grid that is not many times 256 workgroups quantises badly.  Choose the waves per
@@ -2396,6 +2718,7 @@ bool to_framek(const GpnerfFrame* f, FrameK& k, bool need_vol, bool need_img) {
     for (int a = 0; a < 3; ++a) k.out_sh[a] = (float)f->out_sh[a];
     k.head_blob = f->head_blob;
     k.head_blob_split = f->head_blob_split;
+    k.head_blob_ref = f->head_blob_ref;
     k.occ = f->occ;
     // folded volumes: all four levels or none; 64 values per voxel must still be addressable with 32-bit byte offsets
     bool fold = true;
@@ -2634,6 +2957,33 @@ int gpnerf_pack_head(const GpnerfHeadParams* p, float* blob) {
     return GPNERF_OK;
 }
 
+int gpnerf_pack_head_ref(const GpnerfHeadParams* p, float* blob) {
+    if (!p || !blob) return GPNERF_E_ARG;
+    const float* const* all = reinterpret_cast<const float* const*>(p);
+    for (size_t i = 0; i < sizeof(GpnerfHeadParams) / sizeof(float*); ++i)
+        if (!all[i]) return GPNERF_E_ARG;
+    memset(blob, 0, sizeof(float) * gpl::BLOB_FLOATS);
+    pack_layer_ref(gpl::GEO, p->geo_w, p->geo_b, 64, 128, blob);
+    pack_layer_ref(gpl::D1, p->d1_w, p->d1_b, 64, 134, blob);
+    pack_layer_ref(gpl::D2, p->d2_w, p->d2_b, 32, 64, blob);
+    pack_layer_ref(gpl::D3, p->d3_w, p->d3_b, 16, 32, blob);
+    pack_layer_ref(gpl::BS, p->b1_w, p->b1_b, 64, 105, blob);     // [mean, var] columns; the bias tile is added after BV's chain
+    pack_layer_ref(gpl::BV, p->b1_w, nullptr, 64, 105, blob);
+    pack_layer_ref(gpl::B2, p->b2_w, p->b2_b, 32, 64, blob);
+    pack_layer_ref(gpl::V1, p->v1_w, p->v1_b, 32, 32, blob);
+    pack_layer_ref(gpl::V2, p->v2_w, p->v2_b, 32, 32, blob);
+    pack_layer_ref(gpl::R1, p->r1_w, p->r1_b, 32, 96, blob);
+    pack_layer_ref(gpl::R2, p->r2_w, p->r2_b, 16, 32, blob);
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 8; ++r) {
+            blob[gpl::D4_W + h * 8 + r] = p->d4_w[2 * r + h];
+            for (int o = 0; o < 3; ++o) blob[gpl::R3_W + o * 16 + h * 8 + r] = p->r3_w[o * 16 + 2 * r + h];
+        }
+    blob[gpl::D4_B] = p->d4_b[0];
+    for (int o = 0; o < 3; ++o) blob[gpl::R3_B + o] = p->r3_b[o];
+    return GPNERF_OK;
+}
+
 int64_t gpnerf_head_blob_split_floats(void) { return gph::BLOB_WORDS; }
 
 int gpnerf_pack_head_split(const GpnerfHeadParams* p, float* blob) {
@@ -2705,15 +3055,20 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
                         size_t workspace_bytes, void* stream) {
     if (n_rays == 0) return GPNERF_OK;          // empty ray list: nothing to do (pointers may be null)
     if (!f || !rays || !out || n_rays < 0 || n_samples < 1) return GPNERF_E_ARG;
-    if (!out->rgb || !out->depth || !out->acc || !out->disp || !f->head_blob) return GPNERF_E_ARG;
+    if (!out->rgb || !out->depth || !out->acc || !out->disp) return GPNERF_E_ARG;
     FrameK k;
     if (!to_framek(f, k, true, true)) return GPNERF_E_ARG;
     if (n_rays >= ((int64_t)1 << 31)) return GPNERF_E_ARG;      // output rows are 32-bit values inside the kernel
     const int64_t tiles = (n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
     const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
     const bool split16 = (flags & GPNERF_FLAG_SPLIT_F16) != 0;
-    const bool folded = !split16 && k.vol_fold[GPNERF_LEVELS - 1] != nullptr;       // the fp32 form interpolates the folded volumes when the frame has them
+    // the fp32 form: reference order (FORM_F32, head_blob_ref) unless the frame carries folded volumes and the caller did not ask
+    // for the reference's order; the guarded split form's fix-up launch is the reference-order form too
+    const bool folded = !split16 && k.vol_fold[GPNERF_LEVELS - 1] != nullptr && !(flags & GPNERF_FLAG_REF_ORDER);
     if (split16 && !f->head_blob_split) return GPNERF_E_ARG;
+    if (!split16 && !folded && !f->head_blob_ref) return GPNERF_E_ARG;
+    if (folded && !f->head_blob) return GPNERF_E_ARG;
+    if (split16 && (flags & GPNERF_FLAG_SPLIT_GUARD) && !f->head_blob_ref) return GPNERF_E_ARG;
     // GPNERF_FLAG_SPLIT_GUARD: the split form records the tiles in which an MFMA operand reached the f16 range, and a second
     // launch renders exactly those again in the fp32 form (it returns at once when there are none).  The flags live in the
     // last guard_bytes() of the workspace.

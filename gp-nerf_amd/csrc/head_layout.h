@@ -66,6 +66,40 @@ constexpr int col_of(int l, int t, int h) {
 }  // namespace gpl
 
 // ------------------------------------------------------------------------------------------------------------------
+// Reference-order image (gpnerf_pack_head_ref; the fp32 form without folded volumes, GPNERF_FLAG_REF_ORDER): the same tiles,
+// offsets and sizes as above, but every layer accumulates in the order the reference's sgemm does -- k ASCENDING from zero,
+// bias added last -- in the unscaled domain, so that on trained parameters the kernel's rounding stays correlated with the
+// reference's through the whole chain (oracle/kernel_order.inc measures what each deviation costs).
+//   k-step t of a layer consumes k = 2t (lane half 0) and k = 2t + 1 (half 1): v_mfma_f32_32x32x2_f32 is fma(a1, b1, fma(a0, b0, c));
+//   accumulator register r of half h therefore has to hold OUTPUT feature 2r + h of its tile (tile row ft(r, h) carries the
+//   weights of feature 32 m + 2 r + h), and the output tile of one layer is again the B operand of the next, in order;
+//   raw inputs are re-interleaved in registers (v_permlane32_swap: channels c, 16 + c of the two halves -> 2i, 2i + 1);
+//   the 35-vectors [r, g, b, f0 .. f31] take 18 k-steps as (r, g) (b, 0) (f0, f1) ... (f30, f31): the zero of step 1 adds
+//   fma(0, 0, s) = s, which keeps the chain's bits and re-aligns the parity of everything behind it.
+// ------------------------------------------------------------------------------------------------------------------
+namespace gpr {
+
+using gpl::GEO; using gpl::D1; using gpl::D2; using gpl::D3; using gpl::BS; using gpl::BV; using gpl::B2;
+using gpl::V1; using gpl::V2; using gpl::R1; using gpl::R2;
+
+// output feature (within its 32-row tile) carried by tile row i: i = ft(r, h)  ->  2 r + h
+constexpr int feat_of_row(int i) { return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
+// index into the reference's 35-vector of slot t (0..17) of half h; -1 = the zero pad of step 1
+constexpr int ref35(int t, int h) { return t == 0 ? h : (t == 1 ? (h == 0 ? 2 : -1) : 3 + 2 * (t - 2) + h); }
+// PyTorch weight column consumed by k-step t, lane-half h of layer l (-1: zero)
+constexpr int col_of(int l, int t, int h) {
+    switch (l) {
+        case D1: return t < 32 ? 2 * t + h : (t < 50 ? (ref35(t - 32, h) < 0 ? -1 : 64 + ref35(t - 32, h))
+                                                     : (ref35(t - 50, h) < 0 ? -1 : 99 + ref35(t - 50, h)));
+        case BS: return t < 18 ? ref35(t, h) : (ref35(t - 18, h) < 0 ? -1 : 35 + ref35(t - 18, h));
+        case BV: return ref35(t, h) < 0 ? -1 : 70 + ref35(t, h);
+        default: return 2 * t + h;                  // GEO (raw, re-interleaved) and every tile-sourced layer
+    }
+}
+
+}  // namespace gpr
+
+// ------------------------------------------------------------------------------------------------------------------
 // Split-precision image (GPNERF_FLAG_SPLIT_F16): the same layers on v_mfma_f32_32x32x16_f16 with every fp32 operand
 // written as hi + lo in f16 (hi = f16(x) toward zero, lo = f16(x - hi)) and three MFMAs per k-step:
 //   W.h ~= Whi.hhi + Whi.hlo + Wlo.hhi        (the dropped lo.lo term is ~2^-22 relative; f32 accumulation)

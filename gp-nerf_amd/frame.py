@@ -67,6 +67,10 @@ def pack_head(state, device):
     sblob = np.zeros(ns, np.float32)
     L.check(lib.gpnerf_pack_head_split(C.byref(params), sblob.ctypes.data_as(L.FP)), "gpnerf_pack_head_split")
     out._gpnerf_split = torch.from_numpy(sblob).to(device)
+    # ... and the reference-order image (GPNERF_FLAG_REF_ORDER; the form every render uses unless it asks for folded levels)
+    rblob = np.zeros(n, np.float32)
+    L.check(lib.gpnerf_pack_head_ref(C.byref(params), rblob.ctypes.data_as(L.FP)), "gpnerf_pack_head_ref")
+    out._gpnerf_ref = torch.from_numpy(rblob).to(device)
     return out
 
 
@@ -149,6 +153,8 @@ class Frame:
         f.head_blob = head_blob.data_ptr()
         self.head_blob_split = getattr(head_blob, "_gpnerf_split", None)
         f.head_blob_split = self.head_blob_split.data_ptr() if self.head_blob_split is not None else None
+        self.head_blob_ref = getattr(head_blob, "_gpnerf_ref", None)
+        f.head_blob_ref = self.head_blob_ref.data_ptr() if self.head_blob_ref is not None else None
         self.c = f
 
     def _set_volumes(self, f, volumes, keep):
@@ -306,10 +312,12 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     32-ray tiles that were (int32 tensor [1]).
     subset: ray_order lists the rows of `rays` to render (any number of distinct rows); outputs keep rays' row count, rows
     that are not listed come back zero.
-    fold: the fp32 form with the coarse levels folded (Frame.fold_volumes).  None: yes for dense launches of whatever size -- a
-    shard of a frame's rays must give the bits the whole frame gives -- folding once per Frame (culled frames evaluate too few
-    samples to gain); True: fold now (a caller that re-uses one Frame for many frames' worth of calls, like the bench, pays the per-frame
-    fold every time); False: the sigma feature layer entirely per sample (what the split form's fix-up launch does)."""
+    fold: which fp32 form.  False / None (default): the REFERENCE-ORDER form -- every dense layer accumulates as the reference's
+    sgemm does (k ascending from zero, bias last, unscaled), x / 3 and the trilinear taps round as the reference's do: on trained
+    parameters it sits at the op-for-op CPU oracle's distance from the reference.  True: the round-4 fast
+    form -- coarse levels folded into the sigma feature layer per frame (Frame.fold_volumes), log2(e)-scaled layers: ~8 % faster,
+    the same 1e-5 at initialisation scale, 5-10 x further from the reference on trained-like parameters.  "keep": True without
+    re-folding a Frame that is already folded."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()
@@ -368,8 +376,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
             raise L.GpnerfError("ray_order must be a contiguous int32 tensor with one entry per ray")
     n_launch = int(ray_order.numel()) if subset else N
     refold = fold is True
-    if fold is None:
-        fold = not split_f16 and not occ_cull
+    fold = bool(fold)
     if fold and not split_f16:
         if refold or not getattr(frame, "_folded_valid", False):
             frame.fold_volumes()
@@ -399,6 +406,14 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     return res
 
 
+def _ref_image(head_blob):
+    """the reference-order image riding on pack_head()'s tensor (what the stage entry points stage into LDS)"""
+    ref = getattr(head_blob, "_gpnerf_ref", None)
+    if ref is None:
+        raise L.GpnerfError("head_blob must be pack_head()'s tensor (it carries the reference-order image)")
+    return ref
+
+
 def head_forward(head_blob, vol_feat, rgb_feat, mask):
     """gpnerf_head_forward: vol_feat [P,128], rgb_feat [P,V,35], mask [P,V] -> raw [P,4]."""
     lib = L.lib()
@@ -407,7 +422,7 @@ def head_forward(head_blob, vol_feat, rgb_feat, mask):
     vol_feat, rgb_feat, mask = vol_feat.contiguous().float(), rgb_feat.contiguous().float(), mask.contiguous().float()
     P = vol_feat.shape[0]
     raw = torch.empty((P, 4), device=vol_feat.device)
-    L.check(lib.gpnerf_head_forward(head_blob.data_ptr(), vol_feat.data_ptr(), rgb_feat.data_ptr(), mask.data_ptr(), P,
+    L.check(lib.gpnerf_head_forward(_ref_image(head_blob).data_ptr(), vol_feat.data_ptr(), rgb_feat.data_ptr(), mask.data_ptr(), P,
                                     raw.data_ptr(), _stream_ptr(vol_feat.device)), "gpnerf_head_forward")
     return raw
 
@@ -422,7 +437,7 @@ def sigma_features(head_blob, vol_feat, rgb_feat):
     P = vol_feat.shape[0]
     sf = torch.empty((P, 64), device=vol_feat.device)
     gf = torch.empty((P, 134), device=vol_feat.device)
-    L.check(lib.gpnerf_sigma_features(head_blob.data_ptr(), vol_feat.data_ptr(), rgb_feat.data_ptr(), P, sf.data_ptr(), gf.data_ptr(),
+    L.check(lib.gpnerf_sigma_features(_ref_image(head_blob).data_ptr(), vol_feat.data_ptr(), rgb_feat.data_ptr(), P, sf.data_ptr(), gf.data_ptr(),
                                       _stream_ptr(vol_feat.device)), "gpnerf_sigma_features")
     return sf, gf
 
@@ -435,7 +450,7 @@ def rgb_head_forward(head_blob, sigma_feat, rgb_feat, mask):
     sigma_feat, rgb_feat, mask = sigma_feat.contiguous().float(), rgb_feat.contiguous().float(), mask.contiguous().float()
     P = sigma_feat.shape[0]
     raw = torch.empty((P, 4), device=sigma_feat.device)
-    L.check(lib.gpnerf_rgb_head_forward(head_blob.data_ptr(), sigma_feat.data_ptr(), rgb_feat.data_ptr(), mask.data_ptr(), P,
+    L.check(lib.gpnerf_rgb_head_forward(_ref_image(head_blob).data_ptr(), sigma_feat.data_ptr(), rgb_feat.data_ptr(), mask.data_ptr(), P,
                                         raw.data_ptr(), _stream_ptr(sigma_feat.device)), "gpnerf_rgb_head_forward")
     return raw
 

@@ -33,7 +33,7 @@ from . import parallel as P_
 class Renderer(nn.Module):
     def __init__(self, encoder, nerfhead, is_train=False, neg_ray_train=False, neg_ray_val=False, n_rays=1024,
                  n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=None, term_eps=1e-5,
-                 progressive=False, split_f16=None, sharded_outputs="all", shard_group=None, encoder_graph=None):
+                 progressive=False, split_f16=None, sharded_outputs="all", shard_group=None, encoder_graph=None, fold_levels=None):
         super().__init__()
         self.encoder = encoder
         self.nerfhead = nerfhead
@@ -75,6 +75,11 @@ class Renderer(nn.Module):
         # split_f16: dense layers on f16 MFMA with hi/lo operand pairs (GPNERF_FLAG_SPLIT_F16); same 1e-4 parity bound,
         # ~1.8x faster.  Default: exact fp32 MFMA, unless GPNERF_SPLIT_F16=1 is set in the environment.
         self.split_f16 = (os.environ.get("GPNERF_SPLIT_F16", "0") == "1") if split_f16 is None else bool(split_f16)
+        # fold_levels: the fp32 form with the two coarse volume levels folded into the sigma feature layer once per frame and
+        # log2(e)-scaled layers (round 4's default; `render.file hip_render_fold`): ~8 % faster, 1e-5 from the reference at
+        # initialisation scale like the default, but 5-10 x further on trained-like parameters.  Default: the reference-order
+        # form (frame.render_fused).  GPNERF_FOLD=1 switches it on from outside.
+        self.fold_levels = (os.environ.get("GPNERF_FOLD", "0") == "1") if fold_levels is None else bool(fold_levels)
 
     # ---- helpers the reference exposes as methods (stage entry points) ----------------------------
     def _neg_ray(self, batch):
@@ -324,7 +329,8 @@ class Renderer(nn.Module):
         def fn(r):
             # sharded: `r` is this rank's share, already in patch-major order
             return F_.render_fused(frame, r, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
-                                   split_f16=self.split_f16, ray_order=None if sharded else order, want=("weights", "z_vals", "rgb_in"))
+                                   split_f16=self.split_f16, ray_order=None if sharded else order, want=("weights", "z_vals", "rgb_in"),
+                                   fold="keep" if self.fold_levels else False)
 
         # every map of the reference's dict travels in ONE packed all-gather; sharded_outputs = "pixels" keeps the exchange at
         # the 16 B/ray of rgb + depth (what an evaluation loop reads, libs/evaluators/if_nerf.py:50-56) and returns only those

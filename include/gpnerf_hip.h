@@ -58,7 +58,7 @@ extern "C" {
                                       32-ray tile (raw features, cross-view mean / variance, every activation); tiles in which it
                                       reaches the f16 range are rendered again by the fp32 form in a second launch of the same
                                       call, so the result never depends on the range of the data.  Needs the workspace
-                                      (gpnerf_render_workspace_bytes) and frame->head_blob */
+                                      (gpnerf_render_workspace_bytes) and frame->head_blob_ref */
 #define GPNERF_FLAG_OCC_CULL 4u    /* the progressive renderer's per-sample rules (libs/renders/demo_render.py): grid coordinates
                                       with its literal voxel size 0.005 instead of frame->voxel (:87-95), a sample is evaluated
                                       only where the occupancy volume (frame->occ) interpolates to > 0 (:270-283), culled
@@ -66,6 +66,12 @@ extern "C" {
                                       ray_mask counts kept samples only.  With the workspace and no per-sample output (weights,
                                       raw) the keep decisions are made in a pass before the launch and the tiles are handed out
                                       longest first; same bits either way */
+
+#define GPNERF_FLAG_REF_ORDER 64u   /* the fp32 form in the REFERENCE's arithmetic order even when the frame carries folded volumes:
+                                      every dense layer as sgemm's chain (k ascending from zero, bias last) in the unscaled
+                                      domain, x / 3 with IEEE rounding, multiply-then-add trilinear taps, no folded levels.
+                                      On trained parameters it sits at the op-for-op CPU oracle's distance from the reference
+                                      where the folded form is 5-10 x further.  Needs frame->head_blob_ref */
 
 /* Per-frame constants (everything render_rays reads that does not depend on the ray).
  * Layouts are channels-last so that one bilinear / trilinear tap is one contiguous
@@ -83,7 +89,8 @@ typedef struct GpnerfFrame {
     float bounds_min[3];                    /* batch['bounds'][0,0], SMPL-frame xyz; BaseRender.py:65 */
     float voxel[3];                         /* cfg.dataset.voxel_size (applied in d,h,w order); BaseRender.py:67 */
     int32_t out_sh[3];                      /* batch['out_sh'] d,h,w; BaseRender.py:69-70 */
-    const float* head_blob;                 /* device; gpnerf_pack_head() image, gpnerf_head_blob_floats() floats */
+    const float* head_blob;                 /* device or NULL (needed only by the folded form and gpnerf_fold_volumes);
+                                               gpnerf_pack_head() image, gpnerf_head_blob_floats() floats */
     const float* head_blob_split;           /* device or NULL; gpnerf_pack_head_split() image (GPNERF_FLAG_SPLIT_F16) */
     const float* occ;                       /* device or NULL; [D_1][H_1][W_1] occupancy `masks3d` at level-1 size
                                                (SparseConvNet.py:135-139), read only with GPNERF_FLAG_OCC_CULL */
@@ -92,6 +99,9 @@ typedef struct GpnerfFrame {
                                                from vol[] and head_blob.  With them the fp32 form of gpnerf_render_fused
                                                interpolates these levels' share of the sigma feature layer's pre-activation
                                                instead of running it per sample (same result up to fp32 rounding) */
+    const float* head_blob_ref;             /* device or NULL; gpnerf_pack_head_ref() image: the fp32 form in the reference's
+                                               summation order (GPNERF_FLAG_REF_ORDER, frames without vol_folded, and the
+                                               fix-up launch of GPNERF_FLAG_SPLIT_GUARD) */
 } GpnerfFrame;
 
 /* The per-ray MLP parameters in PyTorch layout (weight [out][in] row-major, bias [out]),
@@ -134,6 +144,10 @@ int64_t gpnerf_head_blob_floats(void);
  * (MFMA A-operand order).  Host-side, model-load time.
  * Replaces nothing in the reference; it is what load_state_dict is to nn.Linear. */
 int gpnerf_pack_head(const GpnerfHeadParams* params_host, float* blob_host);
+
+/* The same parameters for the reference-order fp32 form (GPNERF_FLAG_REF_ORDER): gpnerf_head_blob_floats() floats, rows and
+ * columns in the order libs/nerfheads/trainhead.py's nn.Linear layers accumulate them on the CPU (sgemm), nothing pre-scaled. */
+int gpnerf_pack_head_ref(const GpnerfHeadParams* params_host, float* blob_host);
 
 /* The same parameters as f16 hi/lo pairs in v_mfma_f32_32x32x16_f16 A-operand order (GPNERF_FLAG_SPLIT_F16). */
 int64_t gpnerf_head_blob_split_floats(void);
@@ -193,8 +207,8 @@ int gpnerf_project_gather(const GpnerfFrame* frame, const float* pts, int64_t n_
 /* NeRFHead.forward on already-gathered features (libs/nerfheads/trainhead.py:159-163, with the
  * sparse volume replaced by its sampled features): P points.
  *   vol_feat [P][128] (level-major), rgb_feat [P][V][35], mask [P][V] (0/1 floats), all device
- *   raw [P][4] = rgb, sigma.   head_blob as in GpnerfFrame. */
-int gpnerf_head_forward(const float* head_blob, const float* vol_feat, const float* rgb_feat, const float* mask,
+ *   raw [P][4] = rgb, sigma.   head_blob_ref: the gpnerf_pack_head_ref() image (reference summation order). */
+int gpnerf_head_forward(const float* head_blob_ref, const float* vol_feat, const float* rgb_feat, const float* mask,
                         int64_t n_points, float* raw, void* stream);
 
 /* The two halves of the head as the reference's progressive renderer calls them (libs/renders/demo_render.py:295-326):
@@ -202,10 +216,10 @@ int gpnerf_head_forward(const float* head_blob, const float* vol_feat, const flo
  *   vol_feat [P][128], rgb_feat [P][V][35] -> sigma_feat [P][64] = ELU(Linear(vol_feat)), globalfeat [P][134] =
  *   [sigma_feat, mean over views (35), population variance over views (35)];
  * gpnerf_rgb_head_forward = NeRFRGBHead.forward (:118-145): sigma_feat [P][64], rgb_feat [P][V][35], mask [P][V] ->
- *   raw [P][4] = (rgb_out, sigma_out).  All device; head_blob as in GpnerfFrame. */
-int gpnerf_sigma_features(const float* head_blob, const float* vol_feat, const float* rgb_feat, int64_t n_points,
+ *   raw [P][4] = (rgb_out, sigma_out).  All device; head_blob_ref: the gpnerf_pack_head_ref() image. */
+int gpnerf_sigma_features(const float* head_blob_ref, const float* vol_feat, const float* rgb_feat, int64_t n_points,
                           float* sigma_feat, float* globalfeat, void* stream);
-int gpnerf_rgb_head_forward(const float* head_blob, const float* sigma_feat, const float* rgb_feat, const float* mask,
+int gpnerf_rgb_head_forward(const float* head_blob_ref, const float* sigma_feat, const float* rgb_feat, const float* mask,
                             int64_t n_points, float* raw, void* stream);
 
 /* Renderer.raw2outputs (BaseRender.py:75-107) alone.  raw [N][S][4], z [N][S],

@@ -194,6 +194,19 @@ static void head_forward(const OracleFrame *f, const float *vol_feat /*128*/, co
     raw[3] = sg;
 }
 
+/* Diagnostic hook (oracle/kernel_order.inc, built as libgpnerf_kernel_order.so by `make kernel_order`): a second library from
+ * this same file in which the per-sample head, the 3-D sampler and exp() can be swapped for restatements of the HIP kernel's
+ * arithmetic ORDER, one deviation at a time.  The oracle proper (libgpnerf_oracle.so) is built without it: the macros below
+ * are then the functions above, and the pinned checker is untouched. */
+#ifdef ORACLE_VARIANT_FILE
+#include ORACLE_VARIANT_FILE
+#else
+#define ORACLE_HEAD_FORWARD head_forward
+#define ORACLE_GRID_SAMPLE3D grid_sample3d
+#define ORACLE_EXPF expf
+#define ORACLE_SAMPLE_HOOK(f, g) ((void)0)
+#endif
+
 /* Renderer.render_rays for one ray (BaseRender.py:110-157) with is_train=False.
  * flags: bit 0 (1)  = neg_ray as the Projector sees it: a point is in front of a view iff h_z < 0 (BaseRender.py:317-320,
  *                     demo_render.py:550-553);
@@ -241,7 +254,7 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
         /* SparseConvNet.forward :113-122 */
         float vf[NL * NC];
         for (int l = 0; l < NL; ++l)
-            grid_sample3d(f->vol[l], NC, f->vol_dhw[l][0], f->vol_dhw[l][1], f->vol_dhw[l][2], g[0], g[1], g[2], vf + l * NC);
+            ORACLE_GRID_SAMPLE3D(f->vol[l], NC, f->vol_dhw[l][0], f->vol_dhw[l][1], f->vol_dhw[l][2], g[0], g[1], g[2], vf + l * NC);
         if (o->st_vol_feat) memcpy(o->st_vol_feat + ((size_t)r * S + k) * 128, vf, 128 * sizeof(float));
         /* Projector.compute :326-363 */
         float x[NV * XF], mask[NV];
@@ -272,7 +285,8 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
             kept = occv > 0.f;
         }
         two[k] = (kept && mask[0] + mask[1] + mask[2] > 1.f) ? 1.f : 0.f;     /* pixel_mask :139 */
-        head_forward(f, vf, x, mask, raw + 4 * k, rin + 9 * k);
+        ORACLE_SAMPLE_HOOK(f, g);
+        ORACLE_HEAD_FORWARD(f, vf, x, mask, raw + 4 * k, rin + 9 * k);
         if (cull) {
             if (!kept) raw[4 * k + 3] = 0.f;
             if (!(1.f - expf(-raw[4 * k + 3]) > 1e-14f)) raw[4 * k] = raw[4 * k + 1] = raw[4 * k + 2] = 0.f;
@@ -283,7 +297,7 @@ static void render_one_ray(const OracleFrame *f, const float *ray /*o3 d3 near f
     float T = 1.f, rgb[3] = {0, 0, 0}, depth = 0.f, acc = 0.f, rgbin[9] = {0};
     for (int k = 0; k < S; ++k) {
         int src = flip ? (S - 1 - k) : k;              /* torch.flip of rgb and sigma only :86-88 */
-        float alpha = 1.f - expf(-raw[4 * src + 3]);
+        float alpha = 1.f - ORACLE_EXPF(-raw[4 * src + 3]);
         const int dead = o->term_eps > 0.f && T < o->term_eps;     /* build-side early termination, see OracleOut */
         float w = dead ? 0.f : alpha * T;
         if (!dead) {

@@ -54,13 +54,48 @@ def build(force=False):
 
 
 _lib = None
+_main_lib = None
+KO_LIB = os.path.join(HERE, "libgpnerf_kernel_order.so")
+KO_BITS = ("DIV3", "BIASFIRST", "KORDER", "SCALED", "EXP2ELU", "TRIFMA", "FOLD", "V1SCALE", "TAILS", "EXPS", "ELU1ULP", "DIV3FMA", "TAILS2")
+KO_KERNEL_R4 = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 256 | 512      # the folded fp32 form's order (round 4's kernel; kernel_order.inc)
+KO_KERNEL_REF = 16 | 512 | 2048 | 4096                        # the reference-order form (round 5): only exp2-based exps, x/3 by FMA, split tails
+
+
+class kernel_order:
+    """Diagnostic (tools/kernel_order_report.py): inside the `with`, render() / head_forward() go through the oracle's twin
+    built with kernel_order.inc, the HIP kernel's deviations from the reference's arithmetic order switched on by `mask`
+    (bit i = KO_BITS[i]; 0 = the oracle itself).  Not a checker."""
+
+    def __init__(self, mask):
+        self.mask = int(mask)
+
+    def __enter__(self):
+        global _lib, _main_lib
+        src = [os.path.join(HERE, n) for n in ("gpnerf_oracle.c", "kernel_order.inc")]
+        if not os.path.exists(KO_LIB) or os.path.getmtime(KO_LIB) < max(os.path.getmtime(s) for s in src):
+            subprocess.check_call(["make", "-C", HERE, "-B", "kernel_order"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _main_lib = lib()
+        _lib = _bind(C.CDLL(KO_LIB))
+        _lib.kernel_order_set.argtypes = [C.c_int]
+        _lib.kernel_order_set(self.mask)
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = _main_lib
+        return False
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(LIB)
+        _lib = _bind(C.CDLL(LIB))
+    return _lib
+
+
+def _bind(_lib):
+    if True:
         _lib.oracle_render.restype = C.c_int
         _lib.oracle_render.argtypes = [C.POINTER(OracleFrame), FP, C.c_int64, C.c_int, C.c_int, C.POINTER(OracleOut), C.c_int]
         _lib.oracle_make_rays.restype = C.c_int64

@@ -161,7 +161,7 @@ def _full_names():
 def test_full_size_frames_match_the_reference_itself(name, fm):
     """configs[1] (512x512x64), configs[2] (512x512x128) and configs[3] (1024x1024x64) on the scenes bench.py renders, against what
     the REFERENCE's Renderer.render produced for every 64th / 256th ray (tests/golden/make_golden.py FULL_CASES; 262 144 - 1 048 576
-    rays through libs/renders/BaseRender.py on the CPU): both kernel forms, and for configs[2] the early-terminated render too
+    rays through libs/renders/BaseRender.py on the CPU): the three kernel forms (reference order = the default, folded, split f16), and for configs[2] the early-terminated render too
     (its bound: the kernel's error + what termination drops, term_eps = 1e-5)."""
     from golden_cases import load, scene_of
     z, meta = load(name)
@@ -171,7 +171,7 @@ def test_full_size_frames_match_the_reference_itself(name, fm):
     rays = to_dev(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32))
     assert rays.shape[0] == meta["n_rays"]
     worst = {}
-    for label, kw in (("fp32", {}), ("split", {"split_f16": True})) + ((("fp32+early-term", {"early_term": True, "term_eps": 1e-5}),) if S == 128 else ()):
+    for label, kw in (("fp32", {}), ("fp32-folded", {"fold": True}), ("split", {"split_f16": True})) + ((("fp32+early-term", {"early_term": True, "term_eps": 1e-5}),) if S == 128 else ()):
         got = cpu(fm.render_fused(fr, rays, S, want=("rgb_in",), **kw))
         for k in ("rgb_map", "depth_map", "acc_map") + (("rgb_in_map",) if "early" not in label else ()):
             worst[(label, k)] = assert_close(got[k][::st], z[k], TOL, f"{name} {label} {k}")

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import assert_close, case_names, demo_case_names, demo_tolerances, load, rays_case_names, scene_of, trained_case_names, trained_tolerance
+from golden_cases import (FAST_FORM_K, assert_close, case_names, demo_case_names, demo_tolerances, load, rays_case_names, scene_of, trained_case_names,
+                          trained_tolerance)
 
 pytestmark = pytest.mark.gpu
 
@@ -61,34 +62,58 @@ def test_fused_matches_reference_golden(name, fm):
         assert np.array_equal(got["ray_mask"][idx].astype(bool), z["st_ray_mask"])
 
 
-@pytest.mark.parametrize("form", ["fp32_folded", "fp32_per_sample", "split_f16"])
+@pytest.mark.parametrize("form", ["fp32_reference_order", "fp32_folded", "split_f16"])
 @pytest.mark.parametrize("name", trained_case_names())
 def test_fused_on_trained_like_parameters(name, form, fm, oracle):
-    """VERDICT r3 next #1a: parity on something other than `weights_init` parameters -- head weights x 1 / 1.5 / 2 / 3 with non-zero
-    biases, feature maps and volumes x 4 with log-normal tails, ReLU-sparse levels, >= 4 096 rays x 64 samples, produced by the
-    reference's Renderer.render.  Every kernel form against (a) the reference's float32 maps and (b) the maps of its head evaluated in
-    float64, both within golden_cases.trained_tolerance -- 1e-4 where float32 can deliver it (x 1, x 1.5), the reference's own
-    rounding-noise yardstick beyond.  Printed beside each: the C oracle's distance (it follows the reference's summation order
-    bit for bit through the gathers, so it shows what is left to exp / sigmoid and the layers' blocking) and the yardstick.
-    tools/trained_like_report.py prints how the error grows with the scale."""
+    """Parity on something other than `weights_init` parameters -- head weights x 1 / 1.5 / 2 / 3 with non-zero biases, feature maps
+    and volumes x 4 with log-normal tails, ReLU-sparse levels, >= 4 096 rays x 64 samples, produced by the reference's Renderer.render.
+    Every kernel form against (a) the reference's float32 maps and (b) the maps of its head evaluated in float64.
+    The DEFAULT form (reference summation order, round 5) is held to 2 x the C ORACLE's own distance from the reference on every
+    map (the oracle follows the reference op for op) and to golden_cases.trained_tolerance (k = 2: 1e-4 where
+    float32 can deliver it, 2 x the reference's own float32-vs-float64 noise beyond).  The two fast forms (`hip_render_fold`,
+    `hip_render_fast`) round in another order and are held to k = FAST_FORM_K.  tools/trained_like_report.py prints the table;
+    oracle/kernel_order.inc attributes the difference deviation by deviation."""
     z, meta = load(name)
     sc = scene_of(meta)
     S = meta["n_samples"]
     fr = build_frame(fm, sc)
-    kw = {"fp32_folded": dict(fold=True), "fp32_per_sample": dict(fold=False), "split_f16": dict(split_f16=True)}[form]
+    kw = {"fp32_reference_order": dict(), "fp32_folded": dict(fold=True), "split_f16": dict(split_f16=True)}[form]
+    k_tol = 2.0 if form == "fp32_reference_order" else FAST_FORM_K
     got = cpu(fm.render_fused(fr, rays_of(sc), S, want=("weights", "z_vals", "rgb_in", "guard_tiles") if form == "split_f16" else ("weights", "z_vals", "rgb_in"), **kw))
     ref = oracle.render(sc, S)
     line = []
     for k in ("rgb_map", "depth_map", "acc_map", "rgb_in_map"):
-        err = assert_close(got[k], z[k], trained_tolerance(z, k), f"{name} {k}")
+        err = assert_close(got[k], z[k], trained_tolerance(z, k, k=k_tol), f"{name} {k}")
         err_o = float(np.abs(ref[k].astype(np.float64) - z[k]).max())
         line.append(f"{k} {err:.2e} (oracle {err_o:.2e}, reference's own {float(z['spread_' + k]):.2e})")
+        if form == "fp32_reference_order":
+            assert err <= 2.0 * err_o + 1e-6, f"{name} {k}: {err:.2e} is more than twice the op-for-op oracle's distance {err_o:.2e}"
+    if form == "fp32_reference_order" and "h1p5" in name:
+        assert float(np.abs(got["depth_map"].astype(np.float64) - z["depth_map"]).max()) <= 1e-4
     for k in ("rgb_map", "depth_map", "acc_map"):
-        assert_close(got[k].astype(np.float64), z[k + "_head64"], trained_tolerance(z, k), f"{name} {k} vs the float64 head")
+        assert_close(got[k].astype(np.float64), z[k + "_head64"], trained_tolerance(z, k, k=k_tol), f"{name} {k} vs the float64 head")
     if "weights" in z:
-        assert_close(got["weights"], z["weights"], max(trained_tolerance(z, k) for k in ("rgb_map", "acc_map")), "weights")
+        assert_close(got["weights"], z["weights"], max(trained_tolerance(z, k, k=k_tol) for k in ("rgb_map", "acc_map")), "weights")
         assert_close(got["z_vals"], z["z_vals"], 1e-6, "z_vals")
     print(f"{name} [{form}]: " + "; ".join(line) + (f"; guard tiles {int(got['guard_tiles'][0])}" if "guard_tiles" in got else ""))
+
+
+def test_reference_order_form_is_its_cpu_twin(fm, oracle):
+    """oracle/kernel_order.inc restates the reference-order form's arithmetic on the CPU (everything but v_exp_f32's last bit): the
+    kernel and its twin must be the same distance from the reference (that is what makes the twin's deviation-by-deviation
+    attribution evidence about the KERNEL), and within rounding of each other."""
+    name = "trained_h1p5_s64"
+    z, meta = load(name)
+    sc = scene_of(meta)
+    S = meta["n_samples"]
+    got = cpu(fm.render_fused(build_frame(fm, sc), rays_of(sc), S))
+    with oracle.kernel_order(oracle.KO_KERNEL_REF):
+        twin = oracle.render(sc, S, want_weights=False)
+    for k in ("rgb_map", "depth_map", "acc_map"):
+        d_hip = float(np.abs(got[k].astype(np.float64) - z[k]).max())
+        d_twin = float(np.abs(twin[k].astype(np.float64) - z[k]).max())
+        assert abs(d_hip - d_twin) <= 0.25 * d_twin + 1e-6, (k, d_hip, d_twin)
+        assert_close(got[k], twin[k], 3e-5, f"{k}: kernel vs its CPU twin")
 
 
 @pytest.mark.parametrize("split_f16", [False, True])
@@ -377,11 +402,10 @@ def test_folded_coarse_levels_equal_the_layer_per_sample(size, S, neg, kw, fm, o
     for k in ("rgb_map", "acc_map", "weights", "rgb_in_map"):
         assert_close(a[k], b[k], 5e-6, k)
     assert_close(a["depth_map"], b["depth_map"], 2e-5, "depth_map")
-    # the default: folded (once per Frame) for dense launches
+    # the default: the reference-order form (round 5), whatever the launch
     c = cpu(fm.render_fused(fr, rays, S, neg_ray=neg, want=("weights", "rgb_in"), **kw))
-    same = a if kw.get("occ_cull") else b
-    for k in same:
-        assert np.array_equal(np.nan_to_num(same[k]), np.nan_to_num(c[k])), k
+    for k in a:
+        assert np.array_equal(np.nan_to_num(a[k]), np.nan_to_num(c[k])), k
     pick = np.random.default_rng(1).choice(rays.shape[0], 128, replace=False)
     if not kw:
         ref = oracle.render(sc, S, neg_ray=neg, rays=rays.cpu().numpy()[pick])
@@ -396,14 +420,14 @@ def test_a_frame_that_gets_new_volumes_drops_what_it_derived_from_the_old_ones(f
     b = syn.make_scene(H=16, W=16, seed=62, fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1)
     fr = build_frame(fm, a)
     rays = rays_of(a)
-    first = fm.render_fused(fr, rays, 32)                         # folds level 2 and 3 of scene a
+    first = fm.render_fused(fr, rays, 32, fold="keep")            # folds level 2 and 3 of scene a
     fr.build_occupancy()
     assert fr._folded_valid and fr.c.occ
     fr._set_volumes(fr.c, [to_dev(v * 0.5) for v in b["volumes"]], fr._keep)
     assert not fr._folded_valid and fr.vols_folded is None and fr.occ is None and not fr.c.occ
-    got = fm.render_fused(fr, rays, 32)
+    got = fm.render_fused(fr, rays, 32, fold="keep")
     fresh_scene = dict(a, volumes=[v * 0.5 for v in b["volumes"]])
-    want = fm.render_fused(build_frame(fm, fresh_scene), rays, 32)
+    want = fm.render_fused(build_frame(fm, fresh_scene), rays, 32, fold="keep")
     assert torch.equal(got["rgb_map"], want["rgb_map"]) and torch.equal(got["depth_map"], want["depth_map"])
     assert not torch.equal(got["rgb_map"], first["rgb_map"])
 

@@ -150,6 +150,136 @@ def test_head_image_reproduces_the_reference_head(pkg, oracle, syn):
     assert (ref[:3, 3] == 0).all() and (got[:3, 3] == 0).all()       # masked_fill(num_valid_obs < 1, 0)
 
 
+def elu_ref(x):
+    """elur_n's activation (gpnerf_kernels.hip): unscaled, x > 0 ? x : 2^(x log2 e) - 1"""
+    x = x.astype(np.float32)
+    return np.where(x > 0, x, np.exp2(np.minimum(x, 0) * LOG2E) - np.float32(1)).astype(np.float32)
+
+
+def div3(x):
+    """div3() of the kernel: q = x c, q + fma(-3, q, x) c -- must equal IEEE x / 3"""
+    x = x.astype(np.float32)
+    c = np.float32(1 / 3)
+    q = (x * c).astype(np.float32)
+    r = (x.astype(np.float64) - 3.0 * q.astype(np.float64)).astype(np.float32)          # fma(-3, q, x) is exact in double
+    return (q.astype(np.float64) + r.astype(np.float64) * np.float64(c)).astype(np.float32)
+
+
+def interleave16(regs):
+    """interleave16(): 16 registers [16][64], register c = channel c (lanes 0..31) / 16 + c (lanes 32..63) ->
+    out[i] = channels (2i, 2i + 1), out[8 + i] = (16 + 2i, 17 + 2i); v_permlane32_swap semantics as measured
+    (tools/micro/permlane32_swap.hip): (a, b) -> ([a.lo, b.lo], [a.hi, b.hi])"""
+    out = np.zeros_like(regs)
+    for i in range(8):
+        a, b = regs[2 * i], regs[2 * i + 1]
+        out[i] = np.concatenate([a[:32], b[:32]])
+        out[8 + i] = np.concatenate([a[32:], b[32:]])
+    return out
+
+
+def emulate_ref(blob, table, vol_feat, rgb_feat, mask):
+    """The reference-order form's register dataflow (mlp_eval_ref / geo_eval_ref / render_tile's FORM_F32 branch): chains from
+    zero, bias after the chain, features re-interleaved to k order.  Any slip in gpr::col_of / feat_of_row / the slot
+    arrangement changes the result."""
+    w = Wave(blob, table)
+    lane_s = np.arange(64) % 32
+    lane_h = np.arange(64) // 32
+    zero = np.zeros((16, 64), np.float32)
+    fv = np.zeros((64, 64), np.float32)
+    for l in range(4):
+        g = np.zeros((16, 64), np.float32)
+        for c in range(16):
+            g[c] = vol_feat[lane_s, 32 * l + 16 * lane_h + c]              # what gather_volume leaves in register c
+        fv[16 * l:16 * l + 16] = interleave16(g)
+    x = np.zeros((3, 18, 64), np.float32)
+    for v in range(3):
+        g = np.zeros((16, 64), np.float32)
+        for c in range(16):
+            g[c] = rgb_feat[lane_s, v, 3 + 16 * lane_h + c]
+        x[v, 2:18] = interleave16(g)
+        x[v, 0] = np.where(lane_h == 1, rgb_feat[lane_s, v, 1], rgb_feat[lane_s, v, 0])
+        x[v, 1] = np.where(lane_h == 1, 0.0, rgb_feat[lane_s, v, 2])
+    nvalid = mask.sum(1)[lane_s]
+    act = lambda name, m, acc: elu_ref(acc + w.bias_tile(name, m))
+    sf = np.concatenate([act("GEO", 0, w.mfma_tile("GEO", 0, fv, zero)), act("GEO", 1, w.mfma_tile("GEO", 1, fv, zero))], 0)
+    m = div3((x[0] + x[1]) + x[2])
+    var = div3(((x[0] - m) ** 2 + (x[1] - m) ** 2) + (x[2] - m) ** 2)
+    mv = np.concatenate([m, var], 0)
+    d1in = np.concatenate([sf, mv], 0)
+    h1 = np.concatenate([act("D1", 0, w.mfma_tile("D1", 0, d1in, zero)), act("D1", 1, w.mfma_tile("D1", 1, d1in, zero))], 0)
+    h2 = act("D2", 0, w.mfma_tile("D2", 0, h1, zero))
+    h3 = act("D3", 0, w.mfma_tile("D3", 0, h2, zero))
+    d4w, d4b, r3w, r3b = w.tail
+    part = np.zeros(64, np.float32)
+    for r in range(8):
+        part += blob[d4w + lane_h * 8 + r] * h3[r]
+    s = part + part[(np.arange(64) + 32) % 64] + blob[d4b]
+    sigma = np.where(nvalid < 1, 0.0, np.maximum(s, 0))
+    s0 = w.mfma_tile("BS", 0, mv, zero)
+    s1 = w.mfma_tile("BS", 1, mv, zero)
+    y = []
+    for v in range(3):
+        hh = np.concatenate([act("BS", 0, w.mfma_tile("BV", 0, x[v], s0)), act("BS", 1, w.mfma_tile("BV", 1, x[v], s1))], 0)
+        xb = act("B2", 0, w.mfma_tile("B2", 0, hh, zero))
+        t1 = act("V1", 0, w.mfma_tile("V1", 0, div3(xb), zero))
+        t2 = act("V2", 0, w.mfma_tile("V2", 0, t1, zero))
+        y.append(xb + t2)
+    y = np.concatenate(y, 0)
+    c1 = act("R1", 0, w.mfma_tile("R1", 0, y, zero))
+    c2 = act("R2", 0, w.mfma_tile("R2", 0, c1, zero))
+    rgb = []
+    for o in range(3):
+        part = np.zeros(64, np.float32)
+        for r in range(8):
+            part += blob[r3w + o * 16 + lane_h * 8 + r] * c2[r]
+        s = part + part[(np.arange(64) + 32) % 64] + blob[r3b + o]
+        rgb.append(1 / (1 + np.exp(-s)))
+    raw = np.stack(rgb + [sigma], 1)
+    assert np.array_equal(raw[:32], raw[32:]), "both lane halves must hold the same result"
+    return raw[:32].astype(np.float32)
+
+
+def test_reference_order_image_reproduces_the_reference_head(pkg, oracle, syn):
+    """gpnerf_pack_head_ref's image through the reference-order form's dataflow = NeRFHead.forward"""
+    L = pkg._lib
+    lib = L.lib()
+    head = syn.make_head_weights(seed=5, bias_std=0.3)
+    params = L.GpnerfHeadParams()
+    keep = []
+    for short, name in L.HEAD_FIELDS:
+        for suf, fld in (("weight", "_w"), ("bias", "_b")):
+            a = np.ascontiguousarray(head[f"{name}.{suf}"], np.float32)
+            keep.append(a)
+            setattr(params, short + fld, a.ctypes.data_as(L.FP))
+    blob = np.zeros(lib.gpnerf_head_blob_floats(), np.float32)
+    assert lib.gpnerf_pack_head_ref(C.byref(params), blob.ctypes.data_as(L.FP)) == 0
+    table = (C.c_int32 * 48)()
+    assert lib.gpnerf_head_layout(table) == 0
+    g = np.random.Generator(np.random.PCG64(13))
+    vol = g.standard_normal((32, 128), dtype=np.float32)
+    feat = g.standard_normal((32, 3, 35), dtype=np.float32)
+    feat[..., :3] = g.random((32, 3, 3), dtype=np.float32)
+    mask = (g.random((32, 3)) > 0.4).astype(np.float32)
+    mask[:3] = 0
+    got = emulate_ref(blob, list(table), vol, feat, mask)
+    ref = oracle.head_forward(head, vol, feat, mask)
+    err = np.abs(got - ref).max()
+    assert err < 2e-5, err
+    assert (ref[:3, 3] == 0).all() and (got[:3, 3] == 0).all()
+    # nothing in the image is pre-scaled: every weight of the state_dict appears in it bit for bit
+    for short, name in L.HEAD_FIELDS:
+        wts = np.ascontiguousarray(head[f"{name}.weight"], np.float32).ravel()
+        assert np.isin(wts, blob).all(), name
+
+
+def test_div3_is_ieee_division():
+    """q = x c; q + fma(-3, q, x) c is the correctly rounded x / 3 (what torch.mean computes) on random and edge values"""
+    g = np.random.Generator(np.random.PCG64(7))
+    x = np.concatenate([g.standard_normal(2_000_000).astype(np.float32) * np.float32(10.0) ** g.integers(-20, 20, 2_000_000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, 3.0, 1e-30, 3e38, -3e38, np.float32(2 ** -120)], np.float32)])
+    assert np.array_equal(div3(x), (x / np.float32(3)).astype(np.float32))
+
+
 def test_pack_rejects_missing_tensors(pkg):
     L = pkg._lib
     blob = np.zeros(L.lib().gpnerf_head_blob_floats(), np.float32)

@@ -28,23 +28,31 @@ def main():
     if gpu:
         fm = importlib.import_module("gp-nerf_amd.frame")
         dev = torch.device("cuda:0")
-    print(f"{'case':18s} {'path':22s} " + " ".join(f"{k + ' vs ref32 / ref-head64':>34s}" for k in KEYS))
+    print(f"{'case':18s} {'path':30s} " + " ".join(f"{k + ' vs ref32 / ref-head64':>34s}" for k in KEYS))
     for name in trained_case_names():
         z, meta = load(name)
         sc = scene_of(meta)
         S = meta["n_samples"]
         rows = [("reference f32 vs its f64 head", {k: (float(z["spread_" + k]), 0.0) for k in KEYS}),
                 ("C oracle", errs(oracle.render(sc, S), z))]
+        twins = {}
+        for tag, mask in (("CPU twin of the ref-order form", oracle.KO_KERNEL_REF), ("CPU twin of the folded form", oracle.KO_KERNEL_R4)):
+            with oracle.kernel_order(mask):          # oracle/kernel_order.inc: the kernel's arithmetic order restated on the CPU
+                twins[tag] = oracle.render(sc, S, want_weights=False)
+            rows.append((tag, errs(twins[tag], z)))
         if gpu:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
             fr = fm.Frame(t(sc["src_imgs"][0]), t(sc["featmaps"]), [t(v) for v in sc["volumes"]], t(sc["src_Ks"][0]), t(sc["src_poses"][0]),
                           sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0], fm.pack_head(sc["head"], dev))
             rays = t(oracle.rays_of(sc))
-            for tag, kw in (("HIP fp32 (folded)", dict(fold=True)), ("HIP fp32 (per sample)", dict(fold=False)), ("HIP split-f16 + guard", dict(split_f16=True))):
-                o = fm.render_fused(fr, rays, S, **kw)
-                rows.append((tag, errs({k: o[k].cpu().numpy() for k in KEYS}, z)))
+            for tag, kw, twin in (("HIP fp32 reference order", dict(fold=False), "CPU twin of the ref-order form"),
+                                  ("HIP fp32 folded", dict(fold=True), "CPU twin of the folded form"), ("HIP split-f16 + guard", dict(split_f16=True), None)):
+                o = {k: v.cpu().numpy() for k, v in fm.render_fused(fr, rays, S, **kw).items() if k in KEYS}
+                rows.append((tag, errs(o, z)))
+                if twin:       # how well the CPU twin predicts the kernel: max-abs between the two (everything but v_exp_f32's last bit is modelled)
+                    rows.append(("   ... vs its CPU twin", {k: (float(np.abs(o[k].astype(np.float64) - twins[twin][k]).max()), 0.0) for k in KEYS}))
         for tag, e in rows:
-            print(f"{name:18s} {tag:22s} " + " ".join(f"{e[k][0]:16.2e} / {e[k][1]:<15.2e}" for k in KEYS))
+            print(f"{name:18s} {tag:30s} " + " ".join(f"{e[k][0]:16.2e} / {e[k][1]:<15.2e}" for k in KEYS))
 
 
 if __name__ == "__main__":
