@@ -121,6 +121,47 @@ def time_launches(fn, steps, warmup):
     return float(np.mean([a.elapsed_time(b) for a, b in ev])), out
 
 
+def device_identity(dev):
+    """What tells two ranks' devices apart in the JSON line: index, marketing name, PCI bus id, uuid (None where the runtime
+    does not say).  A CPU "device" (the gloo dry run's host tensors) reports its host name and pid instead."""
+    import torch
+    if dev.type != "cuda":
+        import socket
+        return {"device_index": None, "device_name": "cpu", "pci_bus_id": None, "uuid": None, "host": socket.gethostname(), "pid": os.getpid()}
+    p = torch.cuda.get_device_properties(dev)
+    bus = None
+    if all(hasattr(p, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+    uuid = getattr(p, "uuid", None)
+    return {"device_index": int(dev.index if dev.index is not None else torch.cuda.current_device()), "device_name": str(p.name),
+            "pci_bus_id": bus, "uuid": str(uuid) if uuid is not None else None, "cus": int(getattr(p, "multi_processor_count", 0)), "pid": os.getpid()}
+
+
+def gather_rank_reports(report, world):
+    """Every rank's report on rank 0 (and everywhere): ONE all_gather_object after the timed region.  `report` = device identity +
+    this rank's own kernel / exchange event times, so a SCALE run shows N distinct devices and where each rank's time went."""
+    if world == 1:
+        return [report]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, report)
+    return out
+
+
+def summarize_ranks(reports):
+    """`ranks` (the reports in rank order) + the fields a reader wants first: how many distinct devices, per-rank kernel time
+    spread, and the exchange's own time."""
+    def ident(r):
+        if r.get("device_index") is None:
+            return ("cpu", r.get("host"), r.get("pid"))
+        return r.get("pci_bus_id") or r.get("uuid") or ("index", r.get("device_index"))
+    k = [r["kernel_ms"] for r in reports if r.get("kernel_ms") is not None]
+    e = [r["exchange_ms"] for r in reports if r.get("exchange_ms") is not None]
+    return {"ranks": reports, "distinct_devices": len({ident(r) for r in reports}),
+            "kernel_ms_per_rank": {"min": min(k), "max": max(k), "mean": sum(k) / len(k)} if k else None,
+            "exchange_ms": {"min": min(e), "max": max(e), "mean": sum(e) / len(e)} if e else None}
+
+
 def launch_command(gpus, port, argv):
     """The command a plain `python bench.py --gpus N ...` runs as a child: the driver's own N > 1 launch line."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
@@ -226,12 +267,14 @@ def main():
                 out = par.gather_frame(local, self.plan if backend == "nccl" else _cpu_plan(par, self.plan), par.PIXEL_KEYS, buffer=self.buf)
             elif world > 1:
                 par.all_gather_pixels(out if backend == "nccl" else {k: out[k].cpu() for k in par.PIXEL_KEYS}, self.buf)
+            if events and len(events) > 2:
+                events[2].record()          # the exchange (pack + all-gather + un-permute) ends here on the device stream (nccl backend)
             return out
 
         def timed(self, steps, warmup):
             for _ in range(warmup):
                 self.step()
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3 if world > 1 else 2)) for _ in range(steps)]
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -248,10 +291,16 @@ def main():
                 tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
-            return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), out
+            # the exchange's own device time (RCCL all-gather + un-permute on the stream); the gloo dry run stages through the host
+            self.exchange_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if (world > 1 and backend == "nccl") else None
+            return dt, float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), out
 
     flow = Flow(wl)
     dt, kernel_ms, out = flow.timed(args.steps, args.warmup)
+    # who ran where: every rank's device identity and its own event times, gathered once, after the timed region
+    report = dict(device_identity(dev), rank=rank, local_rank=local_rank, kernel_ms=kernel_ms, exchange_ms=getattr(flow, "exchange_ms", None),
+                  rays=int(flow.n_local))
+    rank_summary = summarize_ranks(gather_rank_reports(report, world))
 
     extras = {}
     if world > 1 and strong and not args.no_extras and args.size != 1024:
@@ -307,6 +356,7 @@ def main():
                          "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_per_launch},
         }
         line.update(extras)
+        line.update(rank_summary)
         if args.split_f16:
             line["dtype"] = "f32 operands as f16 hi+lo pairs on v_mfma_f32_32x32x16_f16, f32 accumulation"
             line["roofline"]["split_note"] = ("peak = dense f16 MFMA; the form issues 3 MFMAs per 16-deep k-step (3x the algorithmic FLOPs) and is "
@@ -473,6 +523,20 @@ def _timed_sample(render, rays_h, target_s):
     return sample.shape[0], dt
 
 
+def cpu_model():
+    """The host CPU's model string (/proc/cpuinfo) and socket count: what `cores` are cores OF."""
+    try:
+        names, sockets = [], set()
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                names.append(l.split(":", 1)[1].strip())
+            elif l.startswith("physical id"):
+                sockets.add(l.split(":", 1)[1].strip())
+        return f"{names[0]} ({len(names)} hardware threads, {max(1, len(sockets))} socket(s))" if names else None
+    except OSError:
+        return None
+
+
 def cpu_baseline(sc, rays_h, S, target_s):
     """The same workload on this host's cores (the Python reference cannot travel), on bounded, evenly spaced samples of the same
     rays, by two CPU programs:
@@ -518,7 +582,7 @@ def cpu_baseline(sc, rays_h, S, target_s):
             "sample": f"{nb} evenly spaced rays of the same frame x {S} samples, {tb:.1f} s on {threads} OpenMP threads "
                       f"(oracle/gpnerf_cpu_blocked.c, gcc -O3 -march=native, channels-last frame prepared outside the timed call)",
             "max_abs_vs_scalar_oracle": err,
-            "threads_available": hw_threads,
+            "threads_available": hw_threads, "cpu_model": cpu_model(),
             "scalar_oracle": {"value": no / to, "unit": "rays/s", "cores": o_threads, "kind": "port",
                               "ms_per_frame": n_frame / (no / to) * 1e3,
                               "sample": f"{no} evenly spaced rays x {S} samples, {to:.1f} s on {o_threads} OpenMP threads "

@@ -448,7 +448,7 @@ DEV void interleave16(const float* __restrict__ in, float* __restrict__ out) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float a = in[2 * i], b = in[2 * i + 1];
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
         out[i] = a;
         out[8 + i] = b;
     }
@@ -3084,6 +3084,12 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const size_t lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
     int n_cus = 0;
     if (device_ready(&n_cus) != GPNERF_OK) return GPNERF_E_DEVICE;
+    {   // GPNERF_FLAG_RESERVE_CUS(n): plan the launch for n fewer compute units (whole XCD rounds of 8, at least 8 stay), so that
+        // kernels of OTHER streams -- the next frame's encoder and volume builder -- find free CUs while the persistent workgroups run
+        const int reserve = (int)((flags >> 24) & 0xffu) & ~7;
+        if (reserve > 0) n_cus = n_cus - reserve >= 8 ? n_cus - reserve : (n_cus >= 8 ? 8 : n_cus);
+        flags &= 0x00ffffffu;
+    }
     const bool culling = (flags & GPNERF_FLAG_OCC_CULL) != 0 && f->occ != nullptr;
     if (flags & GPNERF_FLAG_OCC_CULL) k.voxel[0] = k.voxel[1] = k.voxel[2] = 0.005f;   // demo_render.py:91 `xyz / 0.005`
     // occupancy culling: the keep bits of every sample in one pass before the launch (occupancy_mask_kernel), in the last

@@ -177,8 +177,12 @@ def _run_of(x):
     run = _runs.get(key)
     if run is None:
         if len(_runs) > 64:
-            _runs.clear()
+            # drop the OLDEST entry only (dicts keep insertion order): clearing the table in the middle of a pass handed the pass's
+            # later convolutions fresh words -- forward() then read a flag the raise never reached
+            _runs.pop(next(iter(_runs)))
         run = _runs[key] = _Run(x.device)
+    else:
+        _runs[key] = _runs.pop(key)       # most recently used last
     return run
 
 
@@ -397,11 +401,13 @@ class ResUNet(nn.Module):
     def check_operand_range(self, H, W, params_key=None):
         """Which guard a frame of H x W images needs, from the PARAMETERS alone (cached per (H, W, parameter versions): one
         device-to-host copy per parameter change).  Never refuses finite parameters:
-          "static"   every convolution's operands are inside the split-f16 range whatever the images: weights |w| < 16 directly,
-                     activations through the bound InstanceNorm gives them -- a normalised value is at most sqrt(h w - 1) in
-                     magnitude, so a norm's output is bounded by sqrt(h w) max|gamma| + max|beta|, a residual unit's by that plus
-                     its shortcut's bound, and upsampling / concatenation / ReLU / ELU do not raise a bound.  The range flag cannot
-                     be raised and nobody waits for it (the reference's initialisation; any InstanceNorm scale below ~10 at 512^2);
+          "static"   every convolution BEHIND the stem has its operands inside the split-f16 range whatever the images: weights
+                     |w| < 16 directly, activations through the bound InstanceNorm gives them -- a normalised value is at most
+                     sqrt(h w - 1) in magnitude, so a norm's output is bounded by sqrt(h w) max|gamma| + max|beta|, a residual
+                     unit's by that plus its shortcut's bound, and upsampling / concatenation / ReLU / ELU do not raise a bound.
+                     The stem reads the IMAGE: a pixel of magnitude >= 4094 or a non-finite one still leaves the range, so the
+                     flag is read for this class too (round 5) -- deferred to the caller's own synchronisation on the
+                     render path, where it costs nothing (the reference's initialisation; any InstanceNorm scale below ~10 at 512^2);
           "dynamic"  the bound does not hold (it grows with the image size and is attained by a one-hot image only): the split form
                      runs and its range flag says whether THIS frame left the range -- if so the frame is encoded again by
                      forward_exact;
@@ -494,12 +500,19 @@ class ResUNet(nn.Module):
         if cls == "exact":
             return self.forward_exact(x)
         run = _run_of(x)
-        y = self.forward_fast(x)
-        if cls == "dynamic":
-            torch.cuda.current_stream(x.device).synchronize()
-            if run.raised():
-                run.clear()
-                return self.forward_exact(x)
+        # the flag word starts every checked pass at zero: a pass that was aborted between launch and check, or an earlier pass on
+        # out-of-range data whose flag nobody looked at, must not send THIS frame to the exact form.  The host owns the
+        # word here: the previous pass on this stream was synchronised with before its flag was read, or never read at all.
+        torch.cuda.current_stream(x.device).synchronize()
+        run.clear()
+        with _pinned_run(run):             # the whole pass on these words, whatever happens to the table meanwhile
+            y = self.forward_fast(x)
+        # "static" parameters bound every operand for images in the documented range only: an out-of-range or non-finite PIXEL still
+        # overflows the stem's f16 split, and ReLU turns the NaNs into silent zeros -- so the flag is read for both classes
+        torch.cuda.current_stream(x.device).synchronize()
+        if run.raised():
+            run.clear()
+            return self.forward_exact(x)
         return y
 
     def forward_fast(self, x):
@@ -594,15 +607,17 @@ def forward_graphed(net, x, defer_range_check=False):
     if hit is None or hit[0] != key:
         hit = (key, _EncoderGraph(net, x.float()))
         net.__dict__["_gpnerf_graph"] = hit
+    if net.__dict__.get("_gpnerf_pending_run") is None:
+        hit[1].run.clear()                 # nothing in flight whose verdict is still owed: this replay starts from a zero flag
     y = hit[1](x)
-    if cls == "dynamic":
-        if defer_range_check:
-            net.__dict__["_gpnerf_pending_run"] = hit[1].run
-        else:
-            torch.cuda.current_stream(x.device).synchronize()
-            if hit[1].run.raised():
-                hit[1].run.clear()
-                return net.forward_exact(x)
+    # both classes: "static" parameters exclude an overflow for in-range images only (see forward())
+    if defer_range_check:
+        net.__dict__["_gpnerf_pending_run"] = hit[1].run
+    else:
+        torch.cuda.current_stream(x.device).synchronize()
+        if hit[1].run.raised():
+            hit[1].run.clear()
+            return net.forward_exact(x)
     return y
 
 

@@ -106,16 +106,23 @@ class Evaluator:
         return metrics
 
 
-def evaluate_loop(render, eval_loader, cfg, device=None, quiet=False):
+def evaluate_loop(render, eval_loader, cfg, device=None, quiet=False, pipeline=None):
     """`Trainer.evaluate` (libs/trainers/BaseTrainer.py:255-280) without its image writing: for every batch of `eval_loader`
     move it to `device` (`_read_inputs`, :89-97), `ret = render.render(batch)` (the reference calls `.module.render` on its
     DataParallel wrapper; a wrapped model is unwrapped here too), `Evaluator.evaluate(ret, batch)`, `total_time += ret["rtime"]`;
     then `summarize()` when the head renders colour.  Returns {"count", "total_time", "avg_time", "metrics" (summarize()'s dict or
-    None), "mse", "psnr", "ssim" (the per-frame lists)} -- the reference prints the average and returns nothing."""
+    None), "mse", "psnr", "ssim" (the per-frame lists), "wall_time" (the loop's own clock)} -- the reference prints the average and
+    returns nothing.
+    pipeline (not in the reference, whose loop is strictly serial): frame t + 1 is fetched, moved to the device and PREFETCHED
+    (Renderer.prefetch: encoder graph, volume builder, frame glue on a second stream) right after frame t's per-ray kernel has been
+    enqueued, so the device goes from one frame's per-ray kernel straight into the next frame's producers while the host evaluates
+    frame t.  Default: on when the renderer offers `prefetch` and is neither progressive nor sharded.  Same bits per frame."""
     model = getattr(render, "module", render)
     model.eval()
     evaluator = Evaluator(cfg, cfg.test.test_seq)
     count, total_time = 0, 0.0
+    if pipeline is None:
+        pipeline = hasattr(model, "prefetch") and not getattr(model, "progressive", False) and getattr(model, "shard_group", None) is None
 
     def move(v):
         if device is None:
@@ -126,15 +133,34 @@ def evaluate_loop(render, eval_loader, cfg, device=None, quiet=False):
             return {k: b.to(device) for k, b in v.items()}
         return v.to(device)
 
-    for data in eval_loader:
+    import time as _time
+    t_loop = _time.time()
+    if not pipeline:
+        for data in eval_loader:
+            with torch.no_grad():
+                val = {k: move(v) for k, v in data.items()}
+                ret = model.render(val)
+                evaluator.evaluate(ret, val)
+            total_time += ret["rtime"]                       # the dense renderer of the reference returns no "rtime": KeyError there
+            count += 1
+    else:
+        it = iter(eval_loader)
         with torch.no_grad():
-            val = {k: move(v) for k, v in data.items()}
-            ret = model.render(val)
-            evaluator.evaluate(ret, val)
-        total_time += ret["rtime"]                       # the dense renderer of the reference returns no "rtime": KeyError there
-        count += 1
+            data = next(it, None)
+            val = {k: move(v) for k, v in data.items()} if data is not None else None
+            pre = model.prefetch(val) if val is not None else None
+            while val is not None:
+                data = next(it, None)
+                nxt = {k: move(v) for k, v in data.items()} if data is not None else None
+                ret = model.render(val, prefetched=pre, next_batch=nxt)
+                pre = ret.pop("next_prefetched", None)
+                evaluator.evaluate(ret, val)
+                total_time += ret["rtime"]
+                count += 1
+                val = nxt
+    wall = _time.time() - t_loop
     per_frame = {"mse": list(evaluator.mse), "psnr": list(evaluator.psnr), "ssim": list(evaluator.ssim)}
     metrics = evaluator.summarize() if cfg.head.rgb.use_rgbhead else None
     if not quiet:
         print(f"avg total render time: {total_time / max(count, 1)}s per sample")
-    return dict(count=count, total_time=total_time, avg_time=total_time / max(count, 1), metrics=metrics, **per_frame)
+    return dict(count=count, total_time=total_time, avg_time=total_time / max(count, 1), metrics=metrics, wall_time=wall, **per_frame)

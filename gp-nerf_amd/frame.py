@@ -298,7 +298,7 @@ def patch_order_rays(mask, H, W, n, patch_w=32, patch_h=8):
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-5,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
-                 split_f16=False, flip=None, subset=False, guard=None, fold=None):
+                 split_f16=False, flip=None, subset=False, guard=None, fold=None, reserve_cus=0):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); defaults to neg_ray for the dense renderer
     (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
@@ -317,7 +317,9 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     parameters it sits at the op-for-op CPU oracle's distance from the reference.  True: the round-4 fast
     form -- coarse levels folded into the sigma feature layer per frame (Frame.fold_volumes), log2(e)-scaled layers: ~8 % faster,
     the same 1e-5 at initialisation scale, 5-10 x further from the reference on trained-like parameters.  "keep": True without
-    re-folding a Frame that is already folded."""
+    re-folding a Frame that is already folded.
+    reserve_cus: plan the launch for that many fewer compute units (multiple of 8), leaving them to kernels of other streams
+    (GPNERF_FLAG_RESERVE_CUS; Renderer.prefetch's overlap).  Same bits for any value."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()
@@ -356,6 +358,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     if flip is None:
         flip = bool(neg_ray) and not occ_cull
     flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_FLIP_SAMPLES if flip else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
+    flags |= (int(reserve_cus) & 0xff) << 24
     if split_f16:
         if not frame.c.head_blob_split:
             raise L.GpnerfError("split_f16 needs the f16 hi/lo head image (build the frame from pack_head()'s tensor)")

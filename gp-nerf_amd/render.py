@@ -22,6 +22,7 @@ from importlib import import_module as impm
 
 import numpy as np
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib as L
@@ -104,7 +105,8 @@ class Renderer(nn.Module):
             # with a shard_group: the source views dealt out over the ranks + a broadcast of each feature map (parallel.py); a
             # rank replays its own views as ONE graph too (per view count: the graph's key holds the input shape) -- enqueued
             # launch by launch through Python the owner of a view was host-bound (~1.4 ms for ~0.4 ms of device time)
-            fn = (lambda t: E_.forward_graphed(self.encoder, t)) if graphed else None
+            # (the range check is deferred here too: render() agrees on ONE verdict across the ranks at the end of the call)
+            fn = (lambda t: E_.forward_graphed(self.encoder, t, defer_range_check=defer_range_check)) if graphed else None
             featmaps = P_.encode_views_sharded(self.encoder, src_imgs.squeeze(0), group=self.shard_group, encode_fn=fn)
         return featmaps[0] if featmaps.dim() == 5 else featmaps
 
@@ -259,15 +261,12 @@ class Renderer(nn.Module):
                 "etime": etime, "rtime": max(0.0, (t4 - te) - etime)}
 
     # ---- the hot path ---------------------------------------------------------------------------------
-    def render(self, batch):
-        if self.progressive:
-            return self.render_progressive(batch)
-        if not self.nerfhead.use_rgbhead:
-            raise L.GpnerfError("mesh extraction (use_rgbhead=False, BaseRender.py:255-272) is outside the per-ray render path")
+    def _produce(self, batch):
+        """Everything of a frame that comes BEFORE the per-ray kernel, enqueued on the current stream (+ a side stream): image
+        encoder, the frame's constants, volume builder, channels-last re-layouts, ray list and patch order.  Returns the
+        `Prefetched` record the per-ray launch consumes.  No device-wide synchronisation."""
         dev = batch["ray_o"].device
-        torch.cuda.synchronize(dev)
-        te = time.time()
-        # The encoder goes FIRST: it needs nothing but the source images, and its ~1.4 ms on the device cover everything the host
+        # The encoder goes FIRST: it needs nothing but the source images, and its ~1 ms on the device cover everything the host
         # has to wait for -- the frame's small constants (one device-to-host copy) and the patch order -- which happen on a SIDE
         # stream meanwhile (the copy's synchronisation then waits for that stream's few microseconds, not for the encoder).  From
         # there to the end of the per-ray kernel the host only enqueues and runs ahead of the device, so a frame's ~130 launches
@@ -279,9 +278,12 @@ class Renderer(nn.Module):
         ev1.record()
         self.nerfhead.head_blob(dev)                                   # (cached; packs on a parameter change)
         main = torch.cuda.current_stream(dev)
-        side = self.__dict__.get("_side_stream")
+        sides = self.__dict__.setdefault("_side_streams", {})
+        side = sides.get(main.cuda_stream)                             # one side stream per producing stream (render's own, prefetch's)
         if side is None or side.device != dev:
-            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+            if len(sides) > 8:
+                sides.clear()
+            side = sides[main.cuda_stream] = torch.cuda.Stream(device=dev)
         group = P_.resolve_group(self.shard_group)
         sharded = group is not None
         # The host enqueues in the order the DEVICE needs things: first what the builder needs (it runs right behind the encoder),
@@ -292,8 +294,9 @@ class Renderer(nn.Module):
         # imgs4, rays, order): the caching allocator knows them as `side`'s blocks, and `main.wait_stream(side)` orders the USE, not
         # the FREE -- a block dropped early could be handed to side's next allocation while main's kernels still read it.  They are
         # therefore recorded on `main` below (record_stream), on top of every one of them staying referenced until the
-        # torch.cuda.synchronize at the end of the call.
-        with torch.cuda.stream(side):              # the batch's tensors are complete: render() synchronised at its top
+        # synchronisation at the end of render().
+        side.wait_stream(main)                     # (the batch's tensors: complete on `main` -- render() synchronised, prefetch() waited)
+        with torch.cuda.stream(side):
             consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
             prepared = self.prepare_builder_inputs(batch, consts)      # what the builder needs that does not depend on the encoder
             imgs4 = F_.relayout_images(batch["src_imgs"][0])           # the frame's channels-last source images
@@ -325,6 +328,67 @@ class Renderer(nn.Module):
                         order = F_.patch_order_rays(m, Hs, Ws, n, patch_w=pw, patch_h=ph)
         main.wait_stream(side)
         _record_on(main, rays, order)
+        return Prefetched(batch=batch, frame=frame, rays=rays, order=order, n=n, neg=neg, ev0=ev0, ev1=ev1, group=group,
+                          keep=(featmaps, consts, prepared, imgs4), own_encoder="featmaps" not in batch)
+
+    def _encoder_flagged(self):
+        """True when the last deferred encoder pass left the split-f16 operand range (its stream has been synchronised)"""
+        return isinstance(self.encoder, E_.ResUNet) and E_.range_check_pending(self.encoder)
+
+    def prefetch(self, batch):
+        """Enqueue everything of `batch`'s frame that comes before the per-ray kernel (`_produce`) on a stream of its own and return
+        at once; `render(batch, prefetched=p)` then only launches the per-ray kernel.  In an evaluation loop this is called for
+        frame t + 1 while frame t's per-ray kernel runs (`render(..., next_batch=...)` does that): the host's ~0.5 ms of enqueueing
+        and the evaluator's work of frame t no longer sit between two frames' device work, and the next frame's encoder / builder
+        launches start the moment frame t's persistent workgroups let go of CUs.  (They do not run BESIDE the per-ray kernel: its
+        workgroups hold every CU's registers and LDS.  Leaving CUs free for them -- GPNERF_FLAG_RESERVE_CUS -- was measured and
+        costs the kernel more than the overlap returns: profiles/r05/d_pipeline.txt.)  Same bits as the serial call.
+        Not in the reference (its loop is strictly serial: libs/trainers/BaseTrainer.py:255-280)."""
+        if self.progressive or P_.resolve_group(self.shard_group) is not None:
+            raise L.GpnerfError("prefetch() is for the dense single-GPU path")
+        dev = batch["ray_o"].device
+        cur = torch.cuda.current_stream(dev)
+        prod = self.__dict__.get("_prod_stream")
+        if prod is None or prod.device != dev:
+            prod = self.__dict__["_prod_stream"] = torch.cuda.Stream(device=dev)
+        # the encoder's graph has ONE range flag: the previous prefetch's verdict is read before the graph runs again
+        prev = self.__dict__.get("_last_prefetch")
+        if prev is not None and prev.flagged is None:
+            prod.synchronize()
+            prev.flagged = self._encoder_flagged() if prev.own_encoder else False
+        t0 = time.time()
+        prod.wait_stream(cur)                      # whatever produced the batch's tensors on the caller's stream
+        with torch.cuda.stream(prod):
+            p = self._produce(batch)
+            p.done = torch.cuda.Event()
+            p.done.record(prod)
+        p.stream = prod
+        p.host_s = time.time() - t0
+        self.__dict__["_last_prefetch"] = p
+        return p
+
+    def render(self, batch, prefetched=None, next_batch=None):
+        """`Renderer.render(batch)` (libs/renders/BaseRender.py:211-274).  prefetched / next_batch (not in the reference): see
+        prefetch(); `next_batch`'s frame is prefetched right after this frame's per-ray kernel is enqueued and returned as
+        ret["next_prefetched"]."""
+        if self.progressive:
+            return self.render_progressive(batch)
+        if not self.nerfhead.use_rgbhead:
+            raise L.GpnerfError("mesh extraction (use_rgbhead=False, BaseRender.py:255-272) is outside the per-ray render path")
+        dev = batch["ray_o"].device
+        main = torch.cuda.current_stream(dev)
+        if prefetched is None:
+            torch.cuda.synchronize(dev)
+            te = time.time()
+            p = self._produce(batch)
+        else:
+            p = prefetched
+            if p.batch is not batch:
+                raise L.GpnerfError("render(batch, prefetched=p): p was prefetched for another batch")
+            te = time.time()
+            main.wait_event(p.done)                # the per-ray kernel reads what the producer stream wrote
+        frame, rays, order, n, neg, group = p.frame, p.rays, p.order, p.n, p.neg, p.group
+        sharded = group is not None
 
         def fn(r):
             # sharded: `r` is this rank's share, already in patch-major order
@@ -337,34 +401,64 @@ class Renderer(nn.Module):
         all_keys = ("rgb_map", "depth_map", "acc_map", "disp_map", "weights", "z_vals", "rgb_in_map")
         keys = P_.PIXEL_KEYS if (sharded and self.sharded_outputs == "pixels") else all_keys
         o = P_.render_sharded(fn, rays, keys=keys, group=group, order=order if sharded else None)
-        torch.cuda.synchronize(dev)
+        nxt = self.prefetch(next_batch) if next_batch is not None else None      # enqueued BEHIND this frame's per-ray kernel
+        if prefetched is None and nxt is None:
+            torch.cuda.synchronize(dev)
+        else:
+            main.synchronize()                     # this frame only: the next frame's producers may still be running
         t2 = time.time()
         # etime = the encoder alone, rtime = everything else of the call (demo_render.py:441-446,494-497 keeps these two clocks;
-        # BaseTrainer.py:276 sums rtime): the encoder's share is its device time between the two events
-        etime = ev0.elapsed_time(ev1) * 1e-3
-        rtime = max(0.0, (t2 - te) - etime)
-        if "featmaps" not in batch and isinstance(self.encoder, E_.ResUNet) and E_.range_check_pending(self.encoder):
+        # BaseTrainer.py:276 sums rtime): the encoder's share is its device time between the two events.  With a prefetched frame
+        # the encoder ran before the call: rtime = the call's wall time + the host time prefetch() took to enqueue the frame.
+        etime = p.ev0.elapsed_time(p.ev1) * 1e-3
+        rtime = max(0.0, (t2 - te) - etime) if prefetched is None else (t2 - te) + p.host_s
+        flagged = p.flagged
+        if flagged is None:
+            flagged = p.flagged = self._encoder_flagged() if p.own_encoder else False
+        if sharded and p.own_encoder:
+            # every rank encoded ITS views: one rank's flag is every rank's (the re-render below issues collectives, so the ranks
+            # must take the same branch) -- one 4-byte all-reduce per frame
+            fl = torch.tensor([1 if flagged else 0], dtype=torch.int32, device=rays.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)
+            flagged = p.flagged = bool(int(fl.item()))
+        if flagged:
             # this frame drove the split-f16 encoder out of its operand range (its feature maps are NaN-ridden): encode it in the
-            # exact form and render again from those maps; the wasted pass stays in rtime, the exact encoder's time goes to etime
+            # exact form and render again from those maps; the wasted per-ray pass stays in rtime (not the wasted encoder pass,
+            # which a normal frame's rtime does not hold either), the exact encoder's time goes to etime
             t3 = time.time()
             fm = self.encoder.forward_exact(batch["src_imgs"].squeeze(0))
             torch.cuda.synchronize(dev)
             t_exact = time.time() - t3
             ret = self.render(dict(batch, featmaps=fm))
             ret["etime"] = t_exact
-            ret["rtime"] = ret["rtime"] + (t2 - te)
+            ret["rtime"] = ret["rtime"] + rtime
+            if nxt is not None:
+                ret["next_prefetched"] = nxt
             return ret
         if keys is P_.PIXEL_KEYS:
-            return {"rgb_map": o["rgb_map"].view(1, n, 3), "depth_map": o["depth_map"].view(1, n, 1), "etime": etime, "rtime": rtime}
-        return {
-            "rgb_map": o["rgb_map"].view(1, n, 3), "disp_map": o["disp_map"].view(1, n, 1),
-            "acc_map": o["acc_map"].view(1, n, 1), "depth_map": o["depth_map"].view(1, n, 1),
-            "alpha": o["weights"].view(1, n, -1), "z_vals": o["z_vals"].view(1, n, -1),
-            "rgb_in_map": o["rgb_in_map"].view(1, n, 9),
-            # BaseRender.render returns neither; the evaluation loop reads ret["rtime"] (BaseTrainer.py:276), which only the
-            # demo renderer provides: encoder time and everything after it, each on its own clock (demo_render.py:441-446,494-497)
-            "etime": etime, "rtime": rtime,
-        }
+            ret = {"rgb_map": o["rgb_map"].view(1, n, 3), "depth_map": o["depth_map"].view(1, n, 1), "etime": etime, "rtime": rtime}
+        else:
+            ret = {
+                "rgb_map": o["rgb_map"].view(1, n, 3), "disp_map": o["disp_map"].view(1, n, 1),
+                "acc_map": o["acc_map"].view(1, n, 1), "depth_map": o["depth_map"].view(1, n, 1),
+                "alpha": o["weights"].view(1, n, -1), "z_vals": o["z_vals"].view(1, n, -1),
+                "rgb_in_map": o["rgb_in_map"].view(1, n, 9),
+                # BaseRender.render returns neither; the evaluation loop reads ret["rtime"] (BaseTrainer.py:276), which only the
+                # demo renderer provides: encoder time and everything after it, each on its own clock (demo_render.py:441-446,494-497)
+                "etime": etime, "rtime": rtime,
+            }
+        if nxt is not None:
+            ret["next_prefetched"] = nxt
+        return ret
+
+
+class Prefetched:
+    """What Renderer._produce leaves for the per-ray launch: the frame, its ray list and patch order, the encoder's two events,
+    and (prefetch()) the event that ends the producer stream's work.  `flagged`: the encoder's range verdict once it is known."""
+
+    def __init__(self, **kw):
+        self.done, self.stream, self.host_s, self.flagged = None, None, 0.0, None
+        self.__dict__.update(kw)
 
 
 def _record_on(stream, *items):

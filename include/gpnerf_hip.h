@@ -73,6 +73,12 @@ extern "C" {
                                       On trained parameters it sits at the op-for-op CPU oracle's distance from the reference
                                       where the folded form is 5-10 x further.  Needs frame->head_blob_ref */
 
+#define GPNERF_FLAG_RESERVE_CUS(n) (((uint32_t)(n) & 0xffu) << 24)
+                                   /* bits 24..31: plan the launch for n fewer compute units (rounded down to a multiple of 8: one
+                                      per XCD round).  The persistent workgroups then leave n CUs idle for kernels of other
+                                      streams -- a pipelined evaluation loop runs the NEXT frame's encoder and volume builder
+                                      there (Renderer.prefetch).  Results are bit-identical for any n */
+
 /* Per-frame constants (everything render_rays reads that does not depend on the ray).
  * Layouts are channels-last so that one bilinear / trilinear tap is one contiguous
  * 128-byte line; gpnerf_relayout_* produce them from the reference's NCHW tensors. */

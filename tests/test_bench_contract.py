@@ -69,6 +69,10 @@ def test_bench_starts_its_own_ranks():
     c4 = j["config4_1024"]
     assert c4["rays_total"] == 1024 * 1024 and c4["rays_per_rank"] * 2 >= c4["rays_total"] and c4["value"] > 0
     assert j["maps_finite"] is True and c4["maps_finite"] is True
+    # who ran where: one report per rank, the device each sat on, its own kernel time
+    assert [r["rank"] for r in j["ranks"]] == [0, 1] and all(r["device_name"] and r["kernel_ms"] > 0 for r in j["ranks"])
+    assert j["distinct_devices"] == (2 if torch.cuda.device_count() >= 2 else 1)
+    assert j["kernel_ms_per_rank"]["max"] >= j["kernel_ms_per_rank"]["min"] > 0
 
 
 def test_bench_launch_line_is_the_drivers():
@@ -109,3 +113,47 @@ def test_bench_self_launch_relays_one_line_and_the_childs_status(tmp_path, monke
     assert rc == 7
     assert [l for l in out.out.splitlines() if l.strip()] == ['{"metric": "rays_per_sec", "n_gpus": 2}']
     assert "launcher chatter" in out.err
+
+
+def _rank_report_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rep = dict(bench.device_identity(torch.device("cpu")), rank=rank, local_rank=rank, kernel_ms=1.0 + rank, exchange_ms=0.25 * (rank + 1), rays=1000 + rank)
+    out = bench.summarize_ranks(bench.gather_rank_reports(rep, world))
+    if rank == 0:
+        q.put(out)
+    dist.destroy_process_group()
+
+
+def test_rank_reports_are_gathered_into_the_line():
+    """N > 1: every rank's device identity, its own kernel time and the exchange's time reach rank 0 through ONE all_gather_object
+    (gloo, world 2): `ranks` in rank order, `distinct_devices`, per-rank kernel spread, exchange time (VERDICT r4 next #5)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rank_report_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = q.get(timeout=120)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and out["distinct_devices"] == 2          # two processes = two "devices" on the CPU
+    assert out["kernel_ms_per_rank"] == {"min": 1.0, "max": 2.0, "mean": 1.5} and out["exchange_ms"]["max"] == 0.5
+    assert all(k in out["ranks"][0] for k in ("device_index", "device_name", "pci_bus_id", "uuid", "rays"))
+    sys.path.insert(0, ROOT)
+    import bench
+    one = bench.summarize_ranks([dict(rank=0, device_index=0, device_name="x", pci_bus_id="0000:05:00.0", uuid=None, kernel_ms=3.0, exchange_ms=None)])
+    assert one["distinct_devices"] == 1 and one["exchange_ms"] is None
+    two_on_one = bench.summarize_ranks([dict(rank=r, device_index=0, device_name="x", pci_bus_id="0000:05:00.0", uuid=None, kernel_ms=3.0, exchange_ms=None) for r in (0, 1)])
+    assert two_on_one["distinct_devices"] == 1          # the gloo dry run's two ranks on cuda:0 show up as what they are

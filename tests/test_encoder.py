@@ -310,6 +310,41 @@ def test_a_frame_that_leaves_the_split_range_is_encoded_exactly():
 
 
 @pytest.mark.gpu
+def test_an_out_of_range_image_is_caught_whatever_the_parameter_class():
+    """"static" parameters bound every operand BEHIND the stem; the stem reads the image itself.  A pixel of 5 000 (beyond
+    the split's 4 094) or a non-finite one used to come back as finite, wrong feature maps (ReLU turns the poisoned channel's NaNs into
+    zeros).  The flag is now read for every class -- eager call, graph replay, deferred check -- and the frame takes the exact form;
+    a stale flag from a pass nobody checked does not send the NEXT frame there."""
+    net, _ = _net(8)
+    net = net.to("cuda:0")
+    assert net.check_operand_range(96, 128) == "static"
+    ordinary = torch.from_numpy(syn.make_encoder_images(96, 128, 8)).to("cuda:0")
+    bad = ordinary.clone()
+    bad[1, 2, 40, 50] = 5000.0
+    want = _float64_encoder(net, bad.cpu())
+    with torch.no_grad():
+        n0 = net.exact_frames
+        got = net(bad)
+        assert net.exact_frames == n0 + 1, "an out-of-range pixel must raise the flag under static parameters too"
+        assert float(np.abs(got.cpu().numpy() - want).max()) < 1e-4 * max(1.0, float(np.abs(want).max()))
+        g2 = enc.forward_graphed(net, bad)
+        assert net.exact_frames == n0 + 2 and torch.equal(got, g2)
+        enc.forward_graphed(net, bad, defer_range_check=True)         # a deferred pass whose verdict ...
+        torch.cuda.synchronize()
+        assert enc.range_check_pending(net)                           # ... is there for the asking
+        enc.forward_graphed(net, bad, defer_range_check=True)         # and one nobody asks about:
+        torch.cuda.synchronize()
+        net.__dict__.pop("_gpnerf_pending_run", None)                 # (a caller that never called range_check_pending)
+        n1 = net.exact_frames
+        again = enc.forward_graphed(net, ordinary)                    # the next ordinary frame starts from a zero flag
+        assert net.exact_frames == n1 and torch.equal(again, net.forward_fast(ordinary))
+        nan_img = ordinary.clone()
+        nan_img[0, 0, 3, 3] = float("nan")
+        net(nan_img)
+        assert net.exact_frames == n1 + 1
+
+
+@pytest.mark.gpu
 def test_weights_beyond_the_split_range_take_the_exact_form():
     net, _ = _net(6)
     with torch.no_grad():

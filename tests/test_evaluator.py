@@ -77,6 +77,33 @@ def test_identical_images_and_bounding_rect():
         ev.ssim_images(torch.rand(5, 20, 3), torch.rand(5, 20, 3))
 
 
+def test_ssim_closed_forms():
+    """skimage is not in the image, so `ssim_images` cannot be pinned to it; what CAN be checked without it is that the
+    restatement IS the published formula (Wang et al. 2004, skimage's defaults for float images: 7x7 uniform window, sample
+    covariance, K1 = 0.01, K2 = 0.03, L = 2) on inputs whose SSIM has a closed form:
+      * identical images: every window gives (2 mu^2 + c1)(2 s^2 + c2) / ((2 mu^2 + c1)(2 s^2 + c2)) = 1;
+      * a constant image a against a + c: all (co)variances vanish, SSIM = (2 a (a + c) + c1) / (a^2 + (a + c)^2 + c1), c1 = (K1 L)^2;
+      * x against its negative -x (zero-mean windows are not needed): numerator (-2 mu^2 + c1)(-2 s^2 + c2), i.e. for a checkerboard of
+        +-v, whose every 7x7 window has the same |mean| = v / 49 and sample variance s^2 = (49 v^2 - v^2 / 49) / 48."""
+    c1, c2 = (0.01 * 2.0) ** 2, (0.03 * 2.0) ** 2
+    x = torch.rand(20, 24, 3)
+    assert abs(ev.ssim_images(x, x) - 1.0) < 1e-12
+    for a, c in ((0.3, 0.1), (0.0, 0.5), (0.7, -0.7), (-0.2, 0.05)):
+        want = (2 * a * (a + c) + c1) / (a * a + (a + c) ** 2 + c1)
+        got = ev.ssim_images(torch.full((9, 11, 3), a, dtype=torch.float64), torch.full((9, 11, 3), a + c, dtype=torch.float64))
+        assert abs(got - want) < 1e-12, (a, c, got, want)
+    v = 0.25
+    yy, xx = torch.meshgrid(torch.arange(15), torch.arange(17), indexing="ij")
+    board = (v * (1 - 2 * ((yy + xx) % 2))).double()[..., None].repeat(1, 1, 3)
+    mu2 = (v / 49.0) ** 2                                    # 25 cells of one sign, 24 of the other
+    s2 = (49 * v * v - 49 * mu2) / 48.0                      # sum x^2 - n mu^2 over n - 1
+    want = ((-2 * mu2 + c1) * (-2 * s2 + c2)) / ((2 * mu2 + c1) * (2 * s2 + c2))
+    assert abs(ev.ssim_images(board, -board) - want) < 1e-12
+    # symmetric, and bounded by 1
+    y = torch.rand(20, 24, 3)
+    assert abs(ev.ssim_images(x, y) - ev.ssim_images(y, x)) < 1e-12 and ev.ssim_images(x, y) < 1.0
+
+
 def test_psnr_matches_the_reference_evaluators_value():
     """tests/golden/e2e_64x64_s32.npz carries the value libs/evaluators/if_nerf.py Evaluator.psnr_metric returned for the
     reference's own render against a seeded ground truth; the device-side formula reproduces it on the same arrays."""

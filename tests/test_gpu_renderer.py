@@ -526,6 +526,68 @@ def test_the_evaluation_loop_matches_the_references_loop(plugins):
     assert set(out["metrics"]) == {"mse", "psnr", "ssim"} and len(out["ssim"]) == 3
 
 
+def test_pipelined_evaluation_loop_is_the_serial_loop_bit_for_bit(plugins):
+    """evaluate_loop(pipeline=True) prefetches frame t + 1 (encoder graph, volume builder, frame glue on a second
+    stream) right behind frame t's per-ray kernel.  Five different frames through the real encoder and builder: every map of every
+    frame, the per-frame PSNR / MSE / SSIM and the summary are IDENTICAL to the serial loop's; the fast-form plugin and a frame
+    whose image leaves the encoder's range (handled at the end of ITS call, with the next frame already prefetched) included."""
+    hip_render, _ = plugins
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    ev = importlib.import_module("gp-nerf_amd.evaluator")
+    c = cfg(n_samples=24)
+    c.encoder.file = "hip_encoder"
+    r = hip_render.build_render(c).to("cuda:0").eval()
+    scenes = [syn.make_scene(H=64, W=64, seed=300 + i, fill="full", pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1, make_volumes=False)
+              for i in range(5)]
+    load_head(r, scenes[0])
+    loader = []
+    for i, sc in enumerate(scenes):
+        sc["src_imgs"] = syn.make_encoder_images(64, 64, 300 + i)[None]
+        b = {k: v.cpu() for k, v in batch_of(sc, with_products=False).items()}          # the loop moves them to the device
+        b["mask_at_box"] = torch.from_numpy(sc["mask_at_box"])
+        b["rgb"] = torch.rand((1, int(sc["mask_at_box"].sum()), 3), generator=torch.Generator().manual_seed(i))
+        loader.append(b)
+    loader[3]["src_imgs"] = loader[3]["src_imgs"].clone()
+    loader[3]["src_imgs"][0, 1, 2, 10, 20] = 6000.0                 # beyond the split-f16 stem's range: this frame takes the exact encoder
+    ce = NS(dataset=NS(H=64, W=64, ratio=1.0), test=NS(test_seq="pipe", save_imgs=False), head=NS(rgb=NS(use_rgbhead=True)))
+    runs = {}
+    for mode in (False, True):
+        rets, depth = [], [0]
+        render = r.render
+
+        def spy(batch, **kw):              # top-level calls only: the out-of-range frame's render() calls itself once more
+            depth[0] += 1
+            try:
+                out = render(batch, **kw)
+            finally:
+                depth[0] -= 1
+            if depth[0] == 0:
+                rets.append(out)
+            return out
+
+        r.render = spy
+        n0 = r.encoder.exact_frames
+        out = ev.evaluate_loop(r, loader, ce, device="cuda:0", pipeline=mode, quiet=True)
+        del r.__dict__["render"]
+        assert r.encoder.exact_frames == n0 + 1, "exactly the out-of-range frame is re-encoded"
+        runs[mode] = (out, rets)
+    (a, ra), (b, rb) = runs[False], runs[True]
+    assert a["count"] == b["count"] == 5 and a["psnr"] == b["psnr"] and a["mse"] == b["mse"] and a["ssim"] == b["ssim"] and a["metrics"] == b["metrics"]
+    for i, (x, y) in enumerate(zip(ra, rb)):
+        for k in ("rgb_map", "depth_map", "acc_map", "disp_map", "alpha", "z_vals", "rgb_in_map"):
+            assert torch.equal(torch.nan_to_num(x[k]), torch.nan_to_num(y[k])), (i, k)
+        assert y["rtime"] > 0 and y["etime"] > 0 and "next_prefetched" not in y
+    assert abs(b["total_time"] - sum(y["rtime"] for y in rb)) < 1e-9
+    # a prefetched record belongs to its batch
+    with torch.no_grad():
+        val = {k: v.to("cuda:0") for k, v in loader[0].items()}
+        p = r.prefetch(val)
+        with pytest.raises(Exception):
+            r.render({k: v.to("cuda:0") for k, v in loader[1].items()}, prefetched=p)
+        ok = r.render(val, prefetched=p)
+    assert torch.equal(ok["rgb_map"], ra[0]["rgb_map"])
+
+
 def test_config5_sized_frame_with_the_real_encoder_matches_the_reference(plugins):
     """The only available stand-in for BASELINE.json configs[4] at its own size (the ZJU-MoCap data is not in the tree): 3 source
     views of 512x512 (1024 x ratio 0.5, configs/trainzju_valzju.yaml) -> 128x128 feature maps, the full-size SMPL box, 112 475 rays
