@@ -427,6 +427,10 @@ def beside_headline(args, fm, wl, kw, flow):
         res["renderer_api_survey_frame"] = renderer_api_wall(args, None, survey=True)
     except Exception as e:
         res["renderer_api_survey_frame"] = {"error": repr(e)[:200]}
+    try:                                         # the evaluation loop over such frames, serial (the reference's) against pipelined
+        res["eval_loop"] = eval_loop_wall(args)
+    except Exception as e:
+        res["eval_loop"] = {"error": repr(e)[:300]}
     return res
 
 
@@ -483,6 +487,53 @@ def renderer_api_wall(args, wl, survey=False):
                          "calls": len(ts), "rays": int(ret["rgb_map"].shape[1]), "returns": sorted(k for k in ret if k not in ("etime", "rtime"))}
     res["note"] = ("products_in_batch: batch carries featmaps + the 4 dense levels; with_producers: hip_encoder + vertex attention + sparse "
                    "volume builder run per frame (their volumes are sparse, the per-ray kernel's work is the same)")
+    return res
+
+
+def eval_loop_wall(args, frames=12):
+    """The evaluation LOOP (libs/trainers/BaseTrainer.py:255-280 = evaluator.evaluate_loop) over `frames` ZJU-sized frames (SURVEY.md
+    8d's f = 1.05 W camera, ~74 k rays x 64 samples, hip_encoder + vertex attention + sparse volume builder per frame, PSNR / MSE /
+    SSIM per frame): wall time per frame of the reference's strictly serial loop against the pipelined one (Renderer.prefetch of
+    frame t + 1 behind frame t's per-ray kernel).  Same bits per frame (tests/test_gpu_renderer.py)."""
+    import torch
+    from types import SimpleNamespace as NS
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    ev = importlib.import_module("gp-nerf_amd.evaluator")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sc = syn.make_scene(H=512, W=512, seed=args.seed, fill="survey", pose="identity", make_volumes=False)
+    p = os.path.join(ROOT, "gp-nerf_amd", "plugins")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    hip_render = importlib.import_module("hip_render")
+    cfg = NS(encoder=NS(file="hip_encoder", name="resnet34", out_ch=32),
+             head=NS(file="hip_head", rgb=NS(use_rgbhead=True), sigma=NS(code_dim=32, n_heads=4, n_layers=4, n_smpl=6890, outdims=[32, 32, 32, 32])),
+             dataset=NS(train=NS(name="zju_mocap", chunk=400), test=NS(name="zju_mocap", chunk=2000), voxel_size=[0.005] * 3, H=512, W=512, ratio=1.0),
+             train=NS(n_rays=1024, n_samples=64), test=NS(mesh_th=50, test_seq="bench", save_imgs=False))
+    torch.manual_seed(args.seed)                 # the encoder's initialisation (the head's comes from the scene)
+    r = hip_render.build_render(cfg).to(dev).eval()
+    sd = r.state_dict()
+    for k, v in sc["head"].items():
+        sd["nerfhead." + k] = torch.from_numpy(v.copy())
+    r.load_state_dict(sd, strict=True)
+    keys = ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "feature", "coord", "out_sh", "bounds", "Rh", "R", "Th", "body_msk",
+            "mask_at_box")
+    b = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in keys}
+    n = int(b["ray_o"].shape[1])
+    b["rgb"] = torch.rand((1, n, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    loader = [dict(b) for _ in range(frames)]
+    res = {"frames": frames, "rays_per_frame": n}
+    for name, mode in (("serial", False), ("pipelined", True)):
+        ev.evaluate_loop(r, loader[:3], cfg, pipeline=mode, quiet=True)               # warm-up: graph capture, allocator
+        walls, rts = [], []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            out = ev.evaluate_loop(r, loader, cfg, pipeline=mode, quiet=True)
+            walls.append(out["wall_time"] / frames * 1e3)
+            rts.append(out["avg_time"] * 1e3)
+        res[name] = {"wall_ms_per_frame": float(np.median(walls)), "wall_ms_per_frame_min_max": [float(np.min(walls)), float(np.max(walls))],
+                     "avg_rtime_ms": float(np.median(rts)), "psnr_first_frame": float(out["psnr"][0])}
+    res["note"] = ("wall = the loop's own clock / frames, evaluator (PSNR, MSE, SSIM on the device) included; pipelined: frame t+1's encoder graph, "
+                   "builder and frame glue are enqueued on a second stream behind frame t's per-ray kernel, the host evaluates frame t meanwhile")
     return res
 
 

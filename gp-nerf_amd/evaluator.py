@@ -145,13 +145,24 @@ def evaluate_loop(render, eval_loader, cfg, device=None, quiet=False, pipeline=N
             count += 1
     else:
         it = iter(eval_loader)
-        with torch.no_grad():
+
+        def fetch():
             data = next(it, None)
-            val = {k: move(v) for k, v in data.items()} if data is not None else None
+            if data is None:
+                return None
+            val = {k: move(v) for k, v in data.items()}
+            if hasattr(model, "host_consts"):
+                # the frame's small constants go to the host NOW, from the loader's CPU tensors when it hands out those (no copy at
+                # all), otherwise while no per-ray kernel is running: inside prefetch() the copy would wait for that kernel
+                src = data if all(not (isinstance(v, torch.Tensor) and v.is_cuda) for v in data.values()) else val
+                val["_gpnerf_consts"] = model.host_consts(src)
+            return val
+
+        with torch.no_grad():
+            val = fetch()
             pre = model.prefetch(val) if val is not None else None
             while val is not None:
-                data = next(it, None)
-                nxt = {k: move(v) for k, v in data.items()} if data is not None else None
+                nxt = fetch()
                 ret = model.render(val, prefetched=pre, next_batch=nxt)
                 pre = ret.pop("next_prefetched", None)
                 evaluator.evaluate(ret, val)

@@ -273,7 +273,7 @@ class Renderer(nn.Module):
         # go back to back.  (Round 2 fetched the constants before the encoder's first launch: the device idled ~0.3 ms per call.)
         # the encoder's time comes from two events on the stream instead of two host synchronisations around it
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
+        ev0.record()                               # (also what the side stream waits for: the batch's tensors, NOT the encoder)
         featmaps = self.encode(batch, defer_range_check=True)
         ev1.record()
         self.nerfhead.head_blob(dev)                                   # (cached; packs on a parameter change)
@@ -295,9 +295,18 @@ class Renderer(nn.Module):
         # the FREE -- a block dropped early could be handed to side's next allocation while main's kernels still read it.  They are
         # therefore recorded on `main` below (record_stream), on top of every one of them staying referenced until the
         # synchronisation at the end of render().
-        side.wait_stream(main)                     # (the batch's tensors: complete on `main` -- render() synchronised, prefetch() waited)
+        # the side stream starts from where `main` stood BEFORE the encoder was enqueued (the batch's tensors are complete there:
+        # render() synchronised, prefetch() made its stream wait for the caller's).  Waiting for `main` as it stands now would put
+        # the constants' device-to-host copy -- which the host blocks on -- behind the encoder, and in a pipelined loop behind the
+        # previous frame's per-ray kernel that the encoder itself is queued behind (measured: prefetch() then took a whole frame).
+        side.wait_event(ev0)
         with torch.cuda.stream(side):
-            consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
+            # (a pipelined loop fetches the constants when it moves the batch to the device -- host_consts() -- because HERE the
+            # device-to-host copy would wait for a CU of the previous frame's persistent per-ray kernel: measured, the host then sat
+            # in prefetch() for that kernel's whole 4.6 ms)
+            consts = batch.get("_gpnerf_consts")
+            if consts is None:
+                consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
             prepared = self.prepare_builder_inputs(batch, consts)      # what the builder needs that does not depend on the encoder
             imgs4 = F_.relayout_images(batch["src_imgs"][0])           # the frame's channels-last source images
         main.wait_stream(side)
@@ -331,11 +340,17 @@ class Renderer(nn.Module):
         return Prefetched(batch=batch, frame=frame, rays=rays, order=order, n=n, neg=neg, ev0=ev0, ev1=ev1, group=group,
                           keep=(featmaps, consts, prepared, imgs4), own_encoder="featmaps" not in batch)
 
+    def host_consts(self, batch):
+        """The frame's small constants (camera matrices, Rh, Th, bounds, out_sh) on the host: ONE device-to-host copy (none for
+        a batch still on the CPU).  A caller that prefetches puts the result into batch["_gpnerf_consts"] while no per-ray
+        kernel is in flight (evaluator.evaluate_loop does)."""
+        return F_.Frame.consts_of_batch(batch, self.voxel_size)
+
     def _encoder_flagged(self):
         """True when the last deferred encoder pass left the split-f16 operand range (its stream has been synchronised)"""
         return isinstance(self.encoder, E_.ResUNet) and E_.range_check_pending(self.encoder)
 
-    def prefetch(self, batch):
+    def prefetch(self, batch, after=None):
         """Enqueue everything of `batch`'s frame that comes before the per-ray kernel (`_produce`) on a stream of its own and return
         at once; `render(batch, prefetched=p)` then only launches the per-ray kernel.  In an evaluation loop this is called for
         frame t + 1 while frame t's per-ray kernel runs (`render(..., next_batch=...)` does that): the host's ~0.5 ms of enqueueing
@@ -343,6 +358,9 @@ class Renderer(nn.Module):
         launches start the moment frame t's persistent workgroups let go of CUs.  (They do not run BESIDE the per-ray kernel: its
         workgroups hold every CU's registers and LDS.  Leaving CUs free for them -- GPNERF_FLAG_RESERVE_CUS -- was measured and
         costs the kernel more than the overlap returns: profiles/r05/d_pipeline.txt.)  Same bits as the serial call.
+        after: an event on the caller's stream behind which the batch's tensors are complete (default: everything enqueued on the
+        caller's stream so far -- render(next_batch=...) passes the point BEFORE its own per-ray kernel, or the producers' first
+        host-side wait would sit behind that kernel).
         Not in the reference (its loop is strictly serial: libs/trainers/BaseTrainer.py:255-280)."""
         if self.progressive or P_.resolve_group(self.shard_group) is not None:
             raise L.GpnerfError("prefetch() is for the dense single-GPU path")
@@ -357,7 +375,10 @@ class Renderer(nn.Module):
             prod.synchronize()
             prev.flagged = self._encoder_flagged() if prev.own_encoder else False
         t0 = time.time()
-        prod.wait_stream(cur)                      # whatever produced the batch's tensors on the caller's stream
+        if after is not None:
+            prod.wait_event(after)
+        else:
+            prod.wait_stream(cur)                  # whatever produced the batch's tensors on the caller's stream
         with torch.cuda.stream(prod):
             p = self._produce(batch)
             p.done = torch.cuda.Event()
@@ -389,6 +410,10 @@ class Renderer(nn.Module):
             main.wait_event(p.done)                # the per-ray kernel reads what the producer stream wrote
         frame, rays, order, n, neg, group = p.frame, p.rays, p.order, p.n, p.neg, p.group
         sharded = group is not None
+        ready = None
+        if next_batch is not None:                 # where the caller's stream stands before this frame's per-ray kernel
+            ready = torch.cuda.Event()
+            ready.record(main)
 
         def fn(r):
             # sharded: `r` is this rank's share, already in patch-major order
@@ -401,7 +426,7 @@ class Renderer(nn.Module):
         all_keys = ("rgb_map", "depth_map", "acc_map", "disp_map", "weights", "z_vals", "rgb_in_map")
         keys = P_.PIXEL_KEYS if (sharded and self.sharded_outputs == "pixels") else all_keys
         o = P_.render_sharded(fn, rays, keys=keys, group=group, order=order if sharded else None)
-        nxt = self.prefetch(next_batch) if next_batch is not None else None      # enqueued BEHIND this frame's per-ray kernel
+        nxt = self.prefetch(next_batch, after=ready) if next_batch is not None else None      # enqueued behind this frame's per-ray kernel
         if prefetched is None and nxt is None:
             torch.cuda.synchronize(dev)
         else:

@@ -413,6 +413,20 @@ def test_folded_coarse_levels_equal_the_layer_per_sample(size, S, neg, kw, fm, o
             assert_close(b[k][pick], ref[k], TOL, k)
 
 
+def test_reserved_cus_do_not_change_a_bit(fm, syn):
+    """GPNERF_FLAG_RESERVE_CUS plans the launch for fewer compute units (the pipelined loop's experiment, profiles/r05/d_pipeline.txt):
+    a ray's result is a function of the ray alone, so every map is bit-identical for any reserve -- plain and early-terminated."""
+    sc = syn.make_scene(H=288, W=288, seed=71, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1, sigma_bias=1.0)
+    fr = build_frame(fm, sc)
+    rays = rays_of(sc)
+    for kw in ({}, {"early_term": True, "term_eps": 1e-5}):
+        base = fm.render_fused(fr, rays, 48, want=("weights", "rgb_in"), **kw)
+        for reserve in (8, 64, 200, 255):
+            got = fm.render_fused(fr, rays, 48, want=("weights", "rgb_in"), reserve_cus=reserve, **kw)
+            for k in base:
+                assert torch.equal(torch.nan_to_num(base[k]), torch.nan_to_num(got[k])), (kw, reserve, k)
+
+
 def test_a_frame_that_gets_new_volumes_drops_what_it_derived_from_the_old_ones(fm, syn):
     """Frame._set_volumes on a used Frame (ADVICE r2): the folded coarse levels and the occupancy volume belong to the old levels;
     kept, the next dense launch would interpolate the old tables with the new levels' dimensions."""
