@@ -427,6 +427,10 @@ def beside_headline(args, fm, wl, kw, flow):
         res["renderer_api_survey_frame"] = renderer_api_wall(args, None, survey=True)
     except Exception as e:
         res["renderer_api_survey_frame"] = {"error": repr(e)[:200]}
+    try:                                         # the README command's renderer on a person-shaped frame
+        res["demo_render_body_frame"] = demo_render_body_frame(args)
+    except Exception as e:
+        res["demo_render_body_frame"] = {"error": repr(e)[:300]}
     try:                                         # the evaluation loop over such frames, serial (the reference's) against pipelined
         res["eval_loop"] = eval_loop_wall(args)
     except Exception as e:
@@ -488,6 +492,77 @@ def renderer_api_wall(args, wl, survey=False):
     res["note"] = ("products_in_batch: batch carries featmaps + the 4 dense levels; with_producers: hip_encoder + vertex attention + sparse "
                    "volume builder run per frame (their volumes are sparse, the per-ray kernel's work is the same)")
     return res
+
+
+def demo_render_body_frame(args):
+    """The README command's renderer (`render.file hip_demo_render` = libs/renders/demo_render.py: pixels selected from the occupied
+    voxels, samples occupancy-culled) on a PERSON-SHAPED frame: synthetic.body_vertices' capsule-limbed figure in the full-size SMPL
+    box, the dense levels non-negative on the voxels the sparse pyramid writes for those vertices, SURVEY.md 8d's f = 1.05 W camera at
+    512x512, 64 samples (the scene of tests/golden/demo_body_s64.npz with pose = identity).  Wall time of render(batch) with the
+    products in the batch, the per-ray kernel alone, the fraction of the samples it evaluates, and the MFMA roofline on those."""
+    import torch
+    from types import SimpleNamespace as NS
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    fm = importlib.import_module("gp-nerf_amd.frame")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    S = 64
+    sc = syn.make_scene(H=512, W=512, seed=args.seed, focal_mul=1.05, body="capsules", sigma_bias=0.5, bias_std=0.1, pose="identity")
+    p = os.path.join(ROOT, "gp-nerf_amd", "plugins")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    demo = importlib.import_module("hip_demo_render")
+    cfg = NS(encoder=NS(file="hip_encoder", name="resnet34", out_ch=32),
+             head=NS(file="hip_head", rgb=NS(use_rgbhead=True), sigma=NS(code_dim=32, n_heads=4, n_layers=4, n_smpl=6890, outdims=[32, 32, 32, 32])),
+             dataset=NS(train=NS(name="zju_mocap", chunk=400), test=NS(name="zju_mocap", chunk=2000), voxel_size=[0.005] * 3),
+             train=NS(n_rays=1024, n_samples=S), test=NS(mesh_th=50))
+    torch.manual_seed(args.seed)
+    r = demo.build_render(cfg).to(dev).eval()
+    sd = r.state_dict()
+    for k, v in sc["head"].items():
+        sd["nerfhead." + k] = torch.from_numpy(v.copy())
+    r.load_state_dict(sd, strict=True)
+    keys = ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "feature", "coord", "out_sh", "bounds", "Rh", "R", "Th", "body_msk",
+            "mask_at_box", "target_K", "target_pose", "target_K_inv")
+    b = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in keys}
+    b["featmaps"] = torch.from_numpy(sc["featmaps"]).to(dev)
+    b["volumes"] = [torch.from_numpy(v).to(dev) for v in sc["volumes"]]
+    with torch.no_grad():
+        for _ in range(2):
+            ret = r.render(b)
+        ts, rt, kr = [], [], []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ret = r.render(b)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            rt.append(ret["rtime"] * 1e3)
+            kr.append(ret["time_slots"]["render"] * 1e3)
+    n_sel = int(ret["mask_at_box"].sum())
+    # the per-ray launch alone + how many samples it evaluates (samples_done counts the steps a ray's wavefront ran for it)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    frame = fm.Frame(t(sc["src_imgs"][0]), t(sc["featmaps"]), [t(v) for v in sc["volumes"]], t(sc["src_Ks"][0]), t(sc["src_poses"][0]),
+                     sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0], fm.pack_head(sc["head"], dev))
+    frame.build_occupancy()
+    rays, mask = fm.select_rays(frame, b["target_K"][0], b["target_pose"][0], 512, 512, sc["voxel_size"], b["bounds"][0, 0], b["Rh"][0], b["Th"][0],
+                                neg_ray=False, target_K_inv=b["target_K_inv"][0], compact=False)
+    idx = torch.nonzero(mask).squeeze(1)
+    order = fm.patch_order_of(idx, 512)
+    k_ms, _ = time_launches(lambda: fm.render_fused(frame, rays, S, occ_cull=True, want=(), ray_order=order, subset=True), 10, 3)
+    occ = frame.occ
+    pts, _, grid = fm.sample_points(frame, rays.index_select(0, idx.long()), S)
+    # evaluated = occupancy interpolates to > 0 at the sample (demo_render.py:270-283), with the renderer's literal 0.005 grid
+    import torch.nn.functional as F
+    g = grid.view(1, -1, 1, 1, 3)
+    ev = float((F.grid_sample(occ.view(1, 1, *occ.shape), g, padding_mode="zeros", align_corners=True).view(-1) > 0).float().mean())
+    flops = n_sel * S * ev * FLOP_PER_SAMPLE
+    return {"workload": "512x512 target, person-shaped vertices in the full-size SMPL box, f = 1.05 W, 64 samples/ray, progressive renderer",
+            "pixels_selected": n_sel, "pyramid_sites_per_level": [int((v.abs().sum(1) > 0).sum()) for v in b["volumes"]],
+            "wall_ms": float(np.median(ts)), "rtime_ms": float(np.median(rt)), "per_ray_kernel_ms_in_call": float(np.median(kr)),
+            "per_ray_kernel_ms": k_ms, "samples_evaluated_frac": ev,
+            "roofline_on_evaluated_samples": {"achieved_tflops": flops / (k_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                              "frac": flops / (k_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "note": "products (feature maps, dense levels) in the batch; wall = encoder-less render(batch) incl. ray selection, occupancy, "
+                    "device-to-host copy of the image"}
 
 
 def eval_loop_wall(args, frames=12):

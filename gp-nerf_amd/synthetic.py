@@ -243,6 +243,92 @@ def out_shape_dhw(bounds_smpl, voxel):
     return ((sh | 31) + 1).astype(np.int32)
 
 
+def body_vertices(n_verts=6890, aabb_half=(0.5, 0.9, 0.25)):
+    """A deterministic SMPL-SHAPED point set: `n_verts` points on the surface of a capsule-limbed figure in an A-pose (ellipsoid
+    torso and head, tapered capsules for neck / upper and lower arms / thighs / shanks, small ellipsoids for hands and feet), laid
+    out for the nominal SMPL box of half extents (0.5, 0.9, 0.25) m and scaled per axis to `aabb_half`.  Vertex budget per part
+    follows SMPL's own density (head and hands much denser than the torso), so that -- as with a real SMPL mesh at 5 mm voxels --
+    torso vertices mostly sit in voxels of their own while head / hand / foot vertices share voxels.  The uniform-in-the-box
+    vertices of the other scenes put a sparse-convolution site into every region of the box; these put them on a body's surface,
+    which is what decides the pyramid's site counts, the occupancy volume and the progressive renderer's cull rate
+    (libs/datasets/ZjumocapDataset.py:207-256 quantises the vertices the same way).  Points: Fibonacci lattices, no randomness."""
+    golden = math.pi * (3.0 - math.sqrt(5.0))
+
+    def ellipsoid(n, c, r):
+        i = np.arange(n, dtype=np.float64) + 0.5
+        z = 1.0 - 2.0 * i / n
+        rad = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+        th = golden * i
+        return np.asarray(c, np.float64) + np.stack([rad * np.cos(th), z, rad * np.sin(th)], 1) * np.asarray(r, np.float64)
+
+    def capsule(n, a, b, ra, rb):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        axis = b - a
+        L = np.linalg.norm(axis)
+        w = axis / L
+        u = np.cross(w, [0.0, 0.0, 1.0] if abs(w[2]) < 0.9 else [1.0, 0.0, 0.0])
+        u /= np.linalg.norm(u)
+        v = np.cross(w, u)
+        i = np.arange(n, dtype=np.float64) + 0.5
+        t = i / n
+        th = golden * i
+        r = ra + (rb - ra) * t
+        return a + t[:, None] * axis + r[:, None] * (np.cos(th)[:, None] * u + np.sin(th)[:, None] * v)
+
+    def cap(n, c, r, half_angle):
+        """n lattice points on the part of an ellipsoid that faces +z within `half_angle` (the face: SMPL spends ~half of the head's
+        vertices on eyes, nose, lips and ears, 2-4 mm apart -- several per 5 mm voxel)"""
+        i = np.arange(n, dtype=np.float64) + 0.5
+        z = 1.0 - (1.0 - math.cos(half_angle)) * i / n
+        rad = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+        th = golden * i
+        return np.asarray(c, np.float64) + np.stack([rad * np.cos(th), rad * np.sin(th), z], 1) * np.asarray(r, np.float64)
+
+    parts = [ellipsoid(600, (0.0, 0.66, 0.02), (0.085, 0.115, 0.10)),                     # head
+             cap(500, (0.0, 0.66, 0.02), (0.085, 0.115, 0.10), math.radians(38.0)),       # face
+             capsule(90, (0.0, 0.50, 0.0), (0.0, 0.58, 0.01), 0.055, 0.05),               # neck
+             ellipsoid(1700, (0.0, 0.16, 0.0), (0.175, 0.36, 0.115))]                     # torso + pelvis
+    for sx in (-1.0, 1.0):
+        parts += [capsule(260, (sx * 0.19, 0.43, 0.0), (sx * 0.33, 0.20, 0.0), 0.05, 0.04),          # upper arm
+                  capsule(240, (sx * 0.33, 0.20, 0.0), (sx * 0.44, -0.02, 0.03), 0.04, 0.03),        # forearm
+                  ellipsoid(400, (sx * 0.465, -0.085, 0.04), (0.028, 0.075, 0.04)),                  # hand
+                  capsule(430, (sx * 0.095, -0.12, 0.0), (sx * 0.12, -0.50, 0.015), 0.08, 0.055),    # thigh
+                  capsule(370, (sx * 0.12, -0.50, 0.015), (sx * 0.125, -0.84, 0.0), 0.055, 0.04),    # shank
+                  ellipsoid(300, (sx * 0.13, -0.875, 0.06), (0.045, 0.035, 0.115))]                  # foot
+    pts = np.concatenate(parts, 0)
+    assert pts.shape[0] == 6890
+    if n_verts != 6890:
+        pts = pts[np.linspace(0, 6889, n_verts).round().astype(np.int64)]
+    pts[:, 1] -= 0.5 * (pts[:, 1].max() + pts[:, 1].min())          # centred like the nominal box
+    scale = np.asarray(aabb_half, np.float64) / np.array([0.5, 0.9, 0.25])
+    return (pts * scale).astype(np.float32)
+
+
+def pyramid_sites(coord, out_sh, n_levels=N_LEVELS):
+    """Which voxels of each dense level the sparse pyramid writes for vertex voxels `coord` [M,3] (d,h,w): level k's sites are the
+    level k-1 sites' images under a 3x3x3 / stride-2 / pad-1 sparse convolution (SparseConvNet.py:85-92,105-111): output o is active
+    iff some active input sits at 2 o - 1 + t, t in {0,1,2}^3.  Returns n_levels bool arrays [D_k,H_k,W_k]."""
+    dims = np.asarray(out_sh, np.int64)
+    cur = np.zeros(tuple(dims), bool)
+    c = np.asarray(coord, np.int64)
+    ok = np.all((c >= 0) & (c < dims), 1)
+    cur[tuple(c[ok].T)] = True
+    out = []
+    for _ in range(n_levels):
+        dims = (dims + 2 - 3) // 2 + 1
+        nxt = np.zeros(tuple(dims), bool)
+        p = np.argwhere(cur)
+        for t in np.ndindex(3, 3, 3):
+            num = p + 1 - np.asarray(t)
+            keep = np.all(num % 2 == 0, 1)
+            o = num[keep] // 2
+            o = o[np.all((o >= 0) & (o < dims), 1)]
+            nxt[tuple(o.T)] = True
+        out.append(nxt)
+        cur = nxt
+    return out
+
+
 def make_scene(
     H=64,
     W=64,
@@ -265,6 +351,7 @@ def make_scene(
     feat_scale=1.0,
     feat_tail=0.0,
     vol_relu=False,
+    body="box",
 ):
     """Build one synthetic frame.
 
@@ -277,6 +364,10 @@ def make_scene(
     feat_scale (feature maps x this), feat_tail t > 0 (feature maps and volumes x exp(t N'): log-normal heavy tails),
     vol_relu (the dense levels are max(., 0): the sparse conv net ends in ReLU, so about half of every level is exactly zero),
     vol_scale (volumes x this).
+    body="capsules": the vertices are body_vertices() -- a capsule-limbed figure's surface instead of points uniform in the box --
+    the bounds are theirs (ZjumocapDataset.py:236-240), and the dense levels are non-negative values on exactly the voxels the
+    sparse pyramid would write for those vertices (pyramid_sites), zero elsewhere: site counts, occupancy and cull rates of a
+    person-shaped frame.
     """
     g = _rng(seed, 7)
     hx, hy, hz = [float(a) for a in aabb_half]
@@ -286,6 +377,10 @@ def make_scene(
     # pin the extremes so the bounds are exactly the nominal box
     verts[0] = [-hx, -hy, -hz]
     verts[1] = [hx, hy, hz]
+    if body == "capsules":
+        verts = body_vertices(n_verts, (hx, hy, hz))                # (the generator's draws above stay: the other arrays keep their streams)
+    elif body != "box":
+        raise ValueError(body)
     bounds = np.stack([verts.min(0), verts.max(0)], 0).astype(np.float32)
     bounds[0, 2] -= 0.05
     bounds[1, 2] += 0.05
@@ -347,6 +442,10 @@ def make_scene(
         featmaps = (featmaps * np.float32(feat_scale)).astype(np.float32)
 
     volumes = []
+    site_masks = None
+    if make_volumes and body == "capsules":
+        dhw0 = verts[:, [2, 1, 0]]
+        site_masks = pyramid_sites(np.round((dhw0 - bounds[0][[2, 1, 0]]) / voxel_size).astype(np.int64), out_sh)
     if make_volumes:
         occ_coarse = None
         if vol_occupancy is not None:
@@ -366,6 +465,8 @@ def make_scene(
                 r = 1 << (N_LEVELS - k)
                 m = np.repeat(np.repeat(np.repeat(occ_coarse, r, 0), r, 1), r, 2)
                 v = np.abs(v) * m[None, None].astype(np.float32)
+            if site_masks is not None:
+                v = np.abs(v) * site_masks[k - 1][None, None].astype(np.float32)
             volumes.append(v)
 
     # voxel index of every vertex, dhw order (ZjumocapDataset.py:243-247); only the

@@ -12,6 +12,45 @@ reference), so one set of weights drives both sides.
   spconv v1.2.1 (SubMConv3d / SparseConv3d by coordinate rulebook, `.dense()`).  spconv is absent from the reference tree and
   not installable here: **parity unpinned**; tests/test_volume_builder.py checks this restatement against the dense
   conv3d-with-mask definition it must agree with.
+
+spconv v1.2.1 semantics this restatement (and csrc/gpnerf_volume.hip behind it) assumes -- the reference pins the version in
+README.md:27-33 (`git checkout abf0acf30f5526ea93e687e3f424f62d9cd8313a`).  The library is NOT in this image and there is no
+network: the locations below are RECALLED from the published repository (traveller59/spconv at that commit), they were not read
+here, and nothing in this list has been executed against spconv.  A maintainer with spconv installed can settle every item with
+the ten-line check at the end.
+
+ 1. Weight layout and tap index.  `SparseConvolution.__init__` (spconv/conv.py) allocates `weight` as
+    `[kd, kh, kw, Cin, Cout]` (the reference's state_dict agrees: `xyzc_net.net.7.0.weight` is (3, 3, 3, 32, 32)) and
+    `indice_conv` (spconv/ops.py -> src/spconv/spconv_ops.cc `indiceConv`) views it as `filters.view(-1, Cin, Cout)`: tap
+    i = (kd * 3 + kh) * 3 + kw, kd slowest.  Here: `weight.view(k * k * k, cin, cout)` and `offs` from
+    `meshgrid(..., indexing="ij")` in the same order.
+ 2. Tap index <-> spatial offset.  include/spconv/geometry.h `getValidOutPos` pairs input position p with output o under
+    offset index built from `(p - o * stride + padding) / dilation` per axis, row-major: tap k reads the input at
+    p = o * stride - padding + k  (cross-correlation, as torch.nn.Conv3d; NOT the flipped convolution).  spconv's own
+    test/test_conv.py checks SparseConv3d against a dense Conv3d whose weight is `filters.transpose(4, 3, 0, 1, 2)` -- the same
+    permutation tests/test_volume_builder.py uses for its F.conv3d reference.  A flipped or axis-swapped tap order fails that
+    test here by 0.5+ (test_a_permuted_tap_order_is_caught): the dense check discriminates.
+ 3. SubMConv3d (k = 3).  `getIndicePairsSubM`: output sites = input sites, same row order; for every input row j at position p
+    and every tap k, the pair (in = j, out = row of the active site at p + padding - k) is recorded when that site exists;
+    `indiceConv` applies the centre tap to all rows at once (`filters[kernelVolume / 2]`) and skips it in the loop.  Same sums.
+ 4. SubMConv3d with k = 1 (`single_conv`, SparseConvNet.py:22-33): `SparseConvolution.forward` takes the `conv1x1` shortcut,
+    `features @ weight.view(Cin, Cout)` on EVERY row -- rows that share a voxel stay separate rows.
+ 5. SparseConv3d (stride 2, padding 1, k = 3; `stride_conv`, SparseConvNet.py:85-92).  `getIndicePairsConv`: every INPUT ROW
+    generates its pairs, so several rows in one voxel (SMPL vertices quantised to 5 mm: the vertex level has them) ALL add into
+    the outputs they reach; output sites = the distinct reachable positions, spatial shape floor((n + 2 p - k) / s) + 1 per axis.
+    Row order of the outputs differs between spconv's CPU and CUDA paths and does not matter to `.dense()`.
+ 6. Duplicate positions and the k = 3 submanifold lookup.  The grid / hash that maps a position to a row is filled by all rows of
+    a voxel in turn (CPU: the last row wins; CUDA: whichever thread writes last -- not deterministic).  In this network the vertex
+    level only feeds a 1 x 1 SubM (item 4) and a strided convolution (item 5), whose outputs have one row per voxel, so no k = 3
+    submanifold lookup and no `.dense()` ever sees duplicate positions; `_lookup` (highest row) is only exercised by tests.
+ 7. `.dense()` (spconv/__init__.py `SparseConvTensor.dense` -> `scatter_nd`): zeros + index assignment of the feature rows at their
+    coordinates, `[N, C, D, H, W]`.
+ 8. BatchNorm1d(eps=1e-3) + ReLU act on the feature rows (spconv.SparseSequential applies plain modules to `.features`).
+
+Settling it with spconv at hand (not possible here):
+    x = spconv.SparseConvTensor(feat, coord_int32, shape, 1); conv = spconv.SparseConv3d(C, C, 3, 2, padding=1, bias=False)
+    ref = sparse_conv3d(SparseTensor(feat, coord[:, 1:].long(), shape), conv.weight, 2, 1).dense()
+    assert torch.allclose(conv(x).dense(), ref, atol=1e-5)        # and the same for SubMConv3d(k=3) on duplicate-free coords
 """
 import torch
 import torch.nn.functional as F
@@ -101,6 +140,36 @@ def _lookup(sorted_keys, order, query):
     return torch.where(hit, order[pos], torch.full_like(pos, -1))
 
 
+def subm_conv3d_rulebook(x, weight):
+    """SubMConv3d as spconv v1.2.1's CPU rulebook treats rows that SHARE a voxel (header item 6, RECALLED -- see there): the grid maps
+    a position to the LAST row written there (the owner); every input row i generates the pairs (i -> owner of each active
+    neighbour position); the centre tap is applied to every row's own features.  So an owner row receives its neighbours' rows --
+    ALL of them, summed --, a non-owner row only its own centre term.  Equal to sparse_conv3d(subm=True) when no voxel is shared.
+    (spconv's CUDA path elects the owner by a write race: the reference itself is not deterministic on such voxels.)"""
+    k = weight.shape[0]
+    cin, cout = weight.shape[3], weight.shape[4]
+    pad = k // 2
+    D, H, W = x.shape
+    dev = x.coords.device
+    offs = torch.stack(torch.meshgrid(torch.arange(k), torch.arange(k), torch.arange(k), indexing="ij"), -1).view(-1, 3).to(dev)
+    Wk = weight.view(k * k * k, cin, cout)
+    sk, order = torch.sort(x.keys(), stable=True)
+    centre = (k * k * k) // 2
+    out = x.features @ Wk[centre]
+    lim = torch.tensor([D, H, W], device=dev)
+    for i in range(k * k * k):
+        if i == centre:
+            continue
+        q = x.coords + pad - offs[i]                            # the output position input row j feeds through tap i: p = q - pad + k
+        ok = ((q >= 0) & (q < lim)).all(1)
+        key = (q[:, 0] * H + q[:, 1]) * W + q[:, 2]
+        o = _lookup(sk, order, torch.where(ok, key, torch.full_like(key, -1)))
+        sel = (o >= 0) & ok
+        if sel.any():
+            out.index_add_(0, o[sel], x.features[sel] @ Wk[i])
+    return SparseTensor(out, x.coords, x.shape)
+
+
 def sparse_conv3d(x, weight, stride=1, padding=0, subm=False):
     """weight [k,k,k,Cin,Cout] as spconv v1.x stores it; out[o] = sum_k W[k] in[o*stride - pad + k]."""
     k, s = weight.shape[0], stride
@@ -144,21 +213,27 @@ def sparse_conv3d(x, weight, stride=1, padding=0, subm=False):
     return SparseTensor(out, oc, (oD, oH, oW))
 
 
-def _sequential(seq, x):
+def _sequential(seq, x, rulebook_duplicates=False):
     """conv -> BatchNorm1d -> ReLU chains on the active features (spconv.SparseSequential); seq: the product's module list."""
     for m in seq:
         if hasattr(m, "subm"):
-            x = sparse_conv3d(x, m.weight, m.stride, m.padding, m.subm)
+            if rulebook_duplicates and m.subm and m.weight.shape[0] == 3:
+                x = subm_conv3d_rulebook(x, m.weight)
+            else:
+                x = sparse_conv3d(x, m.weight, m.stride, m.padding, m.subm)
         else:
             x = SparseTensor(m(x.features), x.coords, x.shape)
     return x
 
 
-def dense_levels(net, code, coord, out_sh):
+def dense_levels(net, code, coord, out_sh, rulebook_duplicates=False):
     """net: the product's SparseConvNet; code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) ->
-    list of 4 dense levels [1,C_k,D/2^k,H/2^k,W/2^k] (SparseConvNet.py:105-111)."""
+    list of 4 dense levels [1,C_k,D/2^k,H/2^k,W/2^k] (SparseConvNet.py:105-111).
+    rulebook_duplicates: the two submanifold convolutions of the VERTEX level (the only one whose rows can share a voxel) as
+    subm_conv3d_rulebook -- what this file's header recalls of spconv's own handling of shared voxels -- instead of the
+    one-representative-per-voxel form the product implements (tools/probes/duplicate_voxels.py measures the difference)."""
     x = SparseTensor(code, coord[:, 1:].long(), out_sh)
-    x = _sequential(net.net[0], x)
+    x = _sequential(net.net[0], x, rulebook_duplicates)
     levels = []
     for i in range(net.n_layers):
         x = _sequential(net.net[2 * i + 1], x)

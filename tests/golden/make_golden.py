@@ -646,6 +646,10 @@ DEMO_CASES = [
     # maps x 4 with log-normal tails -- the distribution of trained_h2_s64, whose float32-vs-float64 yardstick the tests borrow
     ("demo_trained_s32", dict(seed=24, focal_mul=1.5, vol_occupancy=0.4, sigma_bias=-4.0, head_scale=2.0, feat_scale=4.0, feat_tail=0.5,
                               vol_scale=4.0, **dict(DEMO_SMALL, bias_std=0.3)), 32, {}),
+    # a PERSON-SHAPED frame at full size (round 5): vertices on a capsule-limbed figure's surface
+    # (synthetic.body_vertices), the dense levels non-negative on exactly the voxels the sparse pyramid writes for them, the
+    # full-size SMPL box, SURVEY.md 8d's f = 1.05 W camera, 64 samples -- occupancy and cull rate of a body, not of random blocks
+    ("demo_body_s64", dict(H=512, W=512, seed=25, focal_mul=1.05, body="capsules", sigma_bias=0.5, bias_std=0.1, pose="random"), 64, {}),
 ]
 
 
