@@ -45,7 +45,7 @@ PYRAMID_MAX_LEVELS = 4
 class GpnerfSparseConv(C.Structure):
     """include/gpnerf_hip.h: one convolution of the sparse pyramid (gpnerf_sparse_pyramid_run)"""
     _fields_ = [("strided", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("form", C.c_int32),
-                ("weight", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
+                ("weight", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("weight_raw", C.c_void_p)]
 
 
 class GpnerfPyramid(C.Structure):
@@ -54,7 +54,7 @@ class GpnerfPyramid(C.Structure):
                 ("dims", (C.c_int32 * 3) * PYRAMID_MAX_LEVELS), ("cap", C.c_int32 * PYRAMID_MAX_LEVELS), ("ch", C.c_int32 * PYRAMID_MAX_LEVELS),
                 ("coords0", C.c_void_p), ("grid0", C.c_void_p), ("dup_scratch", C.c_void_p),
                 ("grid", C.c_void_p * PYRAMID_MAX_LEVELS), ("coords", C.c_void_p * PYRAMID_MAX_LEVELS), ("m", C.c_void_p * PYRAMID_MAX_LEVELS),
-                ("vol", C.c_void_p * PYRAMID_MAX_LEVELS), ("feat_a", C.c_void_p), ("feat_b", C.c_void_p)]
+                ("vol", C.c_void_p * PYRAMID_MAX_LEVELS), ("feat_a", C.c_void_p), ("feat_b", C.c_void_p), ("feat_c", C.c_void_p)]
 
 
 

@@ -380,6 +380,57 @@ __global__ void merge_duplicates_kernel(float* __restrict__ feat, const int c, c
     if (lane < c) feat[(size_t)site * c + lane] = acc;
 }
 
+// spconv's submanifold rulebook on rows that SHARE a voxel (oracle/producers_ref.py header item 6; recalled from spconv v1.2.1
+// src/spconv/indice.cc create_submconv_indice_pair_cpu + spconv_ops.cc indiceConv): the position -> row grid holds ONE row per
+// voxel (the owner: the highest row); every input row generates a pair towards the owner of each active neighbour position, and
+// the centre tap is a plain `features @ W[13]` on every row.  So
+//     owner j:      out[j] = f_j W_c + sum_{k != c} S(p_j - 1 + k) W_k,   S(v) = the SUM of all rows in voxel v
+//     non-owner j:  out[j] = f_j W_c
+// The convolution kernels compute conv(S) through the grid for every row -- exactly that wherever the row's OWN voxel is not
+// shared (its neighbours' sums S are what the grid's rows hold once gpnerf_sparse_merge_duplicates has run on a copy of the
+// input, and S of its own voxel is f_j).  This kernel recomputes the few rows whose own voxel IS shared
+// (body-like vertices at 5 mm: ~190 of 6 890): one 32-lane group per row, lane = output channel, fp32 FMAs in tap order.
+//   own: the layer's input rows as they are; merged: the copy whose owner rows hold S; count: merge_duplicates' scratch (count[j]
+//   = how many other rows share owner j's voxel); W: raw [27][cin][cout]
+__global__ void __launch_bounds__(256) subm_shared_rows_kernel(const float* __restrict__ own, const float* __restrict__ merged, const int cin,
+                                                               const int32_t* __restrict__ grid, const Dims s, const int32_t* __restrict__ coords,
+                                                               const int m, const int32_t* __restrict__ count, const float* __restrict__ W,
+                                                               const int cout, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               float* __restrict__ out) {
+    const int j = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int co = threadIdx.x & 31;
+    if (j >= m) return;
+    const int d0 = coords[3 * j], h0 = coords[3 * j + 1], w0 = coords[3 * j + 2];
+    if (d0 < 0 || d0 >= s.d || h0 < 0 || h0 >= s.h || w0 < 0 || w0 >= s.w) return;
+    const int owner = grid[cell_of(s, d0, h0, w0)];
+    if (owner == j && count[j] == 0) return;                   // the row has its voxel to itself: the convolution's value stands
+    if (co >= cout) return;
+    float acc = 0.f;
+    {
+        const float* x = own + (size_t)j * cin;
+        const float* wk = W + (size_t)13 * cin * cout + co;
+        for (int ci = 0; ci < cin; ++ci) acc = fmaf(x[ci], wk[(size_t)ci * cout], acc);
+    }
+    if (owner == j) {
+        for (int k = 0; k < KV; ++k) {
+            if (k == 13) continue;
+            const int d = d0 - 1 + k / 9, h = h0 - 1 + (k / 3) % 3, w = w0 - 1 + k % 3;
+            if (d < 0 || d >= s.d || h < 0 || h >= s.h || w < 0 || w >= s.w) continue;
+            const int nb = grid[cell_of(s, d, h, w)];
+            if (nb < 0) continue;
+            const float* x = merged + (size_t)nb * cin;
+            const float* wk = W + (size_t)k * cin * cout + co;
+            for (int ci = 0; ci < cin; ++ci) acc = fmaf(x[ci], wk[(size_t)ci * cout], acc);
+        }
+    }
+    out[(size_t)j * cout + co] = fmaxf(fmaf(acc, scale[co], shift[co]), 0.f);
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, const long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // strided conv, step 1: mark every coarse site reached by an active fine site (out = (p + 1 - k) / 2 when even)
 __global__ void mark_kernel(const int32_t* __restrict__ coords, const int* __restrict__ m_ptr, const int m_cap, const Dims out_dims,
                             int32_t* __restrict__ out_grid) {
@@ -832,13 +883,32 @@ int gpnerf_sparse_pyramid_run(const GpnerfPyramid* p, const float* code, int32_t
                                    c.bn_scale, c.bn_shift, out, stream);
     };
     if (convs[0].cin != code_ch || convs[0].strided || convs[1].strided) return GPNERF_E_ARG;
+    if (!p->feat_c || !convs[0].weight_raw || !convs[1].weight_raw) return GPNERF_E_ARG;
+    // The vertex level: two submanifold convolutions on rows that may SHARE voxels, in spconv's rulebook semantics (see
+    // subm_shared_rows_kernel): each runs on a copy of its input whose owner rows hold their voxel's sum, then the rows whose
+    // own voxel is shared are recomputed from their own features.
+    const Dims d0 = {p->dims0[0], p->dims0[1], p->dims0[2]};
+    auto subm_vertex = [&](const GpnerfSparseConv& c, const float* in, float* merged, float* out) -> int {
+        const long n = (long)p->m0 * c.cin;
+        if (n > 0) hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), in, merged, n);
+        int r = gpnerf_sparse_merge_duplicates(merged, c.cin, p->coords0, p->grid0, p->m0, p->dims0, p->dup_scratch, stream);
+        if (r != GPNERF_OK) return r;
+        r = conv(c, merged, p->grid0, p->dims0, p->coords0, nullptr, p->m0, out);
+        if (r != GPNERF_OK) return r;
+        if (p->m0 > 0)
+            hipLaunchKernelGGL(subm_shared_rows_kernel, dim3((unsigned)((p->m0 + 7) / 8)), dim3(256), 0, S_(stream), in, (const float*)merged, (int)c.cin,
+                               (const int32_t*)p->grid0, d0, p->coords0, (int)p->m0, (const int32_t*)p->dup_scratch, c.weight_raw, (int)c.cout,
+                               c.bn_scale, c.bn_shift, out);
+        return status();
+    };
     float* cur = p->feat_a;
     float* other = p->feat_b;
-    int rc = conv(convs[0], code, p->grid0, p->dims0, p->coords0, nullptr, p->m0, cur);
+    int rc = subm_vertex(convs[0], code, p->feat_c, cur);
     if (rc != GPNERF_OK) return rc;
-    rc = conv(convs[1], cur, p->grid0, p->dims0, p->coords0, nullptr, p->m0, other);
+    rc = subm_vertex(convs[1], cur, p->feat_c, other);
     if (rc != GPNERF_OK) return rc;
     { float* t = cur; cur = other; other = t; }
+    // the strided convolution takes EVERY input row: fold a voxel's rows into its owner, which is what the grid finds
     rc = gpnerf_sparse_merge_duplicates(cur, convs[1].cout, p->coords0, p->grid0, p->m0, p->dims0, p->dup_scratch, stream);
     if (rc != GPNERF_OK) return rc;
     const int32_t* grid = p->grid0;

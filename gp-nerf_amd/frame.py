@@ -319,7 +319,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     the same 1e-5 at initialisation scale, 5-10 x further from the reference on trained-like parameters.  "keep": True without
     re-folding a Frame that is already folded.
     reserve_cus: plan the launch for that many fewer compute units (multiple of 8), leaving them to kernels of other streams
-    (GPNERF_FLAG_RESERVE_CUS; Renderer.prefetch's overlap).  Same bits for any value."""
+    (GPNERF_FLAG_RESERVE_CUS).  The maps are those of a chip with that many fewer CUs."""
     lib = L.lib()
     _require_gpu(rays, "rays")
     rays = rays.contiguous().float()

@@ -248,8 +248,8 @@ class SparseConvNet(nn.Module):
         if x.shape[0] != p.m0 or x.shape[1] != convs[0].cin:
             raise L.GpnerfError(f"code {tuple(x.shape)} does not match the plan's {p.m0} rows / the network's {convs[0].cin} input channels")
         # two feature buffers the convolutions alternate between, then ONE native call for the ~30 launches of the pyramid
-        feat = torch.empty((2, max(plan["max_rows"], 1), 32), device=dev, dtype=torch.float32)
-        p.feat_a, p.feat_b = feat[0].data_ptr(), feat[1].data_ptr()
+        feat = torch.empty((3, max(plan["max_rows"], 1), 32), device=dev, dtype=torch.float32)
+        p.feat_a, p.feat_b, p.feat_c = feat[0].data_ptr(), feat[1].data_ptr(), feat[2].data_ptr()
         L.check(lib.gpnerf_sparse_pyramid_run(C.byref(p), x.data_ptr(), int(x.shape[1]), convs, len(convs), st), "gpnerf_sparse_pyramid_run")
         levels = []
         for lv in plan["levels"]:
@@ -273,7 +273,7 @@ class SparseConvNet(nn.Module):
             return hit[1]
         table = (L.GpnerfSparseConv * len(mods))()
         alive = []
-        for t, (strided, mod, bn) in zip(table, mods):
+        for n_conv, (t, (strided, mod, bn)) in enumerate(zip(table, mods)):
             if mod.cout > 32:
                 raise L.GpnerfError("the sparse convolutions are built for at most 32 output channels")
             scale, shift = self._folded_bn(bn)
@@ -285,6 +285,10 @@ class SparseConvNet(nn.Module):
             t.strided, t.cin, t.cout, t.form = int(strided), mod.cin, mod.cout, form
             t.weight, t.bn_scale, t.bn_shift = w.data_ptr(), scale.data_ptr(), shift.data_ptr()
             alive += [w, scale, shift]
+            if n_conv < 2:                # the two vertex-level convolutions: spconv's own [27][cin][cout] layout for the shared-voxel rows
+                raw = w if form == 0 else mod.weight.detach().float().contiguous().to(dev)
+                t.weight_raw = raw.data_ptr()
+                alive.append(raw)
         self.__dict__["_conv_table_cache"] = _NotCopied((key, table, alive))
         return table
 

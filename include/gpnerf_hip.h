@@ -77,7 +77,8 @@ extern "C" {
                                    /* bits 24..31: plan the launch for n fewer compute units (rounded down to a multiple of 8: one
                                       per XCD round).  The persistent workgroups then leave n CUs idle for kernels of other
                                       streams -- a pipelined evaluation loop runs the NEXT frame's encoder and volume builder
-                                      there (Renderer.prefetch).  Results are bit-identical for any n */
+                                      there (an experiment of the pipelined evaluation loop: profiles/r05/d_pipeline.txt).  The maps are those of
+                                      a chip with n fewer CUs: the same bits unless that makes the launch split tiles (see `workspace`) */
 
 /* Per-frame constants (everything render_rays reads that does not depend on the ray).
  * Layouts are channels-last so that one bilinear / trilinear tap is one contiguous
@@ -312,7 +313,10 @@ int gpnerf_sparse_conv3_mfma16(int32_t strided, const float* in, int32_t cin, co
  *     beside the image encoder.
  *   gpnerf_sparse_pyramid_run: double_conv at full resolution, the duplicate merge, then per level strided conv + double_conv +
  *     scatter into vol[i] (channels-last [D_i][H_i][W_i][ch_i]).  convs: 2 + 3 * n_levels entries in network order.
- * feat_a / feat_b: two float buffers of max(m0, cap[i]) * 32 each (ping-pong).  code: [m0][code_ch] per-vertex features. */
+ * feat_a / feat_b: two float buffers of max(m0, cap[i]) * 32 each (ping-pong).  code: [m0][code_ch] per-vertex features.
+ * Rows that share a voxel (two vertices rounded into one 5 mm cell) follow spconv v1.2.1's rulebook as oracle/producers_ref.py's
+ * header recalls it: a submanifold convolution gives the voxel's OWNER row (the highest) the sum over ALL rows of its neighbour
+ * voxels and every other row of the voxel only its own centre term; a strided convolution takes every row. */
 #define GPNERF_PYRAMID_MAX_LEVELS 4
 typedef struct GpnerfSparseConv {
     int32_t strided, cin, cout;
@@ -320,6 +324,8 @@ typedef struct GpnerfSparseConv {
     const void* weight;
     const float* bn_scale;
     const float* bn_shift;
+    const float* weight_raw;      /* device [27][cin][cout] fp32, spconv's own layout: needed for the two vertex-level convolutions
+                                     (rows that share a voxel are recomputed from it), may be NULL for the others */
 } GpnerfSparseConv;
 typedef struct GpnerfPyramid {
     int32_t n_levels, m0;
@@ -336,6 +342,7 @@ typedef struct GpnerfPyramid {
     float* vol[GPNERF_PYRAMID_MAX_LEVELS];
     float* feat_a;
     float* feat_b;
+    float* feat_c;                /* m0 * 32 floats: the vertex level's input with every shared voxel's rows summed into its owner */
 } GpnerfPyramid;
 int gpnerf_sparse_pyramid_plan(const GpnerfPyramid* p, void* stream);
 int gpnerf_sparse_pyramid_run(const GpnerfPyramid* p, const float* code, int32_t code_ch, const GpnerfSparseConv* convs, int32_t n_convs,

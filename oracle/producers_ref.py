@@ -33,16 +33,25 @@ the ten-line check at the end.
  3. SubMConv3d (k = 3).  `getIndicePairsSubM`: output sites = input sites, same row order; for every input row j at position p
     and every tap k, the pair (in = j, out = row of the active site at p + padding - k) is recorded when that site exists;
     `indiceConv` applies the centre tap to all rows at once (`filters[kernelVolume / 2]`) and skips it in the loop.  Same sums.
- 4. SubMConv3d with k = 1 (`single_conv`, SparseConvNet.py:22-33): `SparseConvolution.forward` takes the `conv1x1` shortcut,
-    `features @ weight.view(Cin, Cout)` on EVERY row -- rows that share a voxel stay separate rows.
+ 4. SubMConv3d with k = 1 (`single_conv`, SparseConvNet.py:22-33; defined but not used by SparseConvNet.__init__):
+    `SparseConvolution.forward` takes the `conv1x1` shortcut, `features @ weight.view(Cin, Cout)` on EVERY row -- rows that share a
+    voxel stay separate rows.  (`sparse_conv3d(subm=True)` with k = 1 routes the centre tap through the lookup instead: not the
+    shortcut's semantics on shared voxels; nothing in the network exercises it.)
  5. SparseConv3d (stride 2, padding 1, k = 3; `stride_conv`, SparseConvNet.py:85-92).  `getIndicePairsConv`: every INPUT ROW
     generates its pairs, so several rows in one voxel (SMPL vertices quantised to 5 mm: the vertex level has them) ALL add into
     the outputs they reach; output sites = the distinct reachable positions, spatial shape floor((n + 2 p - k) / s) + 1 per axis.
     Row order of the outputs differs between spconv's CPU and CUDA paths and does not matter to `.dense()`.
- 6. Duplicate positions and the k = 3 submanifold lookup.  The grid / hash that maps a position to a row is filled by all rows of
-    a voxel in turn (CPU: the last row wins; CUDA: whichever thread writes last -- not deterministic).  In this network the vertex
-    level only feeds a 1 x 1 SubM (item 4) and a strided convolution (item 5), whose outputs have one row per voxel, so no k = 3
-    submanifold lookup and no `.dense()` ever sees duplicate positions; `_lookup` (highest row) is only exercised by tests.
+ 6. Rows that share a position and the k = 3 submanifold convolution -- the network's FIRST block, net[0] = double_conv on the
+    vertex level (SparseConvNet.py:96-97,106), is exactly that.  src/spconv/indice.cc `create_submconv_indice_pair_cpu` fills the
+    position -> row grid with every row in turn (the LAST row of a voxel stays: its owner; the CUDA path elects the owner by a write
+    race, so the reference itself is not deterministic on such voxels), then lets EVERY input row j emit, per tap, the pair
+    (j -> owner of the active position it feeds); src/spconv/spconv_ops.cc `indiceConv` applies the centre tap as
+    `mm_out(output, features, filters[centre])` on all rows and skips it in the pair loop.  Hence
+        owner row:      f W_c + sum over the other taps of (the SUM of all rows in that neighbour voxel) W_k
+        any other row:  f W_c only.
+    `subm_conv3d_rulebook` restates this and csrc/gpnerf_volume.hip implements it (subm_shared_rows_kernel) since round 5; rounds
+    2-4 let every row compute through one-representative lookups instead (`sparse_conv3d(subm=True)`), which agrees wherever no
+    voxel is shared and differs materially where one is (tools/probes/duplicate_voxels.py).
  7. `.dense()` (spconv/__init__.py `SparseConvTensor.dense` -> `scatter_nd`): zeros + index assignment of the feature rows at their
     coordinates, `[N, C, D, H, W]`.
  8. BatchNorm1d(eps=1e-3) + ReLU act on the feature rows (spconv.SparseSequential applies plain modules to `.features`).
@@ -213,7 +222,7 @@ def sparse_conv3d(x, weight, stride=1, padding=0, subm=False):
     return SparseTensor(out, oc, (oD, oH, oW))
 
 
-def _sequential(seq, x, rulebook_duplicates=False):
+def _sequential(seq, x, rulebook_duplicates=True):
     """conv -> BatchNorm1d -> ReLU chains on the active features (spconv.SparseSequential); seq: the product's module list."""
     for m in seq:
         if hasattr(m, "subm"):
@@ -226,12 +235,14 @@ def _sequential(seq, x, rulebook_duplicates=False):
     return x
 
 
-def dense_levels(net, code, coord, out_sh, rulebook_duplicates=False):
+def dense_levels(net, code, coord, out_sh, rulebook_duplicates=True):
     """net: the product's SparseConvNet; code [M,C] per-vertex features, coord [M,4] (batch, d, h, w), out_sh (D,H,W) ->
     list of 4 dense levels [1,C_k,D/2^k,H/2^k,W/2^k] (SparseConvNet.py:105-111).
-    rulebook_duplicates: the two submanifold convolutions of the VERTEX level (the only one whose rows can share a voxel) as
-    subm_conv3d_rulebook -- what this file's header recalls of spconv's own handling of shared voxels -- instead of the
-    one-representative-per-voxel form the product implements (tools/probes/duplicate_voxels.py measures the difference)."""
+    rulebook_duplicates (default, and what csrc/gpnerf_volume.hip implements since round 5): the two submanifold convolutions of
+    the VERTEX level (the only one whose rows can share a voxel) as subm_conv3d_rulebook -- what this file's header recalls of
+    spconv's own handling of shared voxels.  False: one representative row per voxel for every lookup and every row computed
+    through lookups (rounds 2-4's reading; tools/probes/duplicate_voxels.py measures the difference: material wherever voxels are
+    shared -- 1 236 of 18 183 level-0 sites of the body-like frame)."""
     x = SparseTensor(code, coord[:, 1:].long(), out_sh)
     x = _sequential(net.net[0], x, rulebook_duplicates)
     levels = []

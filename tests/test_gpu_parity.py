@@ -413,9 +413,12 @@ def test_folded_coarse_levels_equal_the_layer_per_sample(size, S, neg, kw, fm, o
             assert_close(b[k][pick], ref[k], TOL, k)
 
 
-def test_reserved_cus_do_not_change_a_bit(fm, syn):
-    """GPNERF_FLAG_RESERVE_CUS plans the launch for fewer compute units (the pipelined loop's experiment, profiles/r05/d_pipeline.txt):
-    a ray's result is a function of the ray alone, so every map is bit-identical for any reserve -- plain and early-terminated."""
+def test_reserved_cus_render_the_same_frame(fm, syn):
+    """GPNERF_FLAG_RESERVE_CUS plans the launch for fewer compute units (the pipelined loop's experiment, profiles/r05/d_pipeline.txt).
+    A ray's result is a function of the ray alone, so the maps are the ones a smaller chip gives: bit-identical whenever the launch
+    geometry stays one wavefront per tile (always under early termination), and within the documented ~1e-7 re-association of the
+    transmittance product when the smaller chip makes the launch split a tile's samples over several wavefronts
+    (include/gpnerf_hip.h, `workspace`)."""
     sc = syn.make_scene(H=288, W=288, seed=71, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1, sigma_bias=1.0)
     fr = build_frame(fm, sc)
     rays = rays_of(sc)
@@ -424,7 +427,15 @@ def test_reserved_cus_do_not_change_a_bit(fm, syn):
         for reserve in (8, 64, 200, 255):
             got = fm.render_fused(fr, rays, 48, want=("weights", "rgb_in"), reserve_cus=reserve, **kw)
             for k in base:
-                assert torch.equal(torch.nan_to_num(base[k]), torch.nan_to_num(got[k])), (kw, reserve, k)
+                a, b = torch.nan_to_num(base[k]), torch.nan_to_num(got[k])
+                if kw:
+                    assert torch.equal(a, b), (kw, reserve, k)
+                else:
+                    assert float((a - b).abs().max()) <= 2e-6, (reserve, k)
+    base = fm.render_fused(fr, rays, 48, want=("weights", "rgb_in"))
+    same = fm.render_fused(fr, rays, 48, want=("weights", "rgb_in"), reserve_cus=7)          # rounded down to whole XCD rounds: nothing reserved
+    assert all(torch.equal(torch.nan_to_num(base[k]), torch.nan_to_num(same[k])) for k in base)
+
 
 
 def test_a_frame_that_gets_new_volumes_drops_what_it_derived_from_the_old_ones(fm, syn):

@@ -300,8 +300,8 @@ def test_progressive_renderer_returns_pred_img(plugins, syn, oracle):
     assert np.abs(ret["pred_img"][~mref.reshape(H, W)]).max() == 0
 
 
-@pytest.mark.parametrize("in_dim", [32, 16, 12])      # 32, 16: every conv on the matrix cores; 12: the first one on the VALU form
-def test_hip_volume_builder_matches_dense_conv_formulation(in_dim, syn):
+@pytest.mark.parametrize("in_dim,body", [(32, "box"), (16, "box"), (12, "box"), (32, "capsules")])      # 32, 16: every conv on the matrix cores; 12: the first one on the VALU form
+def test_hip_volume_builder_matches_dense_conv_formulation(in_dim, body, syn):
     """gpnerf_volume.hip (SubM / strided sparse conv + folded BN + ReLU, channels-last .dense()) against the oracle's rulebook
     restatement (oracle/producers_ref.py, torch on the CPU), which tests/test_volume_builder.py pins to a dense
     conv3d-with-mask formulation.  The synthetic vertices round into shared voxels, so spconv's duplicate-row semantics
@@ -314,7 +314,11 @@ def test_hip_volume_builder_matches_dense_conv_formulation(in_dim, syn):
     for m in net.modules():                                  # non-trivial BatchNorm statistics
         if isinstance(m, torch.nn.BatchNorm1d):
             m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
-    sc = syn.make_scene(H=16, W=16, seed=3, aabb_half=(0.1, 0.14, 0.05), make_volumes=False)
+    # "box": 6 890 vertices uniform in a SMALL box -- most voxels shared by several rows, the hard case for spconv's rulebook on
+    # shared voxels (oracle/producers_ref.py item 6, subm_conv3d_rulebook); "capsules": the person-shaped full-size frame (93 shared voxels)
+    sc = syn.make_scene(H=16, W=16, seed=3, make_volumes=False, **(dict(aabb_half=(0.1, 0.14, 0.05)) if body == "box" else dict(body="capsules")))
+    shared = np.unique(sc["coord"][0], axis=0, return_counts=True)[1]
+    assert int((shared > 1).sum()) > (300 if body == "box" else 50)
     coord = torch.from_numpy(sc["coord"][0]).to(dev)
     coord4 = torch.cat([torch.zeros((coord.shape[0], 1), dtype=coord.dtype, device=dev), coord], 1)
     out_sh = [int(v) for v in sc["out_sh"][0]]

@@ -85,8 +85,19 @@ def test_rows_that_share_a_voxel_follow_the_rulebook():
     coords = torch.tensor([[2, 2, 2], [2, 2, 2], [5, 4, 3]])
     x = pref.SparseTensor(feats, coords, (8, 8, 8))
     w1 = torch.tensor([[1.0, 2.0], [3.0, 4.0]]).view(1, 1, 1, 2, 2)
-    y1 = pref.sparse_conv3d(x, w1, subm=True)
-    assert torch.equal(y1.features, feats @ w1.view(2, 2)) and torch.equal(y1.coords, coords)       # three rows stay three rows
+    # the k = 3 submanifold convolution, rulebook form: centre tap on every row's own features; the other taps only onto the OWNER
+    # (row 1 of the shared voxel), carrying the sum of all rows of the neighbour voxel
+    w = torch.zeros(3, 3, 3, 2, 1)
+    w[1, 1, 1, :, 0] = torch.tensor([1.0, 1.0])             # centre
+    w[1, 1, 0, :, 0] = torch.tensor([100.0, 0.0])           # tap (1,1,0): reads p + (0, 0, -1)
+    xs = pref.SparseTensor(torch.tensor([[1.0, 0.0], [0.0, 2.0], [3.0, 1.0], [5.0, 0.0], [7.0, 0.0]]),
+                           torch.tensor([[2, 2, 2], [2, 2, 2], [5, 4, 3], [2, 2, 1], [2, 2, 1]]), (8, 8, 8))
+    yr = pref.subm_conv3d_rulebook(xs, w).features[:, 0]
+    # rows 0, 1 share (2,2,2) [owner 1]; rows 3, 4 share (2,2,1) [owner 4] and are the (0,0,-1) neighbours of (2,2,2)
+    assert yr.tolist() == [1.0, 2.0 + 100.0 * (5.0 + 7.0), 4.0, 5.0, 7.0]
+    # one representative per voxel instead (rounds 2-4): every row of (2,2,2) sees row 4 alone, and its own voxel's owner at the centre
+    ya = pref.sparse_conv3d(xs, w, subm=True).features[:, 0]
+    assert ya.tolist() == [2.0 + 700.0, 2.0 + 700.0, 4.0, 7.0, 7.0]
     w3 = torch.zeros(3, 3, 3, 2, 1)
     w3[1, 1, 1, :, 0] = torch.tensor([1.0, 1.0])            # the tap that reads p = 2 o - 1 + (1,1,1) = 2 o
     w3[2, 1, 0, :, 0] = torch.tensor([10.0, 0.0])           # the tap that reads p = 2 o - 1 + (2,1,0) = 2 o + (1, 0, -1)
