@@ -124,6 +124,10 @@ SYMBOLS = {
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_conv2d_nhwc_exact": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_void_p]),
+    "gpnerf_conv_exact_packed_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gpnerf_conv_pack_weight_exact": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gpnerf_conv2d_nhwc_exact_packed": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_conv2d_norm_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1054,6 +1054,127 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_exact_kernel(const ExactArg
     }
 }
 
+// ---- the exact form, tiled (round 5): the same fp32 FMA chains at ~10x the rate ------------------------------------------------
+// conv2d_exact_kernel above feeds every MFMA with two scalar loads per lane (a channel of a pixel, a weight at a stride of
+// Cin * KS^2 floats): ~6 TFLOP/s, 20 ms for a 3 x 512 x 512 frame.  Here a lane's operands come eight at a time:
+//   B: the pixel's 16-channel block is contiguous in NHWC -- lane (pixel, half) reads channels 8 half .. 8 half + 7 as two float4;
+//   A: the weights are re-laid out once per parameter change (pack_exact_weight_kernel) as [tap][cin / 16][cout tile][lane][8], so lane
+//      (row, half) reads its eight as two float4 from an L2-resident image;
+// eight MFMAs per four vector loads, CT output tiles (32 channels each) sharing one B.  The four wavefronts of a workgroup share
+// ONE 32-pixel x 32 CT-channel tile and deal its K units (tap x 16-channel block) out round-robin, so a deep layer (256 channels
+// x 9 taps = 1 152 MFMAs per tile) is four chains of a quarter the length; the partial tiles meet in LDS and are added in wave
+// order (deterministic).  The next unit's loads are issued before the current unit's MFMAs.  K order within a chain: unit by
+// unit, inside a unit channels (8 half + j) for j = 0..7 -- an fp32 FMA chain like the reference's, in another order (the
+// reference's own two CPU convolution algorithms differ in order too: 2.9e-5 on the feature maps).
+struct ExactTArgs {
+    const float* x; const float* wp; const float* bias; float* y;
+    int H, W, Cin, Ho, Wo, Cout, KS, stride, MT;              // MT: 32-row tiles of the packed image (ceil(Cout / 32))
+};
+
+template <int CT>
+__global__ void __launch_bounds__(256) conv2d_exact_tiled_kernel(const ExactTArgs a) {
+    __shared__ float red[3][CT][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y, ct0 = blockIdx.z * CT;
+    const int howo = a.Ho * a.Wo, pad = a.KS / 2;
+    const int p = (int)blockIdx.x * 32 + px;
+    const bool valid = p < howo;
+    const int pc = valid ? p : howo - 1;
+    const int oy = pc / a.Wo, ox = pc % a.Wo;
+    const int nblk = a.Cin >> 4, U = a.KS * a.KS * nblk;
+    f32x16 acc[CT];
+#pragma unroll
+    for (int m = 0; m < CT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    f32x4 b0, b1, a0[CT], a1[CT];
+    auto load_unit = [&](int u, f32x4& q0, f32x4& q1, f32x4 (&w0)[CT], f32x4 (&w1)[CT]) {
+        const int tap = u / nblk, blk = u - tap * nblk;
+        const int ky = tap / a.KS, kx = tap - ky * a.KS;
+        const int iy = reflect(oy * a.stride + ky - pad, a.H), ix = reflect(ox * a.stride + kx - pad, a.W);
+        const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.Cin + 16 * blk + 8 * half);
+        q0 = xp[0]; q1 = xp[1];
+#pragma unroll
+        for (int m = 0; m < CT; ++m) {
+            const int mt = min(ct0 + m, a.MT - 1);
+            const f32x4* wq = reinterpret_cast<const f32x4*>(a.wp + ((((size_t)tap * nblk + blk) * a.MT + mt) * 64 + lane) * 8);
+            w0[m] = wq[0]; w1[m] = wq[1];
+        }
+    };
+    int u = wave;
+    if (u < U) load_unit(u, b0, b1, a0, a1);
+    while (u < U) {
+        f32x4 nb0 = b0, nb1 = b1, na0[CT], na1[CT];
+#pragma unroll
+        for (int m = 0; m < CT; ++m) { na0[m] = a0[m]; na1[m] = a1[m]; }
+        if (u + 4 < U) load_unit(u + 4, nb0, nb1, na0, na1);
+#pragma unroll
+        for (int m = 0; m < CT; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][0], b0[0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][1], b0[1], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][2], b0[2], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][3], b0[3], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][0], b1[0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][1], b1[1], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][2], b1[2], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][3], b1[3], acc[m], 0, 0, 0);
+        }
+        b0 = nb0; b1 = nb1;
+#pragma unroll
+        for (int m = 0; m < CT; ++m) { a0[m] = na0[m]; a1[m] = na1[m]; }
+        u += 4;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < CT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - 1][m][r][lane] = acc[m][r];
+    }
+    __syncthreads();
+    if (wave != 0 || !valid) return;
+    float* yp = a.y + ((size_t)n * howo + p) * a.Cout;
+#pragma unroll
+    for (int m = 0; m < CT; ++m) {
+        if (ct0 + m >= a.MT) break;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * q + i;
+                v[i] = ((acc[m][r] + red[0][m][r][lane]) + red[1][m][r][lane]) + red[2][m][r][lane];
+            }
+            const int co = 32 * (ct0 + m) + 8 * q + 4 * half;          // ft(4q + i, half) = i + 8q + 4 half: four consecutive channels
+            if (co + 3 < a.Cout) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = v[i] + (a.bias ? a.bias[co + i] : 0.f);
+                *reinterpret_cast<f32x4*>(yp + co) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co + i < a.Cout) yp[co + i] = v[i] + (a.bias ? a.bias[co + i] : 0.f);
+            }
+        }
+    }
+}
+
+// PyTorch [Cout][Cin][KS][KS] -> [tap][Cin / 16][MT][64 lanes][8]: lane (row, half) holds W[32 mt + row][16 blk + 8 half + j][tap]
+__global__ void pack_exact_weight_kernel(const float* __restrict__ w, const int cout, const int cin, const int ks, const int MT,
+                                         float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nblk = cin >> 4;
+    const long total = (long)ks * ks * nblk * MT * 512;
+    if (i >= total) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    long rest = i >> 9;
+    const int mt = (int)(rest % MT); rest /= MT;
+    const int blk = (int)(rest % nblk);
+    const int tap = (int)(rest / nblk);
+    const int co = 32 * mt + (lane & 31), ci = 16 * blk + 8 * (lane >> 5) + j;
+    out[i] = co < cout ? w[((size_t)co * cin + ci) * ks * ks + tap] : 0.f;
+}
+
 hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 int status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
 
@@ -1251,6 +1372,35 @@ int gpnerf_conv2d_nhwc_exact(const float* x, int32_t n, int32_t h, int32_t w, in
     a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
     const int tiles = (a.Ho * a.Wo + WAVES * 32 - 1) / (WAVES * 32);
     hipLaunchKernelGGL(conv2d_exact_kernel, dim3((unsigned)tiles, (unsigned)n, (unsigned)((cout + 31) / 32)), dim3(WAVES * 64), 0, S_(stream), a);
+    return status();
+}
+
+int64_t gpnerf_conv_exact_packed_bytes(int32_t cout, int32_t cin, int32_t ks) {
+    if (cout < 1 || cin < 16 || (cin & 15) || ks < 1 || !(ks & 1)) return 0;          // 0: this convolution has no tiled exact form
+    return (int64_t)ks * ks * (cin >> 4) * ((cout + 31) / 32) * 512 * (int64_t)sizeof(float);
+}
+
+int gpnerf_conv_pack_weight_exact(const float* weight, int32_t cout, int32_t cin, int32_t ks, float* packed, void* stream) {
+    if (!weight || !packed || gpnerf_conv_exact_packed_bytes(cout, cin, ks) == 0) return GPNERF_E_ARG;
+    const int MT = (cout + 31) / 32;
+    const long total = (long)ks * ks * (cin >> 4) * MT * 512;
+    hipLaunchKernelGGL(pack_exact_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_(stream), weight, (int)cout, (int)cin, (int)ks, MT,
+                       packed);
+    return status();
+}
+
+int gpnerf_conv2d_nhwc_exact_packed(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* packed, const float* bias,
+                                    int32_t cout, int32_t ks, int32_t stride, float* y, void* stream) {
+    if (n == 0) return GPNERF_OK;
+    if (!x || !packed || !y || n < 0 || h < 1 || w < 1 || cout < 1 || stride < 1 || gpnerf_conv_exact_packed_bytes(cout, cin, ks) == 0) return GPNERF_E_ARG;
+    const int pad = ks / 2;
+    if (h <= pad || w <= pad) return GPNERF_E_ARG;                       // reflection needs pad < size
+    ExactTArgs a;
+    a.x = x; a.wp = packed; a.bias = bias; a.y = y; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.KS = ks; a.stride = stride;
+    a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1; a.MT = (cout + 31) / 32;
+    const unsigned tiles = (unsigned)((a.Ho * a.Wo + 31) / 32);
+    if (a.MT >= 2) hipLaunchKernelGGL((conv2d_exact_tiled_kernel<2>), dim3(tiles, (unsigned)n, (unsigned)((a.MT + 1) / 2)), dim3(256), 0, S_(stream), a);
+    else hipLaunchKernelGGL((conv2d_exact_tiled_kernel<1>), dim3(tiles, (unsigned)n, 1u), dim3(256), 0, S_(stream), a);
     return status();
 }
 

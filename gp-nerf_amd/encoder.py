@@ -115,10 +115,24 @@ def _conv_exact(conv, x):
     pad = ks // 2
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     out = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-    wt = conv.weight.detach().float().contiguous()
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-    L.check(L.lib().gpnerf_conv2d_nhwc_exact(x.data_ptr(), n, h, w, cin, wt.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                             cout, ks, stride, out.data_ptr(), _st(x)), "gpnerf_conv2d_nhwc_exact")
+    lib = L.lib()
+    nbytes = int(lib.gpnerf_conv_exact_packed_bytes(cout, cin, ks))
+    if nbytes and not (L._DEBUG and os.environ.get("GPNERF_EXACT_UNTILED") == "1"):
+        # the tiled form (Cin a multiple of 16: every convolution but the stem): weights re-laid out once per parameter change
+        wkey = (str(conv.weight.device), conv.weight.data_ptr(), conv.weight._version)
+        hit = conv.__dict__.get("_gpnerf_packed_exact")
+        if hit is None or hit[0] != wkey:
+            buf = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+            src = conv.weight.detach().float().contiguous()
+            L.check(lib.gpnerf_conv_pack_weight_exact(src.data_ptr(), cout, cin, ks, buf.data_ptr(), _st(x)), "gpnerf_conv_pack_weight_exact")
+            hit = conv.__dict__["_gpnerf_packed_exact"] = (wkey, buf)
+        L.check(lib.gpnerf_conv2d_nhwc_exact_packed(x.data_ptr(), n, h, w, cin, hit[1].data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                    cout, ks, stride, out.data_ptr(), _st(x)), "gpnerf_conv2d_nhwc_exact_packed")
+        return out
+    wt = conv.weight.detach().float().contiguous()
+    L.check(lib.gpnerf_conv2d_nhwc_exact(x.data_ptr(), n, h, w, cin, wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                         cout, ks, stride, out.data_ptr(), _st(x)), "gpnerf_conv2d_nhwc_exact")
     return out
 
 
@@ -415,6 +429,10 @@ class ResUNet(nn.Module):
         `self.range_report` names the first layer that decided a "dynamic" / "exact" answer."""
         # params_key: the (storage, version) tuple of the parameters when the caller has just computed it (forward_graphed: walking
         # the 108 parameters costs the host ~0.1 ms, and this runs before the frame's first launch with the device idle)
+        if self.__dict__.get("strict_exact") or os.environ.get("GPNERF_ENCODER_EXACT") == "1":
+            # strict mode (round 5): every frame through the fp32-MFMA form (forward_exact: 2.6 ms for 3 x 512 x 512 against the
+            # split form's 1.0) -- the choice of a user who wants fp32 operands throughout; `net.strict_exact = True` per module
+            return "exact"
         key = (int(H), int(W), params_key if params_key is not None else _graph_key(self, None)[3])
         hit = self.__dict__.get("_gpnerf_range_class")
         if hit is not None and hit[0] == key:

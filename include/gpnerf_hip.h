@@ -425,6 +425,13 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
                             void* stream);
 int gpnerf_conv2d_nhwc_exact(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* weight, const float* bias,
                              int32_t cout, int32_t ks, int32_t stride, float* y, void* stream);
+/* The same exact convolution from a re-laid-out weight image (round 5: ~10x the rate; Cin a multiple of 16 -- every convolution of
+ * the ResUNet but the stem): gpnerf_conv_exact_packed_bytes() bytes (0 = no tiled form for this shape, use gpnerf_conv2d_nhwc_exact),
+ * written by gpnerf_conv_pack_weight_exact from the PyTorch weight [Cout][Cin][KS][KS] (device), once per parameter change. */
+int64_t gpnerf_conv_exact_packed_bytes(int32_t cout, int32_t cin, int32_t ks);
+int gpnerf_conv_pack_weight_exact(const float* weight, int32_t cout, int32_t cin, int32_t ks, float* packed, void* stream);
+int gpnerf_conv2d_nhwc_exact_packed(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* packed, const float* bias,
+                                    int32_t cout, int32_t ks, int32_t stride, float* y, void* stream);
 int gpnerf_norm_apply_nhwc(const float* x, const float* table, const float* residual, const float* res_table, int32_t n, int64_t hw,
                            int32_t c, int32_t act, float* out, void* stream);
 int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c);

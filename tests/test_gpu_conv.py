@@ -60,6 +60,36 @@ def test_conv2d_nhwc_matches_torch(cin, cout, ks, stride, H, W, bias, enc):
     assert float((got2.cpu() - ref2).abs().max()) < 4e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W,bias", CONVS)
+def test_exact_conv_matches_torch(cin, cout, ks, stride, H, W, bias, enc):
+    """enc._conv_exact: fp32 operands on v_mfma_f32_32x32x2_f32 -- the tiled form (round 5: packed weights, four waves sharing a
+    tile's K) for every convolution whose input channels are a multiple of 16, the untiled form for the stem -- against float64
+    torch: an fp32 FMA chain's distance (3e-6 relative to the output range), operands of ANY magnitude (x 1e4 here: the split form's
+    range is 4 094), re-packed on a parameter change; and the two forms agree to summation order."""
+    import os
+    g = torch.Generator().manual_seed(cin * 1000 + cout + ks + 7)
+    conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=bias, padding_mode="reflect")
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    x = (torch.randn((3, cin, H, W), generator=g) * 2.0 + 0.3) * 1e4
+    with torch.no_grad():
+        ref = conv.double()(x.double()).float()
+        conv = conv.float().to("cuda:0")
+        got = enc._conv_exact(conv, x.to("cuda:0"))
+    scale = max(1.0, float(ref.abs().max()))
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert float((got.cpu() - ref).abs().max()) < 3e-6 * scale
+    tiled = int(enc.L.lib().gpnerf_conv_exact_packed_bytes(cout, cin, ks)) > 0
+    assert tiled == (cin % 16 == 0) and ("_gpnerf_packed_exact" in conv.__dict__) == tiled
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+        got2 = enc._conv_exact(conv, x.to("cuda:0"))
+    ref2 = 2 * ref - (conv.bias.detach().cpu()[None, :, None, None] if bias else 0)
+    assert float((got2.cpu() - ref2).abs().max()) < 6e-6 * scale
+
+
 @pytest.mark.parametrize("c,H,W,act,res", [(64, 37, 41, 1, False), (128, 16, 16, 1, True), (32, 24, 40, 2, False), (256, 5, 5, 0, False)])
 def test_instance_norm_act_nhwc_matches_torch(c, H, W, act, res, enc):
     g = torch.Generator().manual_seed(c + H)

@@ -29,7 +29,12 @@ with torch.no_grad():
     print("encoder gpu vs cpu restatement: max", float(d.max()), "mean", float(d.mean()), "absmax value", float(fm_ref.abs().max()))
     print("  per view max", [float(d[v].max()) for v in range(3)])
     print("  cpu restatement vs fixture subset", float((fm_ref[:, :, ::4, ::4] - torch.from_numpy(z["featmaps_sub"])).abs().max()))
-    for name, fm in (("gpu-encoder", None), ("cpu-restatement featmaps", fm_ref.to("cuda:0"))):
+    r.encoder.strict_exact = True
+    fm_exact = r.encoder(b["src_imgs"][0])
+    r.encoder.strict_exact = False
+    de = (fm_exact.cpu() - fm_ref).abs()
+    print("exact (fp32-MFMA) encoder vs cpu restatement: max", float(de.max()), "mean", float(de.mean()))
+    for name, fm in (("gpu-encoder", None), ("gpu exact encoder (GPNERF_ENCODER_EXACT=1)", fm_exact), ("cpu-restatement featmaps", fm_ref.to("cuda:0"))):
         bb = dict(b)
         if fm is not None:
             bb["featmaps"] = fm
