@@ -658,6 +658,17 @@ def test_config5_sized_frame_with_the_real_encoder_matches_the_reference(plugins
     print(f"e2e_512_survey: featmaps {e_fm:.2e}; identical inputs {fmt(same)}; chain {fmt(chain)} (reference's own spread "
           f"{spread}); psnr {m['psnr']:.5f} vs {float(z['psnr']):.5f}")
     assert abs(m["psnr"] - float(z["psnr"])) < 1e-3, (m["psnr"], float(z["psnr"]))
+    # D (round 5): the chain behind the EXACT encoder (encoder strict mode: fp32 operands on the fp32 MFMA, net.strict_exact /
+    # GPNERF_ENCODER_EXACT=1, 2.6 ms per frame instead of 1.0) is inside north_star's 1e-4 on EVERY map -- the split-f16
+    # convolutions' 3.5e-5 on the feature maps was what the head amplified to 2.9e-4 on depth
+    r.encoder.strict_exact = True
+    n0 = r.encoder.exact_frames
+    with torch.no_grad():
+        ret_x = r.render(b)
+    r.encoder.strict_exact = False
+    assert r.encoder.exact_frames == n0 + 1
+    exact = {k: assert_close(ret_x[k][0, ::st].cpu().numpy().reshape(z[k].shape), z[k], TOL, k + " (chain, exact encoder)") for k in ("rgb_map", "depth_map", "acc_map")}
+    print(f"e2e_512_survey, exact encoder: chain {fmt(exact)}")
 
 
 def test_patch_order_from_mask_at_box_is_only_a_launch_choice(plugins, syn):
