@@ -565,7 +565,7 @@ def demo_render_body_frame(args):
                     "device-to-host copy of the image"}
 
 
-def eval_loop_wall(args, frames=12):
+def eval_loop_wall(args, frames=12, fill="survey", reserve=(0,)):
     """The evaluation LOOP (libs/trainers/BaseTrainer.py:255-280 = evaluator.evaluate_loop) over `frames` ZJU-sized frames (SURVEY.md
     8d's f = 1.05 W camera, ~74 k rays x 64 samples, hip_encoder + vertex attention + sparse volume builder per frame, PSNR / MSE /
     SSIM per frame): wall time per frame of the reference's strictly serial loop against the pipelined one (Renderer.prefetch of
@@ -575,7 +575,7 @@ def eval_loop_wall(args, frames=12):
     syn = importlib.import_module("gp-nerf_amd.synthetic")
     ev = importlib.import_module("gp-nerf_amd.evaluator")
     dev = torch.device("cuda", torch.cuda.current_device())
-    sc = syn.make_scene(H=512, W=512, seed=args.seed, fill="survey", pose="identity", make_volumes=False)
+    sc = syn.make_scene(H=512, W=512, seed=args.seed, fill=fill, pose="identity", make_volumes=False)
     p = os.path.join(ROOT, "gp-nerf_amd", "plugins")
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -597,7 +597,9 @@ def eval_loop_wall(args, frames=12):
     b["rgb"] = torch.rand((1, n, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     loader = [dict(b) for _ in range(frames)]
     res = {"frames": frames, "rays_per_frame": n}
-    for name, mode in (("serial", False), ("pipelined", True)):
+    modes = [("serial", False, 0), ("pipelined", True, 0)] + [(f"pipelined_reserve_{n}_cus", True, n) for n in reserve if n]
+    for name, mode, res_cus in modes:
+        r.reserve_cus = res_cus
         ev.evaluate_loop(r, loader[:3], cfg, pipeline=mode, quiet=True)               # warm-up: graph capture, allocator
         walls, rts = [], []
         for _ in range(3):

@@ -2541,7 +2541,7 @@ const int* chain_custom(int* n) {
     *n = f_n;
     return f_len;
 }
-// The launches' sample ranges.  Default: equal segments of chain_len().  GPNERF_CHAIN_MERGE_AFTER=k (experiment knob, under
+// The launches' sample ranges.  Default: four segments of chain_len(), then segments twice as long.  GPNERF_CHAIN_MERGE_AFTER=k (experiment knob, under
 // GPNERF_DEBUG=1): from sample k on every segment is as long as all the samples before it ([0,16) .. [48,64), [64,128), ...).
 // Measured on the 512x512x128 bench frame, where 5 % of the rays are alive after 64 samples: 8.82 ms with equal segments,
 // 8.89 ms with the four tail launches merged into one -- the tail levels already run several samples of a ray per step
@@ -2558,6 +2558,10 @@ int chain_schedule(int S, int* begins) {
         begins[n] = k;
         if (nc > 0) cur = custom[n < nc ? n : nc - 1];
         else if (f_merge > 0 && k >= f_merge) { cur = k; }            // from here on every segment is as long as all before it
+        else if (f_merge == 0 && n >= 4) cur = 2 * len;               // default since round 5: four segments of `len`, then twice
+                                                                      // as long (512x512x128: 16,16,16,16,32,32 -- 8.22 against
+                                                                      // 8.33 ms, profiles/r04/f_c3_schedule_sweep.txt: the few
+                                                                      // rays alive past sample 64 need fewer, fuller launches)
         ++n;
         k += cur;
         if (n == CHAIN_MAX_SEGS - 1 && k < S) { begins[n++] = k; k = S; }     // (the schedule ran out of launches: one last segment to the end)

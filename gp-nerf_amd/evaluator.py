@@ -171,7 +171,13 @@ def evaluate_loop(render, eval_loader, cfg, device=None, quiet=False, pipeline=N
                 val = nxt
     wall = _time.time() - t_loop
     per_frame = {"mse": list(evaluator.mse), "psnr": list(evaluator.psnr), "ssim": list(evaluator.ssim)}
-    metrics = evaluator.summarize() if cfg.head.rgb.use_rgbhead else None
+    if quiet:                                                 # (summarize() prints its three means, as the reference's does)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            metrics = evaluator.summarize() if cfg.head.rgb.use_rgbhead else None
+    else:
+        metrics = evaluator.summarize() if cfg.head.rgb.use_rgbhead else None
     if not quiet:
         print(f"avg total render time: {total_time / max(count, 1)}s per sample")
     return dict(count=count, total_time=total_time, avg_time=total_time / max(count, 1), metrics=metrics, wall_time=wall, **per_frame)

@@ -34,7 +34,7 @@ from . import parallel as P_
 class Renderer(nn.Module):
     def __init__(self, encoder, nerfhead, is_train=False, neg_ray_train=False, neg_ray_val=False, n_rays=1024,
                  n_samples=64, voxel_size=(0.005, 0.005, 0.005), chunk=64, mesh_th=-1, early_term=None, term_eps=1e-5,
-                 progressive=False, split_f16=None, sharded_outputs="all", shard_group=None, encoder_graph=None, fold_levels=None):
+                 progressive=False, split_f16=None, sharded_outputs="all", shard_group=None, encoder_graph=None, fold_levels=None, reserve_cus=None):
         super().__init__()
         self.encoder = encoder
         self.nerfhead = nerfhead
@@ -81,6 +81,11 @@ class Renderer(nn.Module):
         # initialisation scale like the default, but 5-10 x further on trained-like parameters.  Default: the reference-order
         # form (frame.render_fused).  GPNERF_FOLD=1 switches it on from outside.
         self.fold_levels = (os.environ.get("GPNERF_FOLD", "0") == "1") if fold_levels is None else bool(fold_levels)
+        # reserve_cus (GPNERF_RESERVE_CUS): in a PIPELINED loop (render(..., next_batch=...)) plan the per-ray launch for this many
+        # fewer compute units, so that the next frame's encoder / builder run BESIDE it on the CUs it leaves.  Pays on frames of
+        # several rounds of wavefronts (512x512 full frame: -3 % kernel for -1.4 ms of producers); on a ZJU-sized frame of ~one
+        # round the smaller chip quantises badly and it loses (profiles/r05/d_pipeline.txt).  Default 0.
+        self.reserve_cus = int(os.environ.get("GPNERF_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
 
     # ---- helpers the reference exposes as methods (stage entry points) ----------------------------
     def _neg_ray(self, batch):
@@ -419,7 +424,8 @@ class Renderer(nn.Module):
             # sharded: `r` is this rank's share, already in patch-major order
             return F_.render_fused(frame, r, self.n_samples, neg_ray=neg, early_term=self.early_term, term_eps=self.term_eps,
                                    split_f16=self.split_f16, ray_order=None if sharded else order, want=("weights", "z_vals", "rgb_in"),
-                                   fold="keep" if self.fold_levels else False)
+                                   fold="keep" if self.fold_levels else False,
+                                   reserve_cus=self.reserve_cus if (next_batch is not None and not sharded) else 0)
 
         # every map of the reference's dict travels in ONE packed all-gather; sharded_outputs = "pixels" keeps the exchange at
         # the 16 B/ray of rgb + depth (what an evaluation loop reads, libs/evaluators/if_nerf.py:50-56) and returns only those
