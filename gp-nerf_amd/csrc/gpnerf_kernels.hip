@@ -1164,6 +1164,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     int chain, seg, wave_cap;
     int k_begin, k_end;       // chained form: the launch's sample range [k_begin, k_end) (segments need not be equally long, chain_schedule())
     int stagger;              // experiment: wavefronts start up to this many x 1.7 us late, scattered over the chip
+    int seg_major;            // split > 1 on the tile queue: units ordered segment-major (1) or tile-major (0)
     int chunk;                // tiles per chunk of the XCD queues (queue_tile())
     int tail_p;               // chain_plan(): samples per step of the units the last whole round is cut into
     const int* list_in;
@@ -1788,6 +1789,11 @@ render_fused_kernel(const KArgs ka) {
             long n_tiles = (kq->n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
             ChainPlan plan;
             if constexpr (CHAIN) { plan = chain_plan(kq); n_tiles = plan.bulk_tiles + plan.rem_tiles; }
+            // plain form with kq->split > 1: the queue's units are (tile, sample segment) pairs, tile-major -- a frame of one to two
+            // rounds of wavefronts then ends in short units instead of whole 64-step tiles (see gpnerf_render_fused)
+            const int usplit = CHAIN ? 1 : kq->split;
+            const long tiles_per_seg = n_tiles;
+            n_tiles *= usplit;
             // fewer tiles than waves: deal them evenly, so that every CU runs the same few waves (each then steps faster) rather
             // than the first workgroups to arrive running eight and the rest none
             const long share = kq->wave_cap ? (long)kq->wave_cap : (n_tiles + gridDim.x - 1) / gridDim.x;
@@ -1801,6 +1807,10 @@ render_fused_kernel(const KArgs ka) {
                 continue;
             }
             tile = queue_tile(kq->chunk, qx, t);
+            if (usplit > 1) {
+                if (kq->seg_major) { seg = (int)(tile / tiles_per_seg); tile -= (long)seg * tiles_per_seg; }      // all tiles' first segment, then the second ...
+                else { seg = (int)(tile % usplit); tile /= usplit; }
+            }
             if constexpr (CULL) { if (kq->tile_order) tile = kq->tile_order[tile]; }
             if constexpr (CHAIN) {
                 seg = kq->seg;
@@ -3118,16 +3128,38 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const bool remainder = f_rem && workspace && workspace_bytes >= QUEUE_BYTES && !(flags & (GPNERF_FLAG_EARLY_TERM | GPNERF_FLAG_OCC_CULL)) &&
                            n_cus >= 8 && tiles > slots && rem_tiles > 0 && rem_tiles * 8 <= slots && n_samples >= 8 && !dbg_env("GPNERF_WAVES");
     if (remainder) { g.waves = GPNERF_MAX_WAVES; g.split = 1; }
-    int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
-    // more than one round of workgroups and nothing split: persistent workgroups + tile queue (see render_fused_kernel)
+    // EXPERIMENT, not the default (GPNERF_DEBUG=1 GPNERF_QSPLIT=2 / 4 / 8): a frame of one to two rounds of wavefronts (2 048 < tiles
+    // <= 4 096 on 256 CUs: the 74 k-ray ZJU-sized frame, 272^2 ... 360^2 crops) ends with every SIMD's last whole tile running alone
+    // (profiles/r04/l_survey_frame_analysis.md).  Here the persistent workgroups pull (tile, sample segment) UNITS of
+    // S / n samples from the queue instead of whole tiles (same 32 rays per wavefront, same cost per step), each unit parks its
+    // partial composite and combine_segments_kernel merges them as it does for small frames.  Measured, reference-order form
+    // (profiles/r05/l_qsplit_sweep.txt): n = 8: 272^2 4.83 -> 4.40 ms, 320^2 6.39 -> 5.79, 360^2 7.49 -> 7.31, the survey frame
+    // 4.61 -> 4.52 (n = 4: 4.34), exactly one round (256^2) 3.83 -> 3.90; segment-major against tile-major unit order: no
+    // difference.  NOT adopted: the merge associates the transmittance product per segment (~1e-7 relative), so a frame in that
+    // range would no longer be bit-identical to its own shards or to the same rays inside a larger launch -- the invariant the
+    // strong-scaling path is tested on (tests/test_gpu_configs.py: the 8-rank plan of the 1024^2 frame has shares of exactly 4 096
+    // tiles) -- for 2 % on the frame size that matters.  A bit-exact version needs the units of a tile to resume each other's
+    // state in order (the chained form's parked state inside one launch).
     static int f_dynamic = -1;
     if (f_dynamic < 0) f_dynamic = dbg_int("GPNERF_DYNAMIC", 1, 0, 1);
-    const bool dynamic = f_dynamic && workspace && workspace_bytes >= QUEUE_BYTES && g.split == 1 && blocks > n_cus;
+    static int f_qsplit = -1;
+    if (f_qsplit < 0) f_qsplit = dbg_int("GPNERF_QSPLIT", 0, 0, 8);
+    bool qsplit = false;
+    {
+        int q = f_qsplit > 1 ? f_qsplit : 0;
+        while (q > 1 && n_samples / q < 8) q >>= 1;
+        if (q > 1 && may_split && !culling && seg_bytes >= (size_t)n_rays * q * 16 * sizeof(float) && tiles > n_cus && f_dynamic) {
+            g.waves = GPNERF_MAX_WAVES; g.split = q; qsplit = true;
+        }
+    }
+    int64_t blocks = (tiles * g.split + g.waves - 1) / g.waves;
+    // more than one round of workgroups and nothing split: persistent workgroups + tile queue (see render_fused_kernel)
+    const bool dynamic = f_dynamic && workspace && workspace_bytes >= QUEUE_BYTES && (g.split == 1 || qsplit) && blocks > n_cus;
     if (dynamic) {
         if (!zero_async(workspace, QUEUE_BYTES, stream)) return GPNERF_E_LAUNCH;
         blocks = n_cus;
     }
-    const bool do_remainder = remainder && dynamic;
+    const bool do_remainder = remainder && dynamic && !qsplit;
     const OutK ok = to_outk(out, ray_order);
     KArgs ka;
     memset(&ka, 0, sizeof(ka));
@@ -3156,6 +3188,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     static int f_cap = -1;
     if (f_cap < 0) f_cap = dbg_int("GPNERF_WAVE_CAP", 0, 0, 8);      // experiments: waves per CU that pull tiles
     ka.wave_cap = f_cap;
+    static int f_segmajor = -1;
+    if (f_segmajor < 0) f_segmajor = dbg_int("GPNERF_QSPLIT_SEGMAJOR", 0, 0, 1);
+    ka.seg_major = f_segmajor;
     static int f_stagger = -1;
     if (f_stagger < 0) f_stagger = dbg_int("GPNERF_STAGGER", 0, 0, 4096);
     ka.stagger = f_stagger;
