@@ -34,6 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 110848           # 2*MAC of the reference's dense layers, V=3, C=32
+FLOP_SIGMA_LAYER = 16384           # ... of which sigmahead.out_geometry_fc (128 -> 64)
+FLOP_COLOUR_BRANCH = 52608 + 12288 + 7264      # ... and base_fc x 3 views + vis_fc x 3 + rgb_fc
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense f16 MFMA peak (the split-precision form's matrix instructions)
 API_OUTPUTS = ("weights", "z_vals", "rgb_in")      # + rgb, depth, acc, disp (always written) = Renderer.render's dict
@@ -327,7 +329,21 @@ def main():
             evaluated = float(done.float().mean()) / S
             alive_after = {str(k): float((done > k).float().mean()) for k in range(32, S, 32)}
             flops_per_launch *= evaluated
+        # The reference-order form leaves out work that provably cannot change any output, wave step by wave step (bit-exact, see
+        # include/gpnerf_hip.h step_stats): the sigma feature layer where all 32 samples' volume features are zero, the colour branch
+        # where all 32 densities are zero (samples no source view sees: masked_fill; ReLU).  The roofline prices the work DONE:
+        # the launch reports how many steps took each exit, and their layers' FLOPs are taken off the algorithmic count.
+        stt = fm.render_fused(wl.frame, flow.rays, S, want=flow.want + ("step_stats",), ray_order=flow.order, fold=flow.fold, **kw)["step_stats"].cpu().numpy()
+        steps = max(1, int(stt[0]))
+        not_done = (float(stt[1]) * FLOP_SIGMA_LAYER + float(stt[2]) * FLOP_COLOUR_BRANCH) / (steps * FLOP_PER_SAMPLE)
+        exits = {"steps_32_samples": int(stt[0]), "sigma_layer_exit_frac": float(stt[1]) / steps, "colour_branch_exit_frac": float(stt[2]) / steps,
+                 "flop_not_done_frac": not_done,
+                 "note": "bit-exact exits (GPNERF_FLAG_NO_EXITS switches them off): volume features of all 32 samples zero -> ELU(bias) without the "
+                         "sigma feature layer (reference-order form); density of all 32 samples zero -> the colour branch cannot change any map"}
+        # `achieved` / `frac` follow the contract: ALGORITHMIC flops (every sample the launch is answerable for x 110 848) per second.
+        # `frac_of_work_done` takes the exits' layers off the numerator: what the matrix pipe was actually asked to do.
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        achieved_done = achieved * (1.0 - not_done)
         cfg_no = 2 if args.early_term else (3 if (args.size == 1024 and world > 1) else 1)
         if world == 1:
             parallelism = "single GPU"
@@ -353,7 +369,8 @@ def main():
                        "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_per_launch},
+                         "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_per_launch,
+                         "frac_of_work_done": achieved_done / peak, "exits": exits},
         }
         line.update(extras)
         line.update(rank_summary)

@@ -78,7 +78,7 @@ class GpnerfOutputs(C.Structure):
     _fields_ = [
         ("rgb", C.c_void_p), ("depth", C.c_void_p), ("acc", C.c_void_p), ("disp", C.c_void_p),
         ("weights", C.c_void_p), ("z_vals", C.c_void_p), ("rgb_in", C.c_void_p), ("ray_mask", C.c_void_p),
-        ("raw", C.c_void_p), ("samples_done", C.c_void_p),
+        ("raw", C.c_void_p), ("samples_done", C.c_void_p), ("step_stats", C.c_void_p),
     ]
 
 
@@ -89,6 +89,7 @@ FLAG_SPLIT_F16 = 8
 FLAG_FLIP_SAMPLES = 16
 FLAG_SPLIT_GUARD = 32
 FLAG_REF_ORDER = 64
+FLAG_NO_EXITS = 128
 FOLD_FIRST_LEVEL = 2
 
 # every symbol include/gpnerf_hip.h declares: (restype, argtypes)

@@ -266,7 +266,7 @@ DEV void geo_eval(const float* __restrict__ lds, int lane, const float (&fv)[64]
 //   nvalid : number of valid views of this lane's sample
 // returns sigma and rgb (identical in both halves of a ray).
 DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
-                  float nvalid, float& sigma, float (&rgb)[3], Stamps& st) {
+                  float nvalid, float& sigma, float (&rgb)[3], Stamps& st, const bool skip_colour = false) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
     float d1in[68];
@@ -308,6 +308,7 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
         s = fmaxf(s, 0.f);                              // nn.ReLU
         sigma = (nvalid < 1.f) ? 0.f : s;               // masked_fill(num_valid_obs < 1, 0)
     }
+    if (skip_colour && __all(sigma == 0.f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; return; }      // the zero-density exit (see mlp_eval_ref)
 
     STAMP(st, 3);
     // ---- colour branch (trainhead.py:85-100,131,139-143) ----
@@ -465,10 +466,28 @@ DEV void geo_eval_ref(const float* __restrict__ lds, int lane, const float (&fv)
     elur_n<16>(g1, bq_g1, sf + 16);
 }
 
+// the same layer on all-zero volume features: ELU(0 + bias), no matrix work
+DEV void geo_bias_ref(const float* __restrict__ lds, int lane, float (&sf)[32]) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    f32x16 z0 = zero_tile(), z1 = zero_tile();
+    f32x4 b0[4], b1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        b0[q] = *reinterpret_cast<const f32x4*>(bias_ptr<gpl::GEO>(lds, 0, half) + 4 * q);
+        b1[q] = *reinterpret_cast<const f32x4*>(bias_ptr<gpl::GEO>(lds, 1, half) + 4 * q);
+    }
+    elur_n<16>(z0, b0, sf);
+    elur_n<16>(z1, b1, sf + 16);
+}
+
 // The rest of NeRFHead.forward in the reference's order.  x[v][18]: slot t of half h = element gpr::ref35(t, h) of view v's
 // [r, g, b, f0..f31] (slot 1 of half 1 is the zero pad).
+// skip_colour: the caller does not need rgb where the density is zero (no `raw` output): when the density of ALL 32 samples of the
+// step is exactly 0 (nn.ReLU; masked_fill) every weight alpha * T of the step is 0 and 0 * rgb adds exactly 0 to every map for any
+// finite rgb, so the colour branch -- 434 of the step's 748 MFMAs -- is not evaluated.  Same bits; a trained model's empty space.
 DEV void mlp_eval_ref(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
-                      float nvalid, float& sigma, float (&rgb)[3], Stamps& st) {
+                      float nvalid, float& sigma, float (&rgb)[3], Stamps& st, const bool skip_colour = false) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
     float d1in[68];
@@ -515,6 +534,7 @@ DEV void mlp_eval_ref(const float* __restrict__ lds, int lane, const float (&sf)
         s = fmaxf(s, 0.f);                              // nn.ReLU
         sigma = (nvalid < 1.f) ? 0.f : s;               // masked_fill(num_valid_obs < 1, 0)
     }
+    if (skip_colour && __all(sigma == 0.f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; return; }
 
     STAMP(st, 3);
     // ---- colour branch (trainhead.py:85-100,131,139-143) ----
@@ -729,7 +749,7 @@ DEV void geo_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const float
 
 template <class G>
 DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const float (&x)[NV][18], float nvalid,
-                    float& sigma, float (&rgb)[3], Stamps& st) {
+                    float& sigma, float (&rgb)[3], Stamps& st, const bool skip_colour = false) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
     const float* lf = reinterpret_cast<const float*>(lw);
@@ -772,6 +792,7 @@ DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag 
         s = fmaxf(s, 0.f);
         sigma = (nvalid < 1.f) ? 0.f : s;
     }
+    if (skip_colour && __all(sigma == 0.f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; return; }      // the zero-density exit (see mlp_eval_ref)
     STAMP(st, 3);
     // colour branch (trainhead.py:85-100,131,139-143)
     f32x16 s0 = bias_tile_s<gpl::BS>(lw, 0, half), s1 = bias_tile_s<gpl::BS>(lw, 1, half);
@@ -1143,6 +1164,7 @@ struct OutK {
     float *rgb, *depth, *acc, *disp, *weights, *z_vals, *rgb_in, *raw;
     uint8_t* ray_mask;
     int32_t* samples_done;
+    unsigned* step_stats;     // optional [4]: wave-steps walked, sigma-layer exits, colour-branch exits (reference-order form)
     const int32_t* order;     // optional: slot i of the launch renders ray order[i] (locality-friendly tiling)
 };
 
@@ -1165,6 +1187,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     int k_begin, k_end;       // chained form: the launch's sample range [k_begin, k_end) (segments need not be equally long, chain_schedule())
     int stagger;              // experiment: wavefronts start up to this many x 1.7 us late, scattered over the chip
     int seg_major;            // split > 1 on the tile queue: units ordered segment-major (1) or tile-major (0)
+    int skip;                 // reference-order form: bit 0 = empty-space exit of the sigma feature layer, bit 1 = zero-density exit of the colour branch
     int chunk;                // tiles per chunk of the XCD queues (queue_tile())
     int tail_p;               // chain_plan(): samples per step of the units the last whole round is cut into
     const int* list_in;
@@ -1401,6 +1424,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 #pragma unroll
     for (int i = 0; i < 9; ++i) rin[i] = 0.f;
     int n_two = 0, n_done = 0;
+    int st_steps = 0, st_geo = 0, st_col = 0;           // wave-uniform tallies for out.step_stats
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0) && (sub == 0);
 
@@ -1523,13 +1547,26 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
             if constexpr (SPLIT) geo_eval_s(gmax, lw, lane, fv, sff);
             else {
                 // reference order: k-step t of the layer = channels (2i, 2i + 1) of level t >> 4
-                float fk[64];
+                // Empty space: where none of the 32 samples of the step touches an active voxel of any level, all 128 volume features
+                // are exactly zero, the layer's chain is fma(w, 0, s) from s = 0, i.e. 0, and its output is ELU(bias) -- the SAME
+                // bits without the 128 MFMAs.  A real frame's pyramid is ReLU-sparse and mostly empty (body-like frame: 2 % of
+                // level 0's voxels are sites), so most steps of most wavefronts take this exit; the dense synthetic bench frame
+                // never does and pays the test (32 v_or3 + a ballot).  (kp->skip: off under GPNERF_FLAG_NO_EXITS.)
+                unsigned bits = 0u;
 #pragma unroll
-                for (int l = 0; l < GPNERF_LEVELS; ++l) interleave16(fv + 16 * l, fk + 16 * l);
+                for (int i = 0; i < 64; i += 2) bits |= __builtin_bit_cast(unsigned, fv[i]) | __builtin_bit_cast(unsigned, fv[i + 1]);
+                if ((kp->skip & 1) && __all((bits << 1) == 0u)) {          // (-0.0 counts as zero: fma(w, -0, +0) = +0 too)
+                    ++st_geo;
+                    geo_bias_ref(lds, lane, sf);
+                } else {
+                    float fk[64];
+#pragma unroll
+                    for (int l = 0; l < GPNERF_LEVELS; ++l) interleave16(fv + 16 * l, fk + 16 * l);
 #ifdef GPNERF_X_DUMP
-                dbg[0] = fk[0]; dbg[1] = fk[1]; dbg[2] = fk[8]; dbg[3] = fk[16];
+                    dbg[0] = fk[0]; dbg[1] = fk[1]; dbg[2] = fk[8]; dbg[3] = fk[16];
 #endif
-                geo_eval_ref(lds, lane, fk, sf);
+                    geo_eval_ref(lds, lane, fk, sf);
+                }
             }
         }
         STAMP(st, 1);
@@ -1567,9 +1604,12 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 
         STAMP(st, 2);
         float sigma, rgb[3];
-        if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
-        else if constexpr (FORM == FORM_F32) mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st);
-        else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
+        const bool may_skip = (kp->skip & 2) && !out.raw;
+        if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st, may_skip);
+        else if constexpr (FORM == FORM_F32) mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
+        else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
+        ++st_steps;
+        if (may_skip && __all(sigma == 0.f)) ++st_col;
         if (CULL || cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
@@ -1657,6 +1697,13 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     st.flush(lane);
     kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
+    {
+        if (kp->out.step_stats && lane == 0) {
+            atomicAdd(kp->out.step_stats + 0, (unsigned)st_steps);
+            if (st_geo) atomicAdd(kp->out.step_stats + 1, (unsigned)st_geo);
+            if (st_col) atomicAdd(kp->out.step_stats + 2, (unsigned)st_col);
+        }
+    }
     if constexpr (FORM == FORM_SPLIT_GUARD) {
         // an operand at or beyond the f16 range (or a NaN): the hi/lo pair no longer carries the value, flag the tile
         unsigned* const gs = guard_slot();
@@ -2748,7 +2795,7 @@ OutK to_outk(const GpnerfOutputs* o, const int32_t* order = nullptr) {
     OutK k;
     k.order = order;
     k.rgb = o->rgb; k.depth = o->depth; k.acc = o->acc; k.disp = o->disp; k.weights = o->weights;
-    k.z_vals = o->z_vals; k.rgb_in = o->rgb_in; k.raw = o->raw; k.ray_mask = o->ray_mask; k.samples_done = o->samples_done;
+    k.z_vals = o->z_vals; k.rgb_in = o->rgb_in; k.raw = o->raw; k.ray_mask = o->ray_mask; k.samples_done = o->samples_done; k.step_stats = o->step_stats;
     return k;
 }
 
@@ -3188,6 +3235,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     static int f_cap = -1;
     if (f_cap < 0) f_cap = dbg_int("GPNERF_WAVE_CAP", 0, 0, 8);      // experiments: waves per CU that pull tiles
     ka.wave_cap = f_cap;
+    ka.skip = (flags & GPNERF_FLAG_NO_EXITS) ? 0 : 3;
     static int f_segmajor = -1;
     if (f_segmajor < 0) f_segmajor = dbg_int("GPNERF_QSPLIT_SEGMAJOR", 0, 0, 1);
     ka.seg_major = f_segmajor;

@@ -298,7 +298,7 @@ def patch_order_rays(mask, H, W, n, patch_w=32, patch_h=8):
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-5,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
-                 split_f16=False, flip=None, subset=False, guard=None, fold=None, reserve_cus=0):
+                 split_f16=False, flip=None, subset=False, guard=None, fold=None, reserve_cus=0, exits=True):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); defaults to neg_ray for the dense renderer
     (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
@@ -318,6 +318,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     form -- coarse levels folded into the sigma feature layer per frame (Frame.fold_volumes), log2(e)-scaled layers: ~8 % faster,
     the same 1e-5 at initialisation scale, 5-10 x further from the reference on trained-like parameters.  "keep": True without
     re-folding a Frame that is already folded.
+    exits=False: the reference-order form without its two bit-exact exits (GPNERF_FLAG_NO_EXITS; want=("step_stats",) counts them).
     reserve_cus: plan the launch for that many fewer compute units (multiple of 8), leaving them to kernels of other streams
     (GPNERF_FLAG_RESERVE_CUS).  The maps are those of a chip with that many fewer CUs."""
     lib = L.lib()
@@ -352,6 +353,9 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     if "raw" in want:
         res["raw"] = torch.empty((N, S, 4), device=dev)
         o.raw = res["raw"].data_ptr()
+    if "step_stats" in want:                               # [steps walked, sigma-layer exits, colour-branch exits, 0] (reference-order form)
+        res["step_stats"] = torch.zeros((4,), device=dev, dtype=torch.int32)
+        o.step_stats = res["step_stats"].data_ptr()
     if "samples_done" in want:
         res["samples_done"] = torch.empty((N,), device=dev, dtype=torch.int32)
         o.samples_done = res["samples_done"].data_ptr()
@@ -359,6 +363,8 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
         flip = bool(neg_ray) and not occ_cull
     flags = (L.FLAG_NEG_RAY if neg_ray else 0) | (L.FLAG_FLIP_SAMPLES if flip else 0) | (L.FLAG_EARLY_TERM if early_term else 0)
     flags |= (int(reserve_cus) & 0xff) << 24
+    if not exits:
+        flags |= L.FLAG_NO_EXITS
     if split_f16:
         if not frame.c.head_blob_split:
             raise L.GpnerfError("split_f16 needs the f16 hi/lo head image (build the frame from pack_head()'s tensor)")

@@ -413,6 +413,36 @@ def test_folded_coarse_levels_equal_the_layer_per_sample(size, S, neg, kw, fm, o
             assert_close(b[k][pick], ref[k], TOL, k)
 
 
+def test_the_two_exits_of_the_reference_order_form_change_no_bit(fm, syn):
+    """Where none of a step's 32 samples touches an active voxel the sigma feature layer is ELU(bias); where all 32 densities are
+    exactly 0 (no source view sees the samples: masked_fill; ReLU) the colour branch cannot change a map.  The default form leaves
+    both out, wave step by wave step, and reports how often (step_stats); every map is bit-identical to the launch that evaluates
+    everything (GPNERF_FLAG_NO_EXITS) -- on a sparse person-shaped pyramid, on a frame whose source views miss part of the box, under
+    early termination -- and a launch that returns `raw` (which needs every colour) agrees too."""
+    cases = [dict(H=96, W=96, seed=81, fill="survey", pose="identity", body="capsules", sigma_bias=-1.0, bias_std=0.1, vol_scale=2.0),
+             dict(H=64, W=64, seed=82, focal_mul=5.0, pose="random", aabb_half=(0.12, 0.16, 0.05), bias_std=0.1, sigma_bias=-0.5),
+             dict(H=288, W=288, seed=83, fill="full", pose="identity", bias_std=0.1)]
+    seen = [0, 0]
+    for kw in cases:
+        sc = syn.make_scene(**kw)
+        fr = build_frame(fm, sc)
+        rays = rays_of(sc)
+        for extra in ({}, {"early_term": True, "term_eps": 1e-5}):
+            want = ("weights", "z_vals", "rgb_in", "ray_mask", "step_stats")
+            a = fm.render_fused(fr, rays, 48, want=want, **extra)
+            b = fm.render_fused(fr, rays, 48, want=want, exits=False, **extra)
+            st_a, st_b = a.pop("step_stats").cpu().numpy(), b.pop("step_stats").cpu().numpy()
+            assert st_b[1] == 0 and st_b[2] == 0 and st_a[0] == st_b[0] > 0
+            seen[0] += int(st_a[1]); seen[1] += int(st_a[2])
+            for k in a:
+                assert torch.equal(torch.nan_to_num(a[k].float()), torch.nan_to_num(b[k].float())), (kw.get("seed"), extra, k)
+        r = fm.render_fused(fr, rays, 48, want=("raw", "weights"))
+        assert torch.equal(r["rgb_map"], a["rgb_map"]) if not extra else True
+        full = fm.render_fused(fr, rays, 48, want=("weights",))
+        assert torch.equal(r["rgb_map"], full["rgb_map"]) and torch.equal(r["weights"], full["weights"])
+    assert seen[0] > 0 and seen[1] > 0, f"the test scenes never took an exit: {seen}"
+
+
 def test_reserved_cus_render_the_same_frame(fm, syn):
     """GPNERF_FLAG_RESERVE_CUS plans the launch for fewer compute units (the pipelined loop's experiment, profiles/r05/d_pipeline.txt).
     A ray's result is a function of the ray alone, so the maps are the ones a smaller chip gives: bit-identical whenever the launch
