@@ -339,7 +339,7 @@ def main():
         exits = {"steps_32_samples": int(stt[0]), "sigma_layer_exit_frac": float(stt[1]) / steps, "colour_branch_exit_frac": float(stt[2]) / steps,
                  "flop_not_done_frac": not_done,
                  "note": "bit-exact exits (GPNERF_FLAG_NO_EXITS switches them off): volume features of all 32 samples zero -> ELU(bias) without the "
-                         "sigma feature layer (reference-order form); density of all 32 samples zero -> the colour branch cannot change any map"}
+                         "sigma feature layer; density of all 32 samples zero -> the colour branch cannot change any map (both in the reference-order form only)"}
         # `achieved` / `frac` follow the contract: ALGORITHMIC flops (every sample the launch is answerable for x 110 848) per second.
         # `frac_of_work_done` takes the exits' layers off the numerator: what the matrix pipe was actually asked to do.
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12

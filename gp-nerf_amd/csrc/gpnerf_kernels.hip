@@ -266,7 +266,7 @@ DEV void geo_eval(const float* __restrict__ lds, int lane, const float (&fv)[64]
 //   nvalid : number of valid views of this lane's sample
 // returns sigma and rgb (identical in both halves of a ray).
 DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
-                  float nvalid, float& sigma, float (&rgb)[3], Stamps& st, const bool skip_colour = false) {
+                  float nvalid, float& sigma, float (&rgb)[3], Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
     float d1in[68];
@@ -308,7 +308,6 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
         s = fmaxf(s, 0.f);                              // nn.ReLU
         sigma = (nvalid < 1.f) ? 0.f : s;               // masked_fill(num_valid_obs < 1, 0)
     }
-    if (skip_colour && __all(sigma == 0.f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; return; }      // the zero-density exit (see mlp_eval_ref)
 
     STAMP(st, 3);
     // ---- colour branch (trainhead.py:85-100,131,139-143) ----
@@ -749,7 +748,7 @@ DEV void geo_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const float
 
 template <class G>
 DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const float (&x)[NV][18], float nvalid,
-                    float& sigma, float (&rgb)[3], Stamps& st, const bool skip_colour = false) {
+                    float& sigma, float (&rgb)[3], Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
     const float* lf = reinterpret_cast<const float*>(lw);
@@ -792,7 +791,6 @@ DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag 
         s = fmaxf(s, 0.f);
         sigma = (nvalid < 1.f) ? 0.f : s;
     }
-    if (skip_colour && __all(sigma == 0.f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; return; }      // the zero-density exit (see mlp_eval_ref)
     STAMP(st, 3);
     // colour branch (trainhead.py:85-100,131,139-143)
     f32x16 s0 = bias_tile_s<gpl::BS>(lw, 0, half), s1 = bias_tile_s<gpl::BS>(lw, 1, half);
@@ -1604,12 +1602,16 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 
         STAMP(st, 2);
         float sigma, rgb[3];
-        const bool may_skip = (kp->skip & 2) && !out.raw;
-        if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st, may_skip);
-        else if constexpr (FORM == FORM_F32) mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
-        else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
+        // (the zero-density exit in the reference-order form only: built into the folded and split forms too, the early return
+        // cost their sample loops their register allocation -- 13.3 -> 15.1 ms and 7.5 -> 10.3 ms on the bench frame)
+        if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
+        else if constexpr (FORM == FORM_F32) {
+            const bool may_skip = (kp->skip & 2) && !out.raw;
+            mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
+            if (may_skip && __all(sigma == 0.f)) ++st_col;
+        }
+        else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
         ++st_steps;
-        if (may_skip && __all(sigma == 0.f)) ++st_col;
         if (CULL || cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
