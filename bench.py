@@ -298,6 +298,10 @@ def main():
             return dt, float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), out
 
     flow = Flow(wl)
+    # how many 32-sample steps take the kernel's bit-exact exits: counted by one launch BEFORE the warm-up (it is the process's cold
+    # launch; behind the timed region it would be a second cold one -- the device clocks down while the host reduces the timings --
+    # and sit in the profiler's average of this kernel)
+    step_stats = fm.render_fused(wl.frame, flow.rays, S, want=flow.want + ("step_stats",), ray_order=flow.order, fold=flow.fold, **kw)["step_stats"].cpu().numpy()
     dt, kernel_ms, out = flow.timed(args.steps, args.warmup)
     # who ran where: every rank's device identity and its own event times, gathered once, after the timed region
     report = dict(device_identity(dev), rank=rank, local_rank=local_rank, kernel_ms=kernel_ms, exchange_ms=getattr(flow, "exchange_ms", None),
@@ -333,7 +337,7 @@ def main():
         # include/gpnerf_hip.h step_stats): the sigma feature layer where all 32 samples' volume features are zero, the colour branch
         # where all 32 densities are zero (samples no source view sees: masked_fill; ReLU).  The roofline prices the work DONE:
         # the launch reports how many steps took each exit, and their layers' FLOPs are taken off the algorithmic count.
-        stt = fm.render_fused(wl.frame, flow.rays, S, want=flow.want + ("step_stats",), ray_order=flow.order, fold=flow.fold, **kw)["step_stats"].cpu().numpy()
+        stt = step_stats
         steps = max(1, int(stt[0]))
         not_done = (float(stt[1]) * FLOP_SIGMA_LAYER + float(stt[2]) * FLOP_COLOUR_BRANCH) / (steps * FLOP_PER_SAMPLE)
         exits = {"steps_32_samples": int(stt[0]), "sigma_layer_exit_frac": float(stt[1]) / steps, "colour_branch_exit_frac": float(stt[2]) / steps,

@@ -1422,7 +1422,6 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 #pragma unroll
     for (int i = 0; i < 9; ++i) rin[i] = 0.f;
     int n_two = 0, n_done = 0;
-    int st_steps = 0, st_geo = 0, st_col = 0;           // wave-uniform tallies for out.step_stats
     const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
     const bool writer = active && (half == 0) && (sub == 0);
 
@@ -1554,7 +1553,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 #pragma unroll
                 for (int i = 0; i < 64; i += 2) bits |= __builtin_bit_cast(unsigned, fv[i]) | __builtin_bit_cast(unsigned, fv[i + 1]);
                 if ((kp->skip & 1) && __all((bits << 1) == 0u)) {          // (-0.0 counts as zero: fma(w, -0, +0) = +0 too)
-                    ++st_geo;
+                    if (out.step_stats && lane == 0) atomicAdd(out.step_stats + 1, 1u);      // (the diagnostic launch only: no tally lives in the loop)
                     geo_bias_ref(lds, lane, sf);
                 } else {
                     float fk[64];
@@ -1608,10 +1607,13 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         else if constexpr (FORM == FORM_F32) {
             const bool may_skip = (kp->skip & 2) && !out.raw;
             mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
-            if (may_skip && __all(sigma == 0.f)) ++st_col;
+            if (out.step_stats) {                                   // (the diagnostic launch only)
+                const bool all_zero = may_skip && __all(sigma == 0.f);
+                if (all_zero && lane == 0) atomicAdd(out.step_stats + 2, 1u);
+            }
         }
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
-        ++st_steps;
+        if (out.step_stats && lane == 0) atomicAdd(out.step_stats + 0, 1u);
         if (CULL || cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
@@ -1699,13 +1701,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     st.flush(lane);
     kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
-    {
-        if (kp->out.step_stats && lane == 0) {
-            atomicAdd(kp->out.step_stats + 0, (unsigned)st_steps);
-            if (st_geo) atomicAdd(kp->out.step_stats + 1, (unsigned)st_geo);
-            if (st_col) atomicAdd(kp->out.step_stats + 2, (unsigned)st_col);
-        }
-    }
+
     if constexpr (FORM == FORM_SPLIT_GUARD) {
         // an operand at or beyond the f16 range (or a NaN): the hi/lo pair no longer carries the value, flag the tile
         unsigned* const gs = guard_slot();
