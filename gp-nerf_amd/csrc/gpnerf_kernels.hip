@@ -485,16 +485,8 @@ DEV void geo_bias_ref(const float* __restrict__ lds, int lane, float (&sf)[32]) 
 // skip_colour: the caller does not need rgb where the density is zero (no `raw` output): when the density of ALL 32 samples of the
 // step is exactly 0 (nn.ReLU; masked_fill) every weight alpha * T of the step is 0 and 0 * rgb adds exactly 0 to every map for any
 // finite rgb, so the colour branch -- 434 of the step's 748 MFMAs -- is not evaluated.  Same bits; a trained model's empty space.
-DEV void mlp_eval_ref(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
-                      float nvalid, float& sigma, float (&rgb)[3], Stamps& st, const bool skip_colour = false) {
-    asm volatile("" : "+v"(lane));
-    const int half = lane >> 5;
-    float d1in[68];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) d1in[r] = sf[r];
-
-    // ---- fused_mean_variance (trainhead.py:20-24): x.mean(-2) = sum / 3, then mean((x - mean)^2) = sum / 3 ----
-    float mv[36];
+// fused_mean_variance (trainhead.py:20-24): x.mean(-2) = sum / 3, then mean((x - mean)^2) = sum / 3
+DEV void mean_var_ref(const float (&x)[NV][18], float (&mv)[36]) {
 #pragma unroll
     for (int t = 0; t < 18; t += 2) {
         const f32x2 x0 = {x[0][t], x[0][t + 1]}, x1 = {x[1][t], x[1][t + 1]}, x2 = {x[2][t], x[2][t + 1]};
@@ -504,6 +496,15 @@ DEV void mlp_eval_ref(const float* __restrict__ lds, int lane, const float (&sf)
         mv[t] = m[0]; mv[t + 1] = m[1];
         mv[18 + t] = v[0]; mv[18 + t + 1] = v[1];
     }
+}
+
+// density branch alone (the deferred-colour sample loop, render_tile): sigma of this lane's sample
+DEV void mlp_density_ref(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&mv)[36], float nvalid, float& sigma) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    float d1in[68];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) d1in[r] = sf[r];
 #pragma unroll
     for (int t = 0; t < 36; ++t) d1in[32 + t] = mv[t];
 
@@ -533,9 +534,12 @@ DEV void mlp_eval_ref(const float* __restrict__ lds, int lane, const float (&sf)
         s = fmaxf(s, 0.f);                              // nn.ReLU
         sigma = (nvalid < 1.f) ? 0.f : s;               // masked_fill(num_valid_obs < 1, 0)
     }
-    if (skip_colour && __all(sigma == 0.f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; return; }
+}
 
-    STAMP(st, 3);
+// colour branch alone: rgb of this lane's sample from the three views' 35-vectors (and their mean / variance)
+DEV void mlp_colour_ref(const float* __restrict__ lds, int lane, const float (&x)[NV][18], const float (&mv)[36], float (&rgb)[3], Stamps& st) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
     // ---- colour branch (trainhead.py:85-100,131,139-143) ----
     // base_fc.0 on [mean, var, x_v]: k = 0..69 ([mean, var]) is the same for the three views, computed once; each view's chain
     // goes on from there over its own 35 columns, then the bias
@@ -592,6 +596,16 @@ DEV void mlp_eval_ref(const float* __restrict__ lds, int lane, const float (&sf)
         }
     }
     STAMP(st, 5);
+}
+
+DEV void mlp_eval_ref(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
+                      float nvalid, float& sigma, float (&rgb)[3], Stamps& st, const bool skip_colour = false) {
+    float mv[36];
+    mean_var_ref(x, mv);
+    mlp_density_ref(lds, lane, sf, mv, nvalid, sigma);
+    if (skip_colour && __all(sigma == 0.f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; return; }
+    STAMP(st, 3);
+    mlp_colour_ref(lds, lane, x, mv, rgb, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -944,6 +958,45 @@ DEV void gather_volume(const float* __restrict__ vol, int D, int H, int W, float
         }
 }
 
+// The same sample with all eight taps' 32 loads issued before the first is used (128 registers: for the sample loops that
+// have them free at the top of a step -- the deferred-colour form): one round trip per level.  Same arithmetic, same order.
+DEV void gather_volume_batched(const float* __restrict__ vol, int D, int H, int W, float gx, float gy, float gz, int half, float* f) {
+    const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
+    const unsigned zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1};
+    const float zw[2] = {az.w0, az.w1}, yw[2] = {ay.w0, ay.w1}, xw[2] = {ax.w0, ax.w1};
+    const unsigned row_bytes = (unsigned)W * 128u;
+    const unsigned xb[2] = {ax.i0 * 128u + (unsigned)half * 64u, ax.i1 * 128u + (unsigned)half * 64u};
+    f32x4 q[8][4];
+    float wt[8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const unsigned rowb = __umul24(mad24(zi[a], (unsigned)H, yi[b]), row_bytes);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(at_byte(vol, rowb + xb[e]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[4 * a + 2 * b + e][i] = p[i];
+                wt[4 * a + 2 * b + e] = (xw[e] * yw[b]) * zw[a];
+            }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const f32x2 w2 = {wt[t], wt[t]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 r0 = f32x2{f[4 * i], f[4 * i + 1]} + f32x2{q[t][i][0], q[t][i][1]} * w2;
+            const f32x2 r1 = f32x2{f[4 * i + 2], f[4 * i + 3]} + f32x2{q[t][i][2], q[t][i][3]} * w2;
+            f[4 * i] = r0[0]; f[4 * i + 1] = r0[1]; f[4 * i + 2] = r1[0]; f[4 * i + 3] = r1[1];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // The sigma feature layer is linear in the volume features and trilinear sampling is linear in the voxels, so
 //   W (sum_t w_t v_t) = sum_t w_t (W v_t):
 // gpnerf_fold_volumes applies out_geometry_fc's 32 columns of level l to every voxel of level l once per frame (64 values per
@@ -1205,7 +1258,8 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
 };
 
 // the forms of the fused kernel
-constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3, FORM_F32_FOLD = 4;
+constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3, FORM_F32_FOLD = 4,
+              FORM_F32_DEFER = 5;       // FORM_F32 with the colour branch deferred sample by sample (render_tile<.., DEFER>)
 constexpr int GUARD_HEADER_WORDS = 64;
 
 // bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
@@ -1229,6 +1283,15 @@ DEV long queue_tile(int chunk, int x, unsigned t) { return ((long)(t / (unsigned
 // torch.linspace(0,1,S)[k] as the CPU kernel evaluates it (one rounding per element; see oracle)
 DEV float linspace01(int k, int S, float step) {
     return (k < (S >> 1)) ? step * (float)k : fmaf(-step, (float)(S - 1 - k), 1.f);
+}
+
+// get_sampling_points (BaseRender.py:37-38,48), jitter off: sample ks of a ray.  One function for every place that needs the point
+// of a sample (the sample loop, the deferred colour passes), so that they contract to the same instructions and agree to the bit.
+DEV void sample_point(float ox, float oy, float oz, float dx, float dy, float dz, float near, float far, int ks, int S, float step,
+                      float& z, float& px, float& py, float& pz) {
+    const float t = (S > 1) ? linspace01(ks, S, step) : 0.f;
+    z = near * (1.f - t) + far * t;
+    px = ox + dx * z; py = oy + dy * z; pz = oz + dz * z;
 }
 
 // pts_to_can_pts (BaseRender.py:52-60): (p - Th) @ Rh, then get_grid_coords (:62-73): voxel-normalised
@@ -1283,6 +1346,8 @@ DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
 #ifndef GPNERF_MAX_WAVES
 #define GPNERF_MAX_WAVES 8
 #endif
+constexpr int DEFER_QUEUE = 64;                 // entries of a wavefront's queue of samples waiting for their colour pass (render_tile)
+constexpr size_t DEFER_LDS_BYTES = (size_t)GPNERF_MAX_WAVES * DEFER_QUEUE * 8;      // behind the head image
 constexpr int LIST_CHUNK_SHIFT = 11, LIST_CHUNK = 1 << LIST_CHUNK_SHIFT;      // entries per survivor counter / per compaction workgroup
 // number of launch slots a chained launch renders: the previous segment's survivors, or every ray (segment 0)
 typedef const __attribute__((address_space(4))) KArgs* kargs_cptr;
@@ -1369,7 +1434,39 @@ __global__ void __launch_bounds__(256) compact_list_kernel(const int* __restrict
 // 32 / P rays, P consecutive samples of each side by side in P neighbouring lanes, and walks a segment in 16 / P steps.  Every
 // lane of a ray's group composites the group's P samples in order from values fetched across the lanes, so the ray's state is
 // replicated in the group and the arithmetic per ray -- and with it every output bit -- is the same as with P = 1.
-template <int FORM, bool CHAIN, int P = 1, bool CULL = false>
+// Projector.compute (:326-363) for the NV views of one sample, in the slot order the form's first colour / density layers take
+// (reference-order form: gpr::ref35, (r, g) (b, 0) (f0, f1) ... (f30, f31)); returns the number of views that see the sample
+template <int FORM>
+DEV float gather_views(const __attribute__((address_space(4))) FrameK& fr, float px, float py, float pz, bool neg, int half,
+                       float (&x)[NV][18], float (&vrgb)[NV][3]) {
+    float nvalid = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const ViewSample s = gather_view<FORM == FORM_F32_FOLD || FORM == FORM_F32>(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
+                                         fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
+                                         px, py, pz, neg, half, x[v]
+#ifdef GPNERF_X_VIEWFOLD_GATHER
+                                         , fr.vol_fold[0] ? fr.vol_fold[0] + (size_t)v * fr.feat_h * fr.feat_w * 64 : nullptr
+#endif
+                                         );
+        if constexpr (FORM == FORM_F32) {
+            float fk[16];
+            interleave16(x[v], fk);
+            x[v][0] = half ? s.rgb[1] : s.rgb[0];
+            x[v][1] = half ? 0.f : s.rgb[2];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[v][2 + c] = fk[c];
+        } else {
+            x[v][16] = half ? s.rgb[1] : s.rgb[0];
+            x[v][17] = half ? 0.f : s.rgb[2];
+        }
+        vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
+        nvalid += s.valid;
+    }
+    return nvalid;
+}
+
+template <int FORM, bool CHAIN, int P = 1, bool CULL = false, bool DEFER = false>
 DEV bool render_tile(float* lds, const int lane, const long tile, const int seg, const long entry_base = 0) {
     static_assert(!CULL || (!CHAIN && P == 1), "occupancy culling: plain form only");
     static_assert(P == 1 || CHAIN, "several samples per step: chained form only");
@@ -1455,12 +1552,65 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         }
     }
     STAMP(st, 7);
-    for (; k < k_end; k += P) {
+    // Deferred colour branch (reference-order form, plain sample loop; kp->skip bit 1, never with a `raw` output).  The colour branch
+    // reads nothing the density branch computes -- only the three views' 35-vectors -- and a sample whose weight alpha * T is exactly
+    // zero adds fma(0, rgb, c) = c to the colour map: its colour branch (434 of a step's 748 MFMAs) need not run.  Zero-density
+    // samples are most of any frame (a trained model's empty space; 71 % of the synthetic bench frame, nn.ReLU on the density), but a
+    // step's 32 rays are rarely ALL empty, so the exit is taken sample by sample: each step runs the density branch and composites
+    // everything but the colour; rays with a non-zero weight append (ray lane, sample, weight) to a 64-entry queue of the wavefront in
+    // LDS; when 32 are waiting, one colour pass evaluates them -- lane i regathers item i's views (the same loads, minutes-old in L2)
+    // -- and every ray takes its own results back in sample order, so c accumulates in exactly the order of the plain loop.  Same bits.
+    static_assert(!DEFER || (FORM == FORM_F32 && !CHAIN && P == 1), "deferred colour branch: reference-order form, plain sample loop");
+    constexpr bool CAN_DEFER = DEFER, defer = DEFER;
+    unsigned long long mine = 0ull;             // bit j: the queue entry j places behind the head is one of this ray's
+    int q_head = 0, q_cnt = 0;                  // (uniform)
+    uint2* dq = nullptr;
+    if constexpr (CAN_DEFER) {
+        dq = reinterpret_cast<uint2*>(lds + gpl::BLOB_FLOATS) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * DEFER_QUEUE;
+    }
+    int k_lim = k_end;                          // (early termination of the tile as a whole moves it to where the loop stopped)
+    for (;; k += P) {
+        if constexpr (CAN_DEFER) {
+            if (defer && (q_cnt >= 32 || (q_cnt > 0 && !(k < k_lim)))) {
+                const int nb = min(q_cnt, 32);
+                const uint2 e = dq[(q_head + (n < nb ? n : 0)) & (DEFER_QUEUE - 1)];        // lanes beyond the last entry redo entry 0
+                const int r = (int)(e.x & 31u), kk = (int)(e.x >> 5);
+                const float wq = __builtin_bit_cast(float, e.y);
+                kargs_ptr kb = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kb));
+                float zq, qx_, qy_, qz_;
+                sample_point(__shfl(ox, r), __shfl(oy, r), __shfl(oz, r), __shfl(dx, r), __shfl(dy, r), __shfl(dz, r), __shfl(near, r), __shfl(far, r),
+                             flip ? (S - 1 - kk) : kk, S, step, zq, qx_, qy_, qz_);
+                float xq[NV][18], vq[NV][3], mvq[36], cq[3];
+                gather_views<FORM>(kb->fr, qx_, qy_, qz_, neg, half, xq, vq);
+                STAMP(st, 14);
+                mean_var_ref(xq, mvq);
+                mlp_colour_ref(lds, lane, xq, mvq, cq, st);
+                if (kb->out.step_stats && lane == 0) atomicSub(kb->out.step_stats + 2, 1u);
+                unsigned todo = (unsigned)mine & (nb >= 32 ? ~0u : ((1u << nb) - 1u));
+                while (__any(todo != 0u)) {             // a ray's entries of this pass, oldest first
+                    const int j = todo ? __builtin_ctz(todo) : 0;
+                    const float wj = __shfl(wq, j), r0 = __shfl(cq[0], j), r1 = __shfl(cq[1], j), r2 = __shfl(cq[2], j);
+                    if (todo) { c_r = fmaf(wj, r0, c_r); c_g = fmaf(wj, r1, c_g); c_b = fmaf(wj, r2, c_b); }
+                    todo &= todo - 1u;
+                }
+                STAMP(st, 15);
+                mine >>= nb;
+                q_head = (q_head + nb) & (DEFER_QUEUE - 1);
+                q_cnt -= nb;
+                k -= P;                                 // (no sample step this time round)
+                continue;
+            }
+        }
+        if (!(k < k_lim)) break;
         if (masked) {                           // the next step >= k at which the tile has anything to do
             const unsigned long long w0 = k < 64 ? (any_keep[0] >> k) << k : 0ull;
             const unsigned long long w1 = k < 64 ? any_keep[1] : (k < 128 ? (any_keep[1] >> (k - 64)) << (k - 64) : 0ull);
             k = w0 ? __builtin_ctzll(w0) : (w1 ? 64 + __builtin_ctzll(w1) : k_end);
-            if (k >= k_end) break;
+            if (k >= k_end) {
+                if (CAN_DEFER && q_cnt > 0) { k_lim = k; k -= P; continue; }       // (the colour passes still waiting, then out)
+                break;
+            }
         }
         kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
@@ -1473,9 +1623,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         // composite step k consumes the network output of sample S-1-k.
         const int ks = flip ? (S - 1 - kl) : kl;
         // get_sampling_points (BaseRender.py:37-38,48), jitter off
-        const float t = (S > 1) ? linspace01(ks, S, step) : 0.f;
-        const float z = near * (1.f - t) + far * t;
-        const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
+        float z, px, py, pz;
+        sample_point(ox, oy, oz, dx, dy, dz, near, far, ks, S, step, z, px, py, pz);
 
         float gx, gy, gz;
         grid_coords(fr, px, py, pz, gx, gy, gz);
@@ -1503,6 +1652,9 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         if constexpr (P == 1) n_done += dead ? 0 : 1;
         float sf[32];
         Frag sff[4];
+        float x[NV][18];                        // Projector.compute (:326-363)
+        float vrgb[NV][3];
+        float nvalid;
 #ifdef GPNERF_X_DUMP
         float dbg[4] = {0.f, 0.f, 0.f, 0.f};
 #endif
@@ -1536,6 +1688,10 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 #pragma unroll
             for (int l = 0; l < GPNERF_LEVELS; ++l)
             {
+                if constexpr (DEFER) {
+                    gather_volume_batched(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
+                    continue;
+                }
                 gather_volume<!SPLIT>(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
                 if (l & 1) __builtin_amdgcn_sched_barrier(0);    // at most two levels' 64 loads in flight (register pressure)
 
@@ -1569,33 +1725,9 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         STAMP(st, 1);
 
         // Projector.compute (:326-363)
-        float x[NV][18];
-        float nvalid = 0.f;
-        float vrgb[NV][3];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const ViewSample s = gather_view<FORM == FORM_F32_FOLD || FORM == FORM_F32>(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
-                                             fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
-                                             px, py, pz, neg, half, x[v]
-#ifdef GPNERF_X_VIEWFOLD_GATHER
-                                             , fr.vol_fold[0] ? fr.vol_fold[0] + (size_t)v * fr.feat_h * fr.feat_w * 64 : nullptr
-#endif
-                                             );
-            if constexpr (FORM == FORM_F32) {
-                // reference order (gpr::ref35): (r, g) (b, 0) (f0, f1) ... (f30, f31)
-                float fk[16];
-                interleave16(x[v], fk);
-                x[v][0] = half ? s.rgb[1] : s.rgb[0];
-                x[v][1] = half ? 0.f : s.rgb[2];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) x[v][2 + c] = fk[c];
-            } else {
-                x[v][16] = half ? s.rgb[1] : s.rgb[0];
-                x[v][17] = half ? 0.f : s.rgb[2];
-            }
-            vrgb[v][0] = s.rgb[0]; vrgb[v][1] = s.rgb[1]; vrgb[v][2] = s.rgb[2];
-            nvalid += s.valid;
-        }
+        // (deferred form: every gather of the step ahead of its matrix work -- one memory phase, one compute phase -- was tried:
+        //  105 spilled registers, 10.35 -> 12.39 ms)
+        nvalid = gather_views<FORM>(fr, px, py, pz, neg, half, x, vrgb);
         const bool two_views = nvalid > 1.f && keep;    // pixel_mask (:139); culled samples never count
         if constexpr (P == 1) { if (two_views && !dead) ++n_two; }
 
@@ -1605,11 +1737,19 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         // cost their sample loops their register allocation -- 13.3 -> 15.1 ms and 7.5 -> 10.3 ms on the bench frame)
         if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
         else if constexpr (FORM == FORM_F32) {
-            const bool may_skip = (kp->skip & 2) && !out.raw;
-            mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
-            if (out.step_stats) {                                   // (the diagnostic launch only)
-                const bool all_zero = may_skip && __all(sigma == 0.f);
-                if (all_zero && lane == 0) atomicAdd(out.step_stats + 2, 1u);
+            if (CAN_DEFER && defer) {
+                float mv[36];
+                mean_var_ref(x, mv);
+                mlp_density_ref(lds, lane, sf, mv, nvalid, sigma);
+                rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;           // (the colour map's terms arrive with the colour passes)
+                if (out.step_stats && lane == 0) atomicAdd(out.step_stats + 2, 1u);     // (diagnostic launch: steps minus colour passes)
+            } else {
+                const bool may_skip = (kp->skip & 2) && !out.raw;
+                mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
+                if (out.step_stats) {                                   // (the diagnostic launch only)
+                    const bool all_zero = may_skip && __all(sigma == 0.f);
+                    if (all_zero && lane == 0) atomicAdd(out.step_stats + 2, 1u);
+                }
             }
         }
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
@@ -1668,6 +1808,19 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 if (out.weights) out.weights[(size_t)ray * S + k] = wgt;
 #endif
             }
+            if constexpr (CAN_DEFER) {
+                if (defer) {
+                    // (culled samples and, under culling, samples with alpha <= 1e-14 carry rgb = 0: nothing to add either)
+                    const bool need = active && wgt != 0.f && !((CULL || cull) && !(alpha > 1e-14f));
+                    const unsigned m = (unsigned)__ballot(need);            // (both lane halves hold the ray: the low word has it all)
+                    const int pos = q_cnt + __popc(m & ((1u << n) - 1u));
+                    if (need) {
+                        mine |= 1ull << pos;
+                        if (half == 0) dq[(q_head + pos) & (DEFER_QUEUE - 1)] = uint2{(unsigned)n | ((unsigned)k << 5), __builtin_bit_cast(unsigned, wgt)};
+                    }
+                    q_cnt += __popc(m);
+                }
+            }
         } else {
             // the group's P samples in order, in every lane of the group alike: sample j's values come from lane (group base + j)
             float my_wgt = 0.f;
@@ -1696,7 +1849,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         }
         STAMP(st, 6);
         // wavefront-level early termination (not in the reference): every ray of the tile is opaque
-        if (early && __all(T < term_eps)) { k += P; break; }
+        if (early && __all(T < term_eps)) k_lim = k + P;
     }
     st.flush(lane);
     kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1798,7 +1951,7 @@ render_fused_kernel(const KArgs ka) {
         if (ka.list_in && *ka.count_in == 0u) return;               // no ray is left for this segment
     }
     {
-        constexpr bool REF = FORM == FORM_F32 || FORM == FORM_F32_FIXUP;
+        constexpr bool REF = FORM == FORM_F32 || FORM == FORM_F32_FIXUP || FORM == FORM_F32_DEFER;
         const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : (REF ? ka.fr.head_blob_ref : ka.fr.head_blob));
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         for (int i = threadIdx.x; i < (SPLIT ? gph::BLOB_WORDS : gpl::BLOB_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
@@ -1866,7 +2019,7 @@ render_fused_kernel(const KArgs ka) {
                 if (wave_load(kq->guard + GUARD_HEADER_WORDS + tile, lane) == 0u) continue;
             }
         }
-        constexpr int F = FORM == FORM_F32_FIXUP ? FORM_F32 : FORM;
+        constexpr int F = (FORM == FORM_F32_FIXUP || FORM == FORM_F32_DEFER) ? FORM_F32 : FORM;
         STAMP_T0();
         if constexpr (CHAIN) {
             if (samples_per_step == 8) render_tile<F, true, 8>(lds, lane, tile, seg, entry_base);
@@ -1874,7 +2027,7 @@ render_fused_kernel(const KArgs ka) {
             else if (samples_per_step == 2) render_tile<F, true, 2>(lds, lane, tile, seg, entry_base);
             else render_tile<F, true, 1>(lds, lane, tile, seg, entry_base);
         } else {
-            render_tile<F, false, 1, CULL>(lds, lane, tile, seg);
+            render_tile<F, false, 1, CULL, FORM == FORM_F32_DEFER>(lds, lane, tile, seg);
         }
         STAMP_ADD(8, lane);
         WT(3);
@@ -2713,7 +2866,7 @@ int device_ready(int* cus) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) {
             d.cus = prop.multiProcessorCount;
-            const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS, lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
+            const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS + DEFER_LDS_BYTES, lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
             auto lds_ok = [](const void* fn, size_t bytes) {
                 return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
             };
@@ -2724,6 +2877,8 @@ int device_ready(int* cus) {
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_DEFER, false>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_DEFER, false, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, false, true>), lds_split) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT_GUARD, false, true>), lds_split + GUARD_LDS_SLOTS * 8) &&
@@ -3119,7 +3274,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (!to_framek(f, k, true, true)) return GPNERF_E_ARG;
     if (n_rays >= ((int64_t)1 << 31)) return GPNERF_E_ARG;      // output rows are 32-bit values inside the kernel
     const int64_t tiles = (n_rays + RAYS_PER_WAVE - 1) / RAYS_PER_WAVE;
-    const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS;
+    const size_t lds_bytes = sizeof(float) * gpl::BLOB_FLOATS + DEFER_LDS_BYTES;       // head image + the wavefronts' colour queues (render_tile)
     const bool split16 = (flags & GPNERF_FLAG_SPLIT_F16) != 0;
     // the fp32 form: reference order (FORM_F32, head_blob_ref) unless the frame carries folded volumes and the caller did not ask
     // for the reference's order; the guarded split form's fix-up launch is the reference-order form too
@@ -3234,6 +3389,10 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (f_cap < 0) f_cap = dbg_int("GPNERF_WAVE_CAP", 0, 0, 8);      // experiments: waves per CU that pull tiles
     ka.wave_cap = f_cap;
     ka.skip = (flags & GPNERF_FLAG_NO_EXITS) ? 0 : 3;
+    // the plain reference-order launches defer the colour branch sample by sample unless the exits are off or `raw` wants every rgb
+    static int f_defer = -1;
+    if (f_defer < 0) f_defer = dbg_int("GPNERF_DEFER", 1, 0, 1);
+    const bool deferred = f_defer && (ka.skip & 2) && !out->raw;
     static int f_segmajor = -1;
     if (f_segmajor < 0) f_segmajor = dbg_int("GPNERF_QSPLIT_SEGMAJOR", 0, 0, 1);
     ka.seg_major = f_segmajor;
@@ -3350,6 +3509,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
             hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
         else if (folded)
             hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
+        else if (deferred)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
         else
             hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     } else if (guard)
@@ -3358,6 +3519,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
     else if (folded)
         hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
+    else if (deferred)
+        hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     else
         hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
     if (do_remainder) {

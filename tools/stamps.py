@@ -46,6 +46,7 @@ print(f"stamped kernel {e0.elapsed_time(e1):.2f} ms; per wave per sample cycles 
 for i, n in enumerate(names):
     print(f"  {n:28s} {buf[i] / waves / S:9.0f}  {100.0 * buf[i] / tot:5.1f}%")
 print(f"  total {tot / waves / S:.0f}")
+print(f"  deferred colour passes (per wave per sample step): regather {buf[14] / waves / S:.0f}, hand-back {buf[15] / waves / S:.0f}")
 print(f"  volume-gather phase of a visit's first step {buf[10] / max(1, buf[12]):.0f}, second step {buf[11] / max(1, buf[12]):.0f}")
 print(f"  per tile visit: prologue (entry -> first sample) {buf[7] / max(1, buf[12]):.0f}, whole visit {buf[8] / max(1, buf[12]):.0f}, "
       f"queue pop {buf[9] / max(1, buf[12]):.0f}; loop phases {tot / max(1, buf[12]):.0f}; visits {buf[12]}")
