@@ -342,10 +342,14 @@ def main():
         not_done = (float(stt[1]) * FLOP_SIGMA_LAYER + float(stt[2]) * FLOP_COLOUR_BRANCH) / (steps * FLOP_PER_SAMPLE)
         exits = {"steps_32_samples": int(stt[0]), "sigma_layer_exit_frac": float(stt[1]) / steps, "colour_branch_exit_frac": float(stt[2]) / steps,
                  "flop_not_done_frac": not_done,
-                 "note": "bit-exact exits (GPNERF_FLAG_NO_EXITS switches them off): volume features of all 32 samples zero -> ELU(bias) without the "
-                         "sigma feature layer; density of all 32 samples zero -> the colour branch cannot change any map (both in the reference-order form only)"}
-        # `achieved` / `frac` follow the contract: ALGORITHMIC flops (every sample the launch is answerable for x 110 848) per second.
-        # `frac_of_work_done` takes the exits' layers off the numerator: what the matrix pipe was actually asked to do.
+                 "note": "bit-exact exits of the reference-order form (GPNERF_FLAG_NO_EXITS switches them off; beside_headline.no_exits_* times that): "
+                         "volume features of all 32 samples of a step zero -> ELU(bias) without the sigma feature layer; a sample whose weight alpha*T is "
+                         "exactly zero (nn.ReLU on the density; masked_fill) adds fma(0, rgb, c) = c to the colour map -> its colour branch is not "
+                         "evaluated: the wavefront queues the samples that do need it and runs the branch on 32 of them at a time "
+                         "(colour_branch_exit_frac = 1 - colour passes / steps)"}
+        # `achieved` / `frac` follow the contract: ALGORITHMIC flops (every sample the launch is answerable for x 110 848) per second --
+        # with most colour branches provably not needed that can exceed the matrix pipe's peak; it is a rate of answers, not of MFMAs.
+        # `frac_of_work_done` takes the exits' layers off the numerator: what the matrix pipe was actually asked to do (the hardware figure).
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         achieved_done = achieved * (1.0 - not_done)
         cfg_no = 2 if args.early_term else (3 if (args.size == 1024 and world > 1) else 1)
@@ -423,6 +427,7 @@ def beside_headline(args, fm, wl, kw, flow):
     head_ms = None
     for name, want, order, extra in (("api_outputs_patch_order", API_OUTPUTS, wl.patch, {}), ("light_outputs_patch_order", (), wl.patch, {}),
                                      ("api_outputs_raster_order", API_OUTPUTS, None, {}),
+                                     ("no_exits_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"exits": False}),
                                      ("fp32_folded_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"fold": True}),
                                      ("split_f16_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True}),
                                      ("split_f16_unguarded_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True, "guard": False})):
@@ -435,7 +440,9 @@ def beside_headline(args, fm, wl, kw, flow):
         if extra:
             res[name]["max_abs_vs_f32_form"] = {"rgb": float((o["rgb_map"] - head_out["rgb_map"]).abs().max()),
                                                 "depth": float((o["depth_map"] - head_out["depth_map"]).abs().max())}
-            res[name]["note"] = ("round 4's fast fp32 form (`render.file hip_render_fold`): coarse levels folded into the sigma feature layer per frame "
+            res[name]["note"] = ("GPNERF_FLAG_NO_EXITS: the headline's form with every layer evaluated for every sample -- the same bits (max_abs 0), "
+                                 "the time the frame takes without the zero-weight colour skip") if extra.get("exits") is False else \
+                                ("round 4's fast fp32 form (`render.file hip_render_fold`): coarse levels folded into the sigma feature layer per frame "
                                  "(the fold is inside the timed step), log2e-scaled layers; not in the reference's summation order") if extra.get("fold") else \
                                 ("dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation; " +
                                  ("no range check (operands must stay below 65504)" if extra.get("guard") is False else

@@ -1560,7 +1560,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     // everything but the colour; rays with a non-zero weight append (ray lane, sample, weight) to a 64-entry queue of the wavefront in
     // LDS; when 32 are waiting, one colour pass evaluates them -- lane i regathers item i's views (the same loads, minutes-old in L2)
     // -- and every ray takes its own results back in sample order, so c accumulates in exactly the order of the plain loop.  Same bits.
-    static_assert(!DEFER || (FORM == FORM_F32 && !CHAIN && P == 1), "deferred colour branch: reference-order form, plain sample loop");
+    static_assert(!DEFER || (FORM == FORM_F32 && P == 1), "deferred colour branch: reference-order form, one sample per step");
     constexpr bool CAN_DEFER = DEFER, defer = DEFER;
     unsigned long long mine = 0ull;             // bit j: the queue entry j places behind the head is one of this ray's
     int q_head = 0, q_cnt = 0;                  // (uniform)
@@ -2025,7 +2025,7 @@ render_fused_kernel(const KArgs ka) {
             if (samples_per_step == 8) render_tile<F, true, 8>(lds, lane, tile, seg, entry_base);
             else if (samples_per_step == 4) render_tile<F, true, 4>(lds, lane, tile, seg, entry_base);
             else if (samples_per_step == 2) render_tile<F, true, 2>(lds, lane, tile, seg, entry_base);
-            else render_tile<F, true, 1>(lds, lane, tile, seg, entry_base);
+            else render_tile<F, true, 1, false, FORM == FORM_F32_DEFER>(lds, lane, tile, seg, entry_base);
         } else {
             render_tile<F, false, 1, CULL, FORM == FORM_F32_DEFER>(lds, lane, tile, seg);
         }
@@ -2875,6 +2875,7 @@ int device_ready(int* cus) {
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_DEFER, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_DEFER, false>), lds_bytes) &&
@@ -3424,6 +3425,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
             hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3((unsigned)n_cus), full_block, lds_split, S_(stream), ku);
         else if (folded)
             hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), ku);
+        else if (deferred)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), ku);
         else
             hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), ku);
         return fixup();
@@ -3471,6 +3474,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
                 hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3(grid), full_block, lds_split, S_(stream), ka);
             else if (folded)
                 hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
+            else if (deferred)
+                hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
             else
                 hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
             if (!last)     // close the gaps of the sparse list, in order: the next launch's dense input
@@ -3542,6 +3547,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
             hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3((unsigned)n_cus), full_block, lds_split, S_(stream), kr);
         else if (folded)
             hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
+        else if (deferred)
+            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
         else
             hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
     }
