@@ -265,16 +265,8 @@ DEV void geo_eval(const float* __restrict__ lds, int lane, const float (&fv)[64]
 //   x[v][18]: this half's slots of [rgb(3), feat(32)] of view v (gpl::idx35)
 //   nvalid : number of valid views of this lane's sample
 // returns sigma and rgb (identical in both halves of a ray).
-DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
-                  float nvalid, float& sigma, float (&rgb)[3], Stamps& st) {
-    asm volatile("" : "+v"(lane));
-    const int half = lane >> 5;
-    float d1in[68];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) d1in[r] = sf[r];
-
-    // ---- cross-view mean / variance (fused_mean_variance, trainhead.py:20-24): all 3 views, unmasked ----
-    float mv[36];
+// cross-view mean / variance (fused_mean_variance, trainhead.py:20-24): all 3 views, unmasked
+DEV void mean_var(const float (&x)[NV][18], float (&mv)[36]) {
 #pragma unroll
     for (int t = 0; t < 18; ++t) {
         const float m = ((x[0][t] + x[1][t]) + x[2][t]) * (1.f / 3.f);
@@ -282,6 +274,15 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
         mv[t] = m;
         mv[18 + t] = ((a * a + b * b) + c * c) * (1.f / 3.f);
     }
+}
+
+// density branch alone (the deferred-colour sample loop, render_tile)
+DEV void mlp_density(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&mv)[36], float nvalid, float& sigma) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    float d1in[68];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) d1in[r] = sf[r];
 #pragma unroll
     for (int t = 0; t < 36; ++t) d1in[32 + t] = mv[t];
 
@@ -308,8 +309,12 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
         s = fmaxf(s, 0.f);                              // nn.ReLU
         sigma = (nvalid < 1.f) ? 0.f : s;               // masked_fill(num_valid_obs < 1, 0)
     }
+}
 
-    STAMP(st, 3);
+// colour branch alone
+DEV void mlp_colour(const float* __restrict__ lds, int lane, const float (&x)[NV][18], const float (&mv)[36], float (&rgb)[3], Stamps& st) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
     // ---- colour branch (trainhead.py:85-100,131,139-143) ----
     // base_fc layer 1 on [mean, var, x_v]: the [mean, var] part is view-independent, computed once
     f32x16 s0 = bias_tile<gpl::BS>(lds, 0, half), s1 = bias_tile<gpl::BS>(lds, 1, half);
@@ -366,6 +371,15 @@ DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32]
         }
     }
     STAMP(st, 5);
+}
+
+DEV void mlp_eval(const float* __restrict__ lds, int lane, const float (&sf)[32], const float (&x)[NV][18],
+                  float nvalid, float& sigma, float (&rgb)[3], Stamps& st) {
+    float mv[36];
+    mean_var(x, mv);
+    mlp_density(lds, lane, sf, mv, nvalid, sigma);
+    STAMP(st, 3);
+    mlp_colour(lds, lane, x, mv, rgb, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -760,27 +774,28 @@ DEV void geo_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const float
     tile_frags(g, g1, sff + 2);
 }
 
+// cross-view mean / variance (trainhead.py:20-24) and their k-steps: mean(2 + rgb), var(2 + rgb)
 template <class G>
-DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const float (&x)[NV][18], float nvalid,
-                    float& sigma, float (&rgb)[3], Stamps& st) {
+DEV void mean_var_s(G& g, const float (&x)[NV][18], Frag (&mvf)[6]) {
+    float mv[36];
+#pragma unroll
+    for (int t = 0; t < 18; ++t) {
+        const float m = ((x[0][t] + x[1][t]) + x[2][t]) * (1.f / 3.f);
+        const float a = x[0][t] - m, b = x[1][t] - m, c = x[2][t] - m;
+        mv[t] = m;
+        mv[18 + t] = ((a * a + b * b) + c * c) * (1.f / 3.f);
+    }
+    guard_n<36>(g, mv);
+    mvf[0] = make_frag(mv, g); mvf[1] = make_frag(mv + 8, g); mvf[2] = make_frag2(mv[16], mv[17], g);
+    mvf[3] = make_frag(mv + 18, g); mvf[4] = make_frag(mv + 26, g); mvf[5] = make_frag2(mv[34], mv[35], g);
+}
+
+// density branch alone (the deferred-colour sample loop, render_tile)
+template <class G>
+DEV void mlp_density_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const Frag (&mvf)[6], float nvalid, float& sigma) {
     asm volatile("" : "+v"(lane));
     const int half = lane >> 5;
     const float* lf = reinterpret_cast<const float*>(lw);
-    // cross-view mean / variance (trainhead.py:20-24) and their k-steps: mean(2 + rgb), var(2 + rgb)
-    Frag mvf[6];
-    {
-        float mv[36];
-#pragma unroll
-        for (int t = 0; t < 18; ++t) {
-            const float m = ((x[0][t] + x[1][t]) + x[2][t]) * (1.f / 3.f);
-            const float a = x[0][t] - m, b = x[1][t] - m, c = x[2][t] - m;
-            mv[t] = m;
-            mv[18 + t] = ((a * a + b * b) + c * c) * (1.f / 3.f);
-        }
-        guard_n<36>(g, mv);
-        mvf[0] = make_frag(mv, g); mvf[1] = make_frag(mv + 8, g); mvf[2] = make_frag2(mv[16], mv[17], g);
-        mvf[3] = make_frag(mv + 18, g); mvf[4] = make_frag(mv + 26, g); mvf[5] = make_frag2(mv[34], mv[35], g);
-    }
     // density branch (trainhead.py:102-110,133-137)
     {
         f32x16 a0 = bias_tile_s<gpl::D1>(lw, 0, half), a1 = bias_tile_s<gpl::D1>(lw, 1, half);
@@ -805,7 +820,14 @@ DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag 
         s = fmaxf(s, 0.f);
         sigma = (nvalid < 1.f) ? 0.f : s;
     }
-    STAMP(st, 3);
+}
+
+// colour branch alone
+template <class G>
+DEV void mlp_colour_s(G& g, const unsigned* __restrict__ lw, int lane, const float (&x)[NV][18], const Frag (&mvf)[6], float (&rgb)[3], Stamps& st) {
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5;
+    const float* lf = reinterpret_cast<const float*>(lw);
     // colour branch (trainhead.py:85-100,131,139-143)
     f32x16 s0 = bias_tile_s<gpl::BS>(lw, 0, half), s1 = bias_tile_s<gpl::BS>(lw, 1, half);
     mfma_steps<gpl::BS, 6>(lw, 0, 0, lane, mvf, s0);
@@ -863,6 +885,16 @@ DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag 
         }
     }
     STAMP(st, 5);
+}
+
+template <class G>
+DEV void mlp_eval_s(G& g, const unsigned* __restrict__ lw, int lane, const Frag (&sff)[4], const float (&x)[NV][18], float nvalid,
+                    float& sigma, float (&rgb)[3], Stamps& st) {
+    Frag mvf[6];
+    mean_var_s(g, x, mvf);
+    mlp_density_s(g, lw, lane, sff, mvf, nvalid, sigma);
+    STAMP(st, 3);
+    mlp_colour_s(g, lw, lane, x, mvf, rgb, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -960,6 +992,7 @@ DEV void gather_volume(const float* __restrict__ vol, int D, int H, int W, float
 
 // The same sample with all eight taps' 32 loads issued before the first is used (128 registers: for the sample loops that
 // have them free at the top of a step -- the deferred-colour form): one round trip per level.  Same arithmetic, same order.
+template <bool UNFUSED>
 DEV void gather_volume_batched(const float* __restrict__ vol, int D, int H, int W, float gx, float gy, float gz, int half, float* f) {
     const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
     const unsigned zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1};
@@ -989,8 +1022,14 @@ DEV void gather_volume_batched(const float* __restrict__ vol, int D, int H, int 
         const f32x2 w2 = {wt[t], wt[t]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x2 r0 = f32x2{f[4 * i], f[4 * i + 1]} + f32x2{q[t][i][0], q[t][i][1]} * w2;
-            const f32x2 r1 = f32x2{f[4 * i + 2], f[4 * i + 3]} + f32x2{q[t][i][2], q[t][i][3]} * w2;
+            f32x2 r0, r1;
+            if constexpr (UNFUSED) {           // multiply, then add (muladd16)
+                r0 = f32x2{f[4 * i], f[4 * i + 1]} + f32x2{q[t][i][0], q[t][i][1]} * w2;
+                r1 = f32x2{f[4 * i + 2], f[4 * i + 3]} + f32x2{q[t][i][2], q[t][i][3]} * w2;
+            } else {                           // fma16
+                r0 = __builtin_elementwise_fma(f32x2{q[t][i][0], q[t][i][1]}, w2, f32x2{f[4 * i], f[4 * i + 1]});
+                r1 = __builtin_elementwise_fma(f32x2{q[t][i][2], q[t][i][3]}, w2, f32x2{f[4 * i + 2], f[4 * i + 3]});
+            }
             f[4 * i] = r0[0]; f[4 * i + 1] = r0[1]; f[4 * i + 2] = r1[0]; f[4 * i + 3] = r1[1];
         }
     }
@@ -1258,8 +1297,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
 };
 
 // the forms of the fused kernel
-constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3, FORM_F32_FOLD = 4,
-              FORM_F32_DEFER = 5;       // FORM_F32 with the colour branch deferred sample by sample (render_tile<.., DEFER>)
+constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3, FORM_F32_FOLD = 4;
 constexpr int GUARD_HEADER_WORDS = 64;
 
 // bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give each XCD a
@@ -1560,13 +1598,15 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     // everything but the colour; rays with a non-zero weight append (ray lane, sample, weight) to a 64-entry queue of the wavefront in
     // LDS; when 32 are waiting, one colour pass evaluates them -- lane i regathers item i's views (the same loads, minutes-old in L2)
     // -- and every ray takes its own results back in sample order, so c accumulates in exactly the order of the plain loop.  Same bits.
-    static_assert(!DEFER || (FORM == FORM_F32 && P == 1), "deferred colour branch: reference-order form, one sample per step");
+    static_assert(!DEFER || P == 1, "deferred colour branch: one sample per step");
     constexpr bool CAN_DEFER = DEFER, defer = DEFER;
     unsigned long long mine = 0ull;             // bit j: the queue entry j places behind the head is one of this ray's
     int q_head = 0, q_cnt = 0;                  // (uniform)
     uint2* dq = nullptr;
     if constexpr (CAN_DEFER) {
-        dq = reinterpret_cast<uint2*>(lds + gpl::BLOB_FLOATS) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * DEFER_QUEUE;
+        // behind the head image (split form: and behind the range guard's slots)
+        constexpr int QUEUE_AT = SPLIT ? gph::BLOB_WORDS + (FORM == FORM_SPLIT_GUARD ? 2 * GUARD_LDS_SLOTS : 0) : gpl::BLOB_FLOATS;
+        dq = reinterpret_cast<uint2*>(lds + QUEUE_AT) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * DEFER_QUEUE;
     }
     int k_lim = k_end;                          // (early termination of the tile as a whole moves it to where the loop stopped)
     for (;; k += P) {
@@ -1581,11 +1621,24 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 float zq, qx_, qy_, qz_;
                 sample_point(__shfl(ox, r), __shfl(oy, r), __shfl(oz, r), __shfl(dx, r), __shfl(dy, r), __shfl(dz, r), __shfl(near, r), __shfl(far, r),
                              flip ? (S - 1 - kk) : kk, S, step, zq, qx_, qy_, qz_);
-                float xq[NV][18], vq[NV][3], mvq[36], cq[3];
+                float xq[NV][18], vq[NV][3], cq[3];
                 gather_views<FORM>(kb->fr, qx_, qy_, qz_, neg, half, xq, vq);
                 STAMP(st, 14);
-                mean_var_ref(xq, mvq);
-                mlp_colour_ref(lds, lane, xq, mvq, cq, st);
+                if constexpr (SPLIT) {
+                    Frag mvf[6];
+#ifdef GPNERF_X_SPLIT_DEFER       // (see SPLIT_DEFERS below: without this copy the unguarded instantiation's colour passes come out wrong)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+#pragma unroll
+                        for (int c = 0; c < 18; ++c) asm volatile("" : "+v"(xq[v][c]));
+#endif
+                    mean_var_s(gmax, xq, mvf);
+                    mlp_colour_s(gmax, lw, lane, xq, mvf, cq, st);
+                } else {
+                    float mvq[36];
+                    if constexpr (FORM == FORM_F32) { mean_var_ref(xq, mvq); mlp_colour_ref(lds, lane, xq, mvq, cq, st); }
+                    else { mean_var(xq, mvq); mlp_colour(lds, lane, xq, mvq, cq, st); }
+                }
                 if (kb->out.step_stats && lane == 0) atomicSub(kb->out.step_stats + 2, 1u);
                 unsigned todo = (unsigned)mine & (nb >= 32 ? ~0u : ((1u << nb) - 1u));
                 while (__any(todo != 0u)) {             // a ray's entries of this pass, oldest first
@@ -1689,7 +1742,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
             for (int l = 0; l < GPNERF_LEVELS; ++l)
             {
                 if constexpr (DEFER) {
-                    gather_volume_batched(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
+                    gather_volume_batched<!SPLIT>(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
                     continue;
                 }
                 gather_volume<!SPLIT>(fr.vol[l], fr.vol_dhw[l][0], fr.vol_dhw[l][1], fr.vol_dhw[l][2], gx, gy, gz, half, fv + 16 * l);
@@ -1735,15 +1788,22 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         float sigma, rgb[3];
         // (the zero-density exit in the reference-order form only: built into the folded and split forms too, the early return
         // cost their sample loops their register allocation -- 13.3 -> 15.1 ms and 7.5 -> 10.3 ms on the bench frame)
-        if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
-        else if constexpr (FORM == FORM_F32) {
-            if (CAN_DEFER && defer) {
-                float mv[36];
-                mean_var_ref(x, mv);
-                mlp_density_ref(lds, lane, sf, mv, nvalid, sigma);
-                rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;           // (the colour map's terms arrive with the colour passes)
-                if (out.step_stats && lane == 0) atomicAdd(out.step_stats + 2, 1u);     // (diagnostic launch: steps minus colour passes)
+        if constexpr (DEFER) {
+            if constexpr (SPLIT) {
+                Frag mvf[6];
+                mean_var_s(gmax, x, mvf);
+                mlp_density_s(gmax, lw, lane, sff, mvf, nvalid, sigma);
             } else {
+                float mv[36];
+                if constexpr (FORM == FORM_F32) { mean_var_ref(x, mv); mlp_density_ref(lds, lane, sf, mv, nvalid, sigma); }
+                else { mean_var(x, mv); mlp_density(lds, lane, sf, mv, nvalid, sigma); }
+            }
+            rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;               // (the colour map's terms arrive with the colour passes)
+            if (out.step_stats && lane == 0) atomicAdd(out.step_stats + 2, 1u);         // (diagnostic launch: steps minus colour passes)
+        }
+        else if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
+        else if constexpr (FORM == FORM_F32) {
+            {
                 const bool may_skip = (kp->skip & 2) && !out.raw;
                 mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
                 if (out.step_stats) {                                   // (the diagnostic launch only)
@@ -1938,9 +1998,10 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 // 8-wave workgroup resident per CU a static grid holds the CU until its slowest tile is done -- the queue hands the next
 // tile to whichever wave is free.  Static launches (one unit per wave, XCD-aware remap) remain for frames smaller than
 // one round and for the sample-split geometry.
-template <int FORM, bool CHAIN, bool CULL = false>
+template <int FORM, bool CHAIN, bool CULL = false, bool DEFER = false>     // DEFER: the colour branch sample by sample (render_tile)
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const KArgs ka) {
+    static_assert(!DEFER || FORM != FORM_F32_FIXUP, "the fix-up launch evaluates everything");
     constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     WT(0);
@@ -1951,7 +2012,7 @@ render_fused_kernel(const KArgs ka) {
         if (ka.list_in && *ka.count_in == 0u) return;               // no ray is left for this segment
     }
     {
-        constexpr bool REF = FORM == FORM_F32 || FORM == FORM_F32_FIXUP || FORM == FORM_F32_DEFER;
+        constexpr bool REF = FORM == FORM_F32 || FORM == FORM_F32_FIXUP;
         const f32x4* src = reinterpret_cast<const f32x4*>(SPLIT ? ka.fr.head_blob_split : (REF ? ka.fr.head_blob_ref : ka.fr.head_blob));
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         for (int i = threadIdx.x; i < (SPLIT ? gph::BLOB_WORDS : gpl::BLOB_FLOATS) / 4; i += blockDim.x) dst[i] = src[i];
@@ -2019,15 +2080,15 @@ render_fused_kernel(const KArgs ka) {
                 if (wave_load(kq->guard + GUARD_HEADER_WORDS + tile, lane) == 0u) continue;
             }
         }
-        constexpr int F = (FORM == FORM_F32_FIXUP || FORM == FORM_F32_DEFER) ? FORM_F32 : FORM;
+        constexpr int F = FORM == FORM_F32_FIXUP ? FORM_F32 : FORM;
         STAMP_T0();
         if constexpr (CHAIN) {
             if (samples_per_step == 8) render_tile<F, true, 8>(lds, lane, tile, seg, entry_base);
             else if (samples_per_step == 4) render_tile<F, true, 4>(lds, lane, tile, seg, entry_base);
             else if (samples_per_step == 2) render_tile<F, true, 2>(lds, lane, tile, seg, entry_base);
-            else render_tile<F, true, 1, false, FORM == FORM_F32_DEFER>(lds, lane, tile, seg, entry_base);
+            else render_tile<F, true, 1, false, DEFER>(lds, lane, tile, seg, entry_base);
         } else {
-            render_tile<F, false, 1, CULL, FORM == FORM_F32_DEFER>(lds, lane, tile, seg);
+            render_tile<F, false, 1, CULL, DEFER>(lds, lane, tile, seg);
         }
         STAMP_ADD(8, lane);
         WT(3);
@@ -2722,6 +2783,39 @@ int dbg_int(const char* name, int dflt, int lo, int hi) {
     const int v = atoi(e);
     return v < lo ? lo : (v > hi ? hi : v);
 }
+// One launch of the fused kernel: which arithmetic (`sel`), whether the colour branch is deferred sample by sample (render_tile), and
+// the sample loop (chained segments / culled) as template arguments.  Dynamic LDS = the form's head image (+ the split form's guard
+// slots) + the wavefronts' colour queues.
+enum { SEL_REF = 0, SEL_FOLD = 1, SEL_SPLIT = 2, SEL_GUARD = 3 };
+// The split-precision forms keep the colour branch in the step.  Deferred, they were built and measured (bench frame 7.30 -> 6.39 ms
+// guarded, 6.2 unguarded; configs[2] 4.8 ms) and the guarded instantiation is bit-identical to its plain loop -- but the UNGUARDED
+// one's colour passes come out 10-30 % off unless the regathered inputs pass through an opaque register copy first
+// (-DGPNERF_X_SPLIT_DEFER builds both, with the copy; tools/probes/defer_debug.py), and a guarded launch flagged tiles on ordinary
+// data.  The cause is not established (no MFMA-shadow consumer: tools/isa_mfma_hazards.py is clean), so it is not shipped.
+#ifdef GPNERF_X_SPLIT_DEFER
+constexpr bool SPLIT_DEFERS = true;
+#else
+constexpr bool SPLIT_DEFERS = false;
+#endif
+template <int FORM> constexpr bool form_defers() { return SPLIT_DEFERS || (FORM != FORM_SPLIT && FORM != FORM_SPLIT_GUARD); }
+template <int FORM, bool CHAIN, bool CULL>
+void launch_form(bool deferred, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const KArgs& ka) {
+    if constexpr (form_defers<FORM>()) {
+        if (deferred) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, CULL, true>), grid, block, lds, stream, ka); return; }
+    }
+    hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, CULL, false>), grid, block, lds, stream, ka);
+}
+template <bool CHAIN, bool CULL>
+void launch_render(int sel, bool deferred, dim3 grid, dim3 block, hipStream_t stream, const KArgs& ka) {
+    const size_t f32 = sizeof(float) * gpl::BLOB_FLOATS + DEFER_LDS_BYTES, split = sizeof(unsigned) * gph::BLOB_WORDS + DEFER_LDS_BYTES;
+    switch (sel) {
+        case SEL_GUARD: launch_form<FORM_SPLIT_GUARD, CHAIN, CULL>(deferred, grid, block, split + GUARD_LDS_SLOTS * 8, stream, ka); break;
+        case SEL_SPLIT: launch_form<FORM_SPLIT, CHAIN, CULL>(deferred, grid, block, split, stream, ka); break;
+        case SEL_FOLD:  launch_form<FORM_F32_FOLD, CHAIN, CULL>(deferred, grid, block, f32, stream, ka); break;
+        default:        launch_form<FORM_F32, CHAIN, CULL>(deferred, grid, block, f32, stream, ka); break;
+    }
+}
+
 constexpr int CHAIN_SEG = 16;
 constexpr int CHAIN_MAX_SEGS = 64;
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -2870,23 +2964,24 @@ int device_ready(int* cus) {
             auto lds_ok = [](const void* fn, size_t bytes) {
                 return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
             };
-            d.ok = lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, true>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false, true>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_DEFER, true>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, true>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_DEFER, false>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_DEFER, false, true>), lds_bytes) &&
+            d.ok = true;
+            // every instantiation the launches below can pick: form x (plain, chained, culled) x (colour branch in the step, deferred)
+            auto all_of = [&](auto form_tag, size_t bytes) {
+                constexpr int F = decltype(form_tag)::value;
+                d.ok = d.ok && lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<F, false, false, false>), bytes) &&
+                       lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<F, true, false, false>), bytes) &&
+                       lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<F, false, true, false>), bytes);
+                if constexpr (form_defers<F>())
+                    d.ok = d.ok && lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<F, false, false, true>), bytes) &&
+                           lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<F, true, false, true>), bytes) &&
+                           lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<F, false, true, true>), bytes);
+            };
+            all_of(std::integral_constant<int, FORM_F32>{}, lds_bytes);
+            all_of(std::integral_constant<int, FORM_F32_FOLD>{}, lds_bytes);
+            all_of(std::integral_constant<int, FORM_SPLIT>{}, lds_split + DEFER_LDS_BYTES);
+            all_of(std::integral_constant<int, FORM_SPLIT_GUARD>{}, lds_split + GUARD_LDS_SLOTS * 8 + DEFER_LDS_BYTES);
+            d.ok = d.ok && lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false, true>), lds_bytes) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, false, true>), lds_split) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT_GUARD, false, true>), lds_split + GUARD_LDS_SLOTS * 8) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, false>), lds_split) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT, true>), lds_split) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT_GUARD, false>), lds_split + GUARD_LDS_SLOTS * 8) &&
-                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_SPLIT_GUARD, true>), lds_split + GUARD_LDS_SLOTS * 8) &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
                    hipFuncSetAttribute(reinterpret_cast<const void*>(&head_forward_kernel<FUSED_WAVES, 1>),
@@ -3296,7 +3391,6 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         guard_words = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + workspace_bytes);
         if (!zero_async(guard_words, gb, stream)) return GPNERF_E_LAUNCH;
     }
-    const size_t lds_split = sizeof(unsigned) * gph::BLOB_WORDS;
     int n_cus = 0;
     if (device_ready(&n_cus) != GPNERF_OK) return GPNERF_E_DEVICE;
     {   // GPNERF_FLAG_RESERVE_CUS(n): plan the launch for n fewer compute units (whole XCD rounds of 8, at least 8 stay), so that
@@ -3390,10 +3484,11 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (f_cap < 0) f_cap = dbg_int("GPNERF_WAVE_CAP", 0, 0, 8);      // experiments: waves per CU that pull tiles
     ka.wave_cap = f_cap;
     ka.skip = (flags & GPNERF_FLAG_NO_EXITS) ? 0 : 3;
-    // the plain reference-order launches defer the colour branch sample by sample unless the exits are off or `raw` wants every rgb
+    // every form defers the colour branch sample by sample (render_tile) unless the exits are off or `raw` wants every rgb
     static int f_defer = -1;
     if (f_defer < 0) f_defer = dbg_int("GPNERF_DEFER", 1, 0, 1);
     const bool deferred = f_defer && (ka.skip & 2) && !out->raw;
+    const int sel = guard ? SEL_GUARD : (split16 ? SEL_SPLIT : (folded ? SEL_FOLD : SEL_REF));
     static int f_segmajor = -1;
     if (f_segmajor < 0) f_segmajor = dbg_int("GPNERF_QSPLIT_SEGMAJOR", 0, 0, 1);
     ka.seg_major = f_segmajor;
@@ -3419,16 +3514,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         ku.first_slot = 0; ku.first_items = (long)n_rays;
         ku.list_in = nullptr; ku.count_in = nullptr; ku.list_out = nullptr; ku.count_out = nullptr; ku.chunk_cnt = nullptr;
         ku.p_cap = (long)(slots * RAYS_PER_WAVE);
-        if (guard)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3((unsigned)n_cus), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ku);
-        else if (split16)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3((unsigned)n_cus), full_block, lds_split, S_(stream), ku);
-        else if (folded)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), ku);
-        else if (deferred)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), ku);
-        else
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), ku);
+        launch_render<true, false>(sel, deferred, dim3((unsigned)n_cus), full_block, S_(stream), ku);
         return fixup();
     }
     // Early termination on frames of at least one round of wavefronts: the samples are walked in segments of chain_len(), one
@@ -3468,16 +3554,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
             ka.list_out = last ? nullptr : sparse;
             ka.count_out = ctrl + 8 * n_seg + sg;
             ka.chunk_cnt = ctrl + 9 * n_seg + (size_t)sg * n_chunks;
-            if (guard)
-                hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3(grid), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
-            else if (split16)
-                hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3(grid), full_block, lds_split, S_(stream), ka);
-            else if (folded)
-                hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
-            else if (deferred)
-                hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
-            else
-                hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3(grid), full_block, lds_bytes, S_(stream), ka);
+            launch_render<true, false>(sel, deferred, dim3(grid), full_block, S_(stream), ka);
             if (!last)     // close the gaps of the sparse list, in order: the next launch's dense input
                 hipLaunchKernelGGL(compact_list_kernel, dim3((unsigned)n_chunks), dim3(256), 0, S_(stream), (const int*)sparse,
                                    (const unsigned*)ka.chunk_cnt, (const unsigned*)ka.count_in, ka.first_items, lists[sg & 1], ka.count_out);
@@ -3508,26 +3585,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
                 ka.tile_order = order;
             }
         }
-        if (guard)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
-        else if (split16)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
-        else if (folded)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
-        else if (deferred)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
-        else
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false, true>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
-    } else if (guard)
-        hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split + GUARD_LDS_SLOTS * 8, S_(stream), ka);
-    else if (split16)
-        hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_split, S_(stream), ka);
-    else if (folded)
-        hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
-    else if (deferred)
-        hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
-    else
-        hipLaunchKernelGGL((render_fused_kernel<FORM_F32, false>), dim3((unsigned)blocks), dim3(g.waves * 64), lds_bytes, S_(stream), ka);
+        launch_render<false, true>(sel, deferred, dim3((unsigned)blocks), dim3(g.waves * 64), S_(stream), ka);
+    } else
+        launch_render<false, false>(sel, deferred, dim3((unsigned)blocks), dim3(g.waves * 64), S_(stream), ka);
     if (do_remainder) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         KArgs kr = ka;
@@ -3541,16 +3601,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         kr.count_out = nullptr; kr.chunk_cnt = nullptr;
         kr.part = nullptr;
         kr.p_cap = (long)(slots * RAYS_PER_WAVE);
-        if (guard)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT_GUARD, true>), dim3((unsigned)n_cus), full_block, lds_split + GUARD_LDS_SLOTS * 8, S_(stream), kr);
-        else if (split16)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_SPLIT, true>), dim3((unsigned)n_cus), full_block, lds_split, S_(stream), kr);
-        else if (folded)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_FOLD, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
-        else if (deferred)
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32_DEFER, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
-        else
-            hipLaunchKernelGGL((render_fused_kernel<FORM_F32, true>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kr);
+        launch_render<true, false>(sel, deferred, dim3((unsigned)n_cus), full_block, S_(stream), kr);
     }
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;

@@ -23,6 +23,7 @@ cfg = NS(encoder=NS(file="hip_encoder", name="resnet34", out_ch=32),
          dataset=NS(train=NS(name="zju_mocap", chunk=400), test=NS(name="zju_mocap", chunk=2000), voxel_size=[0.005] * 3),
          train=NS(n_rays=1024, n_samples=S), test=NS(mesh_th=50))
 dev = "cuda:0"
+torch.manual_seed(0)            # (random-initialised head and encoder: the densities, and with them the time, follow the seed)
 r = hip_render.build_render(cfg).to(dev).eval()
 sc = syn.make_scene(H=size, W=size, seed=0, fill="full", pose="identity", make_volumes=False)
 keys = ("ray_o", "ray_d", "near", "far", "src_imgs", "src_Ks", "src_poses", "feature", "coord", "out_sh", "bounds", "Rh", "R", "Th", "body_msk")
