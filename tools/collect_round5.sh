@@ -25,18 +25,20 @@ cp $o/parity_sweep.txt $d/f_parity_sweep.txt
 cp $o/et_sweep.txt $d/f_et_sweep.txt
 cp $o/producers_sweep.txt $d/f_producers_sweep.txt
 cp $o/micro.txt $d/i_micro_mfma_overlap_permlane_swap.txt
+[ -s $o/stamps_default.txt ] && grep -v amdgpu $o/stamps_default.txt > $d/c_stamps_headline.txt
+[ -s $o/defer_debug.txt ] && grep -v amdgpu $o/defer_debug.txt > $d/c_deferred_vs_in_step_colour.txt
 { echo "# pipelined evaluation loop (VERDICT r4 next #2): measurements of $c"; echo;
   echo "## tools/probes/overlap_probe.py -- per-ray kernel of the ZJU-sized frame + the NEXT frame's encoder graph on a second stream, by reserved CUs"; cat $o/overlap_probe.txt | grep -v amdgpu;
   echo; echo "## tools/probes/eval_loop_time.py -- evaluator.evaluate_loop over 12 such frames, serial against pipelined (bench.py beside_headline.eval_loop)"; cat $o/eval_loop.txt | grep -v amdgpu; } > $d/d_pipeline.txt
 python tools/trace_frames.py $(ls -t $o/trace_eval_loop/runc/*kernel_trace.csv | head -1) 3 > $d/d_pipeline_kernel_timeline.txt 2>&1 || true
-python tools/pmc_derive.py gpurun_out/pmc_r05_default/summary.json "512x512x64 full fill, API output set, patch order, reference-order form (default)" \
-    "render_fused_kernel<0, false, false>" $c $d/b_pmc_summary_headline.json --traffic profiles/pmc_traffic.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
+python tools/pmc_derive.py gpurun_out/pmc_r05_default/summary.json "512x512x64 full fill, API output set, patch order, reference-order form, colour branch deferred (default)" \
+    "render_fused_kernel<0, false, false, true>" $c $d/b_pmc_summary_headline.json --traffic profiles/pmc_traffic.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
 python tools/pmc_derive.py gpurun_out/pmc_r05_folded/summary.json "512x512x64 full fill, API output set, patch order, folded fast form (--fold)" \
-    "render_fused_kernel<4, false, false>" $c $d/b_pmc_summary_headline_folded_form.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
+    "render_fused_kernel<4, false, false, true>" $c $d/b_pmc_summary_headline_folded_form.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
 python tools/pmc_derive.py gpurun_out/pmc_r05_c3/summary.json "512x512x128 early termination (configs[2]), reference-order form, mean over the segment launches of a frame" \
-    "render_fused_kernel<0, true, false>" $c $d/b_pmc_summary_config3_early_term.json | grep -E "busy|hbm_bytes|l2_hit"
+    "render_fused_kernel<0, true, false, true>" $c $d/b_pmc_summary_config3_early_term.json | grep -E "busy|hbm_bytes|l2_hit"
 python tools/pmc_derive.py gpurun_out/pmc_r05_survey/summary.json "512x512x64 survey fill (73 689 rays), API output set, patch order, reference-order form" \
-    "render_fused_kernel<0, true, false> (one launch: 2 048 whole tiles + 255 tiles as eight-samples-per-step units)" $c $d/b_pmc_summary_survey_frame.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
+    "render_fused_kernel<0, true, false, true> (one launch: 2 048 whole tiles + 255 tiles as eight-samples-per-step units)" $c $d/b_pmc_summary_survey_frame.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
 python tools/resource_table.py $d > /dev/null 2>&1 || true
 rm -f $d/h_kernel_resources_wip.md
 ls $d
