@@ -1385,7 +1385,8 @@ DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
 #define GPNERF_MAX_WAVES 8
 #endif
 constexpr int DEFER_QUEUE = 64;                 // entries of a wavefront's queue of samples waiting for their colour pass (render_tile)
-constexpr size_t DEFER_LDS_BYTES = (size_t)GPNERF_MAX_WAVES * DEFER_QUEUE * 8;      // behind the head image
+constexpr int TALLY_WORDS = 4;                  // per wavefront, behind the queues: the tile's step_stats (diagnostic launches)
+constexpr size_t DEFER_LDS_BYTES = (size_t)GPNERF_MAX_WAVES * (DEFER_QUEUE * 8 + TALLY_WORDS * 4);      // behind the head image
 constexpr int LIST_CHUNK_SHIFT = 11, LIST_CHUNK = 1 << LIST_CHUNK_SHIFT;      // entries per survivor counter / per compaction workgroup
 // number of launch slots a chained launch renders: the previous segment's survivors, or every ray (segment 0)
 typedef const __attribute__((address_space(4))) KArgs* kargs_cptr;
@@ -1603,11 +1604,16 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     unsigned long long mine = 0ull;             // bit j: the queue entry j places behind the head is one of this ray's
     int q_head = 0, q_cnt = 0;                  // (uniform)
     uint2* dq = nullptr;
-    if constexpr (CAN_DEFER) {
-        // behind the head image (split form: and behind the range guard's slots)
-        constexpr int QUEUE_AT = SPLIT ? gph::BLOB_WORDS + (FORM == FORM_SPLIT_GUARD ? 2 * GUARD_LDS_SLOTS : 0) : gpl::BLOB_FLOATS;
-        dq = reinterpret_cast<uint2*>(lds + QUEUE_AT) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * DEFER_QUEUE;
-    }
+    // behind the head image (split form: and behind the range guard's slots): the wavefronts' queues, then their tallies
+    constexpr int QUEUE_AT = SPLIT ? gph::BLOB_WORDS + (FORM == FORM_SPLIT_GUARD ? 2 * GUARD_LDS_SLOTS : 0) : gpl::BLOB_FLOATS;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (CAN_DEFER) dq = reinterpret_cast<uint2*>(lds + QUEUE_AT) + wave_in_wg * DEFER_QUEUE;
+    // step_stats (the diagnostic launch only): the tile counts in LDS -- [0] steps, [1] empty-space exits, [2] steps whose colour
+    // branch did not run in the step, [3] colour passes -- and adds them to the launch's counters once, at its end (one global
+    // atomic per step and counter made the counting launch 40 % slower than the launches it describes)
+    unsigned* const tl = reinterpret_cast<unsigned*>(lds) + QUEUE_AT + GPNERF_MAX_WAVES * DEFER_QUEUE * 2 + wave_in_wg * TALLY_WORDS;
+    const bool tally = k0->out.step_stats != nullptr;
+    if (tally && lane < TALLY_WORDS) tl[lane] = 0u;
     int k_lim = k_end;                          // (early termination of the tile as a whole moves it to where the loop stopped)
     for (;; k += P) {
         if constexpr (CAN_DEFER) {
@@ -1639,7 +1645,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                     if constexpr (FORM == FORM_F32) { mean_var_ref(xq, mvq); mlp_colour_ref(lds, lane, xq, mvq, cq, st); }
                     else { mean_var(xq, mvq); mlp_colour(lds, lane, xq, mvq, cq, st); }
                 }
-                if (kb->out.step_stats && lane == 0) atomicSub(kb->out.step_stats + 2, 1u);
+                if (tally && lane == 0) tl[3] += 1u;
                 unsigned todo = (unsigned)mine & (nb >= 32 ? ~0u : ((1u << nb) - 1u));
                 while (__any(todo != 0u)) {             // a ray's entries of this pass, oldest first
                     const int j = todo ? __builtin_ctz(todo) : 0;
@@ -1762,7 +1768,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 #pragma unroll
                 for (int i = 0; i < 64; i += 2) bits |= __builtin_bit_cast(unsigned, fv[i]) | __builtin_bit_cast(unsigned, fv[i + 1]);
                 if ((kp->skip & 1) && __all((bits << 1) == 0u)) {          // (-0.0 counts as zero: fma(w, -0, +0) = +0 too)
-                    if (out.step_stats && lane == 0) atomicAdd(out.step_stats + 1, 1u);      // (the diagnostic launch only: no tally lives in the loop)
+                    if (tally && lane == 0) tl[1] += 1u;
                     geo_bias_ref(lds, lane, sf);
                 } else {
                     float fk[64];
@@ -1799,21 +1805,21 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 else { mean_var(x, mv); mlp_density(lds, lane, sf, mv, nvalid, sigma); }
             }
             rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;               // (the colour map's terms arrive with the colour passes)
-            if (out.step_stats && lane == 0) atomicAdd(out.step_stats + 2, 1u);         // (diagnostic launch: steps minus colour passes)
+            if (tally && lane == 0) tl[2] += 1u;                    // (diagnostic launch: steps minus colour passes)
         }
         else if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
         else if constexpr (FORM == FORM_F32) {
             {
                 const bool may_skip = (kp->skip & 2) && !out.raw;
                 mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
-                if (out.step_stats) {                                   // (the diagnostic launch only)
+                if (tally) {                                            // (the diagnostic launch only)
                     const bool all_zero = may_skip && __all(sigma == 0.f);
-                    if (all_zero && lane == 0) atomicAdd(out.step_stats + 2, 1u);
+                    if (all_zero && lane == 0) tl[2] += 1u;
                 }
             }
         }
         else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
-        if (out.step_stats && lane == 0) atomicAdd(out.step_stats + 0, 1u);
+        if (tally && lane == 0) tl[0] += 1u;
         if (CULL || cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
@@ -1914,6 +1920,10 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     st.flush(lane);
     kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
+    if (tally && lane < 3) {
+        const unsigned v = lane == 2 ? tl[2] - tl[3] : tl[lane];
+        if (v) atomicAdd(kp->out.step_stats + lane, v);
+    }
 
     if constexpr (FORM == FORM_SPLIT_GUARD) {
         // an operand at or beyond the f16 range (or a NaN): the hi/lo pair no longer carries the value, flag the tile

@@ -73,8 +73,9 @@ extern "C" {
                                       On trained parameters it sits at the op-for-op CPU oracle's distance from the reference
                                       where the folded form is 5-10 x further.  Needs frame->head_blob_ref */
 
-#define GPNERF_FLAG_NO_EXITS 128u   /* diagnostic: the reference-order form evaluates every layer of every step, without its two
-                                      bit-exact exits (GpnerfOutputs.step_stats) -- the A/B that shows they change no bit */
+#define GPNERF_FLAG_NO_EXITS 128u   /* diagnostic: every layer of every sample is evaluated -- without the fp32 forms' bit-exact exits
+                                      (the sigma feature layer in empty space; the colour branch run only for samples whose weight
+                                      alpha * T is not zero: GpnerfOutputs.step_stats) -- the A/B that shows they change no bit */
 #define GPNERF_FLAG_RESERVE_CUS(n) (((uint32_t)(n) & 0xffu) << 24)
                                    /* bits 24..31: plan the launch for n fewer compute units (rounded down to a multiple of 8: one
                                       per XCD round).  The persistent workgroups then leave n CUs idle for kernels of other
@@ -144,11 +145,13 @@ typedef struct GpnerfOutputs {
     float* raw;        /* [N,S,4] NeRFHead.forward output (rgb, sigma), un-flipped sample order */
     int32_t* samples_done; /* [N]  diagnostic: samples the ray's wavefront evaluated (S unless early termination / culling
                               skipped some); with it the launch never splits a tile's samples over several wavefronts */
-    uint32_t* step_stats;  /* [4] or NULL, zeroed by the caller; the reference-order fp32 form ADDS: [0] 32-sample steps its wavefronts
-                              walked, [1] steps that took the empty-space exit of the sigma feature layer (all 128 volume features of
-                              all 32 samples exactly zero: ELU(bias) without the layer's MFMAs), [2] steps that took the zero-density
-                              exit (density of all 32 samples exactly 0: the colour branch cannot change any map).  Both exits
-                              are bit-exact; bench.py prices its roofline with the work actually done */
+    uint32_t* step_stats;  /* [4] or NULL, zeroed by the caller; the launch ADDS: [0] 32-sample steps its wavefronts walked, [1] steps
+                              that took the empty-space exit of the sigma feature layer (reference-order form: all 128 volume
+                              features of all 32 samples exactly zero: ELU(bias) without the layer's MFMAs), [2] steps MINUS colour
+                              passes: a sample whose weight alpha * T is exactly 0 adds fma(0, rgb, c) = c to the colour map, so its
+                              colour branch is not run; the fp32 forms queue the samples that need it per wavefront and run the
+                              branch on 32 of them at a time (never with `raw`, never under GPNERF_FLAG_NO_EXITS).  All of it is
+                              bit-exact; bench.py reports its roofline both ways (algorithmic, and on the work done) */
 } GpnerfOutputs;
 
 /* Number of floats of the packed head image. */

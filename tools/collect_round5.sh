@@ -26,6 +26,7 @@ cp $o/et_sweep.txt $d/f_et_sweep.txt
 cp $o/producers_sweep.txt $d/f_producers_sweep.txt
 cp $o/micro.txt $d/i_micro_mfma_overlap_permlane_swap.txt
 [ -s $o/stamps_default.txt ] && grep -v amdgpu $o/stamps_default.txt > $d/c_stamps_headline.txt
+[ -s $o/skip_probe.txt ] && grep -v amdgpu $o/skip_probe.txt > $d/c_exits_on_off.txt
 [ -s $o/defer_debug.txt ] && grep -v amdgpu $o/defer_debug.txt > $d/c_deferred_vs_in_step_colour.txt
 { echo "# pipelined evaluation loop (VERDICT r4 next #2): measurements of $c"; echo;
   echo "## tools/probes/overlap_probe.py -- per-ray kernel of the ZJU-sized frame + the NEXT frame's encoder graph on a second stream, by reserved CUs"; cat $o/overlap_probe.txt | grep -v amdgpu;

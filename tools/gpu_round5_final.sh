@@ -26,6 +26,7 @@ timeout 200 python tools/time_render_api.py > $o/render_api.txt 2>&1
 timeout 200 python tools/time_survey_api.py 20 > $o/render_api_survey.txt 2>&1
 timeout 200 python tools/probes/encoder_time.py > $o/encoder_time.txt 2>&1
 timeout 200 python tools/stamps.py 512 > $o/stamps_default.txt 2>&1
+timeout 300 python tools/probes/skip_probe.py > $o/skip_probe.txt 2>&1
 timeout 200 python tools/probes/defer_debug.py > $o/defer_debug.txt 2>&1
 timeout 600 python tools/parity_sweep.py 300 > $o/parity_sweep.txt 2>&1
 timeout 600 python tools/et_sweep.py 50 > $o/et_sweep.txt 2>&1

@@ -1,6 +1,7 @@
-"""The reference-order form's two bit-exact exits (empty-space sigma layer, zero-density colour branch) on a PERSON-SHAPED frame
-rendered by the dense renderer: kernel time and bits with the exits on (default) and off (GPNERF_FLAG_NO_EXITS, a second
-process), how many sample steps take each exit, and the same on the dense synthetic bench frame (which never takes them).
+"""The reference-order form's bit-exact exits (empty-space sigma layer; colour branch deferred and run only for samples with a
+non-zero weight) on a PERSON-SHAPED frame rendered by the dense renderer: kernel time and bits with the exits on (default) and
+off (GPNERF_FLAG_NO_EXITS, a second process), the fraction of zero-density samples, the same on the dense synthetic bench frame,
+and on that frame with every density positive (nothing to skip: the deferral's own cost).
 usage: python tools/probes/skip_probe.py            (parent)        |   ... child <out.npz>"""
 import importlib, json, os, subprocess, sys
 import numpy as np
@@ -8,7 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 SCENES = {"body (capsule figure, sparse levels, sigma_bias -1.5)": dict(H=512, W=512, seed=0, fill="survey", pose="identity", body="capsules", sigma_bias=-1.5, bias_std=0.1, vol_scale=2.0),
-          "bench frame (dense random levels)": dict(H=512, W=512, seed=0, fill="full", pose="identity")}
+          "bench frame (dense random levels)": dict(H=512, W=512, seed=0, fill="full", pose="identity"),
+          # nothing to skip: what the queue and the regather of the deferred colour branch cost by themselves
+          "bench frame, every density positive (sigma_bias +1)": dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=1.0)}
 
 
 def child(path):
