@@ -1036,6 +1036,48 @@ DEV void gather_volume_batched(const float* __restrict__ vol, int D, int H, int 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// The batched gather in two halves, so that the sample loop can put matrix work between a level's loads and their use: the
+// deferred-colour step of the reference-order form runs level l's 32 MFMAs of the sigma feature layer while level l + 1's 32
+// loads are in flight (render_tile).  vol_finish accumulates as muladd16 does: multiply, then add, taps in the same order.
+struct VolTaps {
+    f32x4 q[8][4];
+    float wt[8];
+};
+DEV void vol_issue(const float* __restrict__ vol, int D, int H, int W, float gx, float gy, float gz, int half, VolTaps& t) {
+    const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), az = axis_taps(gz, D);
+    const unsigned zi[2] = {az.i0, az.i1}, yi[2] = {ay.i0, ay.i1};
+    const float zw[2] = {az.w0, az.w1}, yw[2] = {ay.w0, ay.w1}, xw[2] = {ax.w0, ax.w1};
+    const unsigned row_bytes = (unsigned)W * 128u;
+    const unsigned xb[2] = {ax.i0 * 128u + (unsigned)half * 64u, ax.i1 * 128u + (unsigned)half * 64u};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const unsigned rowb = __umul24(mad24(zi[a], (unsigned)H, yi[b]), row_bytes);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(at_byte(vol, rowb + xb[e]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t.q[4 * a + 2 * b + e][i] = p[i];
+                t.wt[4 * a + 2 * b + e] = (xw[e] * yw[b]) * zw[a];
+            }
+        }
+}
+DEV void vol_finish(const VolTaps& t, float* f) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x2 w2 = {t.wt[k], t.wt[k]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 r0 = f32x2{f[4 * i], f[4 * i + 1]} + f32x2{t.q[k][i][0], t.q[k][i][1]} * w2;
+            const f32x2 r1 = f32x2{f[4 * i + 2], f[4 * i + 3]} + f32x2{t.q[k][i][2], t.q[k][i][3]} * w2;
+            f[4 * i] = r0[0]; f[4 * i + 1] = r0[1]; f[4 * i + 2] = r1[0]; f[4 * i + 3] = r1[1];
+        }
+    }
+}
+
 // The sigma feature layer is linear in the volume features and trilinear sampling is linear in the voxels, so
 //   W (sum_t w_t v_t) = sum_t w_t (W v_t):
 // gpnerf_fold_volumes applies out_geometry_fc's 32 columns of level l to every voxel of level l once per frame (64 values per
@@ -1741,6 +1783,55 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
             }
             elus_n<16>(g0, sf);
             elus_n<16>(g1, sf + 16);
+        } else if constexpr (FORM == FORM_F32 && DEFER) {
+            // SparseConvNet.forward sampling (:113-122) and the sigma feature layer, level by level: level l's 16 k-steps (32 MFMAs,
+            // ~2 000 cycles: about one L2 round trip) run while level l + 1's 32 loads are in flight, so three of the step's four
+            // volume round trips hide behind the wavefront's OWN matrix work -- with the colour branch out of the step the other
+            // wavefront of the SIMD no longer covers them.  The chain is the layer's: k ascending, level-major,
+            // bias last.  A level whose 16 features are zero in all 32 samples adds fma(w, 0, s) = s: its MFMAs are left out (the
+            // empty-space exit, level by level; step_stats counts the steps that skip all four).
+            VolTaps taps;
+            vol_issue(fr.vol[0], fr.vol_dhw[0][0], fr.vol_dhw[0][1], fr.vol_dhw[0][2], gx, gy, gz, half, taps);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 g0 = zero_tile(), g1 = zero_tile();
+            int levels_skipped = 0;
+#pragma unroll
+            for (int l = 0; l < GPNERF_LEVELS; ++l) {
+                float fl[16];
+                vol_finish(taps, fl);
+                __builtin_amdgcn_sched_barrier(0);
+                if (l + 1 < GPNERF_LEVELS) {
+                    vol_issue(fr.vol[l + 1], fr.vol_dhw[l + 1][0], fr.vol_dhw[l + 1][1], fr.vol_dhw[l + 1][2], gx, gy, gz, half, taps);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                unsigned bits = 0u;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) bits |= __builtin_bit_cast(unsigned, fl[i]) | __builtin_bit_cast(unsigned, fl[i + 1]);
+                if ((kp->skip & 1) && __all((bits << 1) == 0u)) { ++levels_skipped; }
+                else {
+                    float fk[16];
+                    interleave16(fl, fk);
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    g0 = mfma_tile_from<16>(wtile<gpl::GEO>(lds, 0) + l * 16 * 64, ln, fk, g0);
+                    g1 = mfma_tile_from<16>(wtile<gpl::GEO>(lds, 1) + l * 16 * 64, ln, fk, g1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (tally && lane == 0 && levels_skipped == GPNERF_LEVELS) tl[1] += 1u;
+            STAMP(st, (k == k_begin ? 10 : (k == k_begin + P ? 11 : 0)));
+            {
+                int hb = half;
+                asm volatile("" : "+v"(hb));
+                f32x4 b0[4], b1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    b0[q] = *reinterpret_cast<const f32x4*>(bias_ptr<gpl::GEO>(lds, 0, hb) + 4 * q);
+                    b1[q] = *reinterpret_cast<const f32x4*>(bias_ptr<gpl::GEO>(lds, 1, hb) + 4 * q);
+                }
+                elur_n<16>(g0, b0, sf);
+                elur_n<16>(g1, b1, sf + 16);
+            }
         } else {
             // SparseConvNet.forward sampling (:113-122): 4 levels, level-major concat
             float fv[64];
