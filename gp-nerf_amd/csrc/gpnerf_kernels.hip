@@ -1675,10 +1675,14 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 if constexpr (SPLIT) {
                     Frag mvf[6];
 #ifdef GPNERF_X_SPLIT_DEFER       // (see SPLIT_DEFERS below: without this copy the unguarded instantiation's colour passes come out wrong)
+#ifndef GPNERF_X_SD_LO
+#define GPNERF_X_SD_LO 0
+#define GPNERF_X_SD_HI 18
+#endif
 #pragma unroll
                     for (int v = 0; v < NV; ++v)
 #pragma unroll
-                        for (int c = 0; c < 18; ++c) asm volatile("" : "+v"(xq[v][c]));
+                        for (int c = GPNERF_X_SD_LO; c < GPNERF_X_SD_HI; ++c) asm volatile("" : "+v"(xq[v][c]));
 #endif
                     mean_var_s(gmax, xq, mvf);
                     mlp_colour_s(gmax, lw, lane, xq, mvf, cq, st);
@@ -2006,7 +2010,10 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         }
         STAMP(st, 6);
         // wavefront-level early termination (not in the reference): every ray of the tile is opaque
-        if (early && __all(T < term_eps)) k_lim = k + P;
+        if (early && __all(T < term_eps)) {
+            if constexpr (DEFER) k_lim = k + P;         // (the colour passes still waiting, then out)
+            else { k += P; break; }
+        }
     }
     st.flush(lane);
     kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 SCENES = {"body (capsule figure, sparse levels, sigma_bias -1.5)": dict(H=512, W=512, seed=0, fill="survey", pose="identity", body="capsules", sigma_bias=-1.5, bias_std=0.1, vol_scale=2.0),
           "bench frame (dense random levels)": dict(H=512, W=512, seed=0, fill="full", pose="identity"),
           # nothing to skip: what the queue and the regather of the deferred colour branch cost by themselves
-          "bench frame, every density positive (sigma_bias +1)": dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=1.0)}
+          "bench frame, density bias +1 (zero only where no view sees the sample)": dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=1.0)}
 
 
 def child(path):
