@@ -2897,9 +2897,12 @@ int dbg_int(const char* name, int dflt, int lo, int hi) {
 enum { SEL_REF = 0, SEL_FOLD = 1, SEL_SPLIT = 2, SEL_GUARD = 3 };
 // The split-precision forms keep the colour branch in the step.  Deferred, they were built and measured (bench frame 7.30 -> 6.39 ms
 // guarded, 6.2 unguarded; configs[2] 4.8 ms) and the guarded instantiation is bit-identical to its plain loop -- but the UNGUARDED
-// one's colour passes come out 10-30 % off unless the regathered inputs pass through an opaque register copy first
+// one's colour passes came out 10-30 % off in one build unless the regathered inputs passed through an opaque register copy first
 // (-DGPNERF_X_SPLIT_DEFER builds both, with the copy; tools/probes/defer_debug.py), and a guarded launch flagged tiles on ordinary
-// data.  The cause is not established (no MFMA-shadow consumer: tools/isa_mfma_hazards.py is clean), so it is not shipped.
+// data; a later build of the same source with unrelated edits elsewhere in the kernel was bit-exact without the copy.  A
+// code-generation sensitivity whose cause is not established (no MFMA-shadow consumer: tools/isa_mfma_hazards.py is clean on the
+// failing build; no instruction-cache or scratch anomaly), so it is not shipped: the fp32 forms' deferral is held to the bit by
+// tests/test_gpu_parity.py::test_deferred_colour_branch_is_the_plain_loop_bit_for_bit on every build.
 #ifdef GPNERF_X_SPLIT_DEFER
 constexpr bool SPLIT_DEFERS = true;
 #else
