@@ -315,10 +315,14 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     fold: which fp32 form.  False / None (default): the REFERENCE-ORDER form -- every dense layer accumulates as the reference's
     sgemm does (k ascending from zero, bias last, unscaled), x / 3 and the trilinear taps round as the reference's do: on trained
     parameters it sits at the op-for-op CPU oracle's distance from the reference.  True: the round-4 fast
-    form -- coarse levels folded into the sigma feature layer per frame (Frame.fold_volumes), log2(e)-scaled layers: ~8 % faster,
+    form -- coarse levels folded into the sigma feature layer per frame (Frame.fold_volumes), log2(e)-scaled layers: ~8 % faster layer for layer (the same time once both defer the colour branch),
     the same 1e-5 at initialisation scale, 5-10 x further from the reference on trained-like parameters.  "keep": True without
     re-folding a Frame that is already folded.
-    exits=False: the reference-order form without its two bit-exact exits (GPNERF_FLAG_NO_EXITS; want=("step_stats",) counts them).
+    exits=False: every layer evaluated for every sample (GPNERF_FLAG_NO_EXITS).  By default the fp32 forms leave out what cannot
+    change an output, bit for bit: the sigma feature layer of levels whose features are zero in all 32 samples of a step, and the
+    colour branch of samples whose weight alpha * T is zero (the rest wait in a per-wavefront queue and are evaluated 32 at a time);
+    want=("step_stats",) returns [steps, empty-space exits, steps minus colour passes, 0].  A launch that returns `raw` keeps the
+    colour branch in the step.
     reserve_cus: plan the launch for that many fewer compute units (multiple of 8), leaving them to kernels of other streams
     (GPNERF_FLAG_RESERVE_CUS).  The maps are those of a chip with that many fewer CUs."""
     lib = L.lib()
@@ -353,7 +357,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     if "raw" in want:
         res["raw"] = torch.empty((N, S, 4), device=dev)
         o.raw = res["raw"].data_ptr()
-    if "step_stats" in want:                               # [steps walked, sigma-layer exits, colour-branch exits, 0] (reference-order form)
+    if "step_stats" in want:                               # [steps walked, sigma-layer exits, steps minus colour passes, 0]
         res["step_stats"] = torch.zeros((4,), device=dev, dtype=torch.int32)
         o.step_stats = res["step_stats"].data_ptr()
     if "samples_done" in want:

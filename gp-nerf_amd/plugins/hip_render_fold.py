@@ -1,7 +1,8 @@
-"""Plugin shim: `render.file hip_render_fold` = hip_render with the fast fp32 form of round 4: the two coarse volume levels
-folded into the sigma feature layer once per frame (gpnerf_fold_volumes) and log2(e)-scaled dense layers.  ~8 % faster than
-the default reference-order form; the same <= 1e-5 at initialisation scale, 5-10 x further from the reference on trained-like
-parameters."""
+"""Plugin shim: `render.file hip_render_fold` = hip_render with round 4's fp32 form: the two coarse volume levels folded into the
+sigma feature layer once per frame (gpnerf_fold_volumes) and log2(e)-scaled dense layers.  Layer for layer ~8 % faster than the
+default reference-order form, but since both defer the colour branch they render the bench frame in the
+same time; the same <= 1e-5 at initialisation scale, 5-10 x further from the reference on trained-like parameters (section 5).
+Kept for comparison with round 4."""
 import importlib
 import os
 import sys
