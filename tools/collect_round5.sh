@@ -24,6 +24,7 @@ cp $o/exchange_local_cost.txt $d/m_exchange_local_cost.txt
 cp $o/parity_sweep.txt $d/f_parity_sweep.txt
 cp $o/et_sweep.txt $d/f_et_sweep.txt
 cp $o/producers_sweep.txt $d/f_producers_sweep.txt
+[ -s $o/defer_sweep.txt ] && grep -v amdgpu $o/defer_sweep.txt > $d/f_defer_sweep.txt
 cp $o/micro.txt $d/i_micro_mfma_overlap_permlane_swap.txt
 [ -s $o/stamps_default.txt ] && grep -v amdgpu $o/stamps_default.txt > $d/c_stamps_headline.txt
 [ -s $o/skip_probe.txt ] && grep -v amdgpu $o/skip_probe.txt > $d/c_exits_on_off.txt

@@ -30,6 +30,7 @@ timeout 300 python tools/probes/skip_probe.py > $o/skip_probe.txt 2>&1
 timeout 200 python tools/probes/defer_debug.py > $o/defer_debug.txt 2>&1
 timeout 600 python tools/parity_sweep.py 300 > $o/parity_sweep.txt 2>&1
 timeout 600 python tools/et_sweep.py 50 > $o/et_sweep.txt 2>&1
+timeout 600 python tools/defer_sweep.py 150 > $o/defer_sweep.txt 2>&1
 timeout 600 python tools/producers_sweep.py 40 > $o/producers_sweep.txt 2>&1
 (cd tools/micro && hipcc -O2 --offload-arch=gfx950 -o /tmp/mdo mfma_dst_overlap.hip 2>/dev/null && /tmp/mdo; hipcc -O2 --offload-arch=gfx950 -o /tmp/pswap permlane32_swap.hip 2>/dev/null && /tmp/pswap) > $o/micro.txt 2>&1
 python - <<'PY'
