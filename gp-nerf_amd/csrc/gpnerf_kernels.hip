@@ -2903,6 +2903,12 @@ enum { SEL_REF = 0, SEL_FOLD = 1, SEL_SPLIT = 2, SEL_GUARD = 3 };
 // code-generation sensitivity whose cause is not established (no MFMA-shadow consumer: tools/isa_mfma_hazards.py is clean on the
 // failing build; no instruction-cache or scratch anomaly), so it is not shipped: the fp32 forms' deferral is held to the bit by
 // tests/test_gpu_parity.py::test_deferred_colour_branch_is_the_plain_loop_bit_for_bit on every build.
+// What is known about the failing build (revision c9a579c with this define, reproducible: the same wrong colours on every box):
+// the regathered inputs, the queue entry and the weights are right, the colour branch's result is wrong in all 64 lanes alike;
+// cured by ANY of: the opaque copy of the inputs, keeping the inputs alive behind the branch (storing them), stores inside the
+// branch, `volatile` on lo_pair's two asm statements, lo_pair written without asm; NOT cured by waits + 32 idle cycles around the
+// pass, by dropping __restrict__, or by storing the branch's result (which changes the wrong values).  Not a write-after-read
+// hazard on the f16 MFMA's four-register A / B operands (tools/micro/mfma_f16_src_war.hip: they are latched at issue).
 #ifdef GPNERF_X_SPLIT_DEFER
 constexpr bool SPLIT_DEFERS = true;
 #else
