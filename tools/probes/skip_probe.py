@@ -26,7 +26,8 @@ def child(path):
         fr = fm.Frame(t(sc["src_imgs"][0]), t(sc["featmaps"]), [t(v) for v in sc["volumes"]], t(sc["src_Ks"][0]), t(sc["src_poses"][0]),
                       sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0], fm.pack_head(sc["head"], dev))
         rays = t(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32))
-        order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], 512, 512, patch_w=32, patch_h=8)).to(dev)
+        pw, ph = (int(v) for v in os.environ.get("SKIP_PROBE_PATCH", "32x8").split("x"))       # pixels per wavefront: W x H
+        order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], 512, 512, patch_w=pw, patch_h=ph)).to(dev)
         want = ("weights", "z_vals", "rgb_in")
         f = lambda: fm.render_fused(fr, rays, 64, want=want, ray_order=order, exits=os.environ.get("SKIP_PROBE_EXITS", "1") == "1")
         for _ in range(3):
