@@ -1160,6 +1160,22 @@ struct ViewSample {
     float valid;
 };
 
+// Only the view's validity test of Projector.compute (front of the camera and inside the image: gather_view's own expressions,
+// so the same decision to the bit): what a step of exactly opaque rays still owes the outputs (ray_mask counts views).
+template <class MP>
+DEV float view_valid(MP M, int ih, int iw, float px, float py, float pz, bool neg) {
+    const float hx = fmaf(M[2], pz, fmaf(M[1], py, M[0] * px)) + M[3];
+    const float hy = fmaf(M[6], pz, fmaf(M[5], py, M[4] * px)) + M[7];
+    const float hz = fmaf(M[10], pz, fmaf(M[9], py, M[8] * px)) + M[11];
+    float u = hx / hz, w = hy / hz;
+    u = fminf(fmaxf(u, -1e6f), 1e6f);
+    w = fminf(fmaxf(w, -1e6f), 1e6f);
+    const bool front = neg ? (hz < 0.f) : (hz > 0.f);
+    const float wm1 = (float)iw - 1.f, hm1 = (float)ih - 1.f;
+    const bool inb = (u <= wm1) && (u >= 0.f) && (w <= hm1) && (w >= 0.f);
+    return (front && inb) ? 1.f : 0.f;
+}
+
 // Projector.compute for one view (libs/renders/BaseRender.py:301-324,296-299,283-294,352-362):
 // project p, bilinear RGB from imgs[v] (NHWC4) and 16 feature channels from featmaps[v] (NHWC32).
 template <bool BATCH = false, class MP>
@@ -1657,6 +1673,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     const bool tally = k0->out.step_stats != nullptr;
     if (tally && lane < TALLY_WORDS) tl[lane] = 0u;
     int k_lim = k_end;                          // (early termination of the tile as a whole moves it to where the loop stopped)
+    int opaque_from = -1;                       // (first step behind the one at which every ray's transmittance was exactly 0)
     for (;; k += P) {
         if constexpr (CAN_DEFER) {
             if (defer && (q_cnt >= 32 || (q_cnt > 0 && !(k < k_lim)))) {
@@ -2013,6 +2030,31 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         if (early && __all(T < term_eps)) {
             if constexpr (DEFER) k_lim = k + P;         // (the colour passes still waiting, then out)
             else { k += P; break; }
+        }
+        // Exactly opaque (plain deferred loop): once the transmittance of all 32 rays has underflowed to 0 -- a few samples behind
+        // a trained model's surface, where 1 - alpha + 1e-10 = 1e-10 -- every later weight is alpha * 0 = 0 and T stays 0: no map
+        // can change any more (fma(0, x, m) = m for finite x).  The sample loop ends here; what the rest of the segment still owes
+        // the outputs -- zero weights, and ray_mask's count of the samples two views see -- is settled behind it without a gather
+        // or an MFMA.  Bit-exact like the other exits (kp->skip; never while culling, whose count depends on the occupancy).
+        if constexpr (DEFER && !CHAIN && !CULL) {
+            if ((kp->skip & 2) && !cull && !early && __all(T == 0.f)) { k_lim = k + P; opaque_from = k + P; }
+        }
+    }
+    if constexpr (DEFER && !CHAIN && !CULL) {
+        if (opaque_from >= 0) {
+            kargs_ptr ko = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ko));
+            for (int kk = opaque_from; kk < k_end; ++kk) {
+                float z, px, py, pz, nv = 0.f;
+                sample_point(ox, oy, oz, dx, dy, dz, near, far, flip ? (S - 1 - kk) : kk, S, step, z, px, py, pz);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) nv += view_valid(ko->fr.proj[v], ko->fr.img_h, ko->fr.img_w, px, py, pz, neg);
+                if (nv > 1.f) ++n_two;
+                ++n_done;
+                if (writer && ko->out.weights) ko->out.weights[(size_t)ray * S + kk] = 0.f;
+                if (tally && lane == 0) { tl[0] += 1u; tl[1] += 1u; tl[2] += 1u; }
+            }
+            k = k_end;
         }
     }
     st.flush(lane);

@@ -320,7 +320,8 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     re-folding a Frame that is already folded.
     exits=False: every layer evaluated for every sample (GPNERF_FLAG_NO_EXITS).  By default the fp32 forms leave out what cannot
     change an output, bit for bit: the sigma feature layer of levels whose features are zero in all 32 samples of a step, and the
-    colour branch of samples whose weight alpha * T is zero (the rest wait in a per-wavefront queue and are evaluated 32 at a time);
+    colour branch of samples whose weight alpha * T is zero (the rest wait in a per-wavefront queue and are evaluated 32 at a time),
+    and everything behind the sample at which all 32 rays of a tile have a transmittance of exactly 0;
     want=("step_stats",) returns [steps, empty-space exits, steps minus colour passes, 0].  A launch that returns `raw` keeps the
     colour branch in the step.
     reserve_cus: plan the launch for that many fewer compute units (multiple of 8), leaving them to kernels of other streams

@@ -488,6 +488,20 @@ def test_deferred_colour_branch_is_the_plain_loop_bit_for_bit(form, fm, syn):
         a = render(fr3, rays_of(sc3), 64, want=want, **kw)
         b = render(fr3, rays_of(sc3), 64, want=want, exits=False, **kw)
         same(a, b, tuple(kw))
+    # exactly opaque rays (density bias + 60: T underflows to 0 behind four samples): the plain deferred loop stops gathering and
+    # multiplying, keeps counting views for ray_mask and writing zero weights -- same bits, samples_done included
+    sc4 = syn.make_scene(H=96, W=96, seed=94, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1, sigma_bias=60.0)
+    fr4 = build_frame(fm, sc4)
+    for kw in ({}, {"load_balance": False}, {"neg_ray": True}):
+        a = render(fr4, rays_of(sc4), 64, want=want + ("step_stats",), **kw)
+        b = render(fr4, rays_of(sc4), 64, want=want, exits=False, **kw)
+        st = a.pop("step_stats").cpu().numpy()
+        same(a, b, ("opaque", tuple(kw)))
+        if "split" not in form and not kw.get("neg_ray"):       # (with the front test inverted no view sees a sample: no density at all)
+            assert st[1] > 0.2 * st[0], st                     # many steps sit behind the surface (a small frame splits its tiles: each segment starts at T = 1)
+        a = render(fr4, rays_of(sc4), 64, want=("samples_done", "ray_mask"), **kw)
+        b = render(fr4, rays_of(sc4), 64, want=("samples_done", "ray_mask"), exits=False, **kw)
+        same(a, b, ("opaque samples_done", tuple(kw)))
     # no density anywhere: not one colour pass; density everywhere: one pass per step
     # (3 samples for the second: behind an opaque sample T = 1e-10, 1e-20, ... underflows to zero weights after four)
     for bias, S, expect in ((-60.0, 64, "none"), (60.0, 3, "all")):

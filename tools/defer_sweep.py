@@ -27,7 +27,7 @@ for case in range(n_cases):
     neg = bool(g.integers(0, 2))
     body = str(g.choice(["box", "capsules"]))
     kw = dict(H=H, W=W, seed=7000 + case, fill=str(g.choice(["full", "survey"])), pose=str(g.choice(["random", "identity"])),
-              bias_std=0.15, sigma_bias=float(g.choice([-1.0, -0.3, 0.0, 0.5, 2.0])), neg_cams=neg, body=body,
+              bias_std=0.15, sigma_bias=float(g.choice([-1.0, -0.3, 0.0, 0.5, 2.0, 60.0])), neg_cams=neg, body=body,
               vol_occupancy=(None if g.random() < 0.5 else float(g.choice([0.05, 0.3]))))
     if body == "box":
         kw["aabb_half"] = (0.1 + 0.1 * g.random(), 0.12 + 0.1 * g.random(), 0.04 + 0.04 * g.random())

@@ -11,7 +11,9 @@ sys.path.insert(0, ROOT)
 SCENES = {"body (capsule figure, sparse levels, sigma_bias -1.5)": dict(H=512, W=512, seed=0, fill="survey", pose="identity", body="capsules", sigma_bias=-1.5, bias_std=0.1, vol_scale=2.0),
           "bench frame (dense random levels)": dict(H=512, W=512, seed=0, fill="full", pose="identity"),
           # nothing to skip: what the queue and the regather of the deferred colour branch cost by themselves
-          "bench frame, density bias +1 (zero only where no view sees the sample)": dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=1.0)}
+          "bench frame, density bias +1 (zero only where no view sees the sample)": dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=1.0),
+          # every ray opaque behind its first few samples: transmittance underflows to exactly 0 and the rest of the ray is skipped
+          "bench frame, density bias +60 (opaque at once)": dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=60.0)}
 
 
 def child(path):
