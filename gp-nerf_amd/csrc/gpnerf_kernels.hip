@@ -2036,11 +2036,11 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         // can change any more (fma(0, x, m) = m for finite x).  The sample loop ends here; what the rest of the segment still owes
         // the outputs -- zero weights, and ray_mask's count of the samples two views see -- is settled behind it without a gather
         // or an MFMA.  Bit-exact like the other exits (kp->skip; never while culling, whose count depends on the occupancy).
-        if constexpr (DEFER && !CHAIN && !CULL) {
+        if constexpr (DEFER && !CULL && P == 1) {      // (chained form too: its launches without early termination are whole rays)
             if ((kp->skip & 2) && !cull && !early && __all(T == 0.f)) { k_lim = k + P; opaque_from = k + P; }
         }
     }
-    if constexpr (DEFER && !CHAIN && !CULL) {
+    if constexpr (DEFER && !CULL && P == 1) {      // (chained form too: its launches without early termination are whole rays)
         if (opaque_from >= 0) {
             kargs_ptr ko = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ko));
