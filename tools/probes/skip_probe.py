@@ -12,6 +12,12 @@ SCENES = {"body (capsule figure, sparse levels, sigma_bias -1.5)": dict(H=512, W
           "bench frame (dense random levels)": dict(H=512, W=512, seed=0, fill="full", pose="identity"),
           # nothing to skip: what the queue and the regather of the deferred colour branch cost by themselves
           "bench frame, density bias +1 (zero only where no view sees the sample)": dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=1.0),
+          # the trained-like parameter distributions of tests/golden/trained_h1 / h3 (heads x 1 / x 3 with biases, heavy-tailed x 4
+          # features, ReLU-sparse levels) at the bench frame's size: a full-size box, 512 x 512 rays
+          "trained-like x 1, 512 x 512 (the distributions of trained_h1_s64)": dict(H=512, W=512, seed=46, fill="full", pose="random", bias_std=0.1, sigma_bias=-10.0,
+                                                                                head_scale=1.0, feat_scale=4.0, feat_tail=0.5, vol_scale=4.0, vol_relu=True),
+          "trained-like x 3, 512 x 512 (the distributions of trained_h3_s64)": dict(H=512, W=512, seed=52, fill="full", pose="random", bias_std=0.5, sigma_bias=-16.0,
+                                                                                head_scale=3.0, feat_scale=4.0, feat_tail=0.5, vol_scale=4.0, vol_relu=True),
           # every ray opaque behind its first few samples: transmittance underflows to exactly 0 and the rest of the ray is skipped
           "bench frame, density bias +60 (opaque at once)": dict(H=512, W=512, seed=0, fill="full", pose="identity", sigma_bias=60.0)}
 
