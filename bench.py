@@ -373,6 +373,9 @@ def main():
                        ("rgb,depth,acc,disp,weights,z_vals,rgb_in (Renderer.render's dict)" if args.outputs == "api" else "rgb,depth,acc,disp"),
                        "early_term": bool(args.early_term), "term_eps": args.term_eps if args.early_term else None, "sigma_bias": sigma_bias,
                        "form": "split-f16" if args.split_f16 else ("fp32, folded coarse levels (round 4)" if flow.fold else "fp32, reference summation order"),
+                       "exits": "none (the split-precision forms evaluate every layer of every sample)" if args.split_f16 else
+                                "bit-exact (roofline.exits): zero-weight samples' colour branch, all-zero volume levels, samples behind an exactly zero "
+                                "transmittance are not evaluated; the same launch with everything evaluated is beside_headline.no_exits_api_outputs_patch_order",
                        "folded_volumes": bool(flow.fold), "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "split_guard": bool(args.split_f16 and not args.no_guard), "vol_occupancy": args.occupancy,
                        "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
