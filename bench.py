@@ -39,6 +39,30 @@ FLOP_COLOUR_BRANCH = 52608 + 12288 + 7264      # ... and base_fc x 3 views + vis
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense f16 MFMA peak (the split-precision form's matrix instructions)
 API_OUTPUTS = ("weights", "z_vals", "rgb_in")      # + rgb, depth, acc, disp (always written) = Renderer.render's dict
+# the second fixed workload of the line: parameter and feature DISTRIBUTIONS of a trained checkpoint (tests/golden/trained_h1_s64's:
+# head weights x 1 with biases, heavy-tailed x 4 features, ReLU-sparse volume levels, a density bias that leaves most of the box
+# empty) at the headline's size -- the headline frame's random-init density net (weights_init) is zero on 71 % of its samples
+TRAINED_LIKE = dict(H=512, W=512, seed=46, fill="full", pose="random", bias_std=0.1, sigma_bias=-10.0, head_scale=1.0, feat_scale=4.0,
+                    feat_tail=0.5, vol_scale=4.0, vol_relu=True)
+
+
+def price_work_done(stats, flops_algorithmic):
+    """FLOPs of the layers a launch actually evaluated, from its step_stats (include/gpnerf_hip.h GpnerfOutputs.step_stats; one
+    step = 32 samples): sample-loop steps x (everything but the colour branch) - volume levels left out x a quarter of the sigma
+    feature layer + colour-branch evaluations x the colour branch.  Steps settled behind the sample loop (exactly opaque rays)
+    ran no layer at all.  Returns (flops done, the exits as fractions of the launch's steps)."""
+    steps = max(1, int(stats[0]))
+    opaque, levels, passes = int(stats[3]), int(stats[4]), int(stats[5])
+    loop = steps - opaque
+    done = loop * (FLOP_PER_SAMPLE - FLOP_COLOUR_BRANCH) - levels * (FLOP_SIGMA_LAYER / 4.0) + passes * FLOP_COLOUR_BRANCH
+    frac_done = done / (steps * FLOP_PER_SAMPLE)
+    exits = {"steps_32_samples": steps,
+             "opaque_tail_frac": opaque / steps,
+             "sigma_layer_levels_left_out_frac": levels / (4.0 * steps),
+             "sigma_layer_all_levels_empty_frac": max(0, int(stats[1]) - opaque) / steps,
+             "colour_branch_not_run_frac": 1.0 - passes / steps,
+             "flop_not_done_frac": 1.0 - frac_done}
+    return flops_algorithmic * frac_done, exits
 
 
 def parse():
@@ -308,6 +332,16 @@ def main():
                   rays=int(flow.n_local))
     rank_summary = summarize_ranks(gather_rank_reports(report, world))
 
+    # the data-independent figure: the same launch with every layer evaluated for every sample (GPNERF_FLAG_NO_EXITS; same bits),
+    # measured right behind the timed region, never part of `value`
+    dense = None
+    if world == 1 and rank == 0 and not args.split_f16 and not args.early_term and not args.occ_cull:
+        d_ms, d_out = time_launches(lambda: fm.render_fused(wl.frame, flow.rays, S, want=flow.want, ray_order=flow.order, fold=flow.fold, exits=False, **kw),
+                                    args.steps, args.warmup)
+        d_tf = float(flow.n_local) * S * FLOP_PER_SAMPLE / (d_ms * 1e-3) / 1e12
+        dense = {"dense_ms": d_ms, "dense_frac": d_tf / PEAK_F32_MFMA_TFLOPS, "dense_rays_per_sec": flow.n_local / (d_ms * 1e-3),
+                 "dense_same_bits": bool(all(torch.equal(torch.nan_to_num(d_out[k]), torch.nan_to_num(out[k])) for k in ("rgb_map", "depth_map", "acc_map"))),
+                 "dense_note": "GPNERF_FLAG_NO_EXITS: every layer of every sample evaluated (all 110 848 FLOP x samples on the matrix pipe), same maps bit for bit"}
     extras = {}
     if world > 1 and strong and not args.no_extras and args.size != 1024:
         # BASELINE.json configs[3]: one 1024x1024x64 frame over the same ranks, same flow
@@ -333,25 +367,20 @@ def main():
             evaluated = float(done.float().mean()) / S
             alive_after = {str(k): float((done > k).float().mean()) for k in range(32, S, 32)}
             flops_per_launch *= evaluated
-        # The reference-order form leaves out work that provably cannot change any output, wave step by wave step (bit-exact, see
-        # include/gpnerf_hip.h step_stats): the sigma feature layer where all 32 samples' volume features are zero, the colour branch
-        # where all 32 densities are zero (samples no source view sees: masked_fill; ReLU).  The roofline prices the work DONE:
-        # the launch reports how many steps took each exit, and their layers' FLOPs are taken off the algorithmic count.
-        stt = step_stats
-        steps = max(1, int(stt[0]))
-        not_done = (float(stt[1]) * FLOP_SIGMA_LAYER + float(stt[2]) * FLOP_COLOUR_BRANCH) / (steps * FLOP_PER_SAMPLE)
-        exits = {"steps_32_samples": int(stt[0]), "sigma_layer_exit_frac": float(stt[1]) / steps, "colour_branch_exit_frac": float(stt[2]) / steps,
-                 "flop_not_done_frac": not_done,
-                 "note": "bit-exact exits of the reference-order form (GPNERF_FLAG_NO_EXITS switches them off; beside_headline.no_exits_* times that): "
-                         "volume features of all 32 samples of a step zero -> ELU(bias) without the sigma feature layer; a sample whose weight alpha*T is "
-                         "exactly zero (nn.ReLU on the density; masked_fill) adds fma(0, rgb, c) = c to the colour map -> its colour branch is not "
-                         "evaluated: the wavefront queues the samples that do need it and runs the branch on 32 of them at a time "
-                         "(colour_branch_exit_frac = 1 - colour passes / steps)"}
-        # `achieved` / `frac` follow the contract: ALGORITHMIC flops (every sample the launch is answerable for x 110 848) per second --
-        # with most colour branches provably not needed that can exceed the matrix pipe's peak; it is a rate of answers, not of MFMAs.
-        # `frac_of_work_done` takes the exits' layers off the numerator: what the matrix pipe was actually asked to do (the hardware figure).
-        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
-        achieved_done = achieved * (1.0 - not_done)
+        # The fp32 forms leave out work that provably cannot change any output, wave step by wave step (bit-exact, see
+        # include/gpnerf_hip.h step_stats).  The roofline prices the work DONE: `achieved` = FLOPs of the layers the launch
+        # evaluated / its duration, so `frac` never exceeds 1 and is what the matrix pipe was asked to do; the rate of ANSWERS
+        # (every sample the launch is answerable for x 110 848 FLOP, which can exceed the pipe's peak when most colour branches are
+        # provably not needed) is roofline.algorithmic_rate; the same launch with every layer evaluated for every sample
+        # (GPNERF_FLAG_NO_EXITS, data-independent) is roofline.dense_ms / dense_frac.
+        flops_done, exits = price_work_done(step_stats, flops_per_launch)
+        exits["note"] = ("bit-exact exits (GPNERF_FLAG_NO_EXITS switches them off: roofline.dense_*): a volume level whose features are zero in all 32 "
+                         "samples of a step is left out of the sigma feature layer; a sample whose weight alpha*T is exactly zero (nn.ReLU on the density; "
+                         "masked_fill) adds fma(0, rgb, c) = c to the colour map, so its colour branch is not evaluated: the wavefront queues the samples "
+                         "that need it and runs the branch on 32 of them at a time; steps behind the sample at which all 32 rays' transmittance is exactly "
+                         "0 are settled without a gather or an MFMA")
+        algorithmic = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        achieved = flops_done / (kernel_ms * 1e-3) / 1e12
         cfg_no = 2 if args.early_term else (3 if (args.size == 1024 and world > 1) else 1)
         if world == 1:
             parallelism = "single GPU"
@@ -375,14 +404,19 @@ def main():
                        "form": "split-f16" if args.split_f16 else ("fp32, folded coarse levels (round 4)" if flow.fold else "fp32, reference summation order"),
                        "exits": "none (the split-precision forms evaluate every layer of every sample)" if args.split_f16 else
                                 "bit-exact (roofline.exits): zero-weight samples' colour branch, all-zero volume levels, samples behind an exactly zero "
-                                "transmittance are not evaluated; the same launch with everything evaluated is beside_headline.no_exits_api_outputs_patch_order",
+                                "transmittance are not evaluated; the same launch with everything evaluated is roofline.dense_ms / dense_frac",
                        "folded_volumes": bool(flow.fold), "occ_cull": bool(args.occ_cull), "split_f16": bool(args.split_f16), "split_guard": bool(args.split_f16 and not args.no_guard), "vol_occupancy": args.occupancy,
                        "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_per_launch,
-                         "frac_of_work_done": achieved_done / peak, "exits": exits},
+                         "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_done,
+                         "accounting": "work done: FLOPs of the dense layers the launch evaluated (step_stats) / kernel_ms; never above the peak",
+                         "algorithmic_rate": {"tflops": algorithmic, "flop_per_launch": flops_per_launch, "over_peak": algorithmic / peak,
+                                              "note": "every sample the launch answers for x 110 848 FLOP per second: a rate of answers, not of MFMAs"},
+                         "exits": exits},
         }
+        if dense is not None:
+            line["roofline"].update(dense)
         line.update(extras)
         line.update(rank_summary)
         if args.split_f16:
@@ -398,6 +432,10 @@ def main():
                                   "note": "a ray stops once its T < term_eps; the launch walks the samples in 16-sample segments and re-packs the rays still alive "
                                           "32 to a wavefront for every segment (frames smaller than one round of wavefronts: a 32-ray tile stops as a whole)"}
         if world == 1 and not args.no_extras:
+            try:        # the second fixed workload: trained-like distributions at the headline's size
+                line["trained_like"] = trained_like_workload(args, fm)
+            except Exception as e:
+                line["trained_like"] = {"error": repr(e)[:300]}
             line["beside_headline"] = beside_headline(args, fm, wl, kw, flow)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl.sc, wl.rays_h, S, args.cpu_seconds)
@@ -415,6 +453,36 @@ def main():
         dist.destroy_process_group()
 
 
+def trained_like_workload(args, fm):
+    """The headline launch on a frame with a trained checkpoint's DISTRIBUTIONS (TRAINED_LIKE; tools/probes/skip_probe.py's
+    "trained-like x 1"): kernel time with the bit-exact exits (the default), priced on the work done, and with every layer
+    evaluated (dense) -- beside the headline, whose random-init density net is zero on 71 % of its samples."""
+    import torch
+    syn = importlib.import_module("gp-nerf_amd.synthetic")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    S = 64
+    sc = syn.make_scene(**TRAINED_LIKE)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fr = fm.Frame(t(sc["src_imgs"][0]), t(sc["featmaps"]), [t(v) for v in sc["volumes"]], t(sc["src_Ks"][0]), t(sc["src_poses"][0]),
+                  sc["Rh"][0], sc["Th"][0], sc["bounds"][0, 0], sc["voxel_size"], sc["out_sh"][0], fm.pack_head(sc["head"], dev))
+    rays = t(np.concatenate([sc["ray_o"][0], sc["ray_d"][0], sc["near"][0][:, None], sc["far"][0][:, None]], 1).astype(np.float32))
+    order = torch.from_numpy(fm.patch_order(sc["mask_at_box"][0], TRAINED_LIKE["H"], TRAINED_LIKE["W"], patch_w=32, patch_h=8)).to(dev)
+    n = int(rays.shape[0])
+    stats = fm.render_fused(fr, rays, S, want=API_OUTPUTS + ("step_stats",), ray_order=order)["step_stats"].cpu().numpy()
+    ms, o = time_launches(lambda: fm.render_fused(fr, rays, S, want=API_OUTPUTS, ray_order=order), args.steps, args.warmup)
+    d_ms, d = time_launches(lambda: fm.render_fused(fr, rays, S, want=API_OUTPUTS, ray_order=order, exits=False), args.steps, args.warmup)
+    alg = float(n) * S * FLOP_PER_SAMPLE
+    done, exits = price_work_done(stats, alg)
+    w = o["weights"]
+    return {"workload": "512x512 frame, 64 samples/ray, trained-like distributions (heads x 1 with biases, heavy-tailed x 4 features, ReLU-sparse levels, "
+                        "density bias -10: tests/golden/trained_h1_s64's), every pixel's ray through the box",
+            "scene": {k: v for k, v in TRAINED_LIKE.items()}, "rays": n, "kernel_ms": ms, "rays_per_sec": n / (ms * 1e-3),
+            "frac": done / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "algorithmic_over_peak": alg / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "dense_ms": d_ms, "dense_frac": alg / (d_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "dense_same_bits": bool(all(torch.equal(torch.nan_to_num(d[k]), torch.nan_to_num(o[k])) for k in ("rgb_map", "depth_map", "acc_map", "weights"))),
+            "zero_weight_samples_frac": float((w == 0).float().mean()), "exits": exits}
+
+
 def _cpu_plan(par, plan):
     """gloo dry run: the same plan with host index tensors."""
     import torch
@@ -430,7 +498,6 @@ def beside_headline(args, fm, wl, kw, flow):
     head_ms = None
     for name, want, order, extra in (("api_outputs_patch_order", API_OUTPUTS, wl.patch, {}), ("light_outputs_patch_order", (), wl.patch, {}),
                                      ("api_outputs_raster_order", API_OUTPUTS, None, {}),
-                                     ("no_exits_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"exits": False}),
                                      ("fp32_folded_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"fold": True}),
                                      ("split_f16_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True}),
                                      ("split_f16_unguarded_api_outputs_patch_order", API_OUTPUTS, wl.patch, {"split_f16": True, "guard": False})):
@@ -443,9 +510,7 @@ def beside_headline(args, fm, wl, kw, flow):
         if extra:
             res[name]["max_abs_vs_f32_form"] = {"rgb": float((o["rgb_map"] - head_out["rgb_map"]).abs().max()),
                                                 "depth": float((o["depth_map"] - head_out["depth_map"]).abs().max())}
-            res[name]["note"] = ("GPNERF_FLAG_NO_EXITS: the headline's form with every layer evaluated for every sample -- the same bits (max_abs 0), "
-                                 "the time the frame takes without the zero-weight colour skip") if extra.get("exits") is False else \
-                                ("round 4's fast fp32 form (`render.file hip_render_fold`): coarse levels folded into the sigma feature layer per frame "
+            res[name]["note"] = ("round 4's fast fp32 form (`render.file hip_render_fold`): coarse levels folded into the sigma feature layer per frame "
                                  "(the fold is inside the timed step), log2e-scaled layers; not in the reference's summation order") if extra.get("fold") else \
                                 ("dense layers as 3 x v_mfma_f32_32x32x16_f16 on f16 hi/lo operand pairs, f32 accumulation; " +
                                  ("no range check (operands must stay below 65504)" if extra.get("guard") is False else

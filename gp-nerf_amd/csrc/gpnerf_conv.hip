@@ -31,6 +31,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DEV __device__ __forceinline__
+#include "gpnerf_diag.h"       // the lab's hook points, empty in the product (csrc/nodiag/)
 
 constexpr int STEP_BYTES = 2048;     // one (chunk, output tile): 64 lanes x 8 halfs hi (1 KB) + the same for lo
 constexpr int PT = 2;                // 32-pixel tiles per wave
@@ -408,9 +409,6 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
             const h8 wh = __builtin_bit_cast(h8, wl[lane]), wlo = __builtin_bit_cast(h8, wl[64 + lane]);
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
-#ifdef GPNERF_X_LOLO
-                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b[t].lo, acc[t][c], 0, 0, 0);
-#endif
                 acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b[t].hi, acc[t][c], 0, 0, 0);
                 acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].lo, acc[t][c], 0, 0, 0);
                 acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].hi, acc[t][c], 0, 0, 0);
@@ -602,19 +600,6 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
             h8 wh[COT], wlo[COT];
 #pragma unroll
             for (int c = 0; c < COT; ++c) { wh[c] = __builtin_bit_cast(h8, wreg[tap][c][0]); wlo[c] = __builtin_bit_cast(h8, wreg[tap][c][1]); }
-            // (GPNERF_X_CONV_*: diagnostic builds of tools/probes/conv_ablate.sh, results wrong on purpose: the loop without one of its parts)
-#ifdef GPNERF_X_CONV_NOMFMA
-#pragma unroll
-            for (int c = 0; c < COT; ++c) asm volatile("" :: "v"(wh[c]), "v"(wlo[c]));
-#pragma unroll
-            for (int t = 0; t < PT; ++t) asm volatile("" :: "v"(b[cur][t].hi), "v"(b[cur][t].lo));
-#else
-#ifdef GPNERF_X_LOLO
-#pragma unroll
-            for (int c = 0; c < COT; ++c)
-#pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[c], b[cur][t].lo, acc[t][c], 0, 0, 0);
-#endif
 #pragma unroll
             for (int c = 0; c < COT; ++c)
 #pragma unroll
@@ -627,13 +612,10 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
             for (int c = 0; c < COT; ++c)
 #pragma unroll
                 for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], b[cur][t].hi, acc[t][c], 0, 0, 0);
-#endif
             if (cb_next >= 0) {
                 wload(tap, cb_next);
-#ifndef GPNERF_X_CONV_NOPARK
                 if (tap < PPASS) park_item(tap, buf ^ 1, cb_next, SET);
                 if (9 + tap < PPASS) park_item(9 + tap, buf ^ 1, cb_next, SET);
-#endif
             }
         }
     };
@@ -655,23 +637,13 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
     __syncthreads();
     for (int i = 0; i < nblk; i += 2) {
         // even block: staged in buffer 0; set 1 holds block i + 1 (in flight since the block before); set 0 is free for block i + 2
-#ifdef GPNERF_X_CONV_NOFETCH
-#define GPNERF_FETCH_(cb, S) ((void)0)
-#else
-#define GPNERF_FETCH_(cb, S) fetch(cb, S)
-#endif
-#ifdef GPNERF_X_CONV_NOSYNC
-#define GPNERF_SYNC_() ((void)0)
-#else
-#define GPNERF_SYNC_() __syncthreads()
-#endif
-        if (i + 2 < nblk) GPNERF_FETCH_(blk(i + 2), S0);
+        if (i + 2 < nblk) fetch(blk(i + 2), S0);
         compute(0, i + 1 < nblk ? blk(i + 1) : -1, S1);
-        GPNERF_SYNC_();
+        __syncthreads();
         if (i + 1 >= nblk) break;
-        if (i + 3 < nblk) GPNERF_FETCH_(blk(i + 3), S1);
+        if (i + 3 < nblk) fetch(blk(i + 3), S1);
         compute(1, i + 2 < nblk ? blk(i + 2) : -1, S0);
-        GPNERF_SYNC_();
+        __syncthreads();
     }
     if constexpr (KSPLIT == 2) {
         // the upper half hands its sums over ([wave][t][c][r][lane] floats, past what the epilogue's reductions use) and is done;
@@ -1195,13 +1167,9 @@ int launch_conv(const ConvArgs& a, int N, void* stream) {
 // A function of the output size ALONE, so that gpnerf_conv_out_tiles() can tell the caller how many tile rows the statistics have.
 int conv3x3_rows(int ho, int wo) {
     static int f_rows = -1, f_max = -1;
-    if (f_rows < 0) {                      // experiment knobs, honoured only under GPNERF_DEBUG=1, clamped
-        const char* d = getenv("GPNERF_DEBUG");
-        const bool dbg = d && d[0] == '1';
-        const char* e = dbg ? getenv("GPNERF_CONV_ROWS") : nullptr;
-        const char* m = dbg ? getenv("GPNERF_CONV_ROWS_MAXTILES") : nullptr;
-        f_rows = e ? min(max(atoi(e), 0), 2) : 0;
-        f_max = m ? min(max(atoi(m), 0), 1 << 20) : 16;
+    if (f_rows < 0) {                      // experiment knobs (gpnerf_diag.h: the product takes the defaults)
+        f_rows = dbg_int("GPNERF_CONV_ROWS", 0, 0, 2);
+        f_max = dbg_int("GPNERF_CONV_ROWS_MAXTILES", 16, 0, 1 << 20);
     }
     if (f_rows) return f_rows;
     return ((ho + 7) / 8) * ((wo + TW - 1) / TW) <= f_max && ho > 4 ? 1 : 2;
@@ -1226,11 +1194,7 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     const int rw = conv3x3_rows(a.Ho, a.Wo), th = tile_rows(rw);
     const int tiles = ((a.Ho + th - 1) / th) * ((a.Wo + TW - 1) / TW);
     static int f_cot = -1;
-    if (f_cot < 0) {                       // experiment knob, honoured only under GPNERF_DEBUG=1, clamped
-        const char* d = getenv("GPNERF_DEBUG");
-        const char* e = (d && d[0] == '1') ? getenv("GPNERF_CONV_COT") : nullptr;
-        f_cot = e ? min(max(atoi(e), 0), 2) : 0;
-    }
+    if (f_cot < 0) f_cot = dbg_int("GPNERF_CONV_COT", 0, 0, 2);      // experiment knob (gpnerf_diag.h)
     // one 32-channel output tile per workgroup everywhere: with the weights in registers and 54 KB of LDS two workgroups share a CU,
     // and one's staging runs under the other's MFMAs (two tiles per workgroup, GPNERF_CONV_COT=2: 1.19 -> 1.38 ms per frame)
     const int cot = (f_cot == 2 && a.CT % 2 == 0) ? 2 : 1;
@@ -1238,11 +1202,7 @@ int launch_conv3x3(const ConvArgs& a, int N, void* stream) {
     // a grid of at most one workgroup per CU (the 32 x 32 stage: 192): the channel blocks are split over the two halves of an
     // eight-wave workgroup (encoder 1.097 -> 1.030 ms; at <= 400 workgroups, which takes in the 64 x 64 stage: 1.087)
     static int f_ksplit = -1;
-    if (f_ksplit < 0) {                    // experiment knob, honoured only under GPNERF_DEBUG=1, clamped
-        const char* d = getenv("GPNERF_DEBUG");
-        const char* e = (d && d[0] == '1') ? getenv("GPNERF_CONV_KSPLIT_MAXWG") : nullptr;
-        f_ksplit = e ? min(max(atoi(e), 0), 1 << 20) : 256;
-    }
+    if (f_ksplit < 0) f_ksplit = dbg_int("GPNERF_CONV_KSPLIT_MAXWG", 256, 0, 1 << 20);     // experiment knob (gpnerf_diag.h)
     if (cot == 1 && rw == 1 && a.CB % 2 == 0 && a.CB >= 4 && (long)tiles * N * a.CT <= f_ksplit)
         return launch_conv3x3_as<1, 1, 1, 2>(a, N, tiles, stream);
     if (rw == 1) return cot == 2 ? launch_conv3x3_as<2, 1>(a, N, tiles, stream) : launch_conv3x3_as<1, 1>(a, N, tiles, stream);

@@ -32,49 +32,10 @@ constexpr int NV = GPNERF_VIEWS;
 constexpr int RAYS_PER_WAVE = 32;
 constexpr float LOG2E = 1.44269504088896340736f;
 
-// ---- diagnostic build only (-DGPNERF_STAMPS): per-phase cycle shares of one wave (never in the product .so) ----
-#ifdef GPNERF_STAMPS
-__device__ unsigned long long g_stamps[16];
-struct Stamps {
-    unsigned long long prev, acc[16];
-    DEV void start() {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0;
-        prev = now();
-    }
-    DEV static unsigned long long now() {
-        unsigned long long t;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return t;
-    }
-    DEV void mark(int i) { const unsigned long long t = now(); acc[i] += t - prev; prev = t; }
-    DEV void flush(int lane) {
-        if (lane == 0)
-            for (int i = 0; i < 16; ++i) atomicAdd(&g_stamps[i], acc[i]);
-    }
-};
-#define STAMP(st, i) (st).mark(i)
-#define STAMP_T0() const unsigned long long stamp_t0 = Stamps::now()
-#define STAMP_ADD(i, lane) do { if ((lane) == 0) { atomicAdd(&g_stamps[i], Stamps::now() - stamp_t0); atomicAdd(&g_stamps[(i) + 4], 1ull); } } while (0)
-#else
-struct Stamps { DEV void start() {} DEV void flush(int) {} };
-#define STAMP(st, i) ((void)0)
-#define STAMP_T0() ((void)0)
-#define STAMP_ADD(i, lane) ((void)0)
-#endif
-// ---- diagnostic build only (-DGPNERF_WAVETIMES): when each wavefront enters the kernel, has its weights, ends its first sample
-// step and leaves (100 MHz real-time counter, comparable across the chip) ----
-#ifdef GPNERF_WAVETIMES
-__device__ unsigned long long g_wt[16384 * 4];
-#define WT(i) do { if ((threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-    g_wt[((blockIdx.x * 8u + (threadIdx.x >> 6)) & 16383u) * 4u + (i)] = t_; } } while (0)
-#define WT_COUNT() do { if ((threadIdx.x & 63) == 0) g_wt[((blockIdx.x * 8u + (threadIdx.x >> 6)) & 16383u) * 4u + 2] += 1ull << 48; } while (0)
-#else
-#define WT(i) ((void)0)
-#define WT_COUNT() ((void)0)
-#endif
+// The lab's hook points (per-phase cycle stamps, per-wavefront time stamps, launcher experiment knobs): EMPTY in the product --
+// this resolves to csrc/nodiag/gpnerf_diag.h on the product's include path; csrc/diag/Makefile builds the diagnostic libraries
+// with csrc/diag/gpnerf_diag.h instead (never loaded by the product).
+#include "gpnerf_diag.h"
 
 DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }       // v_exp_f32
 // nn.ELU(alpha=1) = x > 0 ? x : exp(x) - 1.  exp(x) - 1 >= x everywhere and has x's sign, so the select is the median
@@ -325,14 +286,8 @@ DEV void mlp_colour(const float* __restrict__ lds, int lane, const float (&x)[NV
     for (int v = 0; v < NV; ++v) {
         // the three views share these weights; keep the compiler from holding ~100 VGPRs of them across views
         asm volatile("" : "+v"(lane));
-#ifdef GPNERF_X_VIEWFOLD_SKIP      // proxy (wrong results): what the matrix pipe would save if base_fc.0's per-view columns were folded
-        const float x4[4] = {x[v][16], x[v][17], x[v][0], x[v][1]};
-        f32x16 a0 = mfma_tile_from<4>(wtile<gpl::BV>(lds, 0), lane, x4, s0);
-        f32x16 a1 = mfma_tile_from<4>(wtile<gpl::BV>(lds, 1), lane, x4, s1);
-#else
         f32x16 a0 = mfma_tile_from<18>(wtile<gpl::BV>(lds, 0), lane, x[v], s0);
         f32x16 a1 = mfma_tile_from<18>(wtile<gpl::BV>(lds, 1), lane, x[v], s1);
-#endif
         float h1[32];
         elus_n<16>(a0, h1);
         elus_n<16>(a1, h1 + 16);
@@ -671,14 +626,10 @@ template <int N> DEV void guard_n(Guard&, const float* v) {
     // pads only the consumers it can see, and this file's inline-asm conversions (lo_pair) are opaque to it -- demonstrated on
     // hardware (tools/micro/mfma_asm_hazard.hip: 65 535 of 65 536 results stale) and gated by a static check of the shipped ISA
     // (tools/isa_mfma_hazards.py, tests/test_abi.py).  What is NOT known: whether that was the failing pair in the round-2
-    // schedule -- that source variant was never committed, and the branch form re-created under -DGPNERF_X_BRANCHGUARD is
-    // deterministic and checker-clean.  The mechanism class is established, the instance is not.
-#ifdef GPNERF_X_BRANCHGUARD       // diagnostic build only (tools/probes/branch_guard.sh): the guard as first written, with a branch
-    if (__any(!(m < F16_RANGE))) { if (!(m < F16_RANGE)) guard_slot()[0] = 1u; }
-#else
+    // schedule -- that source variant was never committed, and the branch form re-created in round 3 (a diagnostic build, git
+    // history) was deterministic and checker-clean.  The mechanism class is established, the instance is not.
     unsigned* const sl = guard_slot();
     (m < F16_RANGE ? sl + GUARD_LDS_SLOTS : sl)[0] = 1u;
-#endif
 }
 
 // x = hi + lo with hi = f16(x) toward zero (never overflows to inf), lo = f16(x - hi): ~22 significant bits
@@ -931,9 +882,6 @@ DEV Axis axis_taps(float g, int size) {
 // the base from SGPRs plus a 32-bit VGPR offset, so no 64-bit address arithmetic runs on the VALU.
 DEV unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
 DEV const float* at_byte(const float* base, unsigned byte_off) {
-#ifdef GPNERF_X_SAMELINE       // diagnostic only (wrong results): every lane of a load reads the first lane's line
-    byte_off = ((unsigned)__builtin_amdgcn_readfirstlane((int)byte_off) & ~127u) | (byte_off & 127u);
-#endif
     return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
@@ -1181,7 +1129,7 @@ DEV float view_valid(MP M, int ih, int iw, float px, float py, float pz, bool ne
 template <bool BATCH = false, class MP>
 DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
                            const float* __restrict__ fm, int fh, int fw, float px, float py, float pz, bool neg,
-                           int half, float* f, const float* __restrict__ ftab = nullptr) {
+                           int half, float* f) {
     // (K4 P4) bmm [p, 1] (BaseRender.py:314): on the reference's CPU path an sgemm whose micro-kernel accumulates over k = 0..3 with
     // FMAs, k ascending, the last term (x 1) a plain add -- checked bit for bit against torch.bmm; with this order the pixel
     // coordinates, the in-bounds masks and the gathered view features are the reference's own bits (round 3 summed left to
@@ -1238,28 +1186,6 @@ DEV ViewSample gather_view(MP M, const float* __restrict__ img, int ih, int iw,
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef GPNERF_X_VIEWFOLD_GATHER    // proxy (results unchanged): what the folded table's taps would cost -- 64 values per texel, 32 per lane, 2 taps in flight
-        if (ftab) {
-            f32x16 g0, g1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
-#pragma unroll
-            for (int t0 = 0; t0 < 4; t0 += 2) {
-                f32x4 q2[2][8];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const f32x4* p = reinterpret_cast<const f32x4*>(at_byte(ftab, fo[t0 + t] * 2u));
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) q2[t][i] = p[i];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) fma32(q2[t], fwt[t0 + t], g0, g1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("" ::"v"(g0), "v"(g1));
-        }
-#endif
     } else {
         {   // RGB from the full-resolution image
             const Axis ax = axis_taps(nx, iw), ay = axis_taps(ny, ih);
@@ -1312,7 +1238,7 @@ struct OutK {
     float *rgb, *depth, *acc, *disp, *weights, *z_vals, *rgb_in, *raw;
     uint8_t* ray_mask;
     int32_t* samples_done;
-    unsigned* step_stats;     // optional [4]: wave-steps walked, sigma-layer exits, colour-branch exits (reference-order form)
+    unsigned* step_stats;     // optional [8]: wave-steps walked and which of them took which bit-exact exit (include/gpnerf_hip.h)
     const int32_t* order;     // optional: slot i of the launch renders ray order[i] (locality-friendly tiling)
 };
 
@@ -1443,7 +1369,10 @@ DEV unsigned wave_add(unsigned* p, unsigned d, int lane) {
 #define GPNERF_MAX_WAVES 8
 #endif
 constexpr int DEFER_QUEUE = 64;                 // entries of a wavefront's queue of samples waiting for their colour pass (render_tile)
-constexpr int TALLY_WORDS = 4;                  // per wavefront, behind the queues: the tile's step_stats (diagnostic launches)
+constexpr int TALLY_WORDS = 8;                  // per wavefront, behind the queues: the tile's step_stats (diagnostic launches)
+// a tile's tally in LDS: steps, steps without the sigma feature layer, evaluations of the colour branch (in the step, or a deferred
+// pass), steps settled behind the sample loop (exactly opaque rays), volume levels of the sigma feature layer left out
+enum { T_STEPS = 0, T_EMPTY = 1, T_PASS = 2, T_OPAQUE = 3, T_LEVELS = 4 };
 constexpr size_t DEFER_LDS_BYTES = (size_t)GPNERF_MAX_WAVES * (DEFER_QUEUE * 8 + TALLY_WORDS * 4);      // behind the head image
 constexpr int LIST_CHUNK_SHIFT = 11, LIST_CHUNK = 1 << LIST_CHUNK_SHIFT;      // entries per survivor counter / per compaction workgroup
 // number of launch slots a chained launch renders: the previous segment's survivors, or every ray (segment 0)
@@ -1542,9 +1471,6 @@ DEV float gather_views(const __attribute__((address_space(4))) FrameK& fr, float
         const ViewSample s = gather_view<FORM == FORM_F32_FOLD || FORM == FORM_F32>(fr.proj[v], fr.imgs + (size_t)v * fr.img_h * fr.img_w * 4, fr.img_h, fr.img_w,
                                          fr.featmaps + (size_t)v * fr.feat_h * fr.feat_w * 32, fr.feat_h, fr.feat_w,
                                          px, py, pz, neg, half, x[v]
-#ifdef GPNERF_X_VIEWFOLD_GATHER
-                                         , fr.vol_fold[0] ? fr.vol_fold[0] + (size_t)v * fr.feat_h * fr.feat_w * 64 : nullptr
-#endif
                                          );
         if constexpr (FORM == FORM_F32) {
             float fk[16];
@@ -1666,9 +1592,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     constexpr int QUEUE_AT = SPLIT ? gph::BLOB_WORDS + (FORM == FORM_SPLIT_GUARD ? 2 * GUARD_LDS_SLOTS : 0) : gpl::BLOB_FLOATS;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if constexpr (CAN_DEFER) dq = reinterpret_cast<uint2*>(lds + QUEUE_AT) + wave_in_wg * DEFER_QUEUE;
-    // step_stats (the diagnostic launch only): the tile counts in LDS -- [0] steps, [1] empty-space exits, [2] steps whose colour
-    // branch did not run in the step, [3] colour passes -- and adds them to the launch's counters once, at its end (one global
-    // atomic per step and counter made the counting launch 40 % slower than the launches it describes)
+    // step_stats (the diagnostic launch only): the tile counts in LDS (T_*) and adds them to the launch's counters once, at its
+    // end (one global atomic per step and counter made the counting launch 40 % slower than the launches it describes)
     unsigned* const tl = reinterpret_cast<unsigned*>(lds) + QUEUE_AT + GPNERF_MAX_WAVES * DEFER_QUEUE * 2 + wave_in_wg * TALLY_WORDS;
     const bool tally = k0->out.step_stats != nullptr;
     if (tally && lane < TALLY_WORDS) tl[lane] = 0u;
@@ -1691,16 +1616,6 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 STAMP(st, 14);
                 if constexpr (SPLIT) {
                     Frag mvf[6];
-#ifdef GPNERF_X_SPLIT_DEFER       // (see SPLIT_DEFERS below: without this copy the unguarded instantiation's colour passes come out wrong)
-#ifndef GPNERF_X_SD_LO
-#define GPNERF_X_SD_LO 0
-#define GPNERF_X_SD_HI 18
-#endif
-#pragma unroll
-                    for (int v = 0; v < NV; ++v)
-#pragma unroll
-                        for (int c = GPNERF_X_SD_LO; c < GPNERF_X_SD_HI; ++c) asm volatile("" : "+v"(xq[v][c]));
-#endif
                     mean_var_s(gmax, xq, mvf);
                     mlp_colour_s(gmax, lw, lane, xq, mvf, cq, st);
                 } else {
@@ -1708,7 +1623,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                     if constexpr (FORM == FORM_F32) { mean_var_ref(xq, mvq); mlp_colour_ref(lds, lane, xq, mvq, cq, st); }
                     else { mean_var(xq, mvq); mlp_colour(lds, lane, xq, mvq, cq, st); }
                 }
-                if (tally && lane == 0) tl[3] += 1u;
+                if (tally && lane == 0) tl[T_PASS] += 1u;
                 unsigned todo = (unsigned)mine & (nb >= 32 ? ~0u : ((1u << nb) - 1u));
                 while (__any(todo != 0u)) {             // a ray's entries of this pass, oldest first
                     const int j = todo ? __builtin_ctz(todo) : 0;
@@ -1777,9 +1692,6 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         float x[NV][18];                        // Projector.compute (:326-363)
         float vrgb[NV][3];
         float nvalid;
-#ifdef GPNERF_X_DUMP
-        float dbg[4] = {0.f, 0.f, 0.f, 0.f};
-#endif
         if constexpr (FORM == FORM_F32_FOLD) {
             // the sigma feature layer's pre-activation: levels FOLD_FROM.. interpolated from the folded volumes (see gather_folded),
             // the finer levels' features through the layer's first 16 FOLD_FROM k-steps as before
@@ -1839,7 +1751,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (tally && lane == 0 && levels_skipped == GPNERF_LEVELS) tl[1] += 1u;
+            if (tally && lane == 0) { tl[T_LEVELS] += (unsigned)levels_skipped; if (levels_skipped == GPNERF_LEVELS) tl[T_EMPTY] += 1u; }
             STAMP(st, (k == k_begin ? 10 : (k == k_begin + P ? 11 : 0)));
             {
                 int hb = half;
@@ -1880,15 +1792,12 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 #pragma unroll
                 for (int i = 0; i < 64; i += 2) bits |= __builtin_bit_cast(unsigned, fv[i]) | __builtin_bit_cast(unsigned, fv[i + 1]);
                 if ((kp->skip & 1) && __all((bits << 1) == 0u)) {          // (-0.0 counts as zero: fma(w, -0, +0) = +0 too)
-                    if (tally && lane == 0) tl[1] += 1u;
+                    if (tally && lane == 0) { tl[T_EMPTY] += 1u; tl[T_LEVELS] += (unsigned)GPNERF_LEVELS; }
                     geo_bias_ref(lds, lane, sf);
                 } else {
                     float fk[64];
 #pragma unroll
                     for (int l = 0; l < GPNERF_LEVELS; ++l) interleave16(fv + 16 * l, fk + 16 * l);
-#ifdef GPNERF_X_DUMP
-                    dbg[0] = fk[0]; dbg[1] = fk[1]; dbg[2] = fk[8]; dbg[3] = fk[16];
-#endif
                     geo_eval_ref(lds, lane, fk, sf);
                 }
             }
@@ -1917,21 +1826,20 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 else { mean_var(x, mv); mlp_density(lds, lane, sf, mv, nvalid, sigma); }
             }
             rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;               // (the colour map's terms arrive with the colour passes)
-            if (tally && lane == 0) tl[2] += 1u;                    // (diagnostic launch: steps minus colour passes)
         }
-        else if constexpr (SPLIT) mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st);
+        else if constexpr (SPLIT) { mlp_eval_s(gmax, lw, lane, sff, x, nvalid, sigma, rgb, st); if (tally && lane == 0) tl[T_PASS] += 1u; }
         else if constexpr (FORM == FORM_F32) {
             {
                 const bool may_skip = (kp->skip & 2) && !out.raw;
                 mlp_eval_ref(lds, lane, sf, x, nvalid, sigma, rgb, st, may_skip);
                 if (tally) {                                            // (the diagnostic launch only)
                     const bool all_zero = may_skip && __all(sigma == 0.f);
-                    if (all_zero && lane == 0) tl[2] += 1u;
+                    if (!all_zero && lane == 0) tl[T_PASS] += 1u;
                 }
             }
         }
-        else mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st);
-        if (tally && lane == 0) tl[0] += 1u;
+        else { mlp_eval(lds, lane, sf, x, nvalid, sigma, rgb, st); if (tally && lane == 0) tl[T_PASS] += 1u; }
+        if (tally && lane == 0) tl[T_STEPS] += 1u;
         if (CULL || cull) {
             if (!keep) sigma = 0.f;                     // hold_alpha stays 0 for culled samples (demo_render.py:337-341)
             if (!(1.f - fast_exp(-sigma) > 1e-14f)) { rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f; }   // valid1 (:317)
@@ -1939,9 +1847,6 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 
         if (out.raw && active && half == 0 && in_seg) {
             f32x4 rw; rw[0] = rgb[0]; rw[1] = rgb[1]; rw[2] = rgb[2]; rw[3] = sigma;
-#ifdef GPNERF_X_DUMP          // diagnostic build only: intermediate registers of half 0 instead of (rgb, sigma)
-            if constexpr (FORM == FORM_F32) { rw[0] = dbg[0]; rw[1] = dbg[1]; rw[2] = dbg[2]; rw[3] = dbg[3]; }
-#endif
             *reinterpret_cast<f32x4*>(out.raw + ((size_t)ray * S + ks) * 4) = rw;
         }
 
@@ -1980,11 +1885,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 rin[3 * v + 2] = fmaf(wgt, irgb[v][2], rin[3 * v + 2]);
             }
             if (writer) {
-#ifdef GPNERF_X_WT            // experiment: sample-major store (a wave's 32 lanes write one full line); timing only, the layout is wrong
-                if (out.weights) out.weights[(size_t)k * (size_t)kp->n_rays + (size_t)slot] = wgt;
-#else
                 if (out.weights) out.weights[(size_t)ray * S + k] = wgt;
-#endif
             }
             if constexpr (CAN_DEFER) {
                 if (defer) {
@@ -2052,7 +1953,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 if (nv > 1.f) ++n_two;
                 ++n_done;
                 if (writer && ko->out.weights) ko->out.weights[(size_t)ray * S + kk] = 0.f;
-                if (tally && lane == 0) { tl[0] += 1u; tl[1] += 1u; tl[2] += 1u; }
+                if (tally && lane == 0) { tl[T_STEPS] += 1u; tl[T_EMPTY] += 1u; tl[T_OPAQUE] += 1u; }
             }
             k = k_end;
         }
@@ -2060,8 +1961,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     st.flush(lane);
     kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
-    if (tally && lane < 3) {
-        const unsigned v = lane == 2 ? tl[2] - tl[3] : tl[lane];
+    if (tally && lane < 6) {        // step_stats[0..5] = steps, empty-space steps, steps MINUS colour passes, opaque-tail steps, levels left out, colour passes
+        const unsigned v = lane == 2 ? tl[T_STEPS] - tl[T_PASS] : (lane == 3 ? tl[T_OPAQUE] : (lane == 4 ? tl[T_LEVELS] : (lane == 5 ? tl[T_PASS] : tl[lane])));
         if (v) atomicAdd(kp->out.step_stats + lane, v);
     }
 
@@ -2920,19 +2821,8 @@ constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue c
 // Early termination walks the samples in segments of chain_len(), one launch per segment over the rays still alive (see
 // gpnerf_render_fused); the workspace then holds a control block (per segment: 8 queue counters + the length of its output
 // list), two ray lists (written and read alternately) and 16 floats of parked state per ray.
-// Experiment knobs (tools/*.sh A/B runs): read ONLY when GPNERF_DEBUG=1 is set, and clamped to [lo, hi] -- a stray GPNERF_*
-// variable in a production environment changes nothing.
-const char* dbg_env(const char* name) {
-    static int on = -1;
-    if (on < 0) { const char* d = getenv("GPNERF_DEBUG"); on = (d && d[0] == '1') ? 1 : 0; }
-    return on ? getenv(name) : nullptr;
-}
-int dbg_int(const char* name, int dflt, int lo, int hi) {
-    const char* e = dbg_env(name);
-    if (!e) return dflt;
-    const int v = atoi(e);
-    return v < lo ? lo : (v > hi ? hi : v);
-}
+// Experiment knobs (dbg_int / dbg_env, tools/*.sh A/B runs): hook points of gpnerf_diag.h.  The product's version returns the
+// default, always -- it has no getenv; the diagnostic libraries of csrc/diag/ read the environment under GPNERF_DEBUG=1, clamped.
 // One launch of the fused kernel: which arithmetic (`sel`), whether the colour branch is deferred sample by sample (render_tile), and
 // the sample loop (chained segments / culled) as template arguments.  Dynamic LDS = the form's head image (+ the split form's guard
 // slots) + the wavefronts' colour queues.
@@ -2951,11 +2841,7 @@ enum { SEL_REF = 0, SEL_FOLD = 1, SEL_SPLIT = 2, SEL_GUARD = 3 };
 // branch, `volatile` on lo_pair's two asm statements, lo_pair written without asm; NOT cured by waits + 32 idle cycles around the
 // pass, by dropping __restrict__, or by storing the branch's result (which changes the wrong values).  Not a write-after-read
 // hazard on the f16 MFMA's four-register A / B operands (tools/micro/mfma_f16_src_war.hip: they are latched at issue).
-#ifdef GPNERF_X_SPLIT_DEFER
-constexpr bool SPLIT_DEFERS = true;
-#else
 constexpr bool SPLIT_DEFERS = false;
-#endif
 template <int FORM> constexpr bool form_defers() { return SPLIT_DEFERS || (FORM != FORM_SPLIT && FORM != FORM_SPLIT_GUARD); }
 template <int FORM, bool CHAIN, bool CULL>
 void launch_form(bool deferred, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const KArgs& ka) {
@@ -3351,22 +3237,7 @@ int64_t gpnerf_head_blob_floats(void) { return gpl::BLOB_FLOATS; }
 int32_t gpnerf_rays_per_tile(void) { return RAYS_PER_WAVE; }
 const char* gpnerf_build_info(void) { return "gpnerf-hip gfx950 fp32-mfma32x32x2 waves<=8"; }
 
-#ifdef GPNERF_WAVETIMES
-// diagnostic library only: the per-wavefront time stamps of the last launch
-int gpnerf_debug_read_wavetimes(unsigned long long* out, int n_waves) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wt), sizeof(unsigned long long) * 4 * (size_t)n_waves) != hipSuccess) return GPNERF_E_DEVICE;
-    return GPNERF_OK;
-}
-#endif
-#ifdef GPNERF_STAMPS
-// diagnostic library only: read and clear the per-phase cycle sums
-int gpnerf_debug_read_stamps(unsigned long long* out16) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return GPNERF_E_DEVICE;
-    unsigned long long zero[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero)) != hipSuccess) return GPNERF_E_DEVICE;
-    return GPNERF_OK;
-}
-#endif
+GPNERF_DIAG_EXPORTS        /* nothing in the product (csrc/nodiag/gpnerf_diag.h) */
 
 int gpnerf_head_layout(int32_t* table) {
     if (!table) return GPNERF_E_ARG;

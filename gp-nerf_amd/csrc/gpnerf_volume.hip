@@ -17,6 +17,8 @@
 
 namespace {
 
+#include "gpnerf_diag.h"       // the lab's hook points, empty in the product (csrc/nodiag/)
+
 constexpr int KV = 27;
 
 struct Dims { int d, h, w; };
@@ -951,11 +953,7 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* wq, co
     // the reference's shape: the matrix-core form (GPNERF_ATT_SHUFFLE=1 under GPNERF_DEBUG=1 keeps the shuffle form for comparison)
     if (d_model == 32 && kv_dim == 32 && d_k >= 4) {
         static int f_shuffle = -1;
-        if (f_shuffle < 0) {
-            const char* d = getenv("GPNERF_DEBUG");
-            const char* e = (d && d[0] == '1') ? getenv("GPNERF_ATT_SHUFFLE") : nullptr;
-            f_shuffle = (e && e[0] == '1') ? 1 : 0;
-        }
+        if (f_shuffle < 0) f_shuffle = dbg_int("GPNERF_ATT_SHUFFLE", 0, 0, 1);       // experiment knob (gpnerf_diag.h: 0 in the product)
         if (!f_shuffle) {
             const dim3 grid((unsigned)((n + 31) / 32)), block(64);
             hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -967,11 +965,7 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* wq, co
         }
     }
     int blocks = n < 2048 ? (n + 3) / 4 : 512;
-    {
-        const char* d = getenv("GPNERF_DEBUG");
-        const char* e = (d && d[0] == '1') ? getenv("GPNERF_ATT_BLOCKS") : nullptr;
-        if (e) blocks = atoi(e) < 1 ? 1 : (atoi(e) > 4096 ? 4096 : atoi(e));
-    }
+    blocks = dbg_int("GPNERF_ATT_BLOCKS", blocks, 1, 4096);                         // experiment knob (gpnerf_diag.h)
     if (d_model <= 32 && kv_dim <= 32)
         hipLaunchKernelGGL(vertex_attention_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q,
                            kv, wq, wk, wv, wfc, (int)n, (int)d_model, (int)kv_dim, (int)n_head, (int)views, out);

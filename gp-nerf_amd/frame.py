@@ -322,7 +322,8 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     change an output, bit for bit: the sigma feature layer of levels whose features are zero in all 32 samples of a step, and the
     colour branch of samples whose weight alpha * T is zero (the rest wait in a per-wavefront queue and are evaluated 32 at a time),
     and everything behind the sample at which all 32 rays of a tile have a transmittance of exactly 0;
-    want=("step_stats",) returns [steps, empty-space exits, steps minus colour passes, 0].  A launch that returns `raw` keeps the
+    want=("step_stats",) returns the 8 counters of GpnerfOutputs.step_stats (steps, empty-space steps, steps minus colour
+    evaluations, opaque-tail steps, volume levels left out, colour evaluations, 0, 0).  A launch that returns `raw` keeps the
     colour branch in the step.
     reserve_cus: plan the launch for that many fewer compute units (multiple of 8), leaving them to kernels of other streams
     (GPNERF_FLAG_RESERVE_CUS).  The maps are those of a chip with that many fewer CUs."""
@@ -358,8 +359,8 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     if "raw" in want:
         res["raw"] = torch.empty((N, S, 4), device=dev)
         o.raw = res["raw"].data_ptr()
-    if "step_stats" in want:                               # [steps walked, sigma-layer exits, steps minus colour passes, 0]
-        res["step_stats"] = torch.zeros((4,), device=dev, dtype=torch.int32)
+    if "step_stats" in want:                               # include/gpnerf_hip.h GpnerfOutputs.step_stats: 8 counters
+        res["step_stats"] = torch.zeros((8,), device=dev, dtype=torch.int32)
         o.step_stats = res["step_stats"].data_ptr()
     if "samples_done" in want:
         res["samples_done"] = torch.empty((N,), device=dev, dtype=torch.int32)

@@ -146,14 +146,23 @@ typedef struct GpnerfOutputs {
     float* raw;        /* [N,S,4] NeRFHead.forward output (rgb, sigma), un-flipped sample order */
     int32_t* samples_done; /* [N]  diagnostic: samples the ray's wavefront evaluated (S unless early termination / culling
                               skipped some); with it the launch never splits a tile's samples over several wavefronts */
-    uint32_t* step_stats;  /* [4] or NULL, zeroed by the caller; the launch ADDS: [0] 32-sample steps its wavefronts walked, [1] steps
-                              that took the empty-space exit of the sigma feature layer (reference-order form: all 128 volume
-                              features of all 32 samples exactly zero: ELU(bias) without the layer's MFMAs) or were settled behind
-                              the sample loop because every ray's transmittance was exactly 0, [2] steps MINUS colour
-                              passes: a sample whose weight alpha * T is exactly 0 adds fma(0, rgb, c) = c to the colour map, so its
-                              colour branch is not run; the fp32 forms queue the samples that need it per wavefront and run the
-                              branch on 32 of them at a time (never with `raw`, never under GPNERF_FLAG_NO_EXITS).  All of it is
-                              bit-exact; bench.py reports its roofline both ways (algorithmic, and on the work done) */
+    uint32_t* step_stats;  /* [8] or NULL, zeroed by the caller; the launch ADDS, per wavefront step of 32 samples:
+                              [0] steps the launch answers for (sample-loop steps + [3]);
+                              [1] steps without the sigma feature layer: all four volume levels exactly zero in all 32 samples
+                                  (reference-order form: ELU(bias) without the layer's MFMAs), or counted in [3];
+                              [2] [0] MINUS [5];
+                              [3] steps settled BEHIND the sample loop, without a gather or an MFMA, because every ray's
+                                  transmittance was exactly 0 (zero weights and the ray_mask count are all they still owe);
+                              [4] volume LEVELS left out of the sigma feature layer (each a quarter of the layer; 0..4 per
+                                  sample-loop step: a level whose 16 features are zero in all 32 samples adds fma(w, 0, s) = s);
+                              [5] evaluations of the colour branch on 32 samples: one per step where it runs in the step, one
+                                  per colour pass where it is deferred -- a sample whose weight alpha * T is exactly 0 adds
+                                  fma(0, rgb, c) = c to the colour map, so the fp32 forms queue only the samples that need it,
+                                  per wavefront, and run the branch on 32 of them at a time (never with `raw`, never under
+                                  GPNERF_FLAG_NO_EXITS);
+                              [6], [7] reserved (0).
+                              All of it is bit-exact; bench.py prices its roofline on the work done:
+                              sample-loop steps x (everything but the colour branch) - [4] x layer / 4 + [5] x colour branch */
 } GpnerfOutputs;
 
 /* Number of floats of the packed head image. */

@@ -29,6 +29,32 @@ def test_every_declared_symbol_is_exported_and_bound(pkg):
     assert sorted(pkg._lib.SYMBOLS) == names
 
 
+def test_nothing_is_exported_that_the_header_lacks():
+    """The converse: the product library's dynamic symbol table holds NO gpnerf_* entry beyond include/gpnerf_hip.h -- no
+    gpnerf_debug_* reader of a diagnostic build, no experiment entry point.  The lab's libraries are other files,
+    built by gp-nerf_amd/csrc/diag/Makefile."""
+    import shutil
+    nm = shutil.which("nm") or shutil.which("llvm-nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.check_output([nm, "-D", "--defined-only", os.path.join(ROOT, "gp-nerf_amd", "csrc", "libgpnerf_hip.so")], text=True)
+    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("gpnerf_")})
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+
+
+def test_the_product_sources_carry_no_lab_paths():
+    """No experiment switch in the product's translation units: no GPNERF_X_* path, no stamps / wavetimes code, no getenv -- the
+    kernels' few hook points resolve to the EMPTY definitions of csrc/nodiag/gpnerf_diag.h, and the product Makefile refuses any
+    -DGPNERF_* switch (__graft_entry__.build() checks both before it compiles)."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    assert g.lab_paths_in_product() == []
+    csrc = os.path.join(ROOT, "gp-nerf_amd", "csrc")
+    hooks = open(os.path.join(csrc, "nodiag", "gpnerf_diag.h")).read()
+    code = re.sub(r"//[^\n]*", "", hooks)
+    assert "getenv" not in code and "atomicAdd" not in code and "s_memtime" not in code
+    r = subprocess.run(["make", "-n", "-C", csrc, "HIPFLAGS=-O3 -DGPNERF_X_ANYTHING"], capture_output=True, text=True)
+    assert r.returncode != 0 and "takes no -DGPNERF_" in (r.stderr + r.stdout)
+
+
 def test_struct_layouts_match_the_header(pkg):
     """Compile the header with gcc and compare sizeof/offsetof with the ctypes mirrors."""
     src = r'''

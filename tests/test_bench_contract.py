@@ -31,6 +31,15 @@ def test_bench_line_has_the_contracts_fields():
     assert abs(j["value"] - j["config"]["rays_total"] / (j["ms_per_step"] * 1e-3)) < 1e-3 * j["value"]
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    # a roofline FRACTION: the work the matrix pipe did over its peak; the rate of answers, which the bit-exact exits
+    # can push beyond the peak, sits beside it, and so does the data-independent launch that evaluates every layer
+    assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["dense_frac"] <= 1.0 and r["dense_ms"] > 0 and r["dense_same_bits"] is True
+    assert r["algorithmic_rate"]["tflops"] >= r["achieved"] > 0 and r["flop_per_launch"] <= r["algorithmic_rate"]["flop_per_launch"]
+    ex = r["exits"]
+    assert 0.0 <= ex["flop_not_done_frac"] < 1.0 and 0.0 <= ex["colour_branch_not_run_frac"] <= 1.0 and 0.0 <= ex["opaque_tail_frac"] <= 1.0
+    t = j["trained_like"]
+    assert "error" not in t, t
+    assert 0.0 < t["frac"] <= 1.0 and 0.0 < t["dense_frac"] <= 1.0 and t["dense_same_bits"] is True and t["kernel_ms"] <= t["dense_ms"] * 1.05
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port", "port-blocked") and c["scalar_oracle"]["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "rays/s" and c["sample"]
     assert "beside_headline" in j and "split_f16_api_outputs_patch_order" in j["beside_headline"]

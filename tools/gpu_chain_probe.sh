@@ -1,5 +1,5 @@
 #!/bin/bash
-export GPNERF_DEBUG=1   # the experiment knobs / GPNERF_LIB_PATH below are honoured only under this switch
+source tools/diag_env.sh   # the lab library: launcher experiment knobs exist only there (csrc/diag/)
 # early-termination frame (512x512x128): item length (GPNERF_CHAIN_SEG) x queue chunk (GPNERF_QUEUE_CHUNK)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3))"; }

@@ -1,5 +1,5 @@
 # kernel trace of the culled frame (bench --occ-cull --occupancy $OCC, light outputs) under two builds of the library:
-export GPNERF_DEBUG=1   # the experiment knobs / GPNERF_LIB_PATH below are honoured only under this switch
+source tools/diag_env.sh   # the lab library: launcher experiment knobs exist only there (csrc/diag/)
 # per-kernel mean durations of the last frames (mask pre-pass, tile order, fused kernel)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OCC=${OCC:-1.0}

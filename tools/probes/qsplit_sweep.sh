@@ -1,3 +1,4 @@
+source tools/diag_env.sh   # the lab library: launcher experiment knobs exist only there (csrc/diag/)
 # frames of one to two rounds of wavefronts: persistent workgroups on a queue of (tile, sample segment) units (GPNERF_QSPLIT, experiment)
 # against the default plan (whole tiles + eight-samples-per-step remainder units); GPNERF_QSPLIT_SEGMAJOR=1: all tiles' first segment first
 for args in "--fill survey" "--size 256" "--size 272" "--size 320" "--size 360" "--fill survey --fold"; do

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase cycle shares of the fused kernel (build: make -C gp-nerf_amd/csrc libgpnerf_hip_stamps.so).
+"""Diagnostic: per-phase cycle shares of the fused kernel (build: make -C gp-nerf_amd/csrc/diag libgpnerf_hip_stamps.so).
 Loads the stamped library IN PLACE of the product library for this process only.  Shares, not run times."""
 import ctypes as C
 import importlib
@@ -12,7 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 L = importlib.import_module("gp-nerf_amd._lib")
-L.LIB_PATH = os.path.join(ROOT, "gp-nerf_amd", "csrc", os.environ.get("GPNERF_DIAG_LIB", "libgpnerf_hip_stamps.so"))
+L.LIB_PATH = os.path.join(ROOT, "gp-nerf_amd", "csrc", "diag", os.environ.get("GPNERF_DIAG_LIB", "libgpnerf_hip_stamps.so"))
 fm = importlib.import_module("gp-nerf_amd.frame")
 syn = importlib.import_module("gp-nerf_amd.synthetic")
 

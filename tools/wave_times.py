@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: where a launch's fixed cost goes.  Per wavefront of ONE fused-kernel launch: when it entered the kernel, had its
-weights in LDS, ended its first sample step and left (build: make -C gp-nerf_amd/csrc libgpnerf_hip_wavetimes.so; loaded IN PLACE
+weights in LDS, ended its first sample step and left (build: make -C gp-nerf_amd/csrc/diag libgpnerf_hip_wavetimes.so; loaded IN PLACE
 of the product library for this process only).  usage: wave_times.py [size] [samples]"""
 import ctypes as C
 import importlib
@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 L = importlib.import_module("gp-nerf_amd._lib")
-L.LIB_PATH = os.path.join(ROOT, "gp-nerf_amd", "csrc", "libgpnerf_hip_wavetimes.so")
+L.LIB_PATH = os.path.join(ROOT, "gp-nerf_amd", "csrc", "diag", "libgpnerf_hip_wavetimes.so")
 fm = importlib.import_module("gp-nerf_amd.frame")
 syn = importlib.import_module("gp-nerf_amd.synthetic")
 
