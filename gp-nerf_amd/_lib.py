@@ -119,26 +119,22 @@ SYMBOLS = {
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_make_rays_demo": (C.c_int, [C.c_int32, C.c_int32, FP, FP, FP, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_conv_packed_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
-    "gpnerf_conv_pack_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gpnerf_conv_pack_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_conv_out_tiles": (C.c_int32, [C.c_int32] * 5),
     "gpnerf_conv2d_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gpnerf_conv2d_nhwc_exact": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_void_p]),
-    "gpnerf_conv_exact_packed_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
-    "gpnerf_conv_pack_weight_exact": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "gpnerf_conv2d_nhwc_exact_packed": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
-                                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_conv2d_norm_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gpnerf_conv2d_norm_cat_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
-                                              C.c_void_p]),
+                                              C.c_int32, C.c_void_p]),
     "gpnerf_norm_apply_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                          C.c_void_p]),
     "gpnerf_instance_norm_nhwc_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int64, C.c_int32]),
-    "gpnerf_instance_norm_act_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+    "gpnerf_instance_norm_act_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                                 C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpnerf_upsample2x_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gpnerf_vertex_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p]),

@@ -71,6 +71,25 @@ DEV Frag make_frag(f32x4 a, f32x4 b) {
     return f;
 }
 
+// The EXACT form of every convolution kernel below (template argument EXACT; `ResUNet.precision = "fp32"`, the default): the same
+// implicit GEMM, tiles, staging, fused InstanceNorm tables and launch chain, with the operands as they are -- fp32 on
+// v_mfma_f32_32x32x2_f32, every dot product an fp32 FMA chain over (channel block, tap, channel) like the reference's own,
+// no operand range, no flag.  A lane's eight values of a 16-deep k-step (channels 8 half + j, j = 0..7) are two float4 --
+// byte for byte where the split form keeps its eight hi and eight lo halfs, so the weight image, the LDS patch and the register
+// budget have the same shape -- and a k-step is eight MFMAs pairing channel j of half 0 with channel 8 + j of half 1
+// (fma(a1, b1, fma(a0, b0, c))): 8 x 64 cycles where the split form's three f16 MFMAs take 3 x 32.
+struct FragX { f32x4 q0, q1; };
+DEV void mfma_exact(f32x16& acc, const f32x4& w0, const f32x4& w1, const FragX& x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[0], x.q0[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[1], x.q0[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[2], x.q0[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[3], x.q0[3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[0], x.q1[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[1], x.q1[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2], x.q1[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[3], x.q1[3], acc, 0, 0, 0);
+}
+
 // feature index held by accumulator register r of lane-half h (32x32 C/D layout), as in head_layout.h
 DEV int ft(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -82,8 +101,9 @@ DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)
 // lane l: row co = 32 ct + (l & 31), k = 8 (l >> 5) + j  <->  ci = 16 cb + k   (zero beyond Cin / Cout).
 // flat (inputs with fewer than 8 channels, the 3-channel stem): the K dimension is (tap, ci) flattened, k = tap * Cin + ci, cut
 // into chunks of 16 -- 10 chunks for the 7x7x3 stem instead of 49 mostly empty ones; packed[chunk * CT + ct][...].
+// exact: the fp32 image of the EXACT form -- the same steps, [64 lanes][4 floats: j = 0..3] | [64 lanes][4 floats: j = 4..7], unscaled.
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const int Cout, const int Cin, const int KS, const int CB,
-                                        const int CT, const int flat, uint16_t* __restrict__ packed) {
+                                        const int CT, const int flat, const int exact, uint16_t* __restrict__ packed) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one (step, lane, j)
     const long nstep = flat ? (long)CB * CT : (long)KS * KS * CB * CT;  // flat: CB = number of 16-deep chunks of K
     if (i >= nstep * 512) return;
@@ -100,7 +120,12 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const int C
         tap = k / Cin;
         ci = k % Cin;
     }
-    const float v = W_SCALE * ((co < Cout && in_k) ? w[((long)co * Cin + ci) * KS * KS + tap] : 0.f);
+    const float wv = (co < Cout && in_k) ? w[((long)co * Cin + ci) * KS * KS + tap] : 0.f;
+    if (exact) {
+        reinterpret_cast<float*>(packed)[step * (STEP_BYTES / 4) + (j >> 2) * 256 + lane * 4 + (j & 3)] = wv;
+        return;
+    }
+    const float v = W_SCALE * wv;
     const _Float16 hi = (_Float16)v;                          // round to nearest, as the activations' hi
     const unsigned hw = __builtin_bit_cast(uint16_t, hi);
     const _Float16 lo = (_Float16)(v - (float)hi);
@@ -113,14 +138,23 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const int C
 // 8 columns x 4 channels, 14 chunks of 16: chunk (ky, p), lane half h, j -> kx = 4 p + 2 h + (j >> 2), c = j & 3 -- so that a
 // lane's 8 values of a chunk are two NEIGHBOURING patch pixels x 4 channels, one aligned 16-byte LDS read.  [chunk][ct][hi | lo].
 constexpr int STEM_CHUNKS = 14;
-__global__ void pack_stem_weight_kernel(const float* __restrict__ w, const int Cout, const int Cin, const int CT, uint16_t* __restrict__ packed) {
+// exact: fp32, [64 lanes][4] | [64 lanes][4] as above, with the lane's eight values ordered (pixel 0: c0 c1, pixel 1: c0 c1 | pixel 0: c2
+// c3, pixel 1: c2 c3) -- the two planes the exact stem keeps its patch in (conv7x7_s2_stem_kernel).
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, const int Cout, const int Cin, const int CT, const int exact, uint16_t* __restrict__ packed) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one (step, lane, j)
     if (i >= (long)STEM_CHUNKS * CT * 512) return;
     const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const long step = i >> 9;
     const int ct = (int)(step % CT), ch = (int)(step / CT);
-    const int ky = ch >> 1, pq = ch & 1, kx = 4 * pq + 2 * (lane >> 5) + (j >> 2), c = j & 3;
+    const int ky = ch >> 1, pq = ch & 1;
     const int co = 32 * ct + (lane & 31);
+    if (exact) {        // value j of the lane: plane (j >> 2) holds channels 2 (j >> 2), 2 (j >> 2) + 1; pixel (j >> 1) & 1; channel within the pair j & 1
+        const int kxe = 4 * pq + 2 * (lane >> 5) + ((j >> 1) & 1), ce = 2 * (j >> 2) + (j & 1);
+        reinterpret_cast<float*>(packed)[step * (STEP_BYTES / 4) + (j >> 2) * 256 + lane * 4 + (j & 3)] =
+            (co < Cout && kxe < 7 && ce < Cin) ? w[((long)co * Cin + ce) * 49 + ky * 7 + kxe] : 0.f;
+        return;
+    }
+    const int kx = 4 * pq + 2 * (lane >> 5) + (j >> 2), c = j & 3;
     const float v = W_SCALE * ((co < Cout && kx < 7 && c < Cin) ? w[((long)co * Cin + c) * 49 + ky * 7 + kx] : 0.f);
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
@@ -135,7 +169,7 @@ struct ConvArgs {
     const uint16_t* packed;
     const float* bias;        // [Cout] or nullptr
     float* y;                 // [N][Ho][Wo][Cout]
-    float* stats;             // [N][tiles][Cout][2] per-workgroup sum / sum of squares of the outputs (for the InstanceNorm behind), or nullptr
+    float* stats;             // [N][tiles][Cout][3] per-workgroup-tile sum, sum of squares, and M2 = sum of (y - tile mean)^2 of the outputs (for the InstanceNorm behind), or nullptr
     int H, W, Cin, Ho, Wo, Cout, CB, CT;
     // the InstanceNorm in FRONT of the convolution, applied while the input is staged (3x3 stride-1 kernel only):
     const float* in_tab;      // [N][3][Cin] mean / scale / beta, or nullptr
@@ -158,13 +192,35 @@ struct ConvArgs {
     // again in the exact fp32 form (gpnerf_conv2d_nhwc_exact).  A non-finite INPUT sets the flag too (the exact form then returns
     // what fp32 arithmetic makes of it).  The word is only ever written with 1; the caller zeroes it.
     unsigned* flag;
+    int tile_h, tile_w;       // the kernel's workgroup tile of output pixels (tile_h x tile_w; tile_h = 0: tile_w consecutive pixels): how many
+                              // pixels tile k's statistics cover (tile_pixels), set by the launcher
+    int exact;                // 1: the EXACT form (fp32 operands on the fp32 MFMA; `packed` is the fp32 image); launch dispatch only
 };
 
-// Last-arriving workgroup of (image n, channel group ct0 .. ct0 + COT): every workgroup has written its tile sums; the one whose
-// atomic ticket is the last adds the tiles of its COT * 32 channels in double, in tile order (so the result does not depend on
-// which workgroup that is), and writes mean / gamma * rstd / beta.  256 threads: 256 / (COT * 32) tile lanes per channel.
+// valid output pixels of workgroup tile k (what its statistics cover)
+DEV int tile_pixels(const ConvArgs& a, const int k) {
+    if (a.tile_h == 0) return min(a.tile_w, a.Ho * a.Wo - k * a.tile_w);
+    const int tiles_x = (a.Wo + a.tile_w - 1) / a.tile_w, ty = k / tiles_x, tx = k - ty * tiles_x;
+    return min(a.tile_h, a.Ho - ty * a.tile_h) * min(a.tile_w, a.Wo - tx * a.tile_w);
+}
+// (count, mean, M2) of two disjoint sets -> of their union (Chan et al.), in double
+struct Moments { double n, mean, m2; };
+DEV Moments merge(const Moments& x, const Moments& y) {
+    if (y.n == 0) return x;
+    if (x.n == 0) return y;
+    const double n = x.n + y.n, d = y.mean - x.mean;
+    return Moments{n, x.mean + d * (y.n / n), x.m2 + y.m2 + d * d * (x.n * y.n / n)};
+}
+
+// Last-arriving workgroup of (image n, channel group ct0 .. ct0 + COT): every workgroup has written its tile's (sum, sum of squares,
+// M2); the one whose atomic ticket is the last adds the tiles of its COT * 32 channels in double, in tile order (so the result does
+// not depend on which workgroup that is), and writes mean / gamma * rstd / beta.  256 threads: 256 / (COT * 32) tile lanes per channel.
+// The variance is E[y^2] - mean^2 from the float32 tile sums where that is well conditioned (var >= 1e-3 mean^2: at most three of
+// float32's seven digits cancel), and otherwise assembled from the tiles' sums of squares ABOUT THEIR MEANS (tile_stats) by Chan's
+// pairwise merge: on a channel that is nearly constant over the image (a one-hot source image behind a large InstanceNorm scale)
+// the difference cancels to a few roundings of E[y^2] -- measured 3e-4 of the output range on such a frame, 1e-6 with the merge.
 template <int COT>
-DEV void finalize_if_last(const ConvArgs& a, const int n, const int ct0, const int ntiles, double* red /* [2][256] doubles of LDS */) {
+DEV void finalize_if_last(const ConvArgs& a, const int n, const int ct0, const int ntiles, double* red /* [3][256] doubles of LDS */) {
     // No agent-scope fence here: a release fence would write back this XCD's whole L2 (the convolution's output has just
     // dirtied it; measured: the encoder 1.35 -> 1.9 ms).  The tile sums were stored with agent-scope atomic stores (sc1:
     // written through to the device's coherence point).  What orders them before the ticket is an EXPLICIT s_waitcnt vmcnt(0)
@@ -193,7 +249,7 @@ DEV void finalize_if_last(const ConvArgs& a, const int n, const int ct0, const i
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = k0 + j * LANES;
-                const float* o = a.stats + (((size_t)n * ntiles + (k < ntiles ? k : kl)) * a.Cout + co) * 2;
+                const float* o = a.stats + (((size_t)n * ntiles + (k < ntiles ? k : kl)) * a.Cout + co) * 3;
                 vs[j] = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 vq[j] = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -204,26 +260,56 @@ DEV void finalize_if_last(const ConvArgs& a, const int n, const int ct0, const i
     red[threadIdx.x] = ts;
     red[256 + threadIdx.x] = tq;
     __syncthreads();
+    __shared__ unsigned s_ill;
+    if (threadIdx.x == 0) s_ill = 0u;
+    const double hw = (double)a.Ho * (double)a.Wo;
+    double mean = 0, var = 0, sum_s = 0, sum_q = 0;
     if (kl == 0 && co < a.Cout) {
-        ts = 0; tq = 0;
 #pragma unroll
-        for (int k = 0; k < LANES; ++k) { ts += red[k * NCH + ch]; tq += red[256 + k * NCH + ch]; }
-        const double hw = (double)a.Ho * (double)a.Wo;
-        const double mean = ts / hw;
-        double var = tq / hw - mean * mean;
-        if (var < 0) var = 0;
+        for (int k = 0; k < LANES; ++k) { sum_s += red[k * NCH + ch]; sum_q += red[256 + k * NCH + ch]; }
+        mean = sum_s / hw;
+        var = sum_q / hw - mean * mean;                         // biased variance, as InstanceNorm2d normalises with
+    }
+    __syncthreads();
+    const bool ill = kl == 0 && co < a.Cout && !(var >= 1e-3 * mean * mean);
+    if (ill) s_ill = 1u;                                        // (every writer writes the same value)
+    __syncthreads();
+    if (s_ill) {
+        // some channel of the group is ill-conditioned (or not finite): the tiles' M2 merged as Chan et al., in tile order -- a second
+        // pass over the tile rows that ordinary frames never take
+        Moments mine{0, 0, 0};
+        if (co < a.Cout)
+            for (int k = kl; k < ntiles; k += LANES) {
+                const float* o = a.stats + (((size_t)n * ntiles + k) * a.Cout + co) * 3;
+                const double cnt = (double)tile_pixels(a, k);
+                const double sk = (double)__hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mine = merge(mine, Moments{cnt, cnt > 0 ? sk / cnt : 0.0, (double)__hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)});
+            }
+        red[threadIdx.x] = mine.n;
+        red[256 + threadIdx.x] = mine.mean;
+        red[512 + threadIdx.x] = mine.m2;
+        __syncthreads();
+        if (ill) {
+            Moments all{0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < LANES; ++k) all = merge(all, Moments{red[k * NCH + ch], red[256 + k * NCH + ch], red[512 + k * NCH + ch]});
+            var = all.m2 / hw;
+        }
+    }
+    if (kl == 0 && co < a.Cout) {
+        if (!(var > 0)) var = 0;
         const float g = a.gamma[co] / sqrtf((float)var + a.eps);
         a.out_tab[((size_t)n * 3 + 0) * a.Cout + co] = (float)mean;
         a.out_tab[((size_t)n * 3 + 1) * a.Cout + co] = g;
         a.out_tab[((size_t)n * 3 + 2) * a.Cout + co] = a.beta[co];
         // an operand beyond the f16 range (ConvArgs::flag): the channel's sums are non-finite
-        if (a.flag && !(fabs(ts) < __builtin_inf() && fabs(tq) < __builtin_inf())) __hip_atomic_store(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.flag && !(fabs(sum_s) < __builtin_inf() && fabs(sum_q) < __builtin_inf())) __hip_atomic_store(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (threadIdx.x == 0) __hip_atomic_store(&a.counters[(size_t)n * gridDim.z + blockIdx.z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
-// Per-channel sum and sum of squares of a workgroup's output tile, from the accumulators (the InstanceNorm that follows every
-// convolution but the last would otherwise re-read the whole tensor for them).  Accumulator register r of half h holds channel
+// Per-channel sum, sum of squares and M2 (sum of squares about the tile's mean) of a workgroup's output tile, from the accumulators (the InstanceNorm
+// that follows every convolution but the last would otherwise re-read the whole tensor for them).  Accumulator register r of half h holds channel
 // 32 c + ft(r, h) of the lane's pixel.  The wave's PT pixel tiles are added per lane; the 32 lanes of a half are summed with
 // DPP moves (rotations by 8, 4, 2, 1 inside each 16-lane row, then row_bcast15 carries row 0's total into row 1 and row 2's
 // into row 3: five VALU adds per register, no LDS traffic); lanes 16 and 48 then hold the two halves' totals, and the four
@@ -244,30 +330,51 @@ template <int COT, int NP = 2>
 DEV void tile_stats(const f32x16 (&acc)[NP][COT], const bool (&valid)[NP], float* red, const ConvArgs& a, const int n, const int tile,
                     const int ntiles, const int ct0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    // the wave's valid pixels (the same in both lane halves): its mean per channel, and the squares ABOUT that mean (see finalize_if_last)
+    const int nw = __popc((unsigned)__ballot(valid[0])) + (NP > 1 ? __popc((unsigned)__ballot(valid[NP - 1])) : 0);
+    const float inv = nw > 0 ? 1.f / (float)nw : 0.f;
 #pragma unroll
     for (int c = 0; c < COT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v0 = valid[0] ? acc[0][c][r] : 0.f, v1 = (NP > 1 && valid[NP - 1]) ? acc[NP - 1][c][r] : 0.f;
             const float s = half_sum(v0 + v1), q = half_sum(fmaf(v1, v1, v0 * v0));
+            const float s_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16));
+            const float s_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 48));
+            const float m = (half ? s_hi : s_lo) * inv;
+            const float d0 = valid[0] ? acc[0][c][r] - m : 0.f, d1 = (NP > 1 && valid[NP - 1]) ? acc[NP - 1][c][r] - m : 0.f;
+            const float m2 = half_sum(fmaf(d1, d1, d0 * d0));
             if ((lane & 31) == 16) {
                 const int ch = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * half;
-                red[(wave * COT * 32 + ch) * 2 + 0] = s;
-                red[(wave * COT * 32 + ch) * 2 + 1] = q;
+                red[(wave * COT * 32 + ch) * 3 + 0] = s;
+                red[(wave * COT * 32 + ch) * 3 + 1] = q;
+                red[(wave * COT * 32 + ch) * 3 + 2] = m2;
             }
         }
+    int* const cnt = reinterpret_cast<int*>(red + WAVES * COT * 32 * 3);
+    if (lane == 0) cnt[wave] = nw;
     __syncthreads();
     for (int ch = threadIdx.x; ch < COT * 32; ch += WAVES * 64) {
-        float s = 0.f, q = 0.f;
+        float s = 0.f, q = 0.f, ntot = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) { s += red[(w * COT * 32 + ch) * 2]; q += red[(w * COT * 32 + ch) * 2 + 1]; }
+        for (int w = 0; w < WAVES; ++w) { s += red[(w * COT * 32 + ch) * 3]; q += red[(w * COT * 32 + ch) * 3 + 1]; ntot += (float)cnt[w]; }
+        // M2 of the tile = sum over the waves of M2_w + n_w (mean_w - mean)^2   (float32: every term is a sum about a nearby mean)
+        const float mean = ntot > 0.f ? s / ntot : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const float cw = (float)cnt[w];
+            const float d = cw > 0.f ? red[(w * COT * 32 + ch) * 3] / cw - mean : 0.f;
+            m2 += red[(w * COT * 32 + ch) * 3 + 2] + cw * d * d;
+        }
         const int co = 32 * ct0 + ch;
         if (co < a.Cout) {
             // agent-scope stores: written through to the device's coherence point, so that the last workgroup (possibly on
             // another XCD, behind another L2) can read them without any cache being flushed -- see finalize_if_last
-            float* o = a.stats + (((size_t)n * ntiles + tile) * a.Cout + co) * 2;
+            float* o = a.stats + (((size_t)n * ntiles + tile) * a.Cout + co) * 3;
             __hip_atomic_store(o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 2, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -313,7 +420,7 @@ DEV void load_flat(const ConvArgs& a, const int n, const int oy, const int ox, c
     v1 = f32x4{v[4], v[5], v[6], v[7]};
 }
 
-template <int KS, int STRIDE, int COT, bool NARROW>
+template <int KS, int STRIDE, int COT, bool NARROW, bool EXACT = false>
 __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2;
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[2][COT * STEP_BYTES];
@@ -388,7 +495,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
     __syncthreads();
     for (int q = 0; q < nchunk; ++q) {
         const int buf = q & 1;
-        Frag b[PT];
+        typename std::conditional<EXACT, FragX, Frag>::type b[PT];
         if constexpr (!NARROW) {
             if (a.in_tab) {
 #pragma unroll
@@ -401,27 +508,38 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
             }
         }
 #pragma unroll
-        for (int t = 0; t < PT; ++t) b[t] = make_frag(xin[t][0], xin[t][1]);
+        for (int t = 0; t < PT; ++t) {
+            if constexpr (EXACT) { b[t].q0 = xin[t][0]; b[t].q1 = xin[t][1]; }
+            else b[t] = make_frag(xin[t][0], xin[t][1]);
+        }
         if (q + 1 < nchunk) fetch(q + 1);                 // next chunk's loads fly while this chunk's MFMAs run
 #pragma unroll
         for (int c = 0; c < COT; ++c) {
             const u32x4* wl = reinterpret_cast<const u32x4*>(wbuf[buf] + c * STEP_BYTES);
-            const h8 wh = __builtin_bit_cast(h8, wl[lane]), wlo = __builtin_bit_cast(h8, wl[64 + lane]);
+            if constexpr (EXACT) {
+                const f32x4 w0 = __builtin_bit_cast(f32x4, wl[lane]), w1 = __builtin_bit_cast(f32x4, wl[64 + lane]);
 #pragma unroll
-            for (int t = 0; t < PT; ++t) {
-                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b[t].hi, acc[t][c], 0, 0, 0);
-                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].lo, acc[t][c], 0, 0, 0);
-                acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].hi, acc[t][c], 0, 0, 0);
+                for (int t = 0; t < PT; ++t) mfma_exact(acc[t][c], w0, w1, b[t]);
+            } else {
+                const h8 wh = __builtin_bit_cast(h8, wl[lane]), wlo = __builtin_bit_cast(h8, wl[64 + lane]);
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b[t].hi, acc[t][c], 0, 0, 0);
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].lo, acc[t][c], 0, 0, 0);
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[t].hi, acc[t][c], 0, 0, 0);
+                }
             }
         }
         if (q + 1 < nchunk) park(buf ^ 1);
         __syncthreads();
     }
     // epilogue: accumulator register r of half h holds output channel 32 ct + ft(r, h): four runs of 4 consecutive channels
+    if constexpr (!EXACT) {
 #pragma unroll
-    for (int t = 0; t < PT; ++t)
+        for (int t = 0; t < PT; ++t)
 #pragma unroll
-        for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
+            for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
+    }
     if (a.bias) {
 #pragma unroll
         for (int c = 0; c < COT; ++c)
@@ -435,7 +553,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_nhwc_kernel(const ConvArgs 
     }
     if (a.stats) tile_stats<COT>(acc, valid, reinterpret_cast<float*>(wbuf[0]), a, n, (int)blockIdx.x, (int)gridDim.x, ct0);
     if (a.out_tab) {
-        __shared__ double fin_red[512];
+        __shared__ double fin_red[768];
         finalize_if_last<COT>(a, n, ct0, (int)gridDim.x, fin_red);
     } else if (a.flag) flag_nonfinite<COT, PT>(acc, a);
 #pragma unroll
@@ -478,7 +596,7 @@ __host__ __device__ constexpr int patch_bytes(int rw, int stride = 1) { return p
 // and the halves' accumulators meet in LDS at the end (lower + upper, a fixed order).  For the layers whose grid cannot fill the chip
 // (32 x 32 images: 192 workgroups): the serial chain of a wave halves, and every SIMD has a second wave to issue from while the
 // first waits.
-template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1, bool CAT = false>
+template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1, bool CAT = false, bool EXACT = false>
 __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(const ConvArgs a) {
     constexpr int TH = tile_rows(RW), PH = patch_rows(RW, STRIDE), PATCH_BYTES = patch_bytes(RW, STRIDE), PT = RW;     // (PT shadows the direct kernel's pixel-tile count)
     constexpr int PCOLS = STRIDE == 1 ? PW : 65;             // patch columns actually staged
@@ -494,7 +612,15 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
     const int ty0 = ((int)blockIdx.x / tiles_x) * TH, tx0 = ((int)blockIdx.x % tiles_x) * TW;
     const int n = blockIdx.y, ct0 = blockIdx.z * COT;
 
-    f32x16 acc[PT][COT];
+    // EXACT: BLOCKED summation.  One fp32 FMA chain over all K = 9 Cin terms (2 304 at 256 channels) drifts ~K / sqrt(2) roundings
+    // (of a term's size) from the exact sum; the reference's CPU convolutions block their sums, and what the head behind the encoder
+    // amplifies is the DISTANCE between the two roundings.  So every 16-channel block's 144 terms are summed from zero in a block
+    // accumulator and added to the running total once per block: by the same count ~K / sqrt(2 CB) + sqrt(K CB / 2) roundings, a
+    // quarter of the single chain's at 256 channels, for 16 registers per accumulator tile and 16 adds per 72 MFMAs.  Measured on
+    // the 3 x 512 x 512 reference vector and the config-5-sized end-to-end fixture (profiles/r06/e_encoder_summation_variants.txt):
+    // one chain 4.0e-6 mean from float64 and 1.7e-4 from the reference on depth behind the head; four chains by tap 2.9e-6 / 9.7e-5;
+    // this 2.6e-6 / 7.7e-5 -- the reference's own float32 sits 2.6e-6 from float64 -- and it is the fastest of them (fewest registers).
+    f32x16 acc[PT][COT], blk_acc[PT][COT];
 #pragma unroll
     for (int t = 0; t < PT; ++t)
 #pragma unroll
@@ -570,11 +696,15 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
                     v[k] = a.in_act == 1 ? fmaxf(t, 0.f) : t;
                 }
             }
-            v *= X_SCALE;
-            const unsigned h0 = pk_hi(v[0], v[1]), h1 = pk_hi(v[2], v[3]);
-            unsigned* d = reinterpret_cast<unsigned*>(pb + ppos(pp / PCOLS, pp % PCOLS) * PPX + qd * 8);
-            d[0] = h0; d[1] = h1;
-            d[8] = lo_pair(h0, v[0], v[1]); d[9] = lo_pair(h1, v[2], v[3]);           // lo block starts 32 bytes in
+            if constexpr (EXACT) {       // the pixel's 16 channels as they are: 64 bytes, quad qd at 16 qd
+                *reinterpret_cast<f32x4*>(pb + ppos(pp / PCOLS, pp % PCOLS) * PPX + qd * 16) = v;
+            } else {
+                v *= X_SCALE;
+                const unsigned h0 = pk_hi(v[0], v[1]), h1 = pk_hi(v[2], v[3]);
+                unsigned* d = reinterpret_cast<unsigned*>(pb + ppos(pp / PCOLS, pp % PCOLS) * PPX + qd * 8);
+                d[0] = h0; d[1] = h1;
+                d[8] = lo_pair(h0, v[0], v[1]); d[9] = lo_pair(h1, v[2], v[3]);           // lo block starts 32 bytes in
+            }
         }
     };
     // the 54 x COT MFMAs of the block staged in `buf`: B operands of tap 0, then per tap: read the next tap's B operands, run this
@@ -582,14 +712,20 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
     // other), fetch this tap's weights of block cb_next into the registers just used, and park one item of block cb_next
     auto compute = [&](int buf, int cb_next, auto SET) {
         const unsigned char* const pb = patch0 + buf * PATCH_BYTES;
-        Frag b[2][PT];
+        typename std::conditional<EXACT, FragX, Frag>::type b[2][PT];
         auto read_tap = [&](int tap, int slot) {
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
-                const unsigned char* q = pb + ppos(STRIDE * (RW * wave + t) + ky, STRIDE * px + kx) * PPX + half * 16;
-                b[slot][t].hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q));
-                b[slot][t].lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q + 32));
+                if constexpr (EXACT) {      // this half's eight channels: 32 contiguous bytes of the pixel's 64
+                    const unsigned char* q = pb + ppos(STRIDE * (RW * wave + t) + ky, STRIDE * px + kx) * PPX + half * 32;
+                    b[slot][t].q0 = *reinterpret_cast<const f32x4*>(q);
+                    b[slot][t].q1 = *reinterpret_cast<const f32x4*>(q + 16);
+                } else {
+                    const unsigned char* q = pb + ppos(STRIDE * (RW * wave + t) + ky, STRIDE * px + kx) * PPX + half * 16;
+                    b[slot][t].hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q));
+                    b[slot][t].lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(q + 32));
+                }
             }
         };
         read_tap(0, 0);
@@ -597,21 +733,42 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
         for (int tap = 0; tap < 9; ++tap) {
             const int cur = tap & 1;
             if (tap + 1 < 9) read_tap(tap + 1, cur ^ 1);
-            h8 wh[COT], wlo[COT];
+            if constexpr (EXACT) {
 #pragma unroll
-            for (int c = 0; c < COT; ++c) { wh[c] = __builtin_bit_cast(h8, wreg[tap][c][0]); wlo[c] = __builtin_bit_cast(h8, wreg[tap][c][1]); }
+                for (int c = 0; c < COT; ++c) {
+                    const f32x4 w0 = __builtin_bit_cast(f32x4, wreg[tap][c][0]), w1 = __builtin_bit_cast(f32x4, wreg[tap][c][1]);
 #pragma unroll
-            for (int c = 0; c < COT; ++c)
+                    for (int t = 0; t < PT; ++t) {
+                        if (tap == 0) {         // the block's chain starts from zero
 #pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+                            for (int r = 0; r < 16; ++r) blk_acc[t][c][r] = 0.f;
+                        }
+                        mfma_exact(blk_acc[t][c], w0, w1, b[cur][t]);
+                    }
+                }
+                if (tap == 8) {                 // the block's sums into the running total
 #pragma unroll
-            for (int c = 0; c < COT; ++c)
+                    for (int c = 0; c < COT; ++c)
 #pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], b[cur][t].lo, acc[t][c], 0, 0, 0);
+                        for (int t = 0; t < PT; ++t) acc[t][c] += blk_acc[t][c];
+                }
+            } else {
+                h8 wh[COT], wlo[COT];
 #pragma unroll
-            for (int c = 0; c < COT; ++c)
+                for (int c = 0; c < COT; ++c) { wh[c] = __builtin_bit_cast(h8, wreg[tap][c][0]); wlo[c] = __builtin_bit_cast(h8, wreg[tap][c][1]); }
 #pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+                for (int c = 0; c < COT; ++c)
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], b[cur][t].lo, acc[t][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], b[cur][t].hi, acc[t][c], 0, 0, 0);
+            }
             if (cb_next >= 0) {
                 wload(tap, cb_next);
                 if (tap < PPASS) park_item(tap, buf ^ 1, cb_next, SET);
@@ -670,10 +827,12 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
     bool valid[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) valid[t] = (ty0 + RW * wave + t) < a.Ho && ox < a.Wo;
+    if constexpr (!EXACT) {
 #pragma unroll
-    for (int t = 0; t < PT; ++t)
+        for (int t = 0; t < PT; ++t)
 #pragma unroll
-        for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
+            for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
+    }
     if (a.bias) {
 #pragma unroll
         for (int c = 0; c < COT; ++c)
@@ -715,7 +874,9 @@ __global__ void __launch_bounds__(WAVES * KSPLIT * 64) conv3x3_s1_nhwc_kernel(co
 // (pack_stem_weight_kernel's K order).  No loop over channel blocks, one barrier.
 constexpr int STEM_TH = 8, STEM_PH = 2 * STEM_TH + 5, STEM_PCOLS = 2 * TW + 5, STEM_PITCH = 72;     // patch: 21 rows x 69 (+3 zero) columns
 constexpr int STEM_PLANE = STEM_PH * STEM_PITCH * 8;                                                 // bytes of one plane (hi or lo)
-template <int COT>
+// EXACT: the two planes hold fp32 pairs instead -- plane 0 channels (c0, c1), plane 1 (c2, c3) of every patch pixel, 8 bytes each --
+// so a lane's two neighbouring pixels are again one aligned 16-byte read per plane (pack_stem_weight_kernel orders the weights to match).
+template <int COT, bool EXACT = false>
 __global__ void __launch_bounds__(WAVES * 64) conv7x7_s2_stem_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const phi = smem;                               // [21][72] x 8 bytes: hi halves of (c0, c1, c2, 0)
@@ -760,12 +921,18 @@ __global__ void __launch_bounds__(WAVES * 64) conv7x7_s2_stem_kernel(const ConvA
     for (int s = 0; s < PPASS; ++s) {
         const int i = min(s * (WAVES * 64) + (int)threadIdx.x, STEM_PH * STEM_PITCH - 1);
         const bool real = i % STEM_PITCH < STEM_PCOLS;
-        const float v0 = real ? X_SCALE * pv[s][0] : 0.f, v1 = real ? X_SCALE * pv[s][1] : 0.f, v2 = real ? X_SCALE * pv[s][2] : 0.f,
-                    v3 = real ? X_SCALE * pv[s][3] : 0.f;
-        const unsigned h0 = pk_hi(v0, v1), h1 = pk_hi(v2, v3);
-        unsigned* dh = reinterpret_cast<unsigned*>(phi + i * 8);
-        unsigned* dl = reinterpret_cast<unsigned*>(plo + i * 8);
-        dh[0] = h0; dh[1] = h1; dl[0] = lo_pair(h0, v0, v1); dl[1] = lo_pair(h1, v2, v3);
+        if constexpr (EXACT) {
+            float* dh = reinterpret_cast<float*>(phi + i * 8);
+            float* dl = reinterpret_cast<float*>(plo + i * 8);
+            dh[0] = real ? pv[s][0] : 0.f; dh[1] = real ? pv[s][1] : 0.f; dl[0] = real ? pv[s][2] : 0.f; dl[1] = real ? pv[s][3] : 0.f;
+        } else {
+            const float v0 = real ? X_SCALE * pv[s][0] : 0.f, v1 = real ? X_SCALE * pv[s][1] : 0.f, v2 = real ? X_SCALE * pv[s][2] : 0.f,
+                        v3 = real ? X_SCALE * pv[s][3] : 0.f;
+            const unsigned h0 = pk_hi(v0, v1), h1 = pk_hi(v2, v3);
+            unsigned* dh = reinterpret_cast<unsigned*>(phi + i * 8);
+            unsigned* dl = reinterpret_cast<unsigned*>(plo + i * 8);
+            dh[0] = h0; dh[1] = h1; dl[0] = lo_pair(h0, v0, v1); dl[1] = lo_pair(h1, v2, v3);
+        }
     }
     __syncthreads();
 
@@ -798,28 +965,41 @@ __global__ void __launch_bounds__(WAVES * 64) conv7x7_s2_stem_kernel(const ConvA
     for (int ch = 0; ch < STEM_CHUNKS; ++ch) {
         const int cur = ch & 1;
         if (ch + 1 < STEM_CHUNKS) read_chunk(ch + 1, cur ^ 1);
+        if constexpr (EXACT) {          // (.hi / .lo here = plane 0 / plane 1: the same 16 bytes per lane, read as floats)
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
+            for (int c = 0; c < COT; ++c)
 #pragma unroll
-            for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].lo, b[cur][t].hi, acc[t][c], 0, 0, 0);
+                for (int t = 0; t < PT; ++t) {
+                    FragX xb;
+                    xb.q0 = __builtin_bit_cast(f32x4, b[cur][t].hi); xb.q1 = __builtin_bit_cast(f32x4, b[cur][t].lo);
+                    mfma_exact(acc[t][c], __builtin_bit_cast(f32x4, w[cur][c].hi), __builtin_bit_cast(f32x4, w[cur][c].lo), xb);
+                }
+        } else {
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
+            for (int c = 0; c < COT; ++c)
 #pragma unroll
-            for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].hi, b[cur][t].lo, acc[t][c], 0, 0, 0);
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].lo, b[cur][t].hi, acc[t][c], 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
+            for (int c = 0; c < COT; ++c)
 #pragma unroll
-            for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].hi, b[cur][t].hi, acc[t][c], 0, 0, 0);
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].hi, b[cur][t].lo, acc[t][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][c].hi, b[cur][t].hi, acc[t][c], 0, 0, 0);
+        }
     }
     __syncthreads();                                             // the epilogue's reductions reuse the LDS
     const int ox = tx0 + px;
     bool valid[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) valid[t] = (ty0 + PT * wave + t) < a.Ho && ox < a.Wo;
+    if constexpr (!EXACT) {
 #pragma unroll
-    for (int t = 0; t < PT; ++t)
+        for (int t = 0; t < PT; ++t)
 #pragma unroll
-        for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
+            for (int c = 0; c < COT; ++c) acc[t][c] *= ACC_UNSCALE;
+    }
     if (a.bias) {
 #pragma unroll
         for (int c = 0; c < COT; ++c)
@@ -890,7 +1070,7 @@ __global__ void __launch_bounds__(256) nhwc_stats_kernel(const float* __restrict
 }
 
 // one workgroup per (image, 32 channels): 8 chunk lanes per channel add every 8th chunk in double, then the 8 partial sums in a
-// fixed order; T = double (nhwc_stats_kernel's partials) or float (a convolution's per-tile sums)
+// fixed order; T = double (nhwc_stats_kernel's partials)
 template <class T>
 __global__ void __launch_bounds__(256) nhwc_norm_finalize_kernel(const T* __restrict__ partial, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const long hw, const int C,
@@ -1026,127 +1206,6 @@ __global__ void __launch_bounds__(WAVES * 64) conv2d_exact_kernel(const ExactArg
     }
 }
 
-// ---- the exact form, tiled (round 5): the same fp32 FMA chains at ~10x the rate ------------------------------------------------
-// conv2d_exact_kernel above feeds every MFMA with two scalar loads per lane (a channel of a pixel, a weight at a stride of
-// Cin * KS^2 floats): ~6 TFLOP/s, 20 ms for a 3 x 512 x 512 frame.  Here a lane's operands come eight at a time:
-//   B: the pixel's 16-channel block is contiguous in NHWC -- lane (pixel, half) reads channels 8 half .. 8 half + 7 as two float4;
-//   A: the weights are re-laid out once per parameter change (pack_exact_weight_kernel) as [tap][cin / 16][cout tile][lane][8], so lane
-//      (row, half) reads its eight as two float4 from an L2-resident image;
-// eight MFMAs per four vector loads, CT output tiles (32 channels each) sharing one B.  The four wavefronts of a workgroup share
-// ONE 32-pixel x 32 CT-channel tile and deal its K units (tap x 16-channel block) out round-robin, so a deep layer (256 channels
-// x 9 taps = 1 152 MFMAs per tile) is four chains of a quarter the length; the partial tiles meet in LDS and are added in wave
-// order (deterministic).  The next unit's loads are issued before the current unit's MFMAs.  K order within a chain: unit by
-// unit, inside a unit channels (8 half + j) for j = 0..7 -- an fp32 FMA chain like the reference's, in another order (the
-// reference's own two CPU convolution algorithms differ in order too: 2.9e-5 on the feature maps).
-struct ExactTArgs {
-    const float* x; const float* wp; const float* bias; float* y;
-    int H, W, Cin, Ho, Wo, Cout, KS, stride, MT;              // MT: 32-row tiles of the packed image (ceil(Cout / 32))
-};
-
-template <int CT>
-__global__ void __launch_bounds__(256) conv2d_exact_tiled_kernel(const ExactTArgs a) {
-    __shared__ float red[3][CT][16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, px = lane & 31, half = lane >> 5;
-    const int n = blockIdx.y, ct0 = blockIdx.z * CT;
-    const int howo = a.Ho * a.Wo, pad = a.KS / 2;
-    const int p = (int)blockIdx.x * 32 + px;
-    const bool valid = p < howo;
-    const int pc = valid ? p : howo - 1;
-    const int oy = pc / a.Wo, ox = pc % a.Wo;
-    const int nblk = a.Cin >> 4, U = a.KS * a.KS * nblk;
-    f32x16 acc[CT];
-#pragma unroll
-    for (int m = 0; m < CT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    f32x4 b0, b1, a0[CT], a1[CT];
-    auto load_unit = [&](int u, f32x4& q0, f32x4& q1, f32x4 (&w0)[CT], f32x4 (&w1)[CT]) {
-        const int tap = u / nblk, blk = u - tap * nblk;
-        const int ky = tap / a.KS, kx = tap - ky * a.KS;
-        const int iy = reflect(oy * a.stride + ky - pad, a.H), ix = reflect(ox * a.stride + kx - pad, a.W);
-        const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.Cin + 16 * blk + 8 * half);
-        q0 = xp[0]; q1 = xp[1];
-#pragma unroll
-        for (int m = 0; m < CT; ++m) {
-            const int mt = min(ct0 + m, a.MT - 1);
-            const f32x4* wq = reinterpret_cast<const f32x4*>(a.wp + ((((size_t)tap * nblk + blk) * a.MT + mt) * 64 + lane) * 8);
-            w0[m] = wq[0]; w1[m] = wq[1];
-        }
-    };
-    int u = wave;
-    if (u < U) load_unit(u, b0, b1, a0, a1);
-    while (u < U) {
-        f32x4 nb0 = b0, nb1 = b1, na0[CT], na1[CT];
-#pragma unroll
-        for (int m = 0; m < CT; ++m) { na0[m] = a0[m]; na1[m] = a1[m]; }
-        if (u + 4 < U) load_unit(u + 4, nb0, nb1, na0, na1);
-#pragma unroll
-        for (int m = 0; m < CT; ++m) {
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][0], b0[0], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][1], b0[1], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][2], b0[2], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][3], b0[3], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][0], b1[0], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][1], b1[1], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][2], b1[2], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][3], b1[3], acc[m], 0, 0, 0);
-        }
-        b0 = nb0; b1 = nb1;
-#pragma unroll
-        for (int m = 0; m < CT; ++m) { a0[m] = na0[m]; a1[m] = na1[m]; }
-        u += 4;
-    }
-    if (wave > 0) {
-#pragma unroll
-        for (int m = 0; m < CT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[wave - 1][m][r][lane] = acc[m][r];
-    }
-    __syncthreads();
-    if (wave != 0 || !valid) return;
-    float* yp = a.y + ((size_t)n * howo + p) * a.Cout;
-#pragma unroll
-    for (int m = 0; m < CT; ++m) {
-        if (ct0 + m >= a.MT) break;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * q + i;
-                v[i] = ((acc[m][r] + red[0][m][r][lane]) + red[1][m][r][lane]) + red[2][m][r][lane];
-            }
-            const int co = 32 * (ct0 + m) + 8 * q + 4 * half;          // ft(4q + i, half) = i + 8q + 4 half: four consecutive channels
-            if (co + 3 < a.Cout) {
-                f32x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = v[i] + (a.bias ? a.bias[co + i] : 0.f);
-                *reinterpret_cast<f32x4*>(yp + co) = o;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (co + i < a.Cout) yp[co + i] = v[i] + (a.bias ? a.bias[co + i] : 0.f);
-            }
-        }
-    }
-}
-
-// PyTorch [Cout][Cin][KS][KS] -> [tap][Cin / 16][MT][64 lanes][8]: lane (row, half) holds W[32 mt + row][16 blk + 8 half + j][tap]
-__global__ void pack_exact_weight_kernel(const float* __restrict__ w, const int cout, const int cin, const int ks, const int MT,
-                                         float* __restrict__ out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nblk = cin >> 4;
-    const long total = (long)ks * ks * nblk * MT * 512;
-    if (i >= total) return;
-    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-    long rest = i >> 9;
-    const int mt = (int)(rest % MT); rest /= MT;
-    const int blk = (int)(rest % nblk);
-    const int tap = (int)(rest / nblk);
-    const int co = 32 * mt + (lane & 31), ci = 16 * blk + 8 * (lane >> 5) + j;
-    out[i] = co < cout ? w[((size_t)co * cin + ci) * ks * ks + tap] : 0.f;
-}
-
 hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 int status() { return hipGetLastError() == hipSuccess ? GPNERF_OK : GPNERF_E_LAUNCH; }
 
@@ -1157,9 +1216,18 @@ int launch_conv(const ConvArgs& a, int N, void* stream) {
     int cot = 4;
     while (cot > 1 && (a.CT % cot != 0 || (long)tiles * N * (a.CT / cot) < 256)) cot >>= 1;
     const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / cot));
-    if (cot == 4) hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 4, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a);
-    else if (cot == 2) hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 2, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a);
-    else hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 1, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a);
+    ConvArgs g = a;
+    g.tile_h = 0; g.tile_w = WAVES * PT * 32;
+    const ConvArgs& a2 = g;
+    if (a.exact) {
+        if (cot == 4) hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 4, NARROW, true>), grid, dim3(WAVES * 64), 0, S_(stream), a2);
+        else if (cot == 2) hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 2, NARROW, true>), grid, dim3(WAVES * 64), 0, S_(stream), a2);
+        else hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 1, NARROW, true>), grid, dim3(WAVES * 64), 0, S_(stream), a2);
+        return status();
+    }
+    if (cot == 4) hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 4, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a2);
+    else if (cot == 2) hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 2, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a2);
+    else hipLaunchKernelGGL((conv2d_nhwc_kernel<KS, STRIDE, 1, NARROW>), grid, dim3(WAVES * 64), 0, S_(stream), a2);
     return status();
 }
 
@@ -1175,18 +1243,23 @@ int conv3x3_rows(int ho, int wo) {
     return ((ho + 7) / 8) * ((wo + TW - 1) / TW) <= f_max && ho > 4 ? 1 : 2;
 }
 
-template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1, bool CAT = false>
+template <int COT, int RW, int STRIDE = 1, int KSPLIT = 1, bool CAT = false, bool EXACT = false>
 int launch_conv3x3_as(const ConvArgs& a, int N, int tiles, void* stream) {
+    if constexpr (!EXACT) {
+        if (a.exact) return launch_conv3x3_as<COT, RW, STRIDE, KSPLIT, CAT, true>(a, N, tiles, stream);
+    }
     // two patch buffers per K half (+ the input norm's table); never less than what the epilogue's reductions use (tile sums,
     // finalize: 16 KB; the halves' exchange: RW * COT * 16 KB behind them)
     size_t lds = KSPLIT * 2 * (size_t)patch_bytes(RW, STRIDE) + (a.in_tab ? 3 * (size_t)a.Cin * sizeof(float) : 0);
     const size_t floor_ = 16384 + (KSPLIT == 2 ? (size_t)RW * COT * 16384 : 0);
     if (lds < floor_) lds = floor_;
-    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT, CAT>);
+    const void* fn = reinterpret_cast<const void*>(&conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT, CAT, EXACT>);
     // > 64 KB of dynamic LDS is an opt-in per device; setting it is cheap, so it is simply set before every launch
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
     const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / COT));
-    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT, CAT>), grid, dim3(WAVES * KSPLIT * 64), lds, S_(stream), a);
+    ConvArgs g = a;
+    g.tile_h = tile_rows(RW); g.tile_w = TW;
+    hipLaunchKernelGGL((conv3x3_s1_nhwc_kernel<COT, RW, STRIDE, KSPLIT, CAT, EXACT>), grid, dim3(WAVES * KSPLIT * 64), lds, S_(stream), g);
     return status();
 }
 
@@ -1215,14 +1288,19 @@ int launch_conv3x3_s2(const ConvArgs& a, int N, void* stream) {
     return launch_conv3x3_as<1, 1, 2>(a, N, tiles, stream);
 }
 
-template <int COT>
+template <int COT, bool EXACT = false>
 int launch_stem_as(const ConvArgs& a, int N, void* stream) {
+    if constexpr (!EXACT) {
+        if (a.exact) return launch_stem_as<COT, true>(a, N, stream);
+    }
     const int tiles = ((a.Ho + STEM_TH - 1) / STEM_TH) * ((a.Wo + TW - 1) / TW);
     const size_t lds = 2 * (size_t)STEM_PLANE + (size_t)STEM_CHUNKS * COT * STEP_BYTES;
-    const void* fn = reinterpret_cast<const void*>(&conv7x7_s2_stem_kernel<COT>);
+    const void* fn = reinterpret_cast<const void*>(&conv7x7_s2_stem_kernel<COT, EXACT>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPNERF_E_DEVICE;
     const dim3 grid((unsigned)tiles, (unsigned)N, (unsigned)(a.CT / COT));
-    hipLaunchKernelGGL((conv7x7_s2_stem_kernel<COT>), grid, dim3(WAVES * 64), lds, S_(stream), a);
+    ConvArgs g = a;
+    g.tile_h = STEM_TH; g.tile_w = TW;
+    hipLaunchKernelGGL((conv7x7_s2_stem_kernel<COT, EXACT>), grid, dim3(WAVES * 64), lds, S_(stream), g);
     return status();
 }
 int launch_stem(const ConvArgs& a, int N, void* stream) { return a.CT % 2 == 0 ? launch_stem_as<2>(a, N, stream) : launch_stem_as<1>(a, N, stream); }
@@ -1238,20 +1316,20 @@ int64_t gpnerf_conv_packed_bytes(int32_t cout, int32_t cin, int32_t ks) {
     return chunks * ((cout + 31) / 32) * STEP_BYTES;
 }
 
-int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, void* packed, void* stream) {
-    if (!weight || !packed || cout < 1 || cin < 1 || (ks != 1 && ks != 3 && ks != 7)) return GPNERF_E_ARG;
+int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, int32_t exact, void* packed, void* stream) {
+    if (!weight || !packed || cout < 1 || cin < 1 || (ks != 1 && ks != 3 && ks != 7) || exact < 0 || exact > 1) return GPNERF_E_ARG;
     if (ks == 7 && cin <= 4) {
         const int CT = (cout + 31) / 32;
         const long total = (long)STEM_CHUNKS * CT * 512;
         hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_(stream), weight, (int)cout, (int)cin, CT,
-                           reinterpret_cast<uint16_t*>(packed));
+                           (int)exact, reinterpret_cast<uint16_t*>(packed));
         return status();
     }
     const int flat = cin < 8;
     const int CB = flat ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16, CT = (cout + 31) / 32;
     const long total = (flat ? (long)CB : (long)ks * ks * CB) * CT * 512;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_(stream), weight, (int)cout,
-                       (int)cin, (int)ks, CB, CT, flat, reinterpret_cast<uint16_t*>(packed));
+                       (int)cin, (int)ks, CB, CT, flat, (int)exact, reinterpret_cast<uint16_t*>(packed));
     return status();
 }
 
@@ -1267,8 +1345,10 @@ int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int
 
 int gpnerf_conv2d_norm_cat_nhwc(const float* x, int32_t cin_a, const float* x_b, int32_t cin_b, int32_t n, int32_t h, int32_t w,
                                 const void* packed, const float* bias, int32_t cout, float* y, float* tile_stats, const float* gamma,
-                                const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag, void* stream) {
+                                const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag, int32_t exact,
+                                void* stream) {
     if (n == 0) return GPNERF_OK;
+    if (exact < 0 || exact > 1) return GPNERF_E_ARG;
     if (!x || !x_b || !packed || !y || n < 0 || h < 2 || w < 2 || cin_a < 16 || (cin_a & 15) || cin_b < 16 || (cin_b & 15) || cout < 4 || (cout & 3))
         return GPNERF_E_ARG;
     if (out_table && (!tile_stats || !gamma || !beta || !counters)) return GPNERF_E_ARG;
@@ -1277,15 +1357,16 @@ int gpnerf_conv2d_norm_cat_nhwc(const float* x, int32_t cin_a, const float* x_b,
     a.H = h; a.W = w; a.Cin = cin_a + cin_b; a.Cout = cout; a.Ho = h; a.Wo = w;
     a.CB = a.Cin / 16; a.CT = (cout + 31) / 32;
     a.in_tab = nullptr; a.in_act = 0; a.out_tab = out_table; a.gamma = gamma; a.beta = beta; a.eps = eps; a.counters = counters;
-    a.flag = range_flag;
+    a.flag = exact ? nullptr : range_flag; a.exact = exact;
     return launch_conv3x3(a, n, stream);
 }
 
 int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* in_table, int32_t in_act,
                             const void* packed, const float* bias, int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats,
                             const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag,
-                            void* stream) {
+                            int32_t exact, void* stream) {
     if (n == 0) return GPNERF_OK;
+    if (exact < 0 || exact > 1) return GPNERF_E_ARG;
     if (!x || !packed || !y || n < 0 || h < 1 || w < 1 || cin < 1 || cout < 4 || (cout & 3)) return GPNERF_E_ARG;
     if ((ks != 1 && ks != 3 && ks != 7) || (stride != 1 && stride != 2)) return GPNERF_E_ARG;
     const int pad = ks / 2;
@@ -1301,7 +1382,7 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
     a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
     a.CB = narrow ? (ks * ks * cin + 15) / 16 : (cin + 15) / 16; a.CT = (cout + 31) / 32;
     a.in_tab = in_table; a.in_act = in_act; a.out_tab = out_table; a.gamma = gamma; a.beta = beta; a.eps = eps; a.counters = counters;
-    a.flag = range_flag;
+    a.flag = exact ? nullptr : range_flag; a.exact = exact;
     if (narrow) {
         if (ks == 7 && stride == 2 && cin <= 4) return launch_stem(a, n, stream);
         if (ks == 7) return GPNERF_E_ARG;                                  // (7x7 on 5 .. 7 channels: not built)
@@ -1316,9 +1397,9 @@ int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int
 }
 
 int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
-                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, uint32_t* range_flag, void* stream) {
+                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, uint32_t* range_flag, int32_t exact, void* stream) {
     return gpnerf_conv2d_norm_nhwc(x, n, h, w, cin, nullptr, 0, packed, bias, cout, ks, stride, y, tile_stats, nullptr, nullptr, 0.f, nullptr,
-                                   nullptr, range_flag, stream);
+                                   nullptr, range_flag, exact, stream);
 }
 
 int gpnerf_conv2d_nhwc_exact(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* weight, const float* bias,
@@ -1335,60 +1416,25 @@ int gpnerf_conv2d_nhwc_exact(const float* x, int32_t n, int32_t h, int32_t w, in
     return status();
 }
 
-int64_t gpnerf_conv_exact_packed_bytes(int32_t cout, int32_t cin, int32_t ks) {
-    if (cout < 1 || cin < 16 || (cin & 15) || ks < 1 || !(ks & 1)) return 0;          // 0: this convolution has no tiled exact form
-    return (int64_t)ks * ks * (cin >> 4) * ((cout + 31) / 32) * 512 * (int64_t)sizeof(float);
-}
-
-int gpnerf_conv_pack_weight_exact(const float* weight, int32_t cout, int32_t cin, int32_t ks, float* packed, void* stream) {
-    if (!weight || !packed || gpnerf_conv_exact_packed_bytes(cout, cin, ks) == 0) return GPNERF_E_ARG;
-    const int MT = (cout + 31) / 32;
-    const long total = (long)ks * ks * (cin >> 4) * MT * 512;
-    hipLaunchKernelGGL(pack_exact_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_(stream), weight, (int)cout, (int)cin, (int)ks, MT,
-                       packed);
-    return status();
-}
-
-int gpnerf_conv2d_nhwc_exact_packed(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* packed, const float* bias,
-                                    int32_t cout, int32_t ks, int32_t stride, float* y, void* stream) {
-    if (n == 0) return GPNERF_OK;
-    if (!x || !packed || !y || n < 0 || h < 1 || w < 1 || cout < 1 || stride < 1 || gpnerf_conv_exact_packed_bytes(cout, cin, ks) == 0) return GPNERF_E_ARG;
-    const int pad = ks / 2;
-    if (h <= pad || w <= pad) return GPNERF_E_ARG;                       // reflection needs pad < size
-    ExactTArgs a;
-    a.x = x; a.wp = packed; a.bias = bias; a.y = y; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.KS = ks; a.stride = stride;
-    a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1; a.MT = (cout + 31) / 32;
-    const unsigned tiles = (unsigned)((a.Ho * a.Wo + 31) / 32);
-    if (a.MT >= 2) hipLaunchKernelGGL((conv2d_exact_tiled_kernel<2>), dim3(tiles, (unsigned)n, (unsigned)((a.MT + 1) / 2)), dim3(256), 0, S_(stream), a);
-    else hipLaunchKernelGGL((conv2d_exact_tiled_kernel<1>), dim3(tiles, (unsigned)n, 1u), dim3(256), 0, S_(stream), a);
-    return status();
-}
-
 int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c) {
     if (n < 1 || hw < 1 || c < 1) return 0;
     // per-chunk partial sums (double), then the [N][3][C] mean / scale / beta table
     return (int64_t)n * ((hw + PCH - 1) / PCH) * c * 2 * (int64_t)sizeof(double) + (int64_t)n * 3 * c * (int64_t)sizeof(float);
 }
 
-int gpnerf_instance_norm_act_nhwc(const float* x, const float* tile_stats, int32_t n_tiles, const float* gamma, const float* beta,
+int gpnerf_instance_norm_act_nhwc(const float* x, const float* gamma, const float* beta,
                                   const float* residual, int32_t n, int64_t hw, int32_t c, float eps, int32_t act, float* out,
                                   void* scratch, void* stream) {
     if (n == 0 || c == 0 || hw == 0) return GPNERF_OK;
     if (!x || !gamma || !beta || !out || !scratch || n < 0 || c < 4 || (c & 3) || c > 1024 || hw < 0 || act < 0 || act > 2) return GPNERF_E_ARG;
-    if (tile_stats && n_tiles < 1) return GPNERF_E_ARG;
     const int nchunks = (int)((hw + PCH - 1) / PCH);
     double* const partial = reinterpret_cast<double*>(scratch);
     float* const table = reinterpret_cast<float*>(partial + (size_t)n * nchunks * c * 2);
     const long elems = (long)hw * (c >> 2);
     const dim3 fgrid((unsigned)((c + 31) / 32), (unsigned)n);
-    if (tile_stats) {
-        hipLaunchKernelGGL(nhwc_norm_finalize_kernel<float>, fgrid, dim3(256), 0, S_(stream), tile_stats, gamma, beta, (long)hw, (int)c,
-                           (int)n_tiles, eps, table);
-    } else {
-        hipLaunchKernelGGL(nhwc_stats_kernel, dim3((unsigned)nchunks, (unsigned)n), dim3(256), 0, S_(stream), x, (long)hw, (int)c, nchunks, partial);
-        hipLaunchKernelGGL(nhwc_norm_finalize_kernel<double>, fgrid, dim3(256), 0, S_(stream), (const double*)partial, gamma, beta, (long)hw,
-                           (int)c, nchunks, eps, table);
-    }
+    hipLaunchKernelGGL(nhwc_stats_kernel, dim3((unsigned)nchunks, (unsigned)n), dim3(256), 0, S_(stream), x, (long)hw, (int)c, nchunks, partial);
+    hipLaunchKernelGGL(nhwc_norm_finalize_kernel<double>, fgrid, dim3(256), 0, S_(stream), (const double*)partial, gamma, beta, (long)hw,
+                       (int)c, nchunks, eps, table);
     hipLaunchKernelGGL(nhwc_norm_apply_kernel, dim3((unsigned)((elems + 255) / 256), (unsigned)n), dim3(256), 0, S_(stream), x,
                        (const float*)table, residual, (const float*)nullptr, (long)hw, (int)c, (int)act, out);
     return status();

@@ -3,18 +3,23 @@ state_dict keys (libs/encoders/UNet.py:133-242), so `load_state_dict(strict=True
 
 Per frame, not per ray: V=3 source images [V,3,H,W] -> feature maps [V,32,H/4,W/4], ~120 GFLOP of convolutions at 512x512.
 Everything runs in hand-written HIP kernels on channels-last activations (csrc/gpnerf_conv.hip): the convolutions as implicit
-GEMMs on the f16 matrix cores with fp32 operands split into f16 hi + lo (three MFMAs per k-step, f32 accumulation: fp32-grade
-accuracy), reflection padding as index arithmetic, InstanceNorm fused with the residual add and activation behind it, the two
-bilinear upsamplings as one launch each.  The result leaves with channels-last strides (logical NCHW, physical NHWC), which
+GEMMs on the matrix cores, reflection padding as index arithmetic, InstanceNorm fused with the residual add and activation
+behind it, the two bilinear upsamplings as one launch each -- ONE launch chain (55 launches, replayed as a HIP graph) in two
+arithmetic forms (`ResUNet.precision`):
+  "fp32"  (default) fp32 operands on v_mfma_f32_32x32x2_f32: every dot product an fp32 FMA chain like the reference's own.  No
+          operand range.  The form whose end-to-end chain (encoder -> head -> renderer) stays within 1e-4 of the reference on
+          every map at the config-5 size (tests/test_gpu_renderer.py);
+  "split" fp32 operands split into f16 hi + lo on the f16 MFMA (three per k-step, f32 accumulation: ~23 bits per operand): the
+          fast mode (`encoder.file hip_encoder_fast`), the same 3e-5 on the feature maps but rounding that is uncorrelated with the
+          reference's, which the head amplifies to 2.5e-4 on depth at that size; operand range below.  The result leaves with channels-last strides (logical NCHW, physical NHWC), which
 is the layout the render kernel gathers from, so `Frame` takes it as is, without a re-layout launch.  The nn.Conv2d /
 nn.InstanceNorm2d sub-modules are parameter containers under the reference's names; there is no torch-operator path (the
 one the tests check against is oracle/producers_ref.py `encoder`).
 
-Operand range.  The split-f16 convolutions hold |w| < 16 and |x| < 4 095.  No checkpoint is refused for that: an operand beyond
+Operand range (precision "split" only).  The split-f16 convolutions hold |w| < 16 and |x| < 4 095.  No checkpoint is refused for that: an operand beyond
 the range splits into f16 infinities, the outputs it meets are NaN, and the convolutions raise a flag word when they see a
 non-finite sum in their InstanceNorm table (`_Run.flag`, include/gpnerf_hip.h `range_flag`) -- a DATA-dependent guard that costs
-the kernels nothing.  A flagged pass is discarded and the frame encoded again by `forward_exact` (fp32 operands on
-v_mfma_f32_32x32x2_f32, every norm from a double-precision pass).  `check_operand_range` is the fast accept in front of it: when
+the kernels nothing.  A flagged pass is discarded and the frame encoded again by `forward_exact` (the "fp32" form).  `check_operand_range` is the fast accept in front of it: when
 the parameters alone bound every activation (sqrt(h w) |gamma| + |beta| ...) the flag cannot be raised and is never looked at.
 
 Network (UNet.py:154-234): 7x7/2 stem -> three residual stages of [3,4,6] two-conv units at 64/128/256 channels, every stage
@@ -22,7 +27,6 @@ entered with stride 2 (there is no max-pool), all 3x3 / 7x7 convolutions reflect
 InstanceNorm without running statistics -> two (bilinear x2, align_corners) + conv + concat-skip decoder steps with
 InstanceNorm + ELU -> 1x1 output convolution.
 """
-import os
 import threading
 
 import torch
@@ -61,28 +65,49 @@ def _nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
+def _exact():
+    """the arithmetic form of the convolutions called from here (set by `_form`): True = fp32 operands (exact = 1)"""
+    return bool(getattr(_current, "exact", True))
+
+
+class _form:
+    """with _form(exact): every convolution called inside runs in that arithmetic form (include/gpnerf_hip.h `exact`)"""
+
+    def __init__(self, exact):
+        self.exact = bool(exact)
+
+    def __enter__(self):
+        self.prev = getattr(_current, "exact", True)
+        _current.exact = self.exact
+
+    def __exit__(self, *exc):
+        _current.exact = self.prev
+
+
 def _packed_weight(conv):
-    """gpnerf_conv_pack_weight image of a conv's weight (f16 hi/lo, MFMA A-operand order), re-packed when the parameter changes.
+    """gpnerf_conv_pack_weight image of a conv's weight in the current form (fp32, or f16 hi/lo; MFMA A-operand order), re-packed when the parameter changes.
     The image lives ON the module (not in a table keyed by id(): ids and device pointers are re-used once a model is freed, and
     a second checkpoint would have found the first one's image), so it is freed with the module; the fp32 source the pack kernel
     reads needs no keeping -- stream order protects it."""
     w = conv.weight
+    exact = _exact()
     key = (str(w.device), w.data_ptr(), w._version)
-    hit = conv.__dict__.get("_gpnerf_packed")
+    slot = "_gpnerf_packed_f32" if exact else "_gpnerf_packed"
+    hit = conv.__dict__.get(slot)
     if hit is None or hit[0] != key:
         lib = L.lib()
         cout, cin, ks, _ = w.shape
         buf = torch.empty((int(lib.gpnerf_conv_packed_bytes(cout, cin, ks)),), dtype=torch.uint8, device=w.device)
         src = w.detach().float().contiguous()
-        L.check(lib.gpnerf_conv_pack_weight(src.data_ptr(), cout, cin, ks, buf.data_ptr(), _st(w)), "gpnerf_conv_pack_weight")
+        L.check(lib.gpnerf_conv_pack_weight(src.data_ptr(), cout, cin, ks, int(exact), buf.data_ptr(), _st(w)), "gpnerf_conv_pack_weight")
         hit = (key, buf)
-        conv.__dict__["_gpnerf_packed"] = hit
+        conv.__dict__[slot] = hit
     return hit[1]
 
 
 def _conv(conv, x, stats=False):
     """nn.Conv2d(..., padding=k//2, padding_mode='reflect') on a channels-last tensor -> channels-last tensor (gpnerf_conv2d_nhwc).
-    stats=True: also returns the per-tile channel sums the InstanceNorm behind the convolution needs (`_norm_act(..., stats=)`)."""
+    stats=True: also returns the per-tile (sum, sum of squares, M2) of every output channel (what `_conv_norm`'s table is merged from)."""
     if not x.is_cuda:
         raise L.GpnerfError("the HIP image encoder runs on GPU tensors only (no CPU fallback)")
     x = _nhwc(x)
@@ -94,18 +119,18 @@ def _conv(conv, x, stats=False):
     out = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
     lib = L.lib()
-    if stats and L._DEBUG and os.environ.get("GPNERF_ENC_STATS") == "pass":     # diagnostic: statistics from a separate double-precision pass
-        stats = False
-    ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, cin, ks, stride)), cout, 2), device=x.device, dtype=torch.float32) if stats else None
+    ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, cin, ks, stride)), cout, 3), device=x.device, dtype=torch.float32) if stats else None
     L.check(lib.gpnerf_conv2d_nhwc(x.data_ptr(), n, h, w, cin, _packed_weight(conv).data_ptr(),
                                    bias.data_ptr() if bias is not None else None, cout, ks, stride, out.data_ptr(),
-                                   ts.data_ptr() if ts is not None else None, _run_of(x).flag_ptr, _st(x)), "gpnerf_conv2d_nhwc")
+                                   ts.data_ptr() if ts is not None else None, None if _exact() else _run_of(x).flag_ptr, int(_exact()), _st(x)),
+            "gpnerf_conv2d_nhwc")
     return (out, ts) if stats else out
 
 
 def _conv_exact(conv, x):
-    """The same nn.Conv2d on fp32 operands (gpnerf_conv2d_nhwc_exact: an fp32 FMA chain per output on v_mfma_f32_32x32x2_f32,
-    straight from the PyTorch weight): what a frame is encoded with after the split-f16 form raised its range flag."""
+    """The same nn.Conv2d through gpnerf_conv2d_nhwc_exact: fp32 operands straight from the PyTorch weight, one scalar load per
+    operand, any odd kernel size / stride / channel count.  NOT on the encoder's path (its "fp32" form is the fused kernels with
+    exact = 1): the independent restatement tests hold them against."""
     if not x.is_cuda:
         raise L.GpnerfError("the HIP image encoder runs on GPU tensors only (no CPU fallback)")
     x = _nhwc(x.float())
@@ -116,39 +141,23 @@ def _conv_exact(conv, x):
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     out = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-    lib = L.lib()
-    nbytes = int(lib.gpnerf_conv_exact_packed_bytes(cout, cin, ks))
-    if nbytes and not (L._DEBUG and os.environ.get("GPNERF_EXACT_UNTILED") == "1"):
-        # the tiled form (Cin a multiple of 16: every convolution but the stem): weights re-laid out once per parameter change
-        wkey = (str(conv.weight.device), conv.weight.data_ptr(), conv.weight._version)
-        hit = conv.__dict__.get("_gpnerf_packed_exact")
-        if hit is None or hit[0] != wkey:
-            buf = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
-            src = conv.weight.detach().float().contiguous()
-            L.check(lib.gpnerf_conv_pack_weight_exact(src.data_ptr(), cout, cin, ks, buf.data_ptr(), _st(x)), "gpnerf_conv_pack_weight_exact")
-            hit = conv.__dict__["_gpnerf_packed_exact"] = (wkey, buf)
-        L.check(lib.gpnerf_conv2d_nhwc_exact_packed(x.data_ptr(), n, h, w, cin, hit[1].data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                    cout, ks, stride, out.data_ptr(), _st(x)), "gpnerf_conv2d_nhwc_exact_packed")
-        return out
     wt = conv.weight.detach().float().contiguous()
-    L.check(lib.gpnerf_conv2d_nhwc_exact(x.data_ptr(), n, h, w, cin, wt.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                         cout, ks, stride, out.data_ptr(), _st(x)), "gpnerf_conv2d_nhwc_exact")
+    L.check(L.lib().gpnerf_conv2d_nhwc_exact(x.data_ptr(), n, h, w, cin, wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                             cout, ks, stride, out.data_ptr(), _st(x)), "gpnerf_conv2d_nhwc_exact")
     return out
 
 
-def _norm_act(norm, x, act, residual=None, stats=None):
-    """act(InstanceNorm(x) [+ residual]) on channels-last tensors; act: 0 none, 1 ReLU, 2 ELU.  x may be the (tensor, tile sums)
-    pair `_conv(..., stats=True)` returns: the statistics then come from the convolution's epilogue instead of a pass over x."""
+def _norm_act(norm, x, act, residual=None):
+    """act(InstanceNorm(x) [+ residual]) on channels-last tensors; act: 0 none, 1 ReLU, 2 ELU (gpnerf_instance_norm_act_nhwc: the
+    statistics from a double-precision pass over x).  The stand-alone operator: the encoder's path takes its tables from the
+    convolutions' own epilogues (`_conv_norm`), which the tests hold against this."""
     lib = L.lib()
-    if isinstance(x, tuple):
-        x, stats = x
     x = _nhwc(x)
     n, c, h, w = x.shape
     out = torch.empty_like(x, memory_format=torch.channels_last)
     res = _nhwc(residual) if residual is not None else None
     scratch = torch.empty((int(lib.gpnerf_instance_norm_nhwc_scratch_bytes(n, h * w, c)),), dtype=torch.uint8, device=x.device)
-    L.check(lib.gpnerf_instance_norm_act_nhwc(x.data_ptr(), stats.data_ptr() if stats is not None else None,
-                                              stats.shape[1] if stats is not None else 0, norm.weight.data_ptr(), norm.bias.data_ptr(),
+    L.check(lib.gpnerf_instance_norm_act_nhwc(x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(),
                                               res.data_ptr() if res is not None else None, n, h * w, c, float(norm.eps), act,
                                               out.data_ptr(), scratch.data_ptr(), _st(x)), "gpnerf_instance_norm_act_nhwc")
     return out
@@ -164,10 +173,7 @@ class _Run:
 
     def __init__(self, dev):
         self.tickets = torch.zeros((4096,), dtype=torch.int32, device=dev)
-        if L._DEBUG and os.environ.get("GPNERF_ENC_FLAG_DEVICE") == "1":      # diagnostic: the flag in device memory, read with a copy
-            self.flag = torch.zeros((1,), dtype=torch.int32, device=dev)
-        else:
-            self.flag = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self.flag = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self.flag_ptr = self.flag.data_ptr()
 
     def raised(self):
@@ -236,7 +242,7 @@ def _conv_norm(conv, norm, x, in_tab=None, in_act=0):
     lib = L.lib()
     out = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-    ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, cin, ks, stride)), cout, 2), device=x.device, dtype=torch.float32)
+    ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, cin, ks, stride)), cout, 3), device=x.device, dtype=torch.float32)
     tab = torch.empty((n, 3, cout), device=x.device, dtype=torch.float32)
     run = _run_of(x)
     tick = run.tickets
@@ -245,7 +251,8 @@ def _conv_norm(conv, norm, x, in_tab=None, in_act=0):
     L.check(lib.gpnerf_conv2d_norm_nhwc(x.data_ptr(), n, h, w, cin, in_tab.data_ptr() if in_tab is not None else None, int(in_act),
                                         _packed_weight(conv).data_ptr(), bias.data_ptr() if bias is not None else None, cout, ks, stride,
                                         out.data_ptr(), ts.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
-                                        tab.data_ptr(), tick.data_ptr(), run.flag_ptr, _st(x)), "gpnerf_conv2d_norm_nhwc")
+                                        tab.data_ptr(), tick.data_ptr(), None if _exact() else run.flag_ptr, int(_exact()), _st(x)),
+            "gpnerf_conv2d_norm_nhwc")
     return out, tab
 
 
@@ -259,7 +266,7 @@ def _conv_norm_cat(conv, norm, xa, xb):
     lib = L.lib()
     out = torch.empty((n, cout, h, w), device=xa.device, dtype=torch.float32, memory_format=torch.channels_last)
     bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-    ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, ca + cb, 3, 1)), cout, 2), device=xa.device, dtype=torch.float32)
+    ts = torch.empty((n, int(lib.gpnerf_conv_out_tiles(h, w, ca + cb, 3, 1)), cout, 3), device=xa.device, dtype=torch.float32)
     tab = torch.empty((n, 3, cout), device=xa.device, dtype=torch.float32)
     run = _run_of(xa)
     tick = run.tickets
@@ -268,7 +275,7 @@ def _conv_norm_cat(conv, norm, xa, xb):
     L.check(lib.gpnerf_conv2d_norm_cat_nhwc(xa.data_ptr(), ca, xb.data_ptr(), cb, n, h, w, _packed_weight(conv).data_ptr(),
                                             bias.data_ptr() if bias is not None else None, cout, out.data_ptr(), ts.data_ptr(),
                                             norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), tab.data_ptr(), tick.data_ptr(),
-                                            run.flag_ptr, _st(xa)), "gpnerf_conv2d_norm_cat_nhwc")
+                                            None if _exact() else run.flag_ptr, int(_exact()), _st(xa)), "gpnerf_conv2d_norm_cat_nhwc")
     return out, tab
 
 
@@ -330,13 +337,6 @@ class ResidualUnit(nn.Module):
         d, td = _conv_norm(self.downsample[0], self.downsample[1], x, in_tab=x_tab, in_act=act0)
         return _apply(y2, t2, 1, residual=d, res_tab=td)
 
-    def forward_exact(self, x):
-        """UNet.py:38-53 on the exact kernels, one launch chain per operator (conv / statistics pass / normalise)."""
-        out = _norm_act(self.bn1, _conv_exact(self.conv1, x), 1)
-        out = _conv_exact(self.conv2, out)
-        idn = x if self.downsample is None else _norm_act(self.downsample[1], _conv_exact(self.downsample[0], x), 0)
-        return _norm_act(self.bn2, out, 1, residual=idn)
-
 
 class ConvNormELU(nn.Module):
     """conv (with bias, reflect pad) -> InstanceNorm -> ELU (UNet.py:107-120); sub-modules `conv`, `bn`."""
@@ -349,11 +349,6 @@ class ConvNormELU(nn.Module):
         if isinstance(x, tuple):                     # (a, b): the concatenation [a, b] on channels, read in place
             return _apply(*_conv_norm_cat(self.conv, self.bn, *x), 2)
         return _apply(*_conv_norm(self.conv, self.bn, x), 2)
-
-    def forward_exact(self, x):
-        if isinstance(x, tuple):
-            x = torch.cat([_nhwc(x[0]), _nhwc(x[1])], dim=1)
-        return _norm_act(self.bn, _conv_exact(self.conv, x), 2)
 
 
 class UpsampleConv(nn.Module):
@@ -369,11 +364,6 @@ class UpsampleConv(nn.Module):
             raise L.GpnerfError("the upsampling kernel is built for the reference's x2 bilinear steps on fp32 (UNet.py:185-188)")
         return self.conv(_upsample2x(x))
 
-    def forward_exact(self, x):
-        if self.scale != 2 or x.dtype != torch.float32:
-            raise L.GpnerfError("the upsampling kernel is built for the reference's x2 bilinear steps on fp32 (UNet.py:185-188)")
-        return self.conv.forward_exact(_upsample2x(x))
-
 
 def _stage(cin, cout, n):
     return nn.Sequential(*[ResidualUnit(cin if i == 0 else cout, cout, 2 if i == 0 else 1) for i in range(n)])
@@ -385,8 +375,7 @@ def _concat_skip(skip, up):
     dy, dx = up.shape[2] - skip.shape[2], up.shape[3] - skip.shape[3]
     if dy or dx:
         skip = F.pad(skip, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
-    if (up.is_cuda and up.shape[1] % 16 == 0 and skip.shape[1] % 16 == 0 and up.dtype == torch.float32 and skip.dtype == torch.float32
-            and not (os.environ.get("GPNERF_DEBUG") == "1" and os.environ.get("GPNERF_ENC_CAT") == "0")):
+    if up.is_cuda and up.shape[1] % 16 == 0 and skip.shape[1] % 16 == 0 and up.dtype == torch.float32 and skip.dtype == torch.float32:
         return up, skip                              # the convolution behind reads the two tensors in place (ConvNormELU.forward)
     return torch.cat([up, skip], dim=1)
 
@@ -407,6 +396,18 @@ class ResUNet(nn.Module):
         self.upconv2 = UpsampleConv(128, 64, 3, 2)
         self.iconv2 = ConvNormELU(skip1 + 64, out_ch, 3)
         self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
+
+    # ---- arithmetic form (module docstring): "fp32" (default) or "split"; `net.precision = "split"` per module, or the plugin
+    # `encoder.file hip_encoder_fast`.  Not a parameter: state_dict keys are the reference's 108.
+    @property
+    def precision(self):
+        return self.__dict__.get("_gpnerf_precision", "fp32")
+
+    @precision.setter
+    def precision(self, v):
+        if v not in ("fp32", "split"):
+            raise ValueError(f"precision {v!r}: 'fp32' (default, the reference's arithmetic) or 'split' (f16 hi/lo, fast)")
+        self.__dict__["_gpnerf_precision"] = v
 
     # ---- operand range of the split-f16 convolutions (csrc/gpnerf_conv.hip: weights staged as 2^12 w, activations as 2^4 x) ----
     W_LIMIT, X_LIMIT = 15.99, 4094.0
@@ -429,10 +430,8 @@ class ResUNet(nn.Module):
         `self.range_report` names the first layer that decided a "dynamic" / "exact" answer."""
         # params_key: the (storage, version) tuple of the parameters when the caller has just computed it (forward_graphed: walking
         # the 108 parameters costs the host ~0.1 ms, and this runs before the frame's first launch with the device idle)
-        if self.__dict__.get("strict_exact") or os.environ.get("GPNERF_ENCODER_EXACT") == "1":
-            # strict mode (round 5): every frame through the fp32-MFMA form (forward_exact: 2.6 ms for 3 x 512 x 512 against the
-            # split form's 1.0) -- the choice of a user who wants fp32 operands throughout; `net.strict_exact = True` per module
-            return "exact"
+        if self.precision == "fp32":
+            return "exact"                 # (the default form has no operand range at all: nothing to classify)
         key = (int(H), int(W), params_key if params_key is not None else _graph_key(self, None)[3])
         hit = self.__dict__.get("_gpnerf_range_class")
         if hit is not None and hit[0] == key:
@@ -510,20 +509,21 @@ class ResUNet(nn.Module):
 
     def forward(self, x):
         """x [V,3,H,W] -> [V,out_ch,H/4,W/4].  On the GPU the result leaves with channels-last strides, which `Frame`
-        recognises (no re-layout launch).  The split-f16 form; a frame that leaves its operand range (check_operand_range: only
-        looked at when the parameters do not exclude it -- the host then waits for the stream once) is encoded again by
-        forward_exact.  `self.exact_frames` counts those."""
+        recognises (no re-layout launch).  precision "fp32": the launch chain in the exact form, nothing to check, no
+        synchronisation.  precision "split": the split-f16 form; a frame that leaves its operand range (check_operand_range: the
+        host then waits for the stream once) is encoded again by forward_exact.  `self.exact_frames` counts those."""
         _require_gpu_inference(x, self.training)
         cls = self.check_operand_range(x.shape[-2], x.shape[-1])
         if cls == "exact":
-            return self.forward_exact(x)
+            with _form(True):
+                return self.forward_fast(x)
         run = _run_of(x)
         # the flag word starts every checked pass at zero: a pass that was aborted between launch and check, or an earlier pass on
         # out-of-range data whose flag nobody looked at, must not send THIS frame to the exact form (ADVICE r4).  The host owns the
         # word here: the previous pass on this stream was synchronised with before its flag was read, or never read at all.
         torch.cuda.current_stream(x.device).synchronize()
         run.clear()
-        with _pinned_run(run):             # the whole pass on these words, whatever happens to the table meanwhile
+        with _pinned_run(run), _form(False):             # the whole pass on these words, whatever happens to the table meanwhile
             y = self.forward_fast(x)
         # "static" parameters bound every operand for images in the documented range only: an out-of-range or non-finite PIXEL still
         # overflows the stem's f16 split, and ReLU turns the NaNs into silent zeros -- so the flag is read for both classes
@@ -534,7 +534,8 @@ class ResUNet(nn.Module):
         return y
 
     def forward_fast(self, x):
-        """The split-f16 launch chain alone (what a HIP graph captures): the caller looks at the range flag."""
+        """The launch chain alone, in the arithmetic form the caller set (`_form`; fp32 by default) -- what a HIP graph captures.
+        In the split form the caller looks at the range flag."""
         y0, t0 = _conv_norm(self.conv1, self.bn1, x.float())      # bn1 + ReLU: applied by the two convolutions that read y0
         x1 = self.layer1[0](y0, t0)
         for unit in list(self.layer1)[1:]:
@@ -546,41 +547,30 @@ class ResUNet(nn.Module):
         return _conv(self.out_conv, x)
 
     def forward_exact(self, x):
-        """The same network (UNet.py:154-234) with fp32 operands everywhere: gpnerf_conv2d_nhwc_exact for the convolutions, every
-        InstanceNorm from a double-precision pass over its input.  No operand range; ~20x the split form's time."""
+        """The network (UNet.py:154-234) in the fp32 form, eagerly: what a split-precision frame falls back to when it raised the
+        range flag (`exact_frames` counts those calls).  The same launch chain as every "fp32" frame."""
         _require_gpu_inference(x, self.training)
         self.__dict__["exact_frames"] = self.exact_frames + 1
-        x = _norm_act(self.bn1, _conv_exact(self.conv1, x.float()), 1)
-        x1 = x
-        for unit in self.layer1:
-            x1 = unit.forward_exact(x1)
-        x2 = x1
-        for unit in self.layer2:
-            x2 = unit.forward_exact(x2)
-        x3 = x2
-        for unit in self.layer3:
-            x3 = unit.forward_exact(x3)
-        x = self.iconv3.forward_exact(_concat_skip(x2, self.upconv3.forward_exact(x3)))
-        x = self.iconv2.forward_exact(_concat_skip(x1, self.upconv2.forward_exact(x)))
-        return _conv_exact(self.out_conv, x)
+        with _form(True):
+            return self.forward_fast(x)
 
 
 class _EncoderGraph:
-    """One HIP graph of ResUNet.forward for one (input shape, device, parameter versions): the ~60 launches of a frame's encoding
-    replayed with ONE host call.  The kernels themselves take as long as before (1.3 ms at 3x512x512, and a replay is as
-    GPU-bound as the eager launches) -- what the graph removes is the ~1.4 ms the HOST needs to enqueue them one by one through
-    Python, during which it cannot prepare the rest of the frame: Renderer.render's device then idled ~0.7 ms per call waiting
-    for the frame build's launches (tools/probes/render_phases.py)."""
+    """One HIP graph of ResUNet.forward_fast for one (input shape, device, parameter versions, arithmetic form): the 55 launches of
+    a frame's encoding replayed with ONE host call.  The kernels themselves take as long as before (a replay is as GPU-bound as
+    the eager launches) -- what the graph removes is the ~1.4 ms the HOST needs to enqueue them one by one through Python, during
+    which it cannot prepare the rest of the frame (tools/probes/render_phases.py)."""
 
-    def __init__(self, net, x):
+    def __init__(self, net, x, exact):
         dev = x.device
+        self.exact = bool(exact)
         self.run = _Run(dev)                          # the graph's own ticket words and range flag (baked into its nodes)
         self.static_in = torch.empty(tuple(x.shape), device=dev, dtype=torch.float32)
         self.static_in.copy_(x)
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
-        with _pinned_run(self.run):
+        with _pinned_run(self.run), _form(self.exact):
             with torch.cuda.stream(side):             # eager warm-up: packs the weights, sets the kernels' LDS attributes
                 net.forward_fast(self.static_in)
                 net.forward_fast(self.static_in)
@@ -608,23 +598,26 @@ def _graph_key(net, x):
 
 
 def forward_graphed(net, x, defer_range_check=False):
-    """net(x) through a cached HIP graph (re-captured when the input shape, the device or any parameter changes).  Same bits as
-    the eager call (tests/test_encoder.py).  "Any parameter changes" = the storage pointer or the version counter of one of the
-    module's Parameter OBJECTS (load_state_dict, optimiser steps, .to(), in-place edits); the list of those objects is looked up
-    once -- after REPLACING a Parameter object (`net.conv1.weight = nn.Parameter(...)`) call `forget_graph(net)`.
-    Operand range (ResUNet.check_operand_range): "exact" parameters skip the graph; for "dynamic" ones the replay's range flag
-    decides -- here, after waiting for the stream, or, with defer_range_check=True, whenever the caller next synchronises anyway:
-    it then calls `range_check_pending(net)` and, on True, discards what it computed from the result and encodes again with
-    `net.forward_exact` (Renderer.render does this at the end of the call, so an in-range frame never waits for the encoder)."""
+    """net(x) through a cached HIP graph (re-captured when the input shape, the device, the arithmetic form or any parameter
+    changes).  Same bits as the eager call (tests/test_encoder.py).  "Any parameter changes" = the storage pointer or the version
+    counter of one of the module's Parameter OBJECTS (load_state_dict, optimiser steps, .to(), in-place edits); the list of those
+    objects is looked up once -- after REPLACING a Parameter object (`net.conv1.weight = nn.Parameter(...)`) call `forget_graph(net)`.
+    precision "fp32": that is all.  precision "split" (ResUNet.check_operand_range): parameters beyond the split's range take the
+    fp32 graph; otherwise the replay's range flag decides -- here, after waiting for the stream, or, with defer_range_check=True,
+    whenever the caller next synchronises anyway: the replay's `_Run` is then left in net.__dict__["_gpnerf_pending_run"] for the
+    caller to take (Renderer keeps it with the frame's record), and a raised flag means: discard what was computed from the
+    result and encode again with `net.forward_exact`."""
     _require_gpu_inference(x, net.training)
     key = _graph_key(net, x)
     cls = net.check_operand_range(x.shape[-2], x.shape[-1], params_key=key[3])
-    if cls == "exact":
-        return net.forward_exact(x)
-    hit = net.__dict__.get("_gpnerf_graph")
+    exact = cls == "exact"
+    slot = "_gpnerf_graph_f32" if exact else "_gpnerf_graph"
+    hit = net.__dict__.get(slot)
     if hit is None or hit[0] != key:
-        hit = (key, _EncoderGraph(net, x.float()))
-        net.__dict__["_gpnerf_graph"] = hit
+        hit = (key, _EncoderGraph(net, x.float(), exact))
+        net.__dict__[slot] = hit
+    if exact:
+        return hit[1](x)
     if net.__dict__.get("_gpnerf_pending_run") is None:
         hit[1].run.clear()                 # nothing in flight whose verdict is still owed: this replay starts from a zero flag
     y = hit[1](x)
@@ -652,9 +645,12 @@ def range_check_pending(net):
 def forget_graph(net):
     """Drop the cached graph and parameter list of `net` (see forward_graphed)."""
     net.__dict__.pop("_gpnerf_graph", None)
+    net.__dict__.pop("_gpnerf_graph_f32", None)
     net.__dict__.pop("_gpnerf_params", None)
 
 
-def build_encoder(cfg):
-    """Same cfg keys as UNet.py:236-242."""
-    return ResUNet(encoder=cfg.encoder.name, out_ch=cfg.encoder.out_ch)
+def build_encoder(cfg, precision="fp32"):
+    """Same cfg keys as UNet.py:236-242.  precision: the arithmetic form (plugins hip_encoder = "fp32", hip_encoder_fast = "split")."""
+    net = ResUNet(encoder=cfg.encoder.name, out_ch=cfg.encoder.out_ch)
+    net.precision = precision
+    return net

@@ -278,9 +278,15 @@ class Renderer(nn.Module):
         # go back to back.  (Round 2 fetched the constants before the encoder's first launch: the device idled ~0.3 ms per call.)
         # the encoder's time comes from two events on the stream instead of two host synchronisations around it
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        own_encoder = "featmaps" not in batch
+        if own_encoder:
+            self._settle_encoder_verdicts()        # (split precision only) every earlier pass's range verdict is read before the graph runs again
         ev0.record()                               # (also what the side stream waits for: the batch's tensors, NOT the encoder)
         featmaps = self.encode(batch, defer_range_check=True)
         ev1.record()
+        # the split-precision encoder's range flag of THIS pass (None in the default fp32 form, which has no range): kept with the
+        # frame's record, so that two frames in flight never read each other's verdict
+        enc_run = self.encoder.__dict__.pop("_gpnerf_pending_run", None) if isinstance(self.encoder, E_.ResUNet) else None
         self.nerfhead.head_blob(dev)                                   # (cached; packs on a parameter change)
         main = torch.cuda.current_stream(dev)
         sides = self.__dict__.setdefault("_side_streams", {})
@@ -334,16 +340,16 @@ class Renderer(nn.Module):
                     pw, ph = (8, 4) if self.early_term else (32, 8)
                     # (a mask that does not keep exactly the n pixels the rays belong to cannot order them: the kernels then leave
                     # list order -- decided on the device, reading the count on the host would be a synchronisation)
-                    if os.environ.get("GPNERF_DEBUG") == "1" and os.environ.get("GPNERF_PATCH_ORDER_TORCH") == "1":
-                        mb = m.bool()          # the same list from ~25 small library launches (the A/B of tools/time_survey_api.py)
-                        order = F_.patch_order_device(mb, Hs, Ws, patch_w=pw, patch_h=ph, n_kept=n)
-                        order = torch.where(mb.sum() == n, order, torch.arange(n, device=dev, dtype=order.dtype))
-                    else:
-                        order = F_.patch_order_rays(m, Hs, Ws, n, patch_w=pw, patch_h=ph)
+                    order = F_.patch_order_rays(m, Hs, Ws, n, patch_w=pw, patch_h=ph)
         main.wait_stream(side)
         _record_on(main, rays, order)
-        return Prefetched(batch=batch, frame=frame, rays=rays, order=order, n=n, neg=neg, ev0=ev0, ev1=ev1, group=group,
-                          keep=(featmaps, consts, prepared, imgs4), own_encoder="featmaps" not in batch)
+        p = Prefetched(batch=batch, frame=frame, rays=rays, order=order, n=n, neg=neg, ev0=ev0, ev1=ev1, group=group,
+                       keep=(featmaps, consts, prepared, imgs4), own_encoder=own_encoder, enc_run=enc_run)
+        if enc_run is None:
+            p.flagged = False                      # nothing can have left a range
+        else:
+            self.__dict__.setdefault("_enc_outstanding", []).append(p)
+        return p
 
     def host_consts(self, batch):
         """The frame's small constants (camera matrices, Rh, Th, bounds, out_sh) on the host: ONE device-to-host copy (none for
@@ -351,9 +357,20 @@ class Renderer(nn.Module):
         kernel is in flight (evaluator.evaluate_loop does)."""
         return F_.Frame.consts_of_batch(batch, self.voxel_size)
 
-    def _encoder_flagged(self):
-        """True when the last deferred encoder pass left the split-f16 operand range (its stream has been synchronised)"""
-        return isinstance(self.encoder, E_.ResUNet) and E_.range_check_pending(self.encoder)
+    def _settle_encoder_verdicts(self):
+        """Split-precision encoder only: the encoder's HIP graph has ONE range flag, so the verdict of every pass still in flight
+        is read -- in the order the passes were enqueued, each after waiting for ITS encoder to finish (the event behind it, not
+        the frame's per-ray kernel) -- before the graph is replayed again or a frame's result is trusted.  A raised flag is cleared
+        once its frame has taken it.  (Round 5 kept one pending flag per module: render(next_batch=...) on a frame that was not
+        itself prefetched then let two frames share it.)"""
+        pending = self.__dict__.get("_enc_outstanding")
+        while pending:
+            q = pending.pop(0)
+            q.ev1.synchronize()
+            q.flagged = bool(q.enc_run.raised())
+            if q.flagged:
+                q.enc_run.clear()
+            q.enc_run = None
 
     def prefetch(self, batch, after=None):
         """Enqueue everything of `batch`'s frame that comes before the per-ray kernel (`_produce`) on a stream of its own and return
@@ -374,11 +391,6 @@ class Renderer(nn.Module):
         prod = self.__dict__.get("_prod_stream")
         if prod is None or prod.device != dev:
             prod = self.__dict__["_prod_stream"] = torch.cuda.Stream(device=dev)
-        # the encoder's graph has ONE range flag: the previous prefetch's verdict is read before the graph runs again
-        prev = self.__dict__.get("_last_prefetch")
-        if prev is not None and prev.flagged is None:
-            prod.synchronize()
-            prev.flagged = self._encoder_flagged() if prev.own_encoder else False
         t0 = time.time()
         if after is not None:
             prod.wait_event(after)
@@ -386,11 +398,10 @@ class Renderer(nn.Module):
             prod.wait_stream(cur)                  # whatever produced the batch's tensors on the caller's stream
         with torch.cuda.stream(prod):
             p = self._produce(batch)
-            p.done = torch.cuda.Event()
+            p.done = torch.cuda.Event(enable_timing=True)
             p.done.record(prod)
         p.stream = prod
         p.host_s = time.time() - t0
-        self.__dict__["_last_prefetch"] = p
         return p
 
     def render(self, batch, prefetched=None, next_batch=None):
@@ -440,14 +451,16 @@ class Renderer(nn.Module):
         t2 = time.time()
         # etime = the encoder alone, rtime = everything else of the call (demo_render.py:441-446,494-497 keeps these two clocks;
         # BaseTrainer.py:276 sums rtime): the encoder's share is its device time between the two events.  With a prefetched frame
-        # the encoder ran before the call: rtime = the call's wall time + the host time prefetch() took to enqueue the frame.
+        # the producers ran before the call, on their own stream: rtime = the call's wall time (the per-ray kernel) + the DEVICE
+        # time of everything the producer stream ran behind the encoder (volume builder, re-layouts, ray list: ev1 .. done), so
+        # that it still measures what the reference's rtime measures -- everything of the frame but the encoder.
         etime = p.ev0.elapsed_time(p.ev1) * 1e-3
-        rtime = max(0.0, (t2 - te) - etime) if prefetched is None else (t2 - te) + p.host_s
-        flagged = p.flagged
-        if flagged is None:
-            flagged = p.flagged = self._encoder_flagged() if p.own_encoder else False
-        if sharded and p.own_encoder:
-            # every rank encoded ITS views: one rank's flag is every rank's (the re-render below issues collectives, so the ranks
+        rtime = max(0.0, (t2 - te) - etime) if prefetched is None else (t2 - te) + p.ev1.elapsed_time(p.done) * 1e-3
+        if p.flagged is None:
+            self._settle_encoder_verdicts()
+        flagged = bool(p.flagged)
+        if sharded and p.own_encoder and getattr(self.encoder, "precision", "split") != "fp32":
+            # (split-precision encoder only) every rank encoded ITS views: one rank's flag is every rank's (the re-render below issues collectives, so the ranks
             # must take the same branch) -- one 4-byte all-reduce per frame
             fl = torch.tensor([1 if flagged else 0], dtype=torch.int32, device=rays.device if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)
@@ -488,7 +501,7 @@ class Prefetched:
     and (prefetch()) the event that ends the producer stream's work.  `flagged`: the encoder's range verdict once it is known."""
 
     def __init__(self, **kw):
-        self.done, self.stream, self.host_s, self.flagged = None, None, 0.0, None
+        self.done, self.stream, self.host_s, self.flagged, self.enc_run = None, None, 0.0, None, None
         self.__dict__.update(kw)
 
 

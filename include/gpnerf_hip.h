@@ -397,16 +397,24 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
 
 /* The image encoder on channels-last activations (gpnerf_conv.hip), all tensors device fp32 [N][H][W][C].
  * conv2d_nhwc = nn.Conv2d(cin, cout, ks, stride, padding=ks/2, padding_mode='reflect') (UNet.py:6-14,108-115,154-155) as an
- *   implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32 operands split into f16 hi + lo (three MFMAs per k-step, f32
- *   accumulation; operands must stay below the f16 range, which InstanceNorm'd / ReLU'd activations of images do).
+ *   implicit GEMM on the matrix cores, in one of two arithmetic forms chosen by `exact` (the SAME kernels, tiles, staging and
+ *   fused InstanceNorm tables either way; `packed` must be the image gpnerf_conv_pack_weight wrote for that form):
+ *     exact = 1  fp32 operands on v_mfma_f32_32x32x2_f32: every dot product an fp32 FMA chain over (channel block, tap, channel),
+ *                the reference's own arithmetic up to the order of the sum; no operand range, range_flag is not looked at.  The
+ *                encoder's default (ResUNet.precision = "fp32"): the end-to-end chain then stays inside 1e-4 of the reference.
+ *     exact = 0  fp32 operands split into f16 hi + lo on v_mfma_f32_32x32x16_f16 (three MFMAs per k-step, f32 accumulation:
+ *                ~23 bits per operand, 3/16 of the matrix time); operands must stay below the f16 range, which InstanceNorm'd /
+ *                ReLU'd activations of images do -- see range_flag.  The fast mode (ResUNet.precision = "split").
  *   ks in {1, 3, 7}, stride in {1, 2}; cin a multiple of 16, or < 8 for the 7x7/2 stem; cout a multiple of 4.
  *   packed: gpnerf_conv_pack_weight()'s device image of the PyTorch weight [cout][cin][ks][ks] (gpnerf_conv_packed_bytes()
  *   bytes; re-pack when the parameter changes); bias: [cout] or NULL.  y: [N][Ho][Wo][cout], Ho = (H + 2 (ks/2) - ks) / stride + 1.
- *   tile_stats: NULL, or [N][gpnerf_conv_out_tiles()][cout][2] floats that receive every workgroup tile's per-channel sum and
- *   sum of squares of the outputs -- the statistics the InstanceNorm behind the convolution needs, without re-reading y.
+ *   tile_stats: NULL, or [N][gpnerf_conv_out_tiles()][cout][3] floats that receive every workgroup tile's per-channel sum, sum of
+ *   squares, and M2 (sum of squares about the tile's own mean) of the outputs -- the statistics the InstanceNorm behind the
+ *   convolution needs, without re-reading y.  out_table below takes the variance as E[y^2] - mean^2 from the sums where that is
+ *   well conditioned and from the M2's (merged as Chan et al.) on a channel whose values are nearly constant over the image.
  * instance_norm_act_nhwc = act(InstanceNorm2d(x; gamma, beta, eps, biased variance, no running statistics) [+ residual]),
- *   act 0 none / 1 ReLU / 2 ELU (UNet.py:38-53,117-120,180-183); statistics from tile_stats (n_tiles rows per image) when
- *   given, else from a pass over x; either way added up in double in a fixed order (deterministic);
+ *   act 0 none / 1 ReLU / 2 ELU (UNet.py:38-53,117-120,180-183); statistics from a double-precision pass over x, added up in a
+ *   fixed order (deterministic): the stand-alone operator, what the fused tables of conv2d_norm_nhwc are tested against;
  *   scratch: gpnerf_instance_norm_nhwc_scratch_bytes() bytes.
  * conv2d_norm_nhwc = conv2d_nhwc with the InstanceNorms on either side of it fused in (a residual unit is conv - norm - ReLU -
  *   conv - norm, UNet.py:38-53):
@@ -414,7 +422,7 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
  *               convolution then reads act((x - mean) * scale + beta) instead of x while it stages its input, act = ReLU for
  *               in_act 1, identity for 0 -- the normalised tensor is never written.  3x3 and 1x1 convolutions with cin % 16 == 0.
  *     out_table NULL, or [N][3][cout] floats that receive mean / gamma * rstd / beta of InstanceNorm2d(y; gamma, beta, eps): the
- *               last workgroup to finish an (image, 32..64-channel group) adds that group's tile_stats rows in double, in tile
+ *               last workgroup to finish an (image, 32..64-channel group) merges that group's tile_stats rows in double, in a fixed
  *               order (deterministic), so no separate reduction launch follows the convolution.  Needs tile_stats, gamma, beta and
  *               `counters`: at least N * ceil(cout / 32) uint32 words that are zero before the call; they are zero again after it.
  * conv2d_norm_cat_nhwc = the 3x3 stride-1 convolution of conv2d_norm_nhwc on the channel concatenation [x (cin_a channels), x_b (cin_b)]
@@ -423,7 +431,7 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
  * norm_apply_nhwc = act((x - mean) * scale + beta [+ residual]) from such a table; with res_table the residual is itself
  *   normalised on the fly ((residual - rmean) * rscale + rbeta: the projected shortcut's InstanceNorm, UNet.py:48-51).
  * upsample2x_nhwc = F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (UNet.py:129).
- * range_flag (the three split-f16 convolutions): NULL, or ONE uint32 word (device memory, or pinned host memory the device can
+ * range_flag (the three convolutions, exact = 0 only): NULL, or ONE uint32 word (device memory, or pinned host memory the device can
  *   write) that the call sets to 1 -- it never clears it -- when an operand was beyond what the f16 hi/lo split holds (an
  *   activation with |x| >= 4095, a weight with |w| >= 16, or a non-finite input): such an operand splits into f16 infinities and
  *   the outputs it meets are NaN, which the call finds in the sums of the InstanceNorm table (out_table given) or in its
@@ -431,32 +439,29 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
  *   again through conv2d_nhwc_exact, so that parameters of any size are served (a trained InstanceNorm scale times sqrt(h w) can
  *   exceed the range on a one-hot image; ordinary images stay orders of magnitude below it).
  * conv2d_nhwc_exact = the same nn.Conv2d on fp32 operands (v_mfma_f32_32x32x2_f32, an fp32 FMA chain per output, any odd ks,
- *   any stride, any channel counts), from the PyTorch weight [cout][cin][ks][ks] as it is: the fall-back form, ~20x slower. */
+ *   any stride, any channel counts), from the PyTorch weight [cout][cin][ks][ks] as it is, one scalar load per operand: the
+ *   independent restatement the tests hold the fused exact = 1 form against (and a way to run shapes the fused kernels do not
+ *   cover); ~20x slower, not on the encoder's path. */
 int64_t gpnerf_conv_packed_bytes(int32_t cout, int32_t cin, int32_t ks);
-int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, void* packed, void* stream);
+int gpnerf_conv_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ks, int32_t exact, void* packed, void* stream);
 int32_t gpnerf_conv_out_tiles(int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t stride);
 int gpnerf_conv2d_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const void* packed, const float* bias,
-                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, uint32_t* range_flag, void* stream);
+                       int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats, uint32_t* range_flag, int32_t exact,
+                       void* stream);
 int gpnerf_conv2d_norm_cat_nhwc(const float* x, int32_t cin_a, const float* x_b, int32_t cin_b, int32_t n, int32_t h, int32_t w,
                                 const void* packed, const float* bias, int32_t cout, float* y, float* tile_stats, const float* gamma,
-                                const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag, void* stream);
+                                const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag, int32_t exact,
+                                void* stream);
 int gpnerf_conv2d_norm_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* in_table, int32_t in_act,
                             const void* packed, const float* bias, int32_t cout, int32_t ks, int32_t stride, float* y, float* tile_stats,
                             const float* gamma, const float* beta, float eps, float* out_table, uint32_t* counters, uint32_t* range_flag,
-                            void* stream);
+                            int32_t exact, void* stream);
 int gpnerf_conv2d_nhwc_exact(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* weight, const float* bias,
                              int32_t cout, int32_t ks, int32_t stride, float* y, void* stream);
-/* The same exact convolution from a re-laid-out weight image (round 5: ~10x the rate; Cin a multiple of 16 -- every convolution of
- * the ResUNet but the stem): gpnerf_conv_exact_packed_bytes() bytes (0 = no tiled form for this shape, use gpnerf_conv2d_nhwc_exact),
- * written by gpnerf_conv_pack_weight_exact from the PyTorch weight [Cout][Cin][KS][KS] (device), once per parameter change. */
-int64_t gpnerf_conv_exact_packed_bytes(int32_t cout, int32_t cin, int32_t ks);
-int gpnerf_conv_pack_weight_exact(const float* weight, int32_t cout, int32_t cin, int32_t ks, float* packed, void* stream);
-int gpnerf_conv2d_nhwc_exact_packed(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, const float* packed, const float* bias,
-                                    int32_t cout, int32_t ks, int32_t stride, float* y, void* stream);
 int gpnerf_norm_apply_nhwc(const float* x, const float* table, const float* residual, const float* res_table, int32_t n, int64_t hw,
                            int32_t c, int32_t act, float* out, void* stream);
 int64_t gpnerf_instance_norm_nhwc_scratch_bytes(int32_t n, int64_t hw, int32_t c);
-int gpnerf_instance_norm_act_nhwc(const float* x, const float* tile_stats, int32_t n_tiles, const float* gamma, const float* beta,
+int gpnerf_instance_norm_act_nhwc(const float* x, const float* gamma, const float* beta,
                                   const float* residual, int32_t n, int64_t hw, int32_t c, float eps, int32_t act, float* out,
                                   void* scratch, void* stream);
 int gpnerf_upsample2x_nhwc(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* out, void* stream);

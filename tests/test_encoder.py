@@ -30,11 +30,16 @@ syn = importlib.import_module("gp-nerf_amd.synthetic")
 enc = importlib.import_module("gp-nerf_amd.encoder")
 
 
-def _net(seed):
+def _net(seed, precision="fp32"):
+    """precision: the arithmetic form of the convolutions (ResUNet.precision): "fp32" = the default, "split" = the fast mode"""
     state = syn.make_encoder_weights(seed)
     net = enc.ResUNet(encoder="resnet34", out_ch=32)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)   # key + shape map
+    net.precision = precision
     return net.eval(), state
+
+
+PRECISIONS = ["fp32", "split"]
 
 
 def _sha(imgs, state):
@@ -54,7 +59,12 @@ def test_state_dict_keys_follow_the_table():
 
 def test_build_encoder_cfg_keys_and_rejected_names():
     cfg = types.SimpleNamespace(encoder=types.SimpleNamespace(name="resnet34", out_ch=32, file="hip_encoder"))
-    assert isinstance(enc.build_encoder(cfg), enc.ResUNet)
+    net = enc.build_encoder(cfg)
+    assert isinstance(net, enc.ResUNet) and net.precision == "fp32"           # the default: the reference's arithmetic
+    assert enc.build_encoder(cfg, precision="split").precision == "split"     # `encoder.file hip_encoder_fast`
+    with pytest.raises(ValueError):
+        net.precision = "bf16"
+    assert "precision" not in "".join(net.state_dict().keys()) and len(net.state_dict()) == 108
     with pytest.raises(ValueError):
         enc.ResUNet(encoder="resnet50")     # the reference's own forward fails for the wide names (skip widths)
 
@@ -74,21 +84,22 @@ def test_encoder_restatement_matches_reference_golden_cpu(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", encoder_case_names())
-def test_encoder_on_gpu_feeds_frame_without_relayout(name):
-    """The hand-written convolutions (gpnerf_conv.hip: split-f16 MFMA implicit GEMMs, their own summation order) stay inside
+def test_encoder_on_gpu_feeds_frame_without_relayout(name, precision):
+    """The hand-written convolutions (gpnerf_conv.hip: MFMA implicit GEMMs in either arithmetic form, their own summation order) stay inside
     north_star's 1e-4 of the reference vectors, including the 512x512 case (128x128 feature maps, K up to 2 304, InstanceNorm
     reductions over up to 65 536 pixels: the size BASELINE configs[4] encodes at); and the output is physically [V,h,w,32],
     which Frame takes by pointer."""
     fm = importlib.import_module("gp-nerf_amd.frame")
     z, meta = load(name)
-    net, _ = _net(meta["seed"])
+    net, _ = _net(meta["seed"], precision)
     net = net.to("cuda:0")
     imgs = torch.from_numpy(syn.make_encoder_images(meta["H"], meta["W"], meta["seed"])).to("cuda:0")
     with torch.no_grad():
         out = net(imgs)
     err = check_featmaps(out.cpu().numpy(), z, 1e-4)
-    print(f"{name}: encoder max-abs vs the reference vector {err:.3e}")
+    print(f"{name} ({precision}): encoder max-abs vs the reference vector {err:.3e}")
     assert out.is_contiguous(memory_format=torch.channels_last)
     sc = syn.make_scene(H=meta["H"], W=meta["W"], seed=1, aabb_half=(0.12, 0.16, 0.05))
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
@@ -122,11 +133,13 @@ def test_encoder_restatement_on_trained_like_parameters_cpu():
 
 
 @pytest.mark.gpu
-def test_encoder_on_trained_like_parameters():
-    """The split-f16 encoder on the same parameters (at 96 x 128 scales of 6 still pass the parameter-only bound; at 512 x 512 they
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_encoder_on_trained_like_parameters(precision):
+    """The encoder (both forms; for the split form:) on the same parameters (at 96 x 128 scales of 6 still pass the parameter-only bound; at 512 x 512 they
     would be "dynamic", which test_trained_sized_norm_scales_are_served_not_refused covers): no exact pass, and the result is
     within max(1e-4, 2 x the reference's own float32-vs-float64 distance) of the reference's."""
     z, meta, net, imgs = _trained_net()
+    net.precision = precision
     net = net.to("cuda:0")
     with torch.no_grad():
         out = net(torch.from_numpy(imgs).to("cuda:0"))
@@ -138,13 +151,14 @@ def test_encoder_on_trained_like_parameters():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("H,W", [(100, 140), (136, 72), (200, 264), (52, 60)])
-def test_encoder_at_sizes_that_pad_the_skips_and_leave_ragged_tiles(H, W):
+def test_encoder_at_sizes_that_pad_the_skips_and_leave_ragged_tiles(H, W, precision):
     """Sizes that are not multiples of 8: the decoder pads its skip tensors (UNet.py:199-211), every layer has ragged workgroup
     tiles (stem and stride-2 patches hanging over the image, reflection at both borders), and the concatenations are read in
     place.  Checked against the float64 run of the torch-operator restatement (which the golden vectors pin to the reference)."""
     from oracle import producers_ref as ref
-    net, _ = _net(H + W)
+    net, _ = _net(H + W, precision)
     imgs = torch.from_numpy(syn.make_encoder_images(H, W, H * W))
     with torch.no_grad():
         want = ref.encoder(__import__("copy").deepcopy(net).double(), imgs.double()).float().numpy()
@@ -157,11 +171,12 @@ def test_encoder_at_sizes_that_pad_the_skips_and_leave_ragged_tiles(H, W):
 
 
 @pytest.mark.gpu
-def test_encoder_is_bit_deterministic_at_full_size():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_encoder_is_bit_deterministic_at_full_size(precision):
     """Three forwards of a 3x512x512 frame give the same bits (every reduction of the kernels has a fixed order, and no result
     may depend on how the wavefronts of a CU interleave): a timing-dependent difference would mean an MFMA result is being read
     before it is complete."""
-    net, _ = _net(3)
+    net, _ = _net(3, precision)
     net = net.to("cuda:0")
     imgs = torch.from_numpy(syn.make_encoder_images(512, 512, 3)).to("cuda:0")
     with torch.no_grad():
@@ -171,19 +186,21 @@ def test_encoder_is_bit_deterministic_at_full_size():
 
 
 @pytest.mark.gpu
-def test_encoder_through_a_hip_graph_gives_the_eager_bits_and_follows_its_parameters():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_encoder_through_a_hip_graph_gives_the_eager_bits_and_follows_its_parameters(precision):
     """forward_graphed: one replay instead of ~60 launches; re-captured when the input shape or a parameter changes; the result is
     the caller's own tensor (a later replay must not change it)."""
-    net, _ = _net(5)
+    net, _ = _net(5, precision)
     net = net.to("cuda:0")
+    slot = "_gpnerf_graph_f32" if precision == "fp32" else "_gpnerf_graph"
     a = torch.from_numpy(syn.make_encoder_images(96, 128, 5)).to("cuda:0")
     b = torch.from_numpy(syn.make_encoder_images(96, 128, 6)).to("cuda:0")
     with torch.no_grad():
         ea, eb = net(a), net(b)
         ga = enc.forward_graphed(net, a)
-        g1 = net.__dict__["_gpnerf_graph"][1]
+        g1 = net.__dict__[slot][1]
         gb = enc.forward_graphed(net, b)
-        assert net.__dict__["_gpnerf_graph"][1] is g1                      # same shape, same parameters: the same graph
+        assert net.__dict__[slot][1] is g1                                 # same shape, same parameters: the same graph
         assert torch.equal(ga, ea) and torch.equal(gb, eb) and ga.is_contiguous(memory_format=torch.channels_last)
         c = torch.from_numpy(syn.make_encoder_images(64, 64, 7)).to("cuda:0")
         assert torch.equal(enc.forward_graphed(net, c), net(c))            # other shape: re-captured
@@ -191,6 +208,14 @@ def test_encoder_through_a_hip_graph_gives_the_eager_bits_and_follows_its_parame
         net.out_conv.bias.add_(0.25)
         assert torch.equal(enc.forward_graphed(net, c), net(c))            # parameters changed: re-packed and re-captured
         assert torch.equal(ga, ea)                                         # earlier results untouched
+        # the other arithmetic form is another graph, and the two agree to the split's ~23 bits per operand
+        other = "split" if precision == "fp32" else "fp32"
+        net.precision = other
+        oc = enc.forward_graphed(net, c)
+        assert torch.equal(oc, net(c))
+        net.precision = precision
+        mine = enc.forward_graphed(net, c)
+        assert 0.0 < float((oc - mine).abs().max()) < 1e-4
 
 
 def test_operand_range_classes_come_from_the_parameters_and_never_refuse():
@@ -201,6 +226,8 @@ def test_operand_range_classes_come_from_the_parameters_and_never_refuse():
     frame, forward_exact re-encodes a flagged one), "exact" for weights beyond 16.  Round 3 RAISED in the last two cases, which
     turned an ordinary trained InstanceNorm scale (>= 8 at 512x512, >= 4 at 1024x1024) into an unloadable checkpoint."""
     net, _ = _net(3)
+    assert net.check_operand_range(512, 512) == "exact"                 # the default form has no operand range: nothing to classify
+    net.precision = "split"
     assert net.check_operand_range(512, 512) == "static" and net.range_report is None
     assert net.check_operand_range(1024, 1024) == "static"              # the reference's full-resolution images
     with torch.no_grad():
@@ -246,7 +273,7 @@ def test_trained_sized_norm_scales_are_served_not_refused(size, gamma):
     form's range ("dynamic"); on an ordinary image nothing leaves it: the split form's result stands (no exact pass, no flag) and
     matches the float64 run of the restatement.  Tolerance: 1e-4 of the output's scale -- the LAST norm multiplies every absolute
     error by its gamma, the reference's own float32 included."""
-    net, _ = _net(11)
+    net, _ = _net(11, "split")
     _set_norm_scales(net, gamma, 0.1)
     net = net.to("cuda:0")
     imgs = torch.from_numpy(syn.make_encoder_images(size, size, 11))
@@ -279,7 +306,7 @@ def test_a_frame_that_leaves_the_split_range_is_encoded_exactly():
     it raises the range flag (a NaN sum in its norm table), the pass is discarded and the frame encoded by forward_exact: eager
     call, graph replay and the deferred check all end up with the float64 restatement's values; the next ordinary frame takes the
     split form again.  Also: forward_exact on ordinary parameters agrees with the split form to 1e-4."""
-    net, _ = _net(4)
+    net, _ = _net(4, "split")
     net = net.to("cuda:0")
     ordinary = torch.from_numpy(syn.make_encoder_images(256, 256, 4)).to("cuda:0")
     with torch.no_grad():
@@ -302,6 +329,11 @@ def test_a_frame_that_leaves_the_split_range_is_encoded_exactly():
         # (the discarded pass itself may look finite: ReLU maps the NaNs of a poisoned channel to 0 -- the flag is the signal)
         assert float((g3 - got).abs().max()) > 1e-2 * scale
         assert enc.range_check_pending(net) and not enc.range_check_pending(net)
+        # the default form needs none of this: the same frame, first time, no flag, no second pass
+        net.precision = "fp32"
+        direct = enc.forward_graphed(net, hot.to("cuda:0"), defer_range_check=True)
+        assert net.exact_frames == n0 + 2 and "_gpnerf_pending_run" not in net.__dict__ and torch.equal(direct, got)
+        net.precision = "split"
         again = net(ordinary)                         # the flag does not stick: the next ordinary frame runs the split form
         assert net.exact_frames == n0 + 2 and bool(torch.isfinite(again).all())
     err = float(np.abs(got.cpu().numpy() - want).max())
@@ -315,7 +347,7 @@ def test_an_out_of_range_image_is_caught_whatever_the_parameter_class():
     the split's 4 094) or a non-finite one used to come back as finite, wrong feature maps (ReLU turns the poisoned channel's NaNs into
     zeros).  The flag is now read for every class -- eager call, graph replay, deferred check -- and the frame takes the exact form;
     a stale flag from a pass nobody checked does not send the NEXT frame there."""
-    net, _ = _net(8)
+    net, _ = _net(8, "split")
     net = net.to("cuda:0")
     assert net.check_operand_range(96, 128) == "static"
     ordinary = torch.from_numpy(syn.make_encoder_images(96, 128, 8)).to("cuda:0")
@@ -337,7 +369,8 @@ def test_an_out_of_range_image_is_caught_whatever_the_parameter_class():
         net.__dict__.pop("_gpnerf_pending_run", None)                 # (a caller that never called range_check_pending)
         n1 = net.exact_frames
         again = enc.forward_graphed(net, ordinary)                    # the next ordinary frame starts from a zero flag
-        assert net.exact_frames == n1 and torch.equal(again, net.forward_fast(ordinary))
+        with enc._form(False):
+            assert net.exact_frames == n1 and torch.equal(again, net.forward_fast(ordinary))
         nan_img = ordinary.clone()
         nan_img[0, 0, 3, 3] = float("nan")
         net(nan_img)
@@ -346,7 +379,7 @@ def test_an_out_of_range_image_is_caught_whatever_the_parameter_class():
 
 @pytest.mark.gpu
 def test_weights_beyond_the_split_range_take_the_exact_form():
-    net, _ = _net(6)
+    net, _ = _net(6, "split")
     with torch.no_grad():
         net.layer1[1].conv1.weight[3, 5, 1, 1] = 40.0
     net = net.to("cuda:0")
@@ -355,7 +388,8 @@ def test_weights_beyond_the_split_range_take_the_exact_form():
     with torch.no_grad():
         got = net(imgs.to("cuda:0"))
         g2 = enc.forward_graphed(net, imgs.to("cuda:0"))
-    assert net.exact_frames == 2 and torch.equal(got, g2)
+    # (parameters beyond the split's range run the fp32 form's launch chain and graph from the start: no wasted pass, nothing counted)
+    assert net.exact_frames == 0 and torch.equal(got, g2) and "_gpnerf_graph_f32" in net.__dict__ and "_gpnerf_graph" not in net.__dict__
     want = _float64_encoder(net, imgs)
     err = float(np.abs(got.cpu().numpy() - want).max())
     assert err < 1e-4 * max(1.0, float(np.abs(want).max())), err

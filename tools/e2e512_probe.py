@@ -24,17 +24,18 @@ with torch.no_grad():
     cpu_net = importlib.import_module("gp-nerf_amd.encoder").ResUNet()
     cpu_net.load_state_dict({k: v.cpu() for k, v in r.encoder.state_dict().items()})
     fm_ref = ref.encoder(cpu_net.eval(), torch.from_numpy(sc["src_imgs"][0]))
+    r.encoder.precision = "split"
     fm_gpu = r.encoder(b["src_imgs"][0])
     d = (fm_gpu.cpu() - fm_ref).abs()
     print("encoder gpu vs cpu restatement: max", float(d.max()), "mean", float(d.mean()), "absmax value", float(fm_ref.abs().max()))
     print("  per view max", [float(d[v].max()) for v in range(3)])
     print("  cpu restatement vs fixture subset", float((fm_ref[:, :, ::4, ::4] - torch.from_numpy(z["featmaps_sub"])).abs().max()))
-    r.encoder.strict_exact = True
+    r.encoder.precision = "fp32"
     fm_exact = r.encoder(b["src_imgs"][0])
-    r.encoder.strict_exact = False
+    r.encoder.precision = "split"
     de = (fm_exact.cpu() - fm_ref).abs()
-    print("exact (fp32-MFMA) encoder vs cpu restatement: max", float(de.max()), "mean", float(de.mean()))
-    for name, fm in (("gpu-encoder", None), ("gpu exact encoder (GPNERF_ENCODER_EXACT=1)", fm_exact), ("cpu-restatement featmaps", fm_ref.to("cuda:0"))):
+    print("fp32-precision encoder vs cpu restatement: max", float(de.max()), "mean", float(de.mean()))
+    for name, fm in (("gpu-encoder precision split", None), ("gpu encoder precision fp32 (default)", fm_exact), ("cpu-restatement featmaps", fm_ref.to("cuda:0"))):
         bb = dict(b)
         if fm is not None:
             bb["featmaps"] = fm

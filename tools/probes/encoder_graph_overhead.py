@@ -9,7 +9,7 @@ net = enc.ResUNet(); net.load_state_dict({k: torch.from_numpy(v) for k, v in syn
 imgs = torch.from_numpy(syn.make_encoder_images(512, 512, 3)).to(dev)
 with torch.no_grad():
     enc.forward_graphed(net, imgs)
-    g = net.__dict__["_gpnerf_graph"][1]
+    g = net.__dict__["_gpnerf_graph_f32" if net.precision == "fp32" else "_gpnerf_graph"][1]
     ev = lambda: torch.cuda.Event(enable_timing=True)
     acc = [0.0, 0.0, 0.0, 0.0]
     n = 30

@@ -1,5 +1,6 @@
-"""ResUNet.forward_exact on 3 x 512 x 512: the tiled fp32-MFMA convolutions (round 5) against the untiled form (GPNERF_DEBUG=1
-GPNERF_EXACT_UNTILED=1), the split-f16 graph for scale, and the distance of each from the float64 torch-CPU restatement."""
+"""The image encoder's two arithmetic forms on 3 x 512 x 512 (ResUNet.precision): "fp32" (default: fp32 operands on the fp32 MFMA, the
+fused launch chain as one HIP graph) against "split" (f16 hi/lo operands), and the distance of each from the float64 torch-CPU
+restatement; the fp32 form against the independent per-operand restatement gpnerf_conv2d_nhwc_exact on one layer."""
 import importlib, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,11 +16,12 @@ net.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_encoder_weights
 imgs = torch.from_numpy(syn.make_encoder_images(size, size, 11))
 with torch.no_grad():
     want = ref.encoder(importlib.import_module("copy").deepcopy(net).double(), imgs.double()).numpy()
+    want32 = ref.encoder(net, imgs).numpy()
 net = net.to(dev)
 x = imgs.to(dev)
 
 
-def timed(fn, n=5):
+def timed(fn, n=20):
     with torch.no_grad():
         out = fn(); fn()
         torch.cuda.synchronize()
@@ -30,8 +32,11 @@ def timed(fn, n=5):
     return (time.perf_counter() - t0) / n * 1e3, out
 
 
-ms, out = timed(lambda: net.forward_exact(x))
-print(f"forward_exact ({'untiled' if os.environ.get('GPNERF_EXACT_UNTILED') == '1' else 'tiled'}) 3x{size}x{size}: {ms:.2f} ms; max-abs vs float64 {np.abs(out.cpu().numpy() - want).max():.2e} "
-      f"(output range {np.abs(want).max():.2f})")
-ms2, out2 = timed(lambda: E.forward_graphed(net, x), 20)
-print(f"split-f16 graph: {ms2:.2f} ms; max-abs vs float64 {np.abs(out2.cpu().numpy() - want).max():.2e}")
+print(f"reference arithmetic (torch CPU float32) vs float64: max {np.abs(want32 - want).max():.2e} mean {np.abs(want32 - want).mean():.2e}")
+for prec in ("fp32", "split"):
+    net.precision = prec
+    ms_e, out_e = timed(lambda: net(x), 5)
+    ms, out = timed(lambda: E.forward_graphed(net, x))
+    o = out.cpu().numpy()
+    print(f"precision {prec}: graph {ms:.3f} ms, eager {ms_e:.2f} ms; vs float64 max {np.abs(o - want).max():.2e} mean {np.abs(o - want).mean():.2e}; "
+          f"vs the reference's float32 arithmetic max {np.abs(o - want32).max():.2e} mean {np.abs(o - want32).mean():.2e}; graph == eager {bool(torch.equal(out, out_e))}")
