@@ -27,12 +27,23 @@ def fetch_host(*items):
     dev = [i for i, t in enumerate(items) if isinstance(t, torch.Tensor) and t.is_cuda]
     out = [None] * len(items)
     if dev:
-        flat = torch.cat([items[i].detach().reshape(-1).to(torch.float64) for i in dev]).cpu().numpy()
-        pos = 0
-        for i in dev:
-            n = items[i].numel()
-            out[i] = flat[pos:pos + n].reshape(tuple(items[i].shape))
-            pos += n
+        # float32 tensors travel as they are (the widening to float64 is exact and happens on the host: a cast per item on the
+        # device was six launches per frame); anything else (int64 out_sh, float64 cameras) is widened on the device first
+        f32 = [i for i in dev if items[i].dtype == torch.float32]
+        rest = [i for i in dev if items[i].dtype != torch.float32]
+        for group, widen in ((f32, False), (rest, True)):
+            if not group:
+                continue
+            parts = [items[i].detach().reshape(-1) for i in group]
+            if widen:
+                parts = [p.to(torch.float64) for p in parts]
+            cat = parts[0] if len(parts) == 1 else torch.cat(parts)
+            flat = cat.cpu().numpy().astype(np.float64)
+            pos = 0
+            for i in group:
+                n = items[i].numel()
+                out[i] = flat[pos:pos + n].reshape(tuple(items[i].shape))
+                pos += n
     for i, t in enumerate(items):
         if out[i] is None:
             out[i] = (t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)).astype(np.float64)
@@ -125,30 +136,25 @@ class Frame:
         # K4 @ P4 in fp32, as train_intrinsics.bmm(train_poses) does (BaseRender.py:233-247,314)
         Ks_h, poses_h, Rh_h, Th_h, bmin_h, vox_h, osh_h = consts if consts is not None else fetch_host(src_Ks, src_poses, Rh, Th, bounds_min,
                                                                                                           voxel_size, out_sh)
-        K4 = torch.eye(4, dtype=torch.float32).repeat(V, 1, 1)
-        K4[:, :3, :3] = torch.from_numpy(Ks_h.astype(np.float32)).reshape(V, 3, 3)
-        P4 = torch.eye(4, dtype=torch.float32).repeat(V, 1, 1)
-        P4[:, :3, :4] = torch.from_numpy(poses_h.astype(np.float32)).reshape(V, 3, 4)
-        M = torch.bmm(K4, P4).numpy()
+        KP = np.zeros((2, V, 4, 4), np.float32)
+        KP[:, :, 3, 3] = 1.0
+        KP[0, :, :3, :3] = Ks_h.astype(np.float32).reshape(V, 3, 3)
+        KP[1, :, :3, :4] = poses_h.astype(np.float32).reshape(V, 3, 4)
+        KPt = torch.from_numpy(KP)
+        M = torch.bmm(KPt[0], KPt[1]).numpy()              # (torch's own CPU product: its multiply-add order is the reference's)
         for v in range(V):
-            for i in range(12):
-                f.proj[v][i] = float(M[v].ravel()[i])
+            f.proj[v][:] = M[v].ravel()[:12].tolist()
 
         def flat(a, n):
             a = a.astype(np.float32).ravel()
             assert a.size == n, (a.shape, n)
-            return a
+            return a.tolist()
 
-        for i, v in enumerate(flat(Rh_h, 9)):
-            f.Rh[i] = float(v)
-        for i, v in enumerate(flat(Th_h, 3)):
-            f.Th[i] = float(v)
-        for i, v in enumerate(flat(bmin_h, 3)):
-            f.bounds_min[i] = float(v)
-        for i, v in enumerate(flat(vox_h, 3)):
-            f.voxel[i] = float(v)
-        for i in range(3):
-            f.out_sh[i] = int(osh_h.ravel()[i])
+        f.Rh[:] = flat(Rh_h, 9)
+        f.Th[:] = flat(Th_h, 3)
+        f.bounds_min[:] = flat(bmin_h, 3)
+        f.voxel[:] = flat(vox_h, 3)
+        f.out_sh[:] = [int(v) for v in osh_h.ravel()[:3]]
         self.head_blob = head_blob
         f.head_blob = head_blob.data_ptr()
         self.head_blob_split = getattr(head_blob, "_gpnerf_split", None)

@@ -151,11 +151,21 @@ class NeRFHead(nn.Module):
         return sd
 
     def head_blob(self, device):
-        """Packed image of the per-ray layers, re-packed only when a parameter changed."""
-        sd = self.per_ray_state()
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in sd.values())
+        """Packed image of the per-ray layers, re-packed only when a parameter changed (storage pointer or version counter of one
+        of the 24 Parameter objects: load_state_dict, .to(), in-place edits).  The objects are looked up once -- walking the module
+        tree costs the host ~0.1 ms per call, twice per frame, with the device idle -- and again whenever one of them was REPLACED
+        (their ids are part of the key)."""
+        plist = self.__dict__.get("_gpnerf_plist")
+        if plist is None or any(getattr(m, n, None) is not p for (m, n, p) in plist):
+            plist = []
+            for _, name in L.HEAD_FIELDS:
+                mod_name, idx = name.rsplit(".", 1)
+                lin = self.get_submodule(mod_name)[int(idx)]
+                plist += [(lin, "weight", lin.weight), (lin, "bias", lin.bias)]
+            self.__dict__["_gpnerf_plist"] = plist
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for (_, _, p) in plist)
         if self._blob is None or self._blob_key != key:
-            self._blob = F_.pack_head(sd, device)
+            self._blob = F_.pack_head(self.per_ray_state(), device)
             self._blob_key = key
         return self._blob
 

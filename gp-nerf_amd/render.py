@@ -290,11 +290,15 @@ class Renderer(nn.Module):
         self.nerfhead.head_blob(dev)                                   # (cached; packs on a parameter change)
         main = torch.cuda.current_stream(dev)
         sides = self.__dict__.setdefault("_side_streams", {})
-        side = sides.get(main.cuda_stream)                             # one side stream per producing stream (render's own, prefetch's)
+        # (a batch that brings its feature maps has no encoder for the side stream's work to hide behind: everything then goes on
+        # `main` in order -- every stream switch is ~10-20 us of dependency latency on an otherwise idle device, and the
+        # record_stream bookkeeping below is host time: 0.71 -> 0.5 ms of glue on the bench frame, profiles/r06/g_render_glue.txt)
+        side = sides.get(main.cuda_stream) if own_encoder else main    # one side stream per producing stream (render's own, prefetch's)
         if side is None or side.device != dev:
             if len(sides) > 8:
                 sides.clear()
             side = sides[main.cuda_stream] = torch.cuda.Stream(device=dev)
+        two_streams = side is not main
         group = P_.resolve_group(self.shard_group)
         sharded = group is not None
         # The host enqueues in the order the DEVICE needs things: first what the builder needs (it runs right behind the encoder),
@@ -310,7 +314,8 @@ class Renderer(nn.Module):
         # render() synchronised, prefetch() made its stream wait for the caller's).  Waiting for `main` as it stands now would put
         # the constants' device-to-host copy -- which the host blocks on -- behind the encoder, and in a pipelined loop behind the
         # previous frame's per-ray kernel that the encoder itself is queued behind (measured: prefetch() then took a whole frame).
-        side.wait_event(ev0)
+        if two_streams:
+            side.wait_event(ev0)
         with torch.cuda.stream(side):
             # (a pipelined loop fetches the constants when it moves the batch to the device -- host_consts() -- because HERE the
             # device-to-host copy would wait for a CU of the previous frame's persistent per-ray kernel: measured, the host then sat
@@ -320,8 +325,9 @@ class Renderer(nn.Module):
                 consts = F_.Frame.consts_of_batch(batch, self.voxel_size)
             prepared = self.prepare_builder_inputs(batch, consts)      # what the builder needs that does not depend on the encoder
             imgs4 = F_.relayout_images(batch["src_imgs"][0])           # the frame's channels-last source images
-        main.wait_stream(side)
-        _record_on(main, consts, prepared, imgs4)
+        if two_streams:
+            main.wait_stream(side)
+            _record_on(main, consts, prepared, imgs4)
         neg = self._neg_ray(batch)
         frame = self.build_frame(batch, featmaps, consts, prepared, imgs4=imgs4)
         with torch.cuda.stream(side):
@@ -341,8 +347,9 @@ class Renderer(nn.Module):
                     # (a mask that does not keep exactly the n pixels the rays belong to cannot order them: the kernels then leave
                     # list order -- decided on the device, reading the count on the host would be a synchronisation)
                     order = F_.patch_order_rays(m, Hs, Ws, n, patch_w=pw, patch_h=ph)
-        main.wait_stream(side)
-        _record_on(main, rays, order)
+        if two_streams:
+            main.wait_stream(side)
+            _record_on(main, rays, order)
         p = Prefetched(batch=batch, frame=frame, rays=rays, order=order, n=n, neg=neg, ev0=ev0, ev1=ev1, group=group,
                        keep=(featmaps, consts, prepared, imgs4), own_encoder=own_encoder, enc_run=enc_run)
         if enc_run is None:

@@ -56,6 +56,16 @@ the ten-line check at the end.
     coordinates, `[N, C, D, H, W]`.
  8. BatchNorm1d(eps=1e-3) + ReLU act on the feature rows (spconv.SparseSequential applies plain modules to `.features`).
 
+What is and is not recall-only (round 6).  Items 1-3, 5, 7 and 8 together say "a sparse convolution is the dense cross-correlation
+of the densified input, restricted to the active (submanifold) / reachable (strided) sites, with BatchNorm + ReLU on those sites" --
+which is spconv's own documented contract and the property its test suite checks against torch.nn.Conv3d.  On inputs with ONE row
+per voxel that contract fixes every output, and the HIP builder is held to it directly, without this file's sparse code:
+tests/test_gpu_sparse_conv.py::test_the_builder_is_the_dense_conv3d_pyramid_where_no_voxel_is_shared builds the whole four-level
+pyramid with F.conv3d in float64 on fifty random person-shaped vertex sets.  What REMAINS recall-only is item 6 alone -- what
+spconv v1.2.1 does with several rows in one voxel in the first submanifold block (owner row / other rows; the CUDA path's owner
+election is a write race, so the reference itself is not deterministic there) -- and item 4, which the network never exercises.
+On a real SMPL frame ~7 % of the level-0 sites are shared voxels (tools/probes/duplicate_voxels.py: 1 236 of 18 183).
+
 Settling it with spconv at hand (not possible here):
     x = spconv.SparseConvTensor(feat, coord_int32, shape, 1); conv = spconv.SparseConv3d(C, C, 3, 2, padding=1, bias=False)
     ref = sparse_conv3d(SparseTensor(feat, coord[:, 1:].long(), shape), conv.weight, 2, 1).dense()

@@ -6,6 +6,7 @@ import importlib
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -108,3 +109,90 @@ def test_pack_refuses_weights_beyond_the_packed_range():
     assert lib.gpnerf_sparse_pack_weight16(w.ctypes.data_as(L.FP), 16, 16, packed.ctypes.data_as(C.c_void_p)) == -1
     w[3, 2, 1] = np.nan
     assert lib.gpnerf_sparse_pack_weight16(w.ctypes.data_as(L.FP), 16, 16, packed.ctypes.data_as(C.c_void_p)) == -1
+
+
+def _body_like_coords(seed, dims, n_vertices=3000):
+    """A person-shaped vertex set on a small grid: a torso box, a head sphere and four capsule limbs sampled on their SURFACES
+    (SMPL vertices are a surface mesh), quantised to voxels of a (D, H, W) grid and de-duplicated -- every active voxel holds ONE
+    row, so no rule about rows that share a voxel enters."""
+    g = np.random.default_rng(seed)
+    D, H, W = dims
+
+    def capsule(a, b, r, n):
+        t = g.random(n)[:, None]
+        axis = (b - a) / np.linalg.norm(b - a)
+        v = g.normal(size=(n, 3))
+        v -= (v @ axis)[:, None] * axis
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return a + t * (b - a) + r * v
+
+    c = np.array([D, H, W], np.float64) / 2
+    sway = g.normal(size=(6, 3)) * np.array([D, H, W]) * 0.04
+    parts = [capsule(c + [0, -0.10 * H, 0] + sway[0], c + [0, 0.22 * H, 0] + sway[1], 0.16 * min(D, W) * 2, n_vertices // 3),        # torso
+             capsule(c + [0, 0.30 * H, 0] + sway[2], c + [0, 0.36 * H, 0] + sway[2], 0.09 * min(D, W) * 2, n_vertices // 8)]           # head
+    for sx in (-1, 1):
+        parts.append(capsule(c + [0, 0.20 * H, sx * 0.18 * W], c + [0, -0.05 * H, sx * 0.40 * W] + sway[3], 0.05 * W, n_vertices // 8))    # arm
+        parts.append(capsule(c + [0, -0.10 * H, sx * 0.10 * W], c + [0, -0.44 * H, sx * 0.14 * W] + sway[4], 0.07 * W, n_vertices // 6))   # leg
+    pts = np.clip(np.round(np.concatenate(parts)), 1, np.array([D, H, W]) - 2).astype(np.int64)
+    return np.unique(pts, axis=0)
+
+
+def test_the_builder_is_the_dense_conv3d_pyramid_where_no_voxel_is_shared():
+    """spconv v1.2.1 is not in the reference tree, so the sparse pyramid cannot be pinned to it -- but wherever
+    no two rows share a voxel NO recalled rule is involved: a submanifold convolution IS a dense conv3d restricted to the active
+    sites, the strided one a dense stride-2 conv3d on the sites it can reach (oracle/producers_ref.py items 1-3, 5, 7, 8 reduce to
+    torch.nn.functional.conv3d's own definition; item 6, rows sharing a voxel, is the one that stays recall-only).  Fifty random
+    person-shaped vertex sets, one row per voxel, random weights and BatchNorm statistics per set: the HIP builder's four dense
+    levels against the pyramid computed with F.conv3d in float64 on the densified input -- no sparse code, no rulebook."""
+    vol = importlib.import_module("gp-nerf_amd.volume")
+    dev = "cuda:0"
+    dims = (32, 64, 32)
+    worst = 0.0
+    for seed in range(50):
+        torch.manual_seed(1000 + seed)
+        in_dim = (32, 16)[seed % 2]
+        net = vol.SparseConvNet(n_layers=4, in_dim=in_dim, out_dim=[32, 32, 32, 32]).eval()
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+        coords = torch.from_numpy(_body_like_coords(seed, dims))
+        assert 500 < coords.shape[0] == torch.unique(coords, dim=0).shape[0]
+        code = torch.randn((coords.shape[0], in_dim))
+        coord4 = torch.cat([torch.zeros((coords.shape[0], 1), dtype=coords.dtype), coords], 1)
+        with torch.no_grad():
+            hip = net.to(dev).dense_levels_hip(code.to(dev), coord4.to(dev), list(dims))
+            net = net.cpu().double()
+            # the dense pyramid: x [1,C,D,H,W], mask [1,1,D,H,W] of active sites
+            x = torch.zeros((1, in_dim) + dims, dtype=torch.float64)
+            x[0, :, coords[:, 0], coords[:, 1], coords[:, 2]] = code.double().t()
+            mask = torch.zeros((1, 1) + dims, dtype=torch.float64)
+            mask[0, 0, coords[:, 0], coords[:, 1], coords[:, 2]] = 1.0
+
+            def block(seq, x, mask):
+                mods = list(seq)
+                for i in range(0, len(mods), 3):
+                    conv, bn = mods[i], mods[i + 1]
+                    w = conv.weight.permute(4, 3, 0, 1, 2)                    # [Cout, Cin, kd, kh, kw]: tap k reads the input at o * stride - pad + k
+                    if conv.subm:
+                        x = F.conv3d(x, w, padding=1)
+                    else:
+                        x = F.conv3d(x, w, stride=2, padding=1)
+                        mask = (F.conv3d(mask, torch.ones((1, 1, 3, 3, 3), dtype=torch.float64), stride=2, padding=1) > 0).double()
+                    x = (x - bn.running_mean.view(1, -1, 1, 1, 1)) / torch.sqrt(bn.running_var.view(1, -1, 1, 1, 1) + bn.eps) * bn.weight.view(1, -1, 1, 1, 1) \
+                        + bn.bias.view(1, -1, 1, 1, 1)
+                    x = F.relu(x) * mask                                       # BatchNorm1d + ReLU act on the rows = the active sites only
+                return x, mask
+
+            x, mask = block(net.net[0], x, mask)
+            want = []
+            for i in range(net.n_layers):
+                x, mask = block(net.net[2 * i + 1], x, mask)
+                x, mask = block(net.net[2 * i + 2], x, mask)
+                want.append(x)
+        for l, (a, b) in enumerate(zip(hip, want)):
+            assert a.shape == tuple(b.shape[2:]) + (32,), (seed, l)
+            err = float((a.permute(3, 0, 1, 2).cpu().double() - b[0]).abs().max()) / max(1.0, float(b.abs().max()))
+            worst = max(worst, err)
+            assert err < 1e-4, (seed, l, err)
+            assert float((a != 0).float().mean()) > 0
+    print(f"50 person-shaped vertex sets without shared voxels: HIP builder vs the dense float64 conv3d pyramid, worst relative max-abs {worst:.2e}")
