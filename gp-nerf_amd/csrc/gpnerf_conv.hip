@@ -65,6 +65,11 @@ DEV Frag make_frag(f32x4 a, f32x4 b) {
     H[1] = pk_hi(a[2], a[3]); Lo[1] = lo_pair(H[1], a[2], a[3]);
     H[2] = pk_hi(b[0], b[1]); Lo[2] = lo_pair(H[2], b[0], b[1]);
     H[3] = pk_hi(b[2], b[3]); Lo[3] = lo_pair(H[3], b[2], b[3]);
+    // (this fragment goes straight into an MFMA: one wait state behind the last inline-asm conversion, carried by a statement every
+    // reader depends on -- gfx950 does not interlock a VALU write with an MFMA read in the next slot, and LLVM cannot see into
+    // lo_pair: tools/micro/asm_producer_hazards.hip, gpnerf_kernels.hip settle_operand.  The 3x3 and stem kernels' conversions
+    // go to LDS first and need none.)
+    asm("s_nop 0" : "+v"(Lo));
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
     f.lo = __builtin_bit_cast(h8, Lo);

@@ -632,6 +632,16 @@ template <int N> DEV void guard_n(Guard&, const float* v) {
     (m < F16_RANGE ? sl + GUARD_LDS_SLOTS : sl)[0] = 1u;
 }
 
+// A VGPR written by a VALU instruction must not be read as an MFMA source operand in the very next issue slot: gfx950 does not
+// interlock that pair (tools/micro/asm_producer_hazards.hip: v_fma_mixhi_f16 directly in front of the v_mfma_f32_32x32x16_f16 that
+// reads its result hands the MFMA the register's PREVIOUS contents in 129 032 of 131 072 lanes; one wait state cures it).  LLVM
+// pads the producers it can see; lo_pair's two instructions are inline assembly, invisible to it, and whether one lands directly
+// in front of its MFMA is the scheduler's accident -- round 5's "deferred colour branch of the split form comes out 10-30 % wrong
+// in one build" (DESIGN.md 4.1).  So the pairs that become an MFMA operand pass through ONE more opaque statement that carries
+// the wait state itself: every reader of the operand depends on it, it depends on every lo_pair, hence >= 1 wait state between the
+// last conversion and the MFMA whatever the schedule.  tools/isa_mfma_hazards.py checks the built code (tests/test_abi.py).
+DEV void settle_operand(u32x4& lo) { asm("s_nop 0" : "+v"(lo)); }
+
 // x = hi + lo with hi = f16(x) toward zero (never overflows to inf), lo = f16(x - hi): ~22 significant bits
 template <class G>
 DEV Frag make_frag(const float* v, G& g) {
@@ -643,6 +653,7 @@ DEV Frag make_frag(const float* v, G& g) {
         Lo[p] = lo_pair(w, v[2 * p], v[2 * p + 1]);
     }
     if constexpr (SPIN) asm volatile("" : "+v"(H), "+v"(Lo));      // complete before the MFMA run that follows (no VALU between MFMAs)
+    settle_operand(Lo);
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
     f.lo = __builtin_bit_cast(h8, Lo);
@@ -653,6 +664,7 @@ template <class G>
 DEV Frag make_frag2(float a, float b, G& g) {              // the rgb k-step: two live slots, six zero pads
     const unsigned w = pk_rtz(a, b);
     u32x4 H = {w, 0u, 0u, 0u}, Lo = {lo_pair(w, a, b), 0u, 0u, 0u};
+    settle_operand(Lo);
     Frag f;
     f.hi = __builtin_bit_cast(h8, H);
     f.lo = __builtin_bit_cast(h8, Lo);
@@ -2827,21 +2839,20 @@ constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue c
 // the sample loop (chained segments / culled) as template arguments.  Dynamic LDS = the form's head image (+ the split form's guard
 // slots) + the wavefronts' colour queues.
 enum { SEL_REF = 0, SEL_FOLD = 1, SEL_SPLIT = 2, SEL_GUARD = 3 };
-// The split-precision forms keep the colour branch in the step.  Deferred, they were built and measured (bench frame 7.30 -> 6.39 ms
-// guarded, 6.2 unguarded; configs[2] 4.8 ms) and the guarded instantiation is bit-identical to its plain loop -- but the UNGUARDED
-// one's colour passes came out 10-30 % off in one build unless the regathered inputs passed through an opaque register copy first
-// (-DGPNERF_X_SPLIT_DEFER builds both, with the copy; tools/probes/defer_debug.py), and a guarded launch flagged tiles on ordinary
-// data; a later build of the same source with unrelated edits elsewhere in the kernel was bit-exact without the copy.  A
-// code-generation sensitivity whose cause is not established (no MFMA-shadow consumer: tools/isa_mfma_hazards.py is clean on the
-// failing build; no instruction-cache or scratch anomaly), so it is not shipped: the fp32 forms' deferral is held to the bit by
-// tests/test_gpu_parity.py::test_deferred_colour_branch_is_the_plain_loop_bit_for_bit on every build.
-// What is known about the failing build (revision c9a579c with this define, reproducible: the same wrong colours on every box):
-// the regathered inputs, the queue entry and the weights are right, the colour branch's result is wrong in all 64 lanes alike;
-// cured by ANY of: the opaque copy of the inputs, keeping the inputs alive behind the branch (storing them), stores inside the
-// branch, `volatile` on lo_pair's two asm statements, lo_pair written without asm; NOT cured by waits + 32 idle cycles around the
-// pass, by dropping __restrict__, or by storing the branch's result (which changes the wrong values).  Not a write-after-read
-// hazard on the f16 MFMA's four-register A / B operands (tools/micro/mfma_f16_src_war.hip: they are latched at issue).
-constexpr bool SPLIT_DEFERS = false;
+// Every form defers the colour branch (round 6; rounds 1-5 kept it in the step for the split-precision forms).  Round 5 built the
+// split forms' deferral (bench frame 7.3 -> 6.4 ms) and did not ship it: ONE build's unguarded instantiation gave colour passes
+// 10-30 % off, the same wrong values on every box, cured by any change that moved the schedule (an opaque copy of the regathered
+// inputs, `volatile` on lo_pair's asm, lo_pair written without asm) and not by waits around the pass.  The mechanism class is
+// now demonstrated on the hardware (tools/micro/asm_producer_hazards.hip, profiles/r06/i_asm_producer_hazards.txt): gfx950 does
+// not interlock a VALU write of a VGPR with an MFMA that reads it as a source operand in the next issue slot -- the MFMA gets the
+// register's previous contents, in every lane alike -- LLVM pads the producers it can see, and lo_pair's v_fma_mixlo/hi_f16 are
+// inline assembly it cannot: whether one lands directly in front of its MFMA is the scheduler's accident, which is exactly how
+// the failure came and went with unrelated edits.  (That build itself can no longer be reproduced -- revision c9a579c without the
+// opaque copy compiles to a schedule with one instruction in between and is bit-exact today, profiles/r06/i_split_defer_rebuild.txt
+// -- so the instance stays inferred; the class is measured.)  Since round 6 every fragment that becomes an MFMA operand passes
+// through settle_operand(), which carries the wait state itself, and tools/isa_mfma_hazards.py fails the CPU suite on any
+// inline-asm producer closer to its MFMA than the measured requirement (tests/test_abi.py).
+constexpr bool SPLIT_DEFERS = true;
 template <int FORM> constexpr bool form_defers() { return SPLIT_DEFERS || (FORM != FORM_SPLIT && FORM != FORM_SPLIT_GUARD); }
 template <int FORM, bool CHAIN, bool CULL>
 void launch_form(bool deferred, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const KArgs& ka) {

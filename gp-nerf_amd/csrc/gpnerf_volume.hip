@@ -277,6 +277,10 @@ __global__ void __launch_bounds__(256) conv_mfma16_kernel(const float* __restric
                 H[2 * q] = pk_hi16(xs[c][q][0], xs[c][q][1]); Lo[2 * q] = lo_pair16(H[2 * q], xs[c][q][0], xs[c][q][1]);
                 H[2 * q + 1] = pk_hi16(xs[c][q][2], xs[c][q][3]); Lo[2 * q + 1] = lo_pair16(H[2 * q + 1], xs[c][q][2], xs[c][q][3]);
             }
+            // (one wait state behind the last inline-asm conversion, carried by a statement every reader of the operand depends on:
+            // gfx950 does not interlock a VALU write with an MFMA read in the next slot, and LLVM cannot see into lo_pair16 --
+            // tools/micro/asm_producer_hazards.hip, gpnerf_kernels.hip settle_operand)
+            asm("s_nop 0" : "+v"(Lo[0]), "+v"(Lo[1]), "+v"(Lo[2]), "+v"(Lo[3]));
             const h8v xh = __builtin_bit_cast(h8v, H), xl = __builtin_bit_cast(h8v, Lo);
             const h8v wh = __builtin_bit_cast(h8v, wbuf[j % DEPTH][c][0]), wl = __builtin_bit_cast(h8v, wbuf[j % DEPTH][c][1]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);

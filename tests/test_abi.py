@@ -211,6 +211,26 @@ def test_the_hazard_checker_flags_an_opaque_consumer(tmp_path):
     assert len(by_mode[1]) == 1 and by_mode[1][0][5] is True and "v_add_f32" in by_mode[1][0][1]
 
 
+def test_the_hazard_checker_flags_an_opaque_producer_in_front_of_its_mfma(tmp_path):
+    """The converse pair (round 6, the root-cause class of round 5's wrong split-precision deferred colour passes): a VGPR written by an
+    inline-asm VALU instruction and read as an MFMA source operand before the wait states gfx950 needs -- it does not interlock the
+    pair (tools/micro/asm_producer_hazards.hip on the GPU: 129 032 of 131 072 lanes read the register's previous contents with no
+    wait state, none with one; the fp32 MFMA behind a plain v_add_f32 needs two).  On the micro kernels' listing the checker must
+    flag exactly the variants below the requirement: f16 MFMA consumers need 1 wait state, fp32 MFMA consumers are held to 2."""
+    import shutil
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "aph.s"
+    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(ROOT, "tools", "micro", "asm_producer_hazards.hip")], stderr=subprocess.DEVNULL)
+    res = {name: [b for b in bad if b[5] == "producer"] for name, _, _, bad in _isa_tool().scan(str(out))}
+    flagged = lambda case, wait: bool(next(b for n, b in res.items() if f"ILi{case}ELi{wait}E" in n))
+    assert flagged(1, 0) and not flagged(1, 1) and not flagged(1, 2)                 # v_fma_mixhi_f16 -> v_mfma_f32_32x32x16_f16
+    assert flagged(5, 0) and not flagged(5, 1)                                       # (plain v_mov_b32, written inside an asm block)
+    assert flagged(3, 0) and flagged(3, 1) and not flagged(3, 2) and not flagged(3, 4)   # v_permlane32_swap_b32 -> v_mfma_f32_32x32x2_f32
+    assert flagged(4, 1) and not flagged(4, 2)                                       # v_add_f32 -> the fp32 MFMA: two wait states (measured)
+
+
 def _ticket_tool():
     import importlib.util
     spec = importlib.util.spec_from_file_location("isa_ticket_release", os.path.join(ROOT, "tools", "isa_ticket_release.py"))

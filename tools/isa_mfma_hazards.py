@@ -6,6 +6,16 @@ inline assembly that consumes a fresh MFMA result gets no wait states.  The list
 order, labels ignored: a branch target is checked as if entered from the instruction above it), one wait state per issued
 instruction, `s_nop n` = n + 1.
 
+The converse pair (round 6): a VGPR WRITTEN by a VALU instruction must not be read as an MFMA source operand (A, B or C) before
+two wait states have passed -- gfx950 does not interlock that either (tools/micro/asm_producer_hazards.hip: a v_fma_mixhi_f16, a
+v_permlane32_swap_b32, even a plain v_mov_b32 / v_add_f32 directly in front of the MFMA that reads its result hands the MFMA the
+register's PREVIOUS contents; one wait state cures three of the four, v_add_f32 -> fp32 MFMA needs two).  LLVM pads the
+producers it can see; the kernels' inline-asm producers (lo_pair's v_fma_mixlo/hi_f16, interleave16's v_permlane32_swap_b32) it
+cannot.  This is the mechanism behind round 5's "split-precision deferred colour branch comes out 10-30 % wrong in one build":
+the regathered inputs' lo halves were converted by asm statements the scheduler had placed directly in front of their MFMA
+(DESIGN.md 4.1).  Checked here for every opaque producer: inside an `asm` block of a listing, or one of those opcodes in a
+disassembled library.
+
 usage: isa_mfma_hazards.py file.s|lib.so [kernel substring]      exit code 1 if a violation is found
 A .so is taken apart with llvm-objdump (--offloading, then -d on every gfx950 code object); tests/test_abi.py runs this on the
 built library, so an inline-asm consumer that lands inside an MFMA's shadow fails the CPU suite."""
@@ -31,8 +41,18 @@ def regs(tok):
     return out
 
 
+OPAQUE_OPS = ("v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_permlane32_swap_b32")      # only ever emitted by inline asm in this code base
+# wait states between an opaque VALU write and an MFMA read of it, by the consumer (measured, tools/micro/asm_producer_hazards.hip:
+# v_fma_mixhi_f16 / v_mov_b32 -> v_mfma_f32_32x32x16_f16: 1 cures; v_add_f32 -> v_mfma_f32_32x32x2_f32: 2; v_permlane32_swap -> the
+# same: 1 -- the fp32 MFMA is held to 2)
+PRODUCER_WAIT = 2
+def producer_wait(mfma_op):
+    return 1 if "f16" in mfma_op.split("x")[-1] or "bf16" in mfma_op else 2
+
+
 def check(rows, name):
     recent, bad, n_mfma, n_asm = [], [], 0, 0          # recent: [dst regs, wait states since issue, needed, text]
+    producers = []                                     # opaque VALU writes: [dst regs, wait states since issue, text]
     in_asm = False
     for ln, l in rows:
         t = l.split("//")[0].split(";")[0].strip()
@@ -47,14 +67,21 @@ def check(rows, name):
             # nothing falls through an unconditional jump: what follows is another block's start, reached only by jumps (the walk
             # is linear; the inline-asm consumers this check is for sit in straight-line code behind their MFMAs)
             recent = []
+            producers = []
             continue
         if op == "s_nop":
             ws = int(t.split()[1], 0) + 1
         if op.startswith("v_mfma") or op.startswith("v_smfma"):
             n_mfma += 1
             dst = regs(t.split(",")[0])
+            srcs = regs(",".join(t.split(None, 1)[1].split(",")[1:])) if " " in t else set()
+            for pdst, el, txt in producers:
+                if el < producer_wait(op) and pdst & srcs:
+                    bad.append((ln, t, txt, el, producer_wait(op), "producer"))
             for r in recent:
                 r[1] += 1
+            for q in producers:
+                q[1] += 1
             recent.append([dst, 0, PASSES.get(op, 16) + 2, f"{ln}: {t}"])
         else:
             touched = regs(t.split(None, 1)[1]) if " " in t else set()
@@ -67,7 +94,15 @@ def check(rows, name):
             n_asm += in_asm
             for r in recent:
                 r[1] += ws
+            for q in producers:
+                q[1] += ws
+            if op.startswith("v_") and (in_asm or op.split("_e32")[0].split("_e64")[0] in OPAQUE_OPS) and " " in t:
+                ops = t.split(None, 1)[1].split(",")
+                # (v_permlane32_swap writes both of its operands)
+                pdst = regs(ops[0]) | (regs(ops[1]) if op.startswith("v_permlane32_swap") and len(ops) > 1 else set())
+                producers.append([pdst, 0, f"{ln}: {t}"])
         recent = [r for r in recent if r[1] < r[2]]
+        producers = [q for q in producers if q[1] < PRODUCER_WAIT]
     return bad, n_mfma, n_asm
 
 
@@ -111,7 +146,10 @@ def main():
     for name, n_mfma, n_asm, bad in scan(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""):
         print(f"{name[:110]}: {n_mfma} MFMAs, {n_asm} inline-asm instructions, {len(bad)} hazard(s)")
         for ln, t, txt, el, need, ia in bad[:12]:
-            print(f"    line {ln}: `{t}`{' [inline asm]' if ia else ''} touches the result of `{txt}` after {el} of {need} wait states")
+            if ia == "producer":
+                print(f"    line {ln}: `{t}` reads the result of the inline-asm `{txt}` after {el} of {need} wait states")
+            else:
+                print(f"    line {ln}: `{t}`{' [inline asm]' if ia else ''} touches the result of `{txt}` after {el} of {need} wait states")
         total += len(bad)
     sys.exit(1 if total else 0)
 
