@@ -531,6 +531,10 @@ def beside_headline(args, fm, wl, kw, flow):
         res["eval_loop"] = eval_loop_wall(args)
     except Exception as e:
         res["eval_loop"] = {"error": repr(e)[:300]}
+    try:                                         # the same loop behind the split-precision encoder (`encoder.file hip_encoder_fast`)
+        res["eval_loop_fast_encoder"] = eval_loop_wall(args, encoder_file="hip_encoder_fast")
+    except Exception as e:
+        res["eval_loop_fast_encoder"] = {"error": repr(e)[:300]}
     return res
 
 
@@ -661,11 +665,12 @@ def demo_render_body_frame(args):
                     "device-to-host copy of the image"}
 
 
-def eval_loop_wall(args, frames=12, fill="survey", reserve=(0,)):
+def eval_loop_wall(args, frames=12, fill="survey", reserve=(0,), encoder_file="hip_encoder"):
     """The evaluation LOOP (libs/trainers/BaseTrainer.py:255-280 = evaluator.evaluate_loop) over `frames` ZJU-sized frames (SURVEY.md
     8d's f = 1.05 W camera, ~74 k rays x 64 samples, hip_encoder + vertex attention + sparse volume builder per frame, PSNR / MSE /
     SSIM per frame): wall time per frame of the reference's strictly serial loop against the pipelined one (Renderer.prefetch of
-    frame t + 1 behind frame t's per-ray kernel).  Same bits per frame (tests/test_gpu_renderer.py)."""
+    frame t + 1 behind frame t's per-ray kernel).  Same bits per frame (tests/test_gpu_renderer.py).  encoder_file: hip_encoder (the
+    default: fp32 operands, the chain inside 1e-4 of the reference) or hip_encoder_fast (f16 hi/lo operands, ~0.9 ms less per frame)."""
     import torch
     from types import SimpleNamespace as NS
     syn = importlib.import_module("gp-nerf_amd.synthetic")
@@ -676,7 +681,7 @@ def eval_loop_wall(args, frames=12, fill="survey", reserve=(0,)):
     if p not in sys.path:
         sys.path.insert(0, p)
     hip_render = importlib.import_module("hip_render")
-    cfg = NS(encoder=NS(file="hip_encoder", name="resnet34", out_ch=32),
+    cfg = NS(encoder=NS(file=encoder_file, name="resnet34", out_ch=32),
              head=NS(file="hip_head", rgb=NS(use_rgbhead=True), sigma=NS(code_dim=32, n_heads=4, n_layers=4, n_smpl=6890, outdims=[32, 32, 32, 32])),
              dataset=NS(train=NS(name="zju_mocap", chunk=400), test=NS(name="zju_mocap", chunk=2000), voxel_size=[0.005] * 3, H=512, W=512, ratio=1.0),
              train=NS(n_rays=1024, n_samples=64), test=NS(mesh_th=50, test_seq="bench", save_imgs=False))
@@ -692,7 +697,7 @@ def eval_loop_wall(args, frames=12, fill="survey", reserve=(0,)):
     n = int(b["ray_o"].shape[1])
     b["rgb"] = torch.rand((1, n, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     loader = [dict(b) for _ in range(frames)]
-    res = {"frames": frames, "rays_per_frame": n}
+    res = {"frames": frames, "rays_per_frame": n, "encoder": encoder_file + " (" + r.encoder.precision + ")"}
     modes = [("serial", False, 0), ("pipelined", True, 0)] + [(f"pipelined_reserve_{n}_cus", True, n) for n in reserve if n]
     for name, mode, res_cus in modes:
         r.reserve_cus = res_cus

@@ -1,0 +1,49 @@
+# round-6 measurements: GPU suite, benches, rocprofv3 kernel stats, PMC passes (separate runs, counters only), probes.
+# -> gpurun_out/r6f, copied to profiles/r06 by tools/collect_round6.sh
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+o=gpurun_out/r6f; rm -rf $o; mkdir -p $o
+timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $o/gpu_tests.txt
+timeout 900 python bench.py > $o/bench_default.json 2> $o/bench_default.err
+timeout 300 python bench.py --steps 20 --warmup 3 --fold --no-cpu-baseline --no-extras > $o/bench_folded.json 2> $o/bench_folded.err
+timeout 300 python bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras > $o/bench_c3.json 2> $o/bench_c3.err
+timeout 300 python bench.py --steps 10 --warmup 3 --samples 128 --early-term --split-f16 --no-cpu-baseline --no-extras > $o/bench_c3_split.json 2> $o/bench_c3s.err
+timeout 300 python bench.py --steps 10 --warmup 3 --split-f16 --no-cpu-baseline --no-extras > $o/bench_split_guarded.json 2> $o/bench_split.err
+timeout 300 python bench.py --steps 10 --warmup 3 --size 1024 --no-cpu-baseline --no-extras > $o/bench_1024.json 2> $o/bench_1024.err
+timeout 300 python bench.py --steps 10 --warmup 3 --size 64 --samples 32 --no-cpu-baseline --no-extras > $o/bench_64.json 2> $o/bench_64.err
+timeout 300 python bench.py --steps 10 --warmup 3 --fill survey --no-cpu-baseline --no-extras > $o/bench_survey.json 2> $o/bench_survey.err
+timeout 300 python bench.py --steps 10 --warmup 3 --occ-cull --occupancy 0.1 --outputs light --no-cpu-baseline --no-extras > $o/bench_cull10.json 2> $o/bench_cull.err
+GPNERF_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 2 --warmup 1 > $o/bench_8ranks_gloo_dry_run.json 2> $o/bench_8ranks.err
+timeout 300 python tools/trained_like_report.py > $o/trained_like.txt 2>&1
+timeout 200 python tools/e2e512_probe.py > $o/e2e512_probe.txt 2>&1
+timeout 200 python tools/probes/exact_encoder_time.py > $o/encoder_forms.txt 2>&1
+timeout 200 python tools/probes/render_glue.py > $o/render_glue.txt 2>&1
+timeout 200 python tools/probes/eval_loop_time.py 2>&1 | grep -v "^ssim\|^mse\|^psnr" > $o/eval_loop.txt
+timeout 200 python tools/probes/demo_body_time.py > $o/demo_body.txt 2>&1
+timeout 200 python tools/time_render_api.py > $o/render_api.txt 2>&1
+timeout 200 python tools/time_survey_api.py 20 > $o/render_api_survey.txt 2>&1
+timeout 300 python tools/probes/skip_probe.py > $o/skip_probe.txt 2>&1
+timeout 600 python tools/parity_sweep.py 300 > $o/parity_sweep.txt 2>&1
+timeout 600 python tools/et_sweep.py 50 > $o/et_sweep.txt 2>&1
+timeout 600 python tools/defer_sweep.py 150 > $o/defer_sweep.txt 2>&1
+timeout 600 python tools/producers_sweep.py 40 > $o/producers_sweep.txt 2>&1
+(cd tools/micro && hipcc -O3 --offload-arch=gfx950 -o /tmp/aph asm_producer_hazards.hip 2>/dev/null && /tmp/aph) > $o/asm_producer_hazards.txt 2>&1
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r6f/bench_*.json")):
+    try:
+        j = json.load(open(f)); r = j["roofline"]
+        print(f.split("/")[-1], round(j["value"]), round(j["ms_per_step"], 3), "frac", round(r["frac"], 4), "dense", r.get("dense_ms"), r.get("dense_frac"), j.get("early_term", {}).get("samples_evaluated_frac"))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_headline -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $o/prof_bench_headline.json 2> $o/stats_headline.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_default -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $o/prof_bench_default.json 2> $o/stats_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c3 -- python3 bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras > $o/prof_bench_c3.json 2> $o/stats_c3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_survey -- python3 bench.py --steps 10 --warmup 3 --fill survey --no-cpu-baseline --no-extras > $o/prof_bench_survey.json 2> $o/stats_survey.err
+for f in $(find $o -name "*kernel_stats.csv"); do echo "== $f"; head -4 $f | cut -c1-160; done
+rm -rf gpurun_out/pmc_r06_default gpurun_out/pmc_r06_c3 gpurun_out/pmc_r06_survey
+PMC_KERNEL='render_fused_kernel<0, false, false, true>' bash tools/pmc_passes.sh r06_default --no-extras | tail -2
+python3 tools/pmc_summary.py gpurun_out/pmc_r06_default 'render_fused_kernel<0, false, false, false>' summary_dense.json > /dev/null
+PMC_KERNEL='render_fused_kernel<0, true, false, true>' bash tools/pmc_passes.sh r06_c3 --samples 128 --early-term --no-extras | tail -2
+PMC_KERNEL='render_fused_kernel<0, true, false, true>' bash tools/pmc_passes.sh r06_survey --fill survey --no-extras | tail -2
+find gpurun_out/pmc_r06_* -name "*.csv" -size +2M -delete

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect rocprofv3 PMC counters for the fused kernel in separate passes (never combined with tracing).
-# usage: tools/pmc_passes.sh <tag> [bench args...]   -> gpurun_out/pmc_<tag>/passN/
+# usage: [PMC_KERNEL='render_fused_kernel<0, false, false, true>'] tools/pmc_passes.sh <tag> [bench args...]   -> gpurun_out/pmc_<tag>/passN/, summary.json
 set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -18,4 +18,4 @@ FETCH_SIZE GRBM_GUI_ACTIVE
 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SALU
 LIST
-python3 tools/pmc_summary.py $out
+python3 tools/pmc_summary.py $out "${PMC_KERNEL:-render_fused}"
