@@ -194,7 +194,7 @@ struct ConvArgs {
     // infinity, and every accumulator it meets ends up NaN -- nothing is silently wrong, the result is loudly non-finite.  That is
     // looked for where it costs nothing: the InstanceNorm table's sums (finalize_if_last: a non-finite sum or sum of squares of any
     // channel), and the accumulators themselves in a convolution with no norm behind it.  The host then runs the layer chain
-    // again in the exact fp32 form (gpnerf_conv2d_nhwc_exact).  A non-finite INPUT sets the flag too (the exact form then returns
+    // again in the exact fp32 form (exact = 1).  A non-finite INPUT sets the flag too (the exact form then returns
     // what fp32 arithmetic makes of it).  The word is only ever written with 1; the caller zeroes it.
     unsigned* flag;
     int tile_h, tile_w;       // the kernel's workgroup tile of output pixels (tile_h x tile_w; tile_h = 0: tile_w consecutive pixels): how many

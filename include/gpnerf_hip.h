@@ -436,7 +436,7 @@ int gpnerf_vertex_attention(const float* q, const float* kv, const float* w_qs, 
  *   activation with |x| >= 4095, a weight with |w| >= 16, or a non-finite input): such an operand splits into f16 infinities and
  *   the outputs it meets are NaN, which the call finds in the sums of the InstanceNorm table (out_table given) or in its
  *   accumulators (no norm behind it).  A result produced with the flag raised must be discarded and the convolution chain run
- *   again through conv2d_nhwc_exact, so that parameters of any size are served (a trained InstanceNorm scale times sqrt(h w) can
+ *   again with exact = 1 (fp32 operands, no range), so that parameters of any size are served (a trained InstanceNorm scale times sqrt(h w) can
  *   exceed the range on a one-hot image; ordinary images stay orders of magnitude below it).
  * conv2d_nhwc_exact = the same nn.Conv2d on fp32 operands (v_mfma_f32_32x32x2_f32, an fp32 FMA chain per output, any odd ks,
  *   any stride, any channel counts), from the PyTorch weight [cout][cin][ks][ks] as it is, one scalar load per operand: the

@@ -2,7 +2,7 @@
 # the encoder's newer entry points: only conv_layer_time.py is run against it)
 cd "$GRAFT_REPO_ROOT"; mkdir -p /tmp/ab
 C=gp-nerf_amd/csrc
-hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function -c -o /tmp/ab/conv_b.o $C/gpnerf_conv_b.hip &&
+hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function -Igp-nerf_amd/csrc/nodiag -c -o /tmp/ab/conv_b.o $C/gpnerf_conv_b.hip &&
 hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/ab/lib_b.so $C/gpnerf_kernels.o $C/gpnerf_volume.o /tmp/ab/conv_b.o || exit 1
 for v in A B A B; do
   if [ $v = A ]; then L=$PWD/$C/libgpnerf_hip.so; else L=/tmp/ab/lib_b.so; fi
