@@ -1290,7 +1290,16 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     // range guard of the split form: guard[0] = number of flagged tiles, guard[64 + tile] = 1 when an MFMA operand of the tile
     // reached the f16 range; the fix-up launch (FORM_F32_FIXUP) renders exactly the flagged tiles again in the fp32 form
     unsigned* guard;
+    // frame-level deferral of the colour branch (render_fused_kernel<., ., ., true, true> + colour_units_kernel +
+    // colour_accumulate_kernel): gd_ctrl = a zeroed 256-byte block (GD_COUNT: entries appended so far; GD_QUEUE..+7: the unit queue's
+    // counters), gd_ent[n] = (launch slot, sample | rank << 8, weight bits, 0), gd_rgbw[slot * S + rank] = (r, g, b, weight),
+    // gd_cnt[slot] = entries of the ray
+    unsigned* gd_ctrl;
+    uint4* gd_ent;
+    f32x4* gd_rgbw;
+    int* gd_cnt;
 };
+constexpr int GD_QUEUE = 0, GD_COUNT = 8;        // words of gd_ctrl's 256-byte block, zero at launch
 
 // the forms of the fused kernel
 constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3, FORM_F32_FOLD = 4;
@@ -1501,9 +1510,10 @@ DEV float gather_views(const __attribute__((address_space(4))) FrameK& fr, float
     return nvalid;
 }
 
-template <int FORM, bool CHAIN, int P = 1, bool CULL = false, bool DEFER = false>
+template <int FORM, bool CHAIN, int P = 1, bool CULL = false, bool DEFER = false, bool GDEF = false>
 DEV bool render_tile(float* lds, const int lane, const long tile, const int seg, const long entry_base = 0) {
     static_assert(!CULL || (!CHAIN && P == 1), "occupancy culling: plain form only");
+    static_assert(!GDEF || (DEFER && !CULL), "frame-level deferral: a deferred sample loop without culling");
     static_assert(P == 1 || CHAIN, "several samples per step: chained form only");
     constexpr int RAYS = RAYS_PER_WAVE / P;             // rays per wavefront
     constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
@@ -1550,6 +1560,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     const float ox = r0[0], oy = r0[1], oz = r0[2], dx = r0[3], dy = r1[0], dz = r1[1], near = r1[2], far = r1[3];
 
     float T = 1.f, c_r = 0.f, c_g = 0.f, c_b = 0.f, depth = 0.f, acc = 0.f;
+    int n_q = 0;                                // (frame-level deferral: entries this ray has listed = the rank of its next one)
     float rin[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) rin[i] = 0.f;
@@ -1565,6 +1576,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         const f32x4* p = reinterpret_cast<const f32x4*>(k0->part + (size_t)slot * 16);
         const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
         c_r = a[0]; c_g = a[1]; c_b = a[2]; depth = a[3];
+        if constexpr (GDEF) { n_q = __builtin_bit_cast(int, a[0]); c_r = 0.f; }      // (the colour map is not the sample loop's: its slot carries the rank)
         acc = b[0]; T = b[1]; rin[0] = b[3];
         const int packed = (int)b[2];
         n_two = packed & 4095; n_done = packed >> 12;
@@ -1595,7 +1607,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     // everything but the colour; rays with a non-zero weight append (ray lane, sample, weight) to a 64-entry queue of the wavefront in
     // LDS; when 32 are waiting, one colour pass evaluates them -- lane i regathers item i's views (the same loads, minutes-old in L2)
     // -- and every ray takes its own results back in sample order, so c accumulates in exactly the order of the plain loop.  Same bits.
-    static_assert(!DEFER || P == 1, "deferred colour branch: one sample per step");
+    static_assert(!DEFER || P == 1 || GDEF, "colour passes of the wavefront: one sample per step");
     constexpr bool CAN_DEFER = DEFER, defer = DEFER;
     unsigned long long mine = 0ull;             // bit j: the queue entry j places behind the head is one of this ray's
     int q_head = 0, q_cnt = 0;                  // (uniform)
@@ -1612,6 +1624,25 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     int k_lim = k_end;                          // (early termination of the tile as a whole moves it to where the loop stopped)
     int opaque_from = -1;                       // (first step behind the one at which every ray's transmittance was exactly 0)
     for (;; k += P) {
+        if constexpr (GDEF) {
+            // Frame-level deferral: the samples waiting for their colour branch leave the wavefront altogether -- 32 at a time (what
+            // is left at the tile's end) they are appended to the launch's entry list, and colour_units_kernel evaluates the list 32
+            // entries per wavefront step, whichever tiles they came from; colour_accumulate_kernel then adds every ray's terms in
+            // sample order.  The same arithmetic on the same operands in the same order as the passes below: the same bits.
+            if (q_cnt >= 32 || (q_cnt > 0 && !(k < k_lim))) {
+                const int nb = min(q_cnt, 32);
+                const uint2 e = dq[(q_head + (n < nb ? n : 0)) & (DEFER_QUEUE - 1)];
+                const int sl = __shfl((int)slot, (int)(e.x & 31u));
+                kargs_ptr kb = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kb));
+                const unsigned base = wave_add(kb->gd_ctrl + GD_COUNT, (unsigned)nb, lane);
+                if (lane < nb) kb->gd_ent[(size_t)base + lane] = uint4{(unsigned)sl, e.x >> 5, e.y, 0u};
+                q_head = (q_head + nb) & (DEFER_QUEUE - 1);
+                q_cnt -= nb;
+                k -= P;
+                continue;
+            }
+        } else
         if constexpr (CAN_DEFER) {
             if (defer && (q_cnt >= 32 || (q_cnt > 0 && !(k < k_lim)))) {
                 const int nb = min(q_cnt, 32);
@@ -1906,8 +1937,9 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                     const unsigned m = (unsigned)__ballot(need);            // (both lane halves hold the ray: the low word has it all)
                     const int pos = q_cnt + __popc(m & ((1u << n) - 1u));
                     if (need) {
-                        mine |= 1ull << pos;
-                        if (half == 0) dq[(q_head + pos) & (DEFER_QUEUE - 1)] = uint2{(unsigned)n | ((unsigned)k << 5), __builtin_bit_cast(unsigned, wgt)};
+                        if constexpr (!GDEF) mine |= 1ull << pos;
+                        if (half == 0) dq[(q_head + pos) & (DEFER_QUEUE - 1)] = uint2{(unsigned)n | ((unsigned)k << 5) | (GDEF ? (unsigned)n_q << 13 : 0u), __builtin_bit_cast(unsigned, wgt)};
+                        ++n_q;
                     }
                     q_cnt += __popc(m);
                 }
@@ -1915,6 +1947,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         } else {
             // the group's P samples in order, in every lane of the group alike: sample j's values come from lane (group base + j)
             float my_wgt = 0.f;
+            int my_rank = 0;
             const int base_lane = lane & ~(P - 1);
 #pragma unroll
             for (int j = 0; j < P; ++j) {
@@ -1934,9 +1967,18 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 }
                 n_done += live ? 1 : 0;
                 n_two += (live && __shfl((int)(two_views ? 1 : 0), src) != 0) ? 1 : 0;
-                if (j == sub) my_wgt = wgt;
+                if (j == sub) { my_wgt = wgt; my_rank = n_q; }
+                if constexpr (GDEF) n_q += wgt != 0.f ? 1 : 0;
             }
             if (active && half == 0 && in_seg && out.weights) out.weights[(size_t)ray * S + kl] = my_wgt;
+            if constexpr (GDEF) {               // this lane's sample joins the launch's entry list (see the top of the loop)
+                const bool need = active && in_seg && my_wgt != 0.f;
+                const unsigned m = (unsigned)__ballot(need);
+                const int pos = q_cnt + __popc(m & ((1u << n) - 1u));
+                if (need && half == 0)
+                    dq[(q_head + pos) & (DEFER_QUEUE - 1)] = uint2{(unsigned)n | ((unsigned)kl << 5) | ((unsigned)my_rank << 13), __builtin_bit_cast(unsigned, my_wgt)};
+                q_cnt += __popc(m);
+            }
         }
         STAMP(st, 6);
         // wavefront-level early termination (not in the reference): every ray of the tile is opaque
@@ -2011,7 +2053,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         if (goes_on) {
             f32x4* p = reinterpret_cast<f32x4*>(part + (size_t)slot * 16);
             f32x4 a, b, c, d;
-            a[0] = c_r; a[1] = c_g; a[2] = c_b; a[3] = depth;
+            a[0] = GDEF ? __builtin_bit_cast(float, n_q) : c_r; a[1] = c_g; a[2] = c_b; a[3] = depth;
             b[0] = acc; b[1] = T; b[2] = (float)(n_two + 4096 * n_done); b[3] = rin[0];
             c[0] = rin[1]; c[1] = rin[2]; c[2] = rin[3]; c[3] = rin[4];
             d[0] = rin[5]; d[1] = rin[6]; d[2] = rin[7]; d[3] = rin[8];
@@ -2039,7 +2081,8 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
         for (k = min(k, k_end); k < S; ++k) {
             if (out.weights) out.weights[(size_t)ray * S + k] = 0.f;
         }
-        out.rgb[(size_t)ray * 3 + 0] = c_r; out.rgb[(size_t)ray * 3 + 1] = c_g; out.rgb[(size_t)ray * 3 + 2] = c_b;
+        if constexpr (GDEF) kp->gd_cnt[slot] = n_q;          // (the colour map is colour_accumulate_kernel's)
+        else { out.rgb[(size_t)ray * 3 + 0] = c_r; out.rgb[(size_t)ray * 3 + 1] = c_g; out.rgb[(size_t)ray * 3 + 2] = c_b; }
         out.depth[ray] = depth;
         out.acc[ray] = acc;
         const float q = depth / acc;                    // 1 / max(1e-10, depth / acc); torch.max keeps NaN
@@ -2061,7 +2104,7 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 // 8-wave workgroup resident per CU a static grid holds the CU until its slowest tile is done -- the queue hands the next
 // tile to whichever wave is free.  Static launches (one unit per wave, XCD-aware remap) remain for frames smaller than
 // one round and for the sample-split geometry.
-template <int FORM, bool CHAIN, bool CULL = false, bool DEFER = false>     // DEFER: the colour branch sample by sample (render_tile)
+template <int FORM, bool CHAIN, bool CULL = false, bool DEFER = false, bool GDEF = false>     // DEFER: the colour branch sample by sample; GDEF: for the launch as a whole (render_tile)
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const KArgs ka) {
     static_assert(!DEFER || FORM != FORM_F32_FIXUP, "the fix-up launch evaluates everything");
@@ -2146,12 +2189,12 @@ render_fused_kernel(const KArgs ka) {
         constexpr int F = FORM == FORM_F32_FIXUP ? FORM_F32 : FORM;
         STAMP_T0();
         if constexpr (CHAIN) {
-            if (samples_per_step == 8) render_tile<F, true, 8>(lds, lane, tile, seg, entry_base);
-            else if (samples_per_step == 4) render_tile<F, true, 4>(lds, lane, tile, seg, entry_base);
-            else if (samples_per_step == 2) render_tile<F, true, 2>(lds, lane, tile, seg, entry_base);
-            else render_tile<F, true, 1, false, DEFER>(lds, lane, tile, seg, entry_base);
+            if (samples_per_step == 8) render_tile<F, true, 8, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
+            else if (samples_per_step == 4) render_tile<F, true, 4, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
+            else if (samples_per_step == 2) render_tile<F, true, 2, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
+            else render_tile<F, true, 1, false, DEFER, GDEF>(lds, lane, tile, seg, entry_base);
         } else {
-            render_tile<F, false, 1, CULL, DEFER>(lds, lane, tile, seg);
+            render_tile<F, false, 1, CULL, DEFER, GDEF>(lds, lane, tile, seg);
         }
         STAMP_ADD(8, lane);
         WT(3);
@@ -2159,6 +2202,96 @@ render_fused_kernel(const KArgs ka) {
     }
 }
 
+
+// Frame-level deferral, second launch: the colour branch of the entries render_fused_kernel<., ., ., true, true> appended, 32 per
+// wavefront step, by persistent workgroups on a unit queue (unit = 32 consecutive entries: neighbouring tiles' samples, dealt to the
+// XCDs in chunks like the tiles).  A unit costs the same whichever rays its entries belong to, so the launch ends with every
+// wavefront within one ~15 us unit of the others -- where the tile-level passes left a frame's end to whichever wavefronts had
+// drawn the tiles with the most non-zero weights (tools/wave_times.py: last exit 0.9 ms behind the median on the bench frame).
+// Lane i evaluates entry i exactly as render_tile's colour pass does (sample_point from the ray's row, gather_views, mean / variance,
+// mlp_colour): same operands, same order, same bits.
+template <int FORM>
+DEV void colour_unit(float* lds, const int lane, const long unit, const unsigned total) {
+    typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
+    kargs_ptr kb = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kb));
+    const int n = lane & 31, half = lane >> 5;
+    const size_t at = (size_t)unit * 32 + n;
+    const bool valid = at < total;
+    const uint4 e = kb->gd_ent[valid ? at : (size_t)total - 1];
+    const int slot = (int)e.x, kk = (int)(e.y & 255u), rank = (int)(e.y >> 8);
+    const int ray = kb->out.order ? kb->out.order[slot] : slot;
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(kb->rays + (size_t)ray * 8);
+    const f32x4 r1 = *reinterpret_cast<const f32x4*>(kb->rays + (size_t)ray * 8 + 4);
+    const int S = kb->S;
+    const unsigned flags = kb->flags;
+    const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0, flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;
+    const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
+    float zq, qx_, qy_, qz_;
+    sample_point(r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], flip ? (S - 1 - kk) : kk, S, step, zq, qx_, qy_, qz_);
+    float xq[NV][18], vq[NV][3], cq[3], mvq[36];
+    gather_views<FORM>(kb->fr, qx_, qy_, qz_, neg, half, xq, vq);
+    Stamps st;
+    if constexpr (FORM == FORM_F32) { mean_var_ref(xq, mvq); mlp_colour_ref(lds, lane, xq, mvq, cq, st); }
+    else { mean_var(xq, mvq); mlp_colour(lds, lane, xq, mvq, cq, st); }
+    kargs_ptr ko = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ko));
+    if (valid && half == 0) {
+        f32x4 v; v[0] = cq[0]; v[1] = cq[1]; v[2] = cq[2]; v[3] = __builtin_bit_cast(float, e.z);
+        ko->gd_rgbw[(size_t)slot * S + rank] = v;
+    }
+    if (ko->out.step_stats && lane == 0) {     // (the diagnostic launch) one colour evaluation; [2] = steps minus colour evaluations
+        atomicAdd(ko->out.step_stats + 5, 1u);
+        atomicAdd(ko->out.step_stats + 2, 0xffffffffu);
+    }
+}
+
+template <int FORM>
+__global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
+colour_units_kernel(const KArgs ka) {
+    static_assert(FORM == FORM_F32 || FORM == FORM_F32_FOLD, "frame-level deferral: the fp32 forms");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned total = ka.gd_ctrl[GD_COUNT];            // (written by the launch before this one)
+    if (total == 0u) return;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(FORM == FORM_F32 ? ka.fr.head_blob_ref : ka.fr.head_blob);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < gpl::BLOB_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long n_units = ((long)total + 31) / 32;
+    int qx = blockIdx.x & 7, dry = 0;
+    for (;;) {
+        typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
+        kargs_ptr kq = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));
+        const unsigned t = wave_add(kq->gd_ctrl + GD_QUEUE + qx, 1u, lane);
+        if ((long)t >= queue_len(n_units, kq->chunk, qx)) {
+            qx = (qx + 1) & 7;
+            if (++dry == 8) return;
+            continue;
+        }
+        colour_unit<FORM>(lds, lane, queue_tile(kq->chunk, qx, t), total);
+    }
+}
+
+// Frame-level deferral, third launch: c = fma(w, rgb, c) over a ray's entries in sample order (rank order) -- the colour map exactly
+// as the sample loop accumulates it.  One thread per launch slot; a ray's entries are consecutive 16-byte rows.
+__global__ void __launch_bounds__(256) colour_accumulate_kernel(const int* __restrict__ gd_cnt, const f32x4* __restrict__ gd_rgbw, const long n_slots,
+                                                                const int S, const int32_t* __restrict__ order, float* __restrict__ rgb) {
+    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n_slots) return;
+    const int cnt = gd_cnt[slot];
+    const f32x4* __restrict__ p = gd_rgbw + (size_t)slot * S;
+    float c_r = 0.f, c_g = 0.f, c_b = 0.f;
+    for (int i = 0; i < cnt; ++i) {
+        const f32x4 v = p[i];
+        c_r = fmaf(v[3], v[0], c_r); c_g = fmaf(v[3], v[1], c_g); c_b = fmaf(v[3], v[2], c_b);
+    }
+    const long ray = order ? (long)order[slot] : slot;
+    rgb[ray * 3 + 0] = c_r; rgb[ray * 3 + 1] = c_g; rgb[ray * 3 + 2] = c_b;
+}
 
 // The keep bits of occupancy culling for every sample of a launch, before it.  One wavefront per tile: lane = (ray of the tile,
 // parity of the sample index), so one load instruction reads the occupancy around 32 neighbouring rays at (nearly) the same depth
@@ -2830,6 +2963,14 @@ void pack_layer_ref(int L, const float* W, const float* b, int n_out, int n_in, 
 // rounds x step time x samples per unit.  GPNERF_WAVES / GPNERF_SPLIT override (diagnostics).
 constexpr int GPNERF_MAX_SPLIT = 8;     // waves that may share one tile's samples
 constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue counters (one per XCD), padded
+// frame-level deferral (colour_units_kernel): per launch slot its entry count, and room for an entry and a result per SAMPLE (a
+// frame whose every weight is non-zero); frames beyond 2^26 samples (1024 x 1024 x 64: 2.1 GB) keep the tile-level passes
+size_t align256(size_t v);
+bool gdef_fits(int64_t n_rays, int32_t n_samples) { return n_samples <= 256 && n_rays * (int64_t)n_samples <= ((int64_t)1 << 26); }
+constexpr size_t GDEF_HEAD_BYTES = 256;        // gd_ctrl: the unit queue's counters and the entry count
+size_t gdef_bytes(int64_t n_rays, int32_t n_samples) {
+    return GDEF_HEAD_BYTES + align256((size_t)n_rays * sizeof(int)) + (size_t)n_rays * n_samples * (sizeof(uint4) + sizeof(f32x4));
+}
 // Early termination walks the samples in segments of chain_len(), one launch per segment over the rays still alive (see
 // gpnerf_render_fused); the workspace then holds a control block (per segment: 8 queue counters + the length of its output
 // list), two ray lists (written and read alternately) and 16 floats of parked state per ray.
@@ -2856,6 +2997,9 @@ constexpr bool SPLIT_DEFERS = true;
 template <int FORM> constexpr bool form_defers() { return SPLIT_DEFERS || (FORM != FORM_SPLIT && FORM != FORM_SPLIT_GUARD); }
 template <int FORM, bool CHAIN, bool CULL>
 void launch_form(bool deferred, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const KArgs& ka) {
+    if constexpr ((FORM == FORM_F32 || FORM == FORM_F32_FOLD) && !CULL) {
+        if (deferred && ka.gd_ent) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true>), grid, block, lds, stream, ka); return; }
+    }
     if constexpr (form_defers<FORM>()) {
         if (deferred) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, CULL, true>), grid, block, lds, stream, ka); return; }
     }
@@ -3034,6 +3178,13 @@ int device_ready(int* cus) {
             };
             all_of(std::integral_constant<int, FORM_F32>{}, lds_bytes);
             all_of(std::integral_constant<int, FORM_F32_FOLD>{}, lds_bytes);
+            // frame-level deferral (fp32 forms)
+            d.ok = d.ok && lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, false, true, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false, false, true, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true, false, true, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, true, false, true, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&colour_units_kernel<FORM_F32>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&colour_units_kernel<FORM_F32_FOLD>), lds_bytes);
             all_of(std::integral_constant<int, FORM_SPLIT>{}, lds_split + DEFER_LDS_BYTES);
             all_of(std::integral_constant<int, FORM_SPLIT_GUARD>{}, lds_split + GUARD_LDS_SLOTS * 8 + DEFER_LDS_BYTES);
             d.ok = d.ok && lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FIXUP, false>), lds_bytes) &&
@@ -3530,6 +3681,39 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (f_defer < 0) f_defer = dbg_int("GPNERF_DEFER", 1, 0, 1);
     const bool deferred = f_defer && (ka.skip & 2) && !out->raw;
     const int sel = guard ? SEL_GUARD : (split16 ? SEL_SPLIT : (folded ? SEL_FOLD : SEL_REF));
+    // Frame-level deferral (fp32 forms, persistent launches of whole tiles): the sample loop only LISTS the samples whose weight is
+    // not zero; colour_units_kernel evaluates the list and colour_accumulate_kernel adds every ray's terms in order (see there).
+    static int f_gdef = -1;
+    if (f_gdef < 0) f_gdef = dbg_int("GPNERF_FRAME_DEFER", 1, 0, 1);
+    const bool gdef_ok = f_gdef && deferred && !culling && !cull_mask && (sel == SEL_REF || sel == SEL_FOLD) && !(flags & GPNERF_FLAG_OCC_CULL) &&
+                         gdef_fits(n_rays, n_samples) && workspace != nullptr;
+    // the block sits behind what the launch's own form keeps in the workspace (`behind` bytes); false: no room, the wavefronts keep their passes
+    auto gdef_setup = [&](KArgs& kx, size_t behind) -> bool {
+        behind = align256(behind);
+        if (!gdef_ok || workspace_bytes < behind + gdef_bytes(n_rays, n_samples)) return false;
+        char* const b = static_cast<char*>(workspace) + behind;
+        if (!zero_async(b, GDEF_HEAD_BYTES, stream)) return false;
+        const size_t cap = (size_t)n_rays * n_samples, cnt_bytes = align256((size_t)n_rays * sizeof(int));
+        kx.gd_ctrl = reinterpret_cast<unsigned*>(b);
+        kx.gd_cnt = reinterpret_cast<int*>(b + GDEF_HEAD_BYTES);
+        kx.gd_ent = reinterpret_cast<uint4*>(b + GDEF_HEAD_BYTES + cnt_bytes);
+        kx.gd_rgbw = reinterpret_cast<f32x4*>(b + GDEF_HEAD_BYTES + cnt_bytes + cap * sizeof(uint4));
+        return true;
+    };
+    // the list's evaluation and the colour map of launch slots [0, n_slots) (behind the launches that listed the entries)
+    auto colour_phase = [&](const KArgs& kx, long n_slots) -> bool {
+        if (hipGetLastError() != hipSuccess) return false;
+        KArgs kc = kx;
+        static int f_uchunk = -1;
+        if (f_uchunk < 0) f_uchunk = dbg_int("GPNERF_UNIT_CHUNK", 64, 1, 4096);
+        kc.chunk = f_uchunk;
+        if (sel == SEL_FOLD) hipLaunchKernelGGL((colour_units_kernel<FORM_F32_FOLD>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kc);
+        else hipLaunchKernelGGL((colour_units_kernel<FORM_F32>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kc);
+        if (hipGetLastError() != hipSuccess) return false;
+        hipLaunchKernelGGL(colour_accumulate_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, S_(stream), (const int*)kx.gd_cnt,
+                           (const f32x4*)kx.gd_rgbw, n_slots, (int)n_samples, ok.order, ok.rgb);
+        return hipGetLastError() == hipSuccess;
+    };
     static int f_segmajor = -1;
     if (f_segmajor < 0) f_segmajor = dbg_int("GPNERF_QSPLIT_SEGMAJOR", 0, 0, 1);
     ka.seg_major = f_segmajor;
@@ -3555,7 +3739,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         ku.first_slot = 0; ku.first_items = (long)n_rays;
         ku.list_in = nullptr; ku.count_in = nullptr; ku.list_out = nullptr; ku.count_out = nullptr; ku.chunk_cnt = nullptr;
         ku.p_cap = (long)(slots * RAYS_PER_WAVE);
+        const bool listed = gdef_setup(ku, QUEUE_BYTES);
         launch_render<true, false>(sel, deferred, dim3((unsigned)n_cus), full_block, S_(stream), ku);
+        if (listed && !colour_phase(ku, (long)n_rays)) return GPNERF_E_LAUNCH;
         return fixup();
     }
     // Early termination on frames of at least one round of wavefronts: the samples are walked in segments of chain_len(), one
@@ -3583,6 +3769,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         if (f_fill < 0.f) { const char* e = dbg_env("GPNERF_CHAIN_PFILL"); f_fill = e ? fminf(fmaxf((float)atof(e), 0.f), 8.f) : 1.f; }
         ka.p_cap = (long)((double)grid * GPNERF_MAX_WAVES * RAYS_PER_WAVE * f_fill);
         ka.first_slot = 0; ka.first_items = (long)n_rays;
+        const bool listed = gdef_setup(ka, need_chain);
         int begins[CHAIN_MAX_SEGS + 2];
         const int n_launch = chain_schedule((int)n_samples, begins);
         for (int sg = 0; sg < n_launch; ++sg) {
@@ -3601,6 +3788,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
                                    (const unsigned*)ka.chunk_cnt, (const unsigned*)ka.count_in, ka.first_items, lists[sg & 1], ka.count_out);
             if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         }
+        if (listed && !colour_phase(ka, (long)n_rays)) return GPNERF_E_LAUNCH;
         return fixup();
     }
     // A frame of q whole rounds of wavefronts plus a FEW tiles (at most an eighth of a round) ends with those few running alone,
@@ -3609,6 +3797,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // P), S / 8 steps each, with the plain form's arithmetic per ray (term_eps = 0: nothing is ever frozen).  Bit-identical
     // results; 576x576x64: 18.8 -> 18.0 ms.  (A larger remainder is better left to the queue: CUs with few waves step faster.)
     if (do_remainder) ka.n_rays = (long)((tiles - rem_tiles) * RAYS_PER_WAVE);
+    const bool gdef = dynamic && !qsplit && !(flags & GPNERF_FLAG_EARLY_TERM) && gdef_setup(ka, QUEUE_BYTES);
     if (cull_mask) {
         ka.cull_mask = cull_mask;
         {
@@ -3644,6 +3833,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         kr.p_cap = (long)(slots * RAYS_PER_WAVE);
         launch_render<true, false>(sel, deferred, dim3((unsigned)n_cus), full_block, S_(stream), kr);
     }
+    if (gdef && !colour_phase(ka, ka.n_rays)) return GPNERF_E_LAUNCH;
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),
@@ -3659,7 +3849,9 @@ size_t gpnerf_render_workspace_bytes(int64_t n_rays, int32_t n_samples) {
     const size_t plain = QUEUE_BYTES + (n_rays <= 131072 ? (size_t)n_rays * GPNERF_MAX_SPLIT * 16 * sizeof(float) : 0);
     const size_t chain = chain_bytes(n_rays, n_samples);
     // + the keep bits of occupancy culling + the split form's range-guard flags
-    return align256(plain > chain ? plain : chain) + cull_mask_bytes(n_rays) + guard_bytes(n_rays);
+    // + the entry list of the frame-level colour deferral, behind whichever of the two the launch uses
+    const size_t gdef = gdef_fits(n_rays, n_samples) && n_rays > 32 * 8 * 8 ? gdef_bytes(n_rays, n_samples) : 0;
+    return align256(plain > chain ? plain : chain) + gdef + cull_mask_bytes(n_rays) + guard_bytes(n_rays);
 }
 
 size_t gpnerf_render_guard_bytes(int64_t n_rays) { return n_rays > 0 ? guard_bytes(n_rays) : 0; }
