@@ -2246,8 +2246,9 @@ DEV void colour_unit(float* lds, const int lane, const long unit, const unsigned
     }
 }
 
+constexpr int UNIT_WAVES = 8;            // wavefronts of a colour_units_kernel workgroup (12, three per SIMD at 168 registers: the same time, A/B on one box)
 template <int FORM>
-__global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
+__global__ void __launch_bounds__(64 * UNIT_WAVES)
 colour_units_kernel(const KArgs ka) {
     static_assert(FORM == FORM_F32 || FORM == FORM_F32_FOLD, "frame-level deferral: the fp32 forms");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -3707,8 +3708,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         static int f_uchunk = -1;
         if (f_uchunk < 0) f_uchunk = dbg_int("GPNERF_UNIT_CHUNK", 64, 1, 4096);
         kc.chunk = f_uchunk;
-        if (sel == SEL_FOLD) hipLaunchKernelGGL((colour_units_kernel<FORM_F32_FOLD>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kc);
-        else hipLaunchKernelGGL((colour_units_kernel<FORM_F32>), dim3((unsigned)n_cus), full_block, lds_bytes, S_(stream), kc);
+        if (sel == SEL_FOLD) hipLaunchKernelGGL((colour_units_kernel<FORM_F32_FOLD>), dim3((unsigned)n_cus), dim3(64 * UNIT_WAVES), lds_bytes, S_(stream), kc);
+        else hipLaunchKernelGGL((colour_units_kernel<FORM_F32>), dim3((unsigned)n_cus), dim3(64 * UNIT_WAVES), lds_bytes, S_(stream), kc);
         if (hipGetLastError() != hipSuccess) return false;
         hipLaunchKernelGGL(colour_accumulate_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, S_(stream), (const int*)kx.gd_cnt,
                            (const f32x4*)kx.gd_rgbw, n_slots, (int)n_samples, ok.order, ok.rgb);
@@ -3833,7 +3834,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         kr.p_cap = (long)(slots * RAYS_PER_WAVE);
         launch_render<true, false>(sel, deferred, dim3((unsigned)n_cus), full_block, S_(stream), kr);
     }
-    if (gdef && !colour_phase(ka, ka.n_rays)) return GPNERF_E_LAUNCH;
+    if (gdef && !colour_phase(ka, (long)n_rays)) return GPNERF_E_LAUNCH;     // (the remainder launch lists into the same block)
     if (g.split > 1) {
         if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         hipLaunchKernelGGL(combine_segments_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, S_(stream),

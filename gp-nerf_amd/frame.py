@@ -304,7 +304,7 @@ def patch_order_rays(mask, H, W, n, patch_w=32, patch_h=8):
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-5,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
-                 split_f16=False, flip=None, subset=False, guard=None, fold=None, reserve_cus=0, exits=True):
+                 split_f16=False, flip=None, subset=False, guard=None, fold=None, reserve_cus=0, exits=True, workspace_cap=None):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); defaults to neg_ray for the dense renderer
     (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
@@ -326,7 +326,8 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     re-folding a Frame that is already folded.
     exits=False: every layer evaluated for every sample (GPNERF_FLAG_NO_EXITS).  By default the fp32 forms leave out what cannot
     change an output, bit for bit: the sigma feature layer of levels whose features are zero in all 32 samples of a step, and the
-    colour branch of samples whose weight alpha * T is zero (the rest wait in a per-wavefront queue and are evaluated 32 at a time),
+    colour branch of samples whose weight alpha * T is zero (the rest are listed and evaluated 32 at a time -- by a second launch
+    over the whole frame's list where the workspace has room for it, out of a per-wavefront queue otherwise: the same bits),
     and everything behind the sample at which all 32 rays of a tile have a transmittance of exactly 0;
     want=("step_stats",) returns the 8 counters of GpnerfOutputs.step_stats (steps, empty-space steps, steps minus colour
     evaluations, opaque-tail steps, volume levels left out, colour evaluations, 0, 0).  A launch that returns `raw` keeps the
@@ -413,6 +414,8 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     if subset and any(k in want for k in ("weights", "z_vals", "raw")):
         raise L.GpnerfError("subset launches return the per-ray maps only")
     ws_bytes = int(lib.gpnerf_render_workspace_bytes(n_launch, S)) if load_balance else 0
+    if workspace_cap is not None:       # lend less than the launch could use (it then keeps to the forms that fit: include/gpnerf_hip.h `workspace`)
+        ws_bytes = min(ws_bytes, int(workspace_cap))
     ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8) if ws_bytes else None
     L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), n_launch, S, flags, float(term_eps),
                                     ray_order.data_ptr() if ray_order is not None else None, C.byref(o),

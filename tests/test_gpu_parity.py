@@ -515,6 +515,56 @@ def test_deferred_colour_branch_is_the_plain_loop_bit_for_bit(form, fm, syn):
         assert (st[2] == st[0]) if expect == "none" else (st[2] == 0), (expect, st)
 
 
+@pytest.mark.parametrize("form", ["reference-order", "folded"])
+def test_frame_level_deferral_is_the_wavefront_level_one_bit_for_bit(form, fm, syn):
+    """Frames of more than one round of wavefronts list the samples whose weight is not zero and evaluate the list in a second,
+    balanced launch (colour_units_kernel; colour_accumulate_kernel adds a ray's terms in sample order) where the workspace has room
+    for the list; with less workspace every wavefront runs its own colour passes.  Same arithmetic on the same operands in the same
+    order: every map must be the same bits, on every launch shape that lists -- whole rounds on the tile queue, whole rounds plus a
+    remainder launch, one launch of whole tiles and eight-samples-per-step units (a ZJU-sized frame), the chained segments of early
+    termination -- and step_stats must count exactly ceil(non-zero weights / 32) colour evaluations (a packed list) where the
+    wavefront-level passes count at least as many."""
+    fkw = {"reference-order": {}, "folded": {"fold": True}}[form]
+    want = ("weights", "z_vals", "rgb_in", "ray_mask")
+    g = torch.Generator().manual_seed(9)
+    small = 48 << 20           # room for the tile queue and the chained form's lists, not for a frame's entry list
+
+    def same(a, b, tag):
+        for k in a:
+            assert torch.equal(torch.nan_to_num(a[k].float()), torch.nan_to_num(b[k].float())), (tag, k)
+
+    listed = 0
+    for size, S, bias in ((362, 64, -0.3), (260, 64, -0.3), (370, 33, -0.3), (300, 128, 1.0)):
+        sc = syn.make_scene(H=size, W=size, seed=100 + size, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1, sigma_bias=bias)
+        fr = build_frame(fm, sc)
+        rays_all = rays_of(sc)
+        for n in (rays_all.shape[0], rays_all.shape[0] - 37):
+            rays = rays_all[:n].contiguous()
+            order = torch.randperm(n, generator=g).int().cuda()
+            for kw in ({}, {"ray_order": order}, {"neg_ray": True}, {"early_term": True, "term_eps": 1e-5}):
+                if kw.get("neg_ray") and n != rays_all.shape[0]:
+                    continue
+                a = fm.render_fused(fr, rays, S, want=want + ("step_stats",), **dict(fkw, **kw))
+                b = fm.render_fused(fr, rays, S, want=want + ("step_stats",), workspace_cap=small, **dict(fkw, **kw))
+                sa, sb = a.pop("step_stats").cpu().numpy().astype(np.int64), b.pop("step_stats").cpu().numpy().astype(np.int64)
+                same(a, b, (size, S, n, tuple(kw)))
+                # (steps and opaque tails are the launch's; the units of several samples per step take the level-by-level exit of the
+                #  sigma feature layer only when they list: never fewer levels left out)
+                assert sa[0] == sb[0] and sa[3] == sb[3] and sa[1] >= sb[1] and sa[4] >= sb[4], (sa, sb)
+                assert sa[5] <= sb[5] and sa[2] == sa[0] - sa[5], (sa, sb)
+                units = (int((a["weights"] != 0).sum()) + 31) // 32
+                if sa[5] < sb[5]:
+                    listed += 1
+                    # (early termination freezes a ray below term_eps: its later weights are written as zeros, listed or not)
+                    assert sa[5] == units, (size, S, n, tuple(kw), sa, units)
+                else:           # a launch shape that does not list (a frame between one and two rounds splits its tiles' samples instead)
+                    assert sa[5] == sb[5], (size, S, n, tuple(kw), sa, sb)
+        c = fm.render_fused(fr, rays_all, S, want=want, exits=False, **fkw)
+        a = fm.render_fused(fr, rays_all, S, want=want, **fkw)
+        same(a, c, (size, S, "every layer of every sample"))
+    assert listed >= 20, listed       # the launches did take the frame-level path (a packed list needs fewer evaluations than per-wavefront passes)
+
+
 def test_reserved_cus_render_the_same_frame(fm, syn):
     """GPNERF_FLAG_RESERVE_CUS plans the launch for fewer compute units (the pipelined loop's experiment, profiles/r05/d_pipeline.txt).
     A ray's result is a function of the ray alone, so the maps are the ones a smaller chip gives: bit-identical whenever the launch

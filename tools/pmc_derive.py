@@ -10,8 +10,10 @@ import json
 import sys
 
 src, workload, kernel, commit, out = sys.argv[1:6]
-raw = {k: v["mean_per_dispatch"] for k, v in json.load(open(src)).items()}
-n = min(v["dispatches"] for v in json.load(open(src)).values())
+loaded = json.load(open(src))
+parts = loaded.pop("parts", None)          # (pmc_summary.py "a+b+c": the kernels of one call, summed; each part's own means)
+raw = {k: v["mean_per_dispatch"] for k, v in loaded.items()}
+n = min(v["dispatches"] for v in loaded.values())
 cyc = raw["GRBM_GUI_ACTIVE"] / 8.0
 d = {"shader_cycles_per_launch": cyc}
 if "SQ_VALU_MFMA_BUSY_CYCLES" in raw:
@@ -30,6 +32,19 @@ d["l2_hit_rate"] = raw["TCC_HIT_sum"] / (raw["TCC_HIT_sum"] + raw["TCC_MISS_sum"
 d["lds_bank_conflict_cycles"] = raw.get("SQ_LDS_BANK_CONFLICT")
 res = {"workload": workload, "kernel": kernel, "commit": commit, "dispatches_averaged": n,
        "collection": "rocprofv3 --pmc, 4 separate passes (tools/pmc_passes.sh), counters only", "raw_mean_per_dispatch": raw, "derived": d}
+if parts:
+    per = {}
+    for name, p in parts.items():
+        r = {k: v["mean_per_dispatch"] for k, v in p.items()}
+        c = r["GRBM_GUI_ACTIVE"] / 8.0
+        per[name] = {"dispatches_per_call": p["GRBM_GUI_ACTIVE"]["dispatches"] / float(n), "shader_cycles_per_dispatch": c,
+                     "mfma_pipe_busy_frac": r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (c * 1024.0),
+                     "valu_active_frac": r.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (c * 1024.0),
+                     "hbm_bytes_per_dispatch": r["FETCH_SIZE"] * 2048.0 + r["WRITE_SIZE"] * 1024.0,
+                     "l2_hit_rate": r["TCC_HIT_sum"] / max(1.0, r["TCC_HIT_sum"] + r["TCC_MISS_sum"])}
+    res["per_kernel"] = per
+    res["note"] = ("one gpnerf_render_fused call = the kernels under per_kernel; raw_mean_per_dispatch / derived are per CALL: every dispatch of "
+                   "these kernels added up (busy fractions over the summed shader cycles)")
 json.dump(res, open(out, "w"), indent=1)
 if "--traffic" in sys.argv:
     t = sys.argv[sys.argv.index("--traffic") + 1]
