@@ -376,8 +376,9 @@ def main():
         flops_done, exits = price_work_done(step_stats, flops_per_launch)
         exits["note"] = ("bit-exact exits (GPNERF_FLAG_NO_EXITS switches them off: roofline.dense_*): a volume level whose features are zero in all 32 "
                          "samples of a step is left out of the sigma feature layer; a sample whose weight alpha*T is exactly zero (nn.ReLU on the density; "
-                         "masked_fill) adds fma(0, rgb, c) = c to the colour map, so its colour branch is not evaluated: the wavefront queues the samples "
-                         "that need it and runs the branch on 32 of them at a time; steps behind the sample at which all 32 rays' transmittance is exactly "
+                         "masked_fill) adds fma(0, rgb, c) = c to the colour map, so its colour branch is not evaluated: the sample loop lists the samples "
+                         "that need it, colour_units_kernel runs the branch on 32 list entries at a time and colour_accumulate_kernel adds every ray's terms "
+                         "in sample order (kernel_ms is the whole call: the three kernels); steps behind the sample at which all 32 rays' transmittance is exactly "
                          "0 are settled without a gather or an MFMA")
         algorithmic = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         achieved = flops_done / (kernel_ms * 1e-3) / 1e12
@@ -409,7 +410,9 @@ def main():
                        "out_sh_dhw": [int(x) for x in wl.sc["out_sh"][0]], "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "render_fused_kernel", "kernel_ms": kernel_ms, "flop_per_launch": flops_done,
+                         "kernel": "render_fused_kernel" if args.split_f16 else
+                         "render_fused_kernel + colour_units_kernel + colour_accumulate_kernel (one gpnerf_render_fused call; kernel_ms = HIP events around the call = the sum of their rocprofv3 averages)",
+                         "kernel_ms": kernel_ms, "flop_per_launch": flops_done,
                          "accounting": "work done: FLOPs of the dense layers the launch evaluated (step_stats) / kernel_ms; never above the peak",
                          "algorithmic_rate": {"tflops": algorithmic, "flop_per_launch": flops_per_launch, "over_peak": algorithmic / peak,
                                               "note": "every sample the launch answers for x 110 848 FLOP per second: a rate of answers, not of MFMAs"},

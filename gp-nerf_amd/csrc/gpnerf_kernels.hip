@@ -3606,7 +3606,15 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // workspace layout: [0, QUEUE_BYTES) the tile queue's counters, then the per-segment partial composites
     const size_t seg_bytes = workspace && workspace_bytes > QUEUE_BYTES ? workspace_bytes - QUEUE_BYTES : 0;
     float* const seg_part = seg_bytes ? reinterpret_cast<float*>(static_cast<char*>(workspace) + QUEUE_BYTES) : nullptr;
-    const bool may_split = seg_bytes && !(flags & GPNERF_FLAG_EARLY_TERM) && !out->samples_done;
+    // A frame of more than ~1.25 rounds of wavefronts whose launch can list its colour work (frame-level deferral, below) keeps whole
+    // tiles on the queue: the sample loop's tiles then cost the same and the listed colour work is balanced by construction, which
+    // is what splitting a tile's samples bought (384 x 384 x 64: 7.06 ms split in two, 6.17 ms whole; 300 / 320 / 448: the same
+    // either way; 272 x 272, 1.13 rounds, still gains from the split: 3.86 against 4.24) -- and the maps stay bit-identical to the
+    // same rays' in any other launch.
+    const bool can_list = workspace && !split16 && !out->raw && !(flags & (GPNERF_FLAG_NO_EXITS | GPNERF_FLAG_OCC_CULL | GPNERF_FLAG_EARLY_TERM)) &&
+                          gdef_fits(n_rays, n_samples) && workspace_bytes >= QUEUE_BYTES + gdef_bytes(n_rays, n_samples);
+    const bool may_split = seg_bytes && !(flags & GPNERF_FLAG_EARLY_TERM) && !out->samples_done &&
+                           !(can_list && tiles * 4 >= (int64_t)n_cus * GPNERF_MAX_WAVES * 5);
     Geometry g = choose_geometry(tiles, n_samples, may_split, seg_bytes, n_rays, n_cus);
     // whole rounds of full workgroups + a remainder launch (below) when the frame is that shape
     static int f_rem = -1;
