@@ -3611,7 +3611,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // is what splitting a tile's samples bought (384 x 384 x 64: 7.06 ms split in two, 6.17 ms whole; 300 / 320 / 448: the same
     // either way; 272 x 272, 1.13 rounds, still gains from the split: 3.86 against 4.24) -- and the maps stay bit-identical to the
     // same rays' in any other launch.
-    const bool can_list = workspace && !split16 && !out->raw && !(flags & (GPNERF_FLAG_NO_EXITS | GPNERF_FLAG_OCC_CULL | GPNERF_FLAG_EARLY_TERM)) &&
+    // (decided by the frame and the workspace alone -- not by GPNERF_FLAG_NO_EXITS or a `raw` output, whose launches list nothing: a
+    //  launch and its diagnostic twin must cut the frame the same way to be compared bit for bit)
+    const bool can_list = workspace && !split16 && !(flags & (GPNERF_FLAG_OCC_CULL | GPNERF_FLAG_EARLY_TERM)) &&
                           gdef_fits(n_rays, n_samples) && workspace_bytes >= QUEUE_BYTES + gdef_bytes(n_rays, n_samples);
     const bool may_split = seg_bytes && !(flags & GPNERF_FLAG_EARLY_TERM) && !out->samples_done &&
                            !(can_list && tiles * 4 >= (int64_t)n_cus * GPNERF_MAX_WAVES * 5);
