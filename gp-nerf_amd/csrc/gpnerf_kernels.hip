@@ -1295,11 +1295,15 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     // counters), gd_ent[n] = (launch slot, sample | rank << 8, weight bits, 0), gd_rgbw[slot * S + rank] = (r, g, b, weight),
     // gd_cnt[slot] = entries of the ray
     unsigned* gd_ctrl;
+    unsigned* gd_flag;        // unified form: gd_flag[u] = 1 once unit u's 32 entries are written (zero at launch)
+    int gd_waves;             // unified form: wavefronts of the launch (every one reports to GD_DONE when it has listed its last entry)
+    int uni_budget;           // unified form: units a wavefront may evaluate between two tiles
     uint4* gd_ent;
     f32x4* gd_rgbw;
     int* gd_cnt;
 };
-constexpr int GD_QUEUE = 0, GD_COUNT = 8;        // words of gd_ctrl's 256-byte block, zero at launch
+constexpr int GD_QUEUE = 0, GD_COUNT = 8, GD_TICKET = 9, GD_DONE = 10;      // words of gd_ctrl's 256-byte block, zero at launch
+// (GD_COUNT counts ENTRIES in the two-launch form and 32-entry UNITS in the unified one, where GD_TICKET hands the units out)
 
 // the forms of the fused kernel
 constexpr int FORM_F32 = 0, FORM_SPLIT = 1, FORM_SPLIT_GUARD = 2, FORM_F32_FIXUP = 3, FORM_F32_FOLD = 4;
@@ -1510,8 +1514,10 @@ DEV float gather_views(const __attribute__((address_space(4))) FrameK& fr, float
     return nvalid;
 }
 
-template <int FORM, bool CHAIN, int P = 1, bool CULL = false, bool DEFER = false, bool GDEF = false>
+DEV void agent_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int FORM, bool CHAIN, int P = 1, bool CULL = false, bool DEFER = false, bool GDEF = false, bool UNI = false>
 DEV bool render_tile(float* lds, const int lane, const long tile, const int seg, const long entry_base = 0) {
+    static_assert(!UNI || (GDEF && !CHAIN && P == 1), "unified form: the plain listing sample loop");
     static_assert(!CULL || (!CHAIN && P == 1), "occupancy culling: plain form only");
     static_assert(!GDEF || (DEFER && !CULL), "frame-level deferral: a deferred sample loop without culling");
     static_assert(P == 1 || CHAIN, "several samples per step: chained form only");
@@ -1635,8 +1641,23 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
                 const int sl = __shfl((int)slot, (int)(e.x & 31u));
                 kargs_ptr kb = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(kb));
+                if constexpr (UNI) {
+                    // unified form: whole units (what is left at the tile's end padded with null entries), written through to the
+                    // device's coherence point and acknowledged (vmcnt) before the unit's flag says so -- wavefronts of other CUs
+                    // evaluate it while this launch is still running (see render_fused_kernel)
+                    const unsigned u = wave_add(kb->gd_ctrl + GD_COUNT, 1u, lane);
+                    if (lane < 32) {
+                        unsigned* const pe = reinterpret_cast<unsigned*>(kb->gd_ent + (size_t)u * 32 + lane);
+                        agent_store(pe, lane < nb ? (unsigned)sl : 0xffffffffu);
+                        agent_store(pe + 1, e.x >> 5);
+                        agent_store(pe + 2, e.y);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) agent_store(kb->gd_flag + u, 1u);
+                } else {
                 const unsigned base = wave_add(kb->gd_ctrl + GD_COUNT, (unsigned)nb, lane);
                 if (lane < nb) kb->gd_ent[(size_t)base + lane] = uint4{(unsigned)sl, e.x >> 5, e.y, 0u};
+                }
                 q_head = (q_head + nb) & (DEFER_QUEUE - 1);
                 q_cnt -= nb;
                 k -= P;
@@ -2104,10 +2125,59 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 // 8-wave workgroup resident per CU a static grid holds the CU until its slowest tile is done -- the queue hands the next
 // tile to whichever wave is free.  Static launches (one unit per wave, XCD-aware remap) remain for frames smaller than
 // one round and for the sample-split geometry.
-template <int FORM, bool CHAIN, bool CULL = false, bool DEFER = false, bool GDEF = false>     // DEFER: the colour branch sample by sample; GDEF: for the launch as a whole (render_tile)
+// Unified form (render_fused_kernel<., false, false, true, true, true>): the launch's wavefronts evaluate the list themselves,
+// between tiles and when the tile queue has nothing left for them.  `pending` = the unit this wavefront holds a ticket for (-1:
+// none).  Takes tickets UNI_BATCH at a time, evaluates the next unit if its flag is up, returns whether it did.
+constexpr unsigned UNI_BATCH = 4;       // tickets a wavefront takes at a time (the ticket counter is one address for 2 048 wavefronts)
+template <int FORM>
+DEV bool consume_unit(float* lds, const int lane, long& pending, long& pending_end) {
+    typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
+    kargs_ptr kb = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kb));
+    if (pending >= pending_end) {
+        pending = (long)wave_add(kb->gd_ctrl + GD_TICKET, UNI_BATCH, lane);
+        pending_end = pending + UNI_BATCH;
+    }
+    if (wave_load(kb->gd_flag + pending, lane) == 0u) return false;         // (not written yet, or a ticket beyond the list so far)
+    const int n = lane & 31, half = lane >> 5;
+    const unsigned* const pe = reinterpret_cast<const unsigned*>(kb->gd_ent + (size_t)pending * 32 + n);
+    uint4 e;
+    e.x = agent_load(pe); e.y = agent_load(pe + 1); e.z = agent_load(pe + 2); e.w = 0u;
+    const bool valid = e.x != 0xffffffffu;
+    const int slot = valid ? (int)e.x : 0, kk = (int)(e.y & 255u), rank = (int)(e.y >> 8);
+    const int ray = kb->out.order ? kb->out.order[slot] : slot;
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(kb->rays + (size_t)ray * 8);
+    const f32x4 r1 = *reinterpret_cast<const f32x4*>(kb->rays + (size_t)ray * 8 + 4);
+    const int S = kb->S;
+    const unsigned flags = kb->flags;
+    const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0, flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;
+    const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
+    float zq, qx_, qy_, qz_;
+    sample_point(r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], flip ? (S - 1 - kk) : kk, S, step, zq, qx_, qy_, qz_);
+    float xq[NV][18], vq[NV][3], cq[3], mvq[36];
+    gather_views<FORM>(kb->fr, qx_, qy_, qz_, neg, half, xq, vq);
+    Stamps st;
+    if constexpr (FORM == FORM_F32) { mean_var_ref(xq, mvq); mlp_colour_ref(lds, lane, xq, mvq, cq, st); }
+    else { mean_var(xq, mvq); mlp_colour(lds, lane, xq, mvq, cq, st); }
+    kargs_ptr ko = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ko));
+    if (valid && half == 0) {
+        f32x4 v; v[0] = cq[0]; v[1] = cq[1]; v[2] = cq[2]; v[3] = __builtin_bit_cast(float, e.z);
+        ko->gd_rgbw[(size_t)slot * S + rank] = v;
+    }
+    if (ko->out.step_stats && lane == 0) {
+        atomicAdd(ko->out.step_stats + 5, 1u);
+        atomicAdd(ko->out.step_stats + 2, 0xffffffffu);
+    }
+    ++pending;
+    return true;
+}
+
+template <int FORM, bool CHAIN, bool CULL = false, bool DEFER = false, bool GDEF = false, bool UNI = false>     // DEFER: the colour branch sample by sample; GDEF: for the launch as a whole (render_tile); UNI: ... and evaluated by this launch's own wavefronts
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const KArgs ka) {
     static_assert(!DEFER || FORM != FORM_F32_FIXUP, "the fix-up launch evaluates everything");
+    static_assert(!UNI || (GDEF && !CHAIN && !CULL && (FORM == FORM_F32 || FORM == FORM_F32_FOLD)), "unified form: the plain listing launch of the fp32 forms");
     constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     WT(0);
@@ -2133,6 +2203,9 @@ render_fused_kernel(const KArgs ka) {
     int qx = home, dry = 0;
     int samples_per_step = 1;                   // chained form: render_tile's P and list offset of the current unit
     long entry_base = 0;
+    long uni_pending = 0, uni_pending_end = 0;  // unified form: the units this wavefront holds tickets for
+    int uni_left = 0;
+    bool uni_drain = false;
     if (ka.stagger) {
         const int u = (int)((blockIdx.x * 8u + (unsigned)wave) * 2654435761u >> 27);        // 0..31, scattered over the chip
         for (int i = 0; i < ((u * ka.stagger) >> 5); ++i) __builtin_amdgcn_s_sleep(64);
@@ -2143,6 +2216,7 @@ render_fused_kernel(const KArgs ka) {
         asm volatile("" : "+s"(kq));            // re-read per tile rather than held across render_tile (see there)
         long tile = 0;
         int seg = 0;
+        bool have_tile = !(UNI && dry >= 8);
         if (!kq->dynamic) {                     // static launch: exactly one unit per wave
             if (dry) return;
             const long unit = (long)xcd_remap(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
@@ -2162,16 +2236,19 @@ render_fused_kernel(const KArgs ka) {
             // fewer tiles than waves: deal them evenly, so that every CU runs the same few waves (each then steps faster) rather
             // than the first workgroups to arrive running eight and the rest none
             const long share = kq->wave_cap ? (long)kq->wave_cap : (n_tiles + gridDim.x - 1) / gridDim.x;
-            if (wave >= share) return;
+            if (wave >= share) { if constexpr (UNI) { have_tile = false; dry = 8; } else return; }
             STAMP_T0();
+            if (have_tile) {
             const unsigned t = wave_add(kq->queue + qx, 1u, lane);
             STAMP_ADD(9, lane);
             if ((long)t >= queue_len(n_tiles, kq->chunk, qx)) {     // this XCD's queue is dry: move on to the next one
                 qx = (qx + 1) & 7;
-                if (++dry == 8) return;
-                continue;
-            }
+                if (++dry == 8) { if constexpr (!UNI) return; }
+                if (!UNI || dry < 8) continue;
+                have_tile = false;
+            } else
             tile = queue_tile(kq->chunk, qx, t);
+            }
             if (usplit > 1) {
                 if (kq->seg_major) { seg = (int)(tile / tiles_per_seg); tile -= (long)seg * tiles_per_seg; }      // all tiles' first segment, then the second ...
                 else { seg = (int)(tile % usplit); tile /= usplit; }
@@ -2188,17 +2265,42 @@ render_fused_kernel(const KArgs ka) {
         }
         constexpr int F = FORM == FORM_F32_FIXUP ? FORM_F32 : FORM;
         STAMP_T0();
+        if (have_tile) {
         if constexpr (CHAIN) {
             if (samples_per_step == 8) render_tile<F, true, 8, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
             else if (samples_per_step == 4) render_tile<F, true, 4, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
             else if (samples_per_step == 2) render_tile<F, true, 2, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
             else render_tile<F, true, 1, false, DEFER, GDEF>(lds, lane, tile, seg, entry_base);
         } else {
-            render_tile<F, false, 1, CULL, DEFER, GDEF>(lds, lane, tile, seg);
+            render_tile<F, false, 1, CULL, DEFER, GDEF, UNI>(lds, lane, tile, seg);
         }
         STAMP_ADD(8, lane);
         WT(3);
         WT_COUNT();
+        }
+        if constexpr (UNI) {
+            // between tiles: what the list holds beyond the tickets, at most uni_budget units; with no tile left (drain): units until
+            // every wavefront has listed its last entry -- render_tile flushes at every tile's end -- and this one's ticket lies
+            // beyond the list.  ONE site for both (the colour branch's code is 28 KB of the instruction cache).
+            uni_left = kq->uni_budget;
+            if (!have_tile && !uni_drain) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wave_add(kq->gd_ctrl + GD_DONE, 1u, lane);
+                uni_drain = true;
+            }
+            for (;;) {
+                if (!uni_drain && uni_left <= 0) break;
+                if (consume_unit<F>(lds, lane, uni_pending, uni_pending_end)) { --uni_left; continue; }
+                if (!uni_drain) break;
+                typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
+                kargs_ptr kd = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kd));
+                if (wave_load(kd->gd_ctrl + GD_DONE, lane) >= (unsigned)kd->gd_waves) {
+                    if (uni_pending >= (long)wave_load(kd->gd_ctrl + GD_COUNT, lane)) return;     // (every ticket it holds lies beyond the list)
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
     }
 }
 
@@ -2969,8 +3071,12 @@ constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue c
 size_t align256(size_t v);
 bool gdef_fits(int64_t n_rays, int32_t n_samples) { return n_samples <= 256 && n_rays * (int64_t)n_samples <= ((int64_t)1 << 26); }
 constexpr size_t GDEF_HEAD_BYTES = 256;        // gd_ctrl: the unit queue's counters and the entry count
+// entries: one per sample + a unit per tile (the unified form pads what a tile leaves to a whole unit); flags: one word per unit
+size_t gdef_entries(int64_t n_rays, int32_t n_samples) { return (size_t)n_rays * n_samples + (size_t)((n_rays + 31) / 32) * 32; }
+size_t gdef_flag_bytes(int64_t n_rays, int32_t n_samples) { return align256((gdef_entries(n_rays, n_samples) / 32 + 64) * sizeof(unsigned)); }
 size_t gdef_bytes(int64_t n_rays, int32_t n_samples) {
-    return GDEF_HEAD_BYTES + align256((size_t)n_rays * sizeof(int)) + (size_t)n_rays * n_samples * (sizeof(uint4) + sizeof(f32x4));
+    return GDEF_HEAD_BYTES + align256((size_t)n_rays * sizeof(int)) + gdef_flag_bytes(n_rays, n_samples) + gdef_entries(n_rays, n_samples) * sizeof(uint4) +
+           (size_t)n_rays * n_samples * sizeof(f32x4);
 }
 // Early termination walks the samples in segments of chain_len(), one launch per segment over the rays still alive (see
 // gpnerf_render_fused); the workspace then holds a control block (per segment: 8 queue counters + the length of its output
@@ -2999,6 +3105,9 @@ template <int FORM> constexpr bool form_defers() { return SPLIT_DEFERS || (FORM 
 template <int FORM, bool CHAIN, bool CULL>
 void launch_form(bool deferred, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const KArgs& ka) {
     if constexpr ((FORM == FORM_F32 || FORM == FORM_F32_FOLD) && !CULL) {
+        if constexpr (!CHAIN) {
+            if (deferred && ka.gd_ent && ka.gd_flag) { hipLaunchKernelGGL((render_fused_kernel<FORM, false, false, true, true, true>), grid, block, lds, stream, ka); return; }
+        }
         if (deferred && ka.gd_ent) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true>), grid, block, lds, stream, ka); return; }
     }
     if constexpr (form_defers<FORM>()) {
@@ -3182,6 +3291,8 @@ int device_ready(int* cus) {
             // frame-level deferral (fp32 forms)
             d.ok = d.ok && lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, false, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false, false, true, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, false, true, true, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false, false, true, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true, false, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, true, false, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&colour_units_kernel<FORM_F32>), lds_bytes) &&
@@ -3698,22 +3809,29 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (f_gdef < 0) f_gdef = dbg_int("GPNERF_FRAME_DEFER", 1, 0, 1);
     const bool gdef_ok = f_gdef && deferred && !culling && !cull_mask && (sel == SEL_REF || sel == SEL_FOLD) && !(flags & GPNERF_FLAG_OCC_CULL) &&
                          gdef_fits(n_rays, n_samples) && workspace != nullptr;
+    unsigned* gd_flags = nullptr;
     // the block sits behind what the launch's own form keeps in the workspace (`behind` bytes); false: no room, the wavefronts keep their passes
     auto gdef_setup = [&](KArgs& kx, size_t behind) -> bool {
         behind = align256(behind);
         if (!gdef_ok || workspace_bytes < behind + gdef_bytes(n_rays, n_samples)) return false;
         char* const b = static_cast<char*>(workspace) + behind;
         if (!zero_async(b, GDEF_HEAD_BYTES, stream)) return false;
-        const size_t cap = (size_t)n_rays * n_samples, cnt_bytes = align256((size_t)n_rays * sizeof(int));
+        const size_t cnt_bytes = align256((size_t)n_rays * sizeof(int)), flag_bytes = gdef_flag_bytes(n_rays, n_samples);
         kx.gd_ctrl = reinterpret_cast<unsigned*>(b);
         kx.gd_cnt = reinterpret_cast<int*>(b + GDEF_HEAD_BYTES);
-        kx.gd_ent = reinterpret_cast<uint4*>(b + GDEF_HEAD_BYTES + cnt_bytes);
-        kx.gd_rgbw = reinterpret_cast<f32x4*>(b + GDEF_HEAD_BYTES + cnt_bytes + cap * sizeof(uint4));
+        gd_flags = reinterpret_cast<unsigned*>(b + GDEF_HEAD_BYTES + cnt_bytes);
+        kx.gd_ent = reinterpret_cast<uint4*>(b + GDEF_HEAD_BYTES + cnt_bytes + flag_bytes);
+        kx.gd_rgbw = reinterpret_cast<f32x4*>(b + GDEF_HEAD_BYTES + cnt_bytes + flag_bytes + gdef_entries(n_rays, n_samples) * sizeof(uint4));
         return true;
     };
     // the list's evaluation and the colour map of launch slots [0, n_slots) (behind the launches that listed the entries)
     auto colour_phase = [&](const KArgs& kx, long n_slots) -> bool {
         if (hipGetLastError() != hipSuccess) return false;
+        if (kx.gd_flag) {       // unified form: the launch has evaluated its list itself
+            hipLaunchKernelGGL(colour_accumulate_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, S_(stream), (const int*)kx.gd_cnt,
+                               (const f32x4*)kx.gd_rgbw, n_slots, (int)n_samples, ok.order, ok.rgb);
+            return hipGetLastError() == hipSuccess;
+        }
         KArgs kc = kx;
         static int f_uchunk = -1;
         if (f_uchunk < 0) f_uchunk = dbg_int("GPNERF_UNIT_CHUNK", 64, 1, 4096);
@@ -3809,6 +3927,19 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // results; 576x576x64: 18.8 -> 18.0 ms.  (A larger remainder is better left to the queue: CUs with few waves step faster.)
     if (do_remainder) ka.n_rays = (long)((tiles - rem_tiles) * RAYS_PER_WAVE);
     const bool gdef = dynamic && !qsplit && !(flags & GPNERF_FLAG_EARLY_TERM) && gdef_setup(ka, QUEUE_BYTES);
+    // Unified form (frames of two rounds or more, nothing left to a remainder launch): the wavefronts evaluate the list themselves,
+    // between tiles and while the last tiles are still being walked (render_fused_kernel, UNI)
+    static int f_uni = -1, f_budget = -1;
+    // (uni_budget = units a wavefront may evaluate between two tiles: measured 0 / 4 / 24 / 100 -> 9.72 / 9.75 / 9.82 / 11.8 ms on the
+    //  bench frame -- colour work between tiles buys no overlap and unbalances the tile queue; the list is evaluated when a wavefront
+    //  has no tile left, which is what fills the end of a frame whose tiles differ in cost)
+    if (f_uni < 0) { f_uni = dbg_int("GPNERF_UNIFIED", 1, 0, 1); f_budget = dbg_int("GPNERF_UNI_BUDGET", 0, 0, 4096); }
+    if (gdef && f_uni && !do_remainder && !cull_mask && tiles >= 2 * slots) {
+        if (!zero_async(gd_flags, gdef_flag_bytes(n_rays, n_samples), stream)) return GPNERF_E_LAUNCH;
+        ka.gd_flag = gd_flags;
+        ka.gd_waves = (int)(blocks * g.waves);
+        ka.uni_budget = f_budget;
+    }
     if (cull_mask) {
         ka.cull_mask = cull_mask;
         {

@@ -158,9 +158,10 @@ typedef struct GpnerfOutputs {
                               [5] evaluations of the colour branch on 32 samples: one per step where it runs in the step, one
                                   per colour pass where it is deferred -- a sample whose weight alpha * T is exactly 0 adds
                                   fma(0, rgb, c) = c to the colour map, so only the samples that need it are evaluated, 32 at a
-                                  time: listed for the launch as a whole and evaluated by a second kernel where the workspace
-                                  has room for the list (fp32 forms on the tile queue: exactly ceil(listed / 32)), out of a
-                                  queue per wavefront otherwise (never with `raw`, never under GPNERF_FLAG_NO_EXITS);
+                                  time: listed for the launch as a whole where the workspace has room for the list (fp32 forms
+                                  on the tile queue) and evaluated by the launch's own wavefronts once they have no tile left
+                                  (frames of two rounds or more) or by a second kernel (exactly ceil(listed / 32) evaluations),
+                                  out of a queue per wavefront otherwise (never with `raw`, never under GPNERF_FLAG_NO_EXITS);
                               [6], [7] reserved (0).
                               All of it is bit-exact; bench.py prices its roofline on the work done:
                               sample-loop steps x (everything but the colour branch) - [4] x layer / 4 + [5] x colour branch */
@@ -211,9 +212,11 @@ int gpnerf_fold_volumes(const GpnerfFrame* frame, float* const* out, void* strea
  *     composites (second small launch); the transmittance product is then associated per segment, a ~1e-7 relative
  *     difference (never with GPNERF_FLAG_EARLY_TERM).  On the tile queue the fp32 forms also keep the LIST of the samples whose
  *     colour branch has to run there (32 bytes per sample of the launch: an entry and a result; launches of up to 2^26 samples)
- *     -- the sample loop then only lists them, a second kernel evaluates the list 32 entries per wavefront step, balanced whatever
- *     the rays, and a third adds every ray's terms in sample order: the colour map's bits are those of the loop that evaluates
- *     them in place, which is what a workspace too small for the list gets (gpnerf_render_workspace_bytes includes it).
+ *     -- the sample loop then only lists them, the list is evaluated 32 entries per wavefront step, balanced whatever the rays
+ *     (by the same launch's wavefronts as they run out of tiles where the frame has two rounds of them or more, by a second
+ *     kernel otherwise), and a last kernel adds every ray's terms in sample order: the colour map's bits are those of the loop
+ *     that evaluates them in place, which is what a workspace too small for the list gets (gpnerf_render_workspace_bytes
+ *     includes it).
  *     The workspace is private to the call until the stream reaches its end. */
 int gpnerf_render_fused(const GpnerfFrame* frame, const float* rays, int64_t n_rays, int32_t n_samples,
                         uint32_t flags, float term_eps, const int32_t* ray_order, const GpnerfOutputs* out,

@@ -565,7 +565,10 @@ def test_frame_level_deferral_is_the_wavefront_level_one_bit_for_bit(form, fm, s
             c = fm.render_fused(fr, rays_all, S, want=want, exits=False, **fkw)
             a = fm.render_fused(fr, rays_all, S, want=want, **fkw)
             same(a, c, (size, S, "every layer of every sample"))
-    assert listed >= 20, listed       # the launches did take the frame-level path (a packed list needs fewer evaluations than per-wavefront passes)
+    # the launches did take the frame-level path: a packed list needs fewer evaluations than per-wavefront passes (frames of two
+    # rounds or more without a remainder launch evaluate the list themselves and pad what a tile leaves to a whole unit: the
+    # per-wavefront count, 362 x 362 here)
+    assert listed >= 12, listed
 
 
 def test_reserved_cus_render_the_same_frame(fm, syn):
