@@ -1302,7 +1302,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     f32x4* gd_rgbw;
     int* gd_cnt;
 };
-constexpr int GD_QUEUE = 0, GD_COUNT = 8, GD_TICKET = 9, GD_DONE = 10;      // words of gd_ctrl's 256-byte block, zero at launch
+constexpr int GD_QUEUE = 0, GD_COUNT = 8, GD_TICKET = 9, GD_DONE = 10;      // words of gd_ctrl's 512-byte block, zero at launch (GD_DONE + segment launch: up to 100)
 // (GD_COUNT counts ENTRIES in the two-launch form and 32-entry UNITS in the unified one, where GD_TICKET hands the units out)
 
 // the forms of the fused kernel
@@ -1438,7 +1438,10 @@ DEV ChainPlan chain_plan(kargs_cptr k) {
 // with ballots.  The workgroup that holds the last entry writes the list's length.
 __global__ void __launch_bounds__(256) compact_list_kernel(const int* __restrict__ sparse, const unsigned* __restrict__ chunk_cnt,
                                                            const unsigned* __restrict__ count_in, const long first_items,
-                                                           int* __restrict__ dense, unsigned* __restrict__ count_out) {
+                                                           int* __restrict__ dense, unsigned* __restrict__ count_out, unsigned* gd_ctrl = nullptr) {
+    // unified form of the colour list: the launch just finished has evaluated every unit listed so far (its wavefronts leave only
+    // then) and abandoned the tickets beyond; the next launch's tickets start at the list's end
+    if (gd_ctrl && blockIdx.x == 0 && threadIdx.x == 0) gd_ctrl[GD_TICKET] = gd_ctrl[GD_COUNT];
     const long n_items = count_in ? (long)*count_in : first_items;
     const long start = (long)blockIdx.x * LIST_CHUNK;
     if (start >= n_items) return;
@@ -1517,7 +1520,7 @@ DEV float gather_views(const __attribute__((address_space(4))) FrameK& fr, float
 DEV void agent_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int FORM, bool CHAIN, int P = 1, bool CULL = false, bool DEFER = false, bool GDEF = false, bool UNI = false>
 DEV bool render_tile(float* lds, const int lane, const long tile, const int seg, const long entry_base = 0) {
-    static_assert(!UNI || (GDEF && !CHAIN && P == 1), "unified form: the plain listing sample loop");
+    static_assert(!UNI || GDEF, "unified form: a listing sample loop");
     static_assert(!CULL || (!CHAIN && P == 1), "occupancy culling: plain form only");
     static_assert(!GDEF || (DEFER && !CULL), "frame-level deferral: a deferred sample loop without culling");
     static_assert(P == 1 || CHAIN, "several samples per step: chained form only");
@@ -2177,7 +2180,7 @@ template <int FORM, bool CHAIN, bool CULL = false, bool DEFER = false, bool GDEF
 __global__ void __launch_bounds__(64 * GPNERF_MAX_WAVES, GPNERF_MAX_WAVES / 4)
 render_fused_kernel(const KArgs ka) {
     static_assert(!DEFER || FORM != FORM_F32_FIXUP, "the fix-up launch evaluates everything");
-    static_assert(!UNI || (GDEF && !CHAIN && !CULL && (FORM == FORM_F32 || FORM == FORM_F32_FOLD)), "unified form: the plain listing launch of the fp32 forms");
+    static_assert(!UNI || (GDEF && !CULL && (FORM == FORM_F32 || FORM == FORM_F32_FOLD)), "unified form: a listing launch of the fp32 forms");
     constexpr bool SPLIT = FORM == FORM_SPLIT || FORM == FORM_SPLIT_GUARD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     WT(0);
@@ -2267,10 +2270,10 @@ render_fused_kernel(const KArgs ka) {
         STAMP_T0();
         if (have_tile) {
         if constexpr (CHAIN) {
-            if (samples_per_step == 8) render_tile<F, true, 8, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
-            else if (samples_per_step == 4) render_tile<F, true, 4, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
-            else if (samples_per_step == 2) render_tile<F, true, 2, false, GDEF, GDEF>(lds, lane, tile, seg, entry_base);
-            else render_tile<F, true, 1, false, DEFER, GDEF>(lds, lane, tile, seg, entry_base);
+            if (samples_per_step == 8) render_tile<F, true, 8, false, GDEF, GDEF, UNI>(lds, lane, tile, seg, entry_base);
+            else if (samples_per_step == 4) render_tile<F, true, 4, false, GDEF, GDEF, UNI>(lds, lane, tile, seg, entry_base);
+            else if (samples_per_step == 2) render_tile<F, true, 2, false, GDEF, GDEF, UNI>(lds, lane, tile, seg, entry_base);
+            else render_tile<F, true, 1, false, DEFER, GDEF, UNI>(lds, lane, tile, seg, entry_base);
         } else {
             render_tile<F, false, 1, CULL, DEFER, GDEF, UNI>(lds, lane, tile, seg);
         }
@@ -2285,7 +2288,7 @@ render_fused_kernel(const KArgs ka) {
             uni_left = kq->uni_budget;
             if (!have_tile && !uni_drain) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wave_add(kq->gd_ctrl + GD_DONE, 1u, lane);
+                wave_add(kq->gd_ctrl + GD_DONE + kq->seg, 1u, lane);       // (a chained call: one counter per segment launch)
                 uni_drain = true;
             }
             for (;;) {
@@ -2295,7 +2298,7 @@ render_fused_kernel(const KArgs ka) {
                 typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
                 kargs_ptr kd = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(kd));
-                if (wave_load(kd->gd_ctrl + GD_DONE, lane) >= (unsigned)kd->gd_waves) {
+                if (wave_load(kd->gd_ctrl + GD_DONE + kd->seg, lane) >= (unsigned)kd->gd_waves) {
                     if (uni_pending >= (long)wave_load(kd->gd_ctrl + GD_COUNT, lane)) return;     // (every ticket it holds lies beyond the list)
                 }
                 __builtin_amdgcn_s_sleep(32);
@@ -3070,7 +3073,7 @@ constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue c
 // frame whose every weight is non-zero); frames beyond 2^26 samples (1024 x 1024 x 64: 2.1 GB) keep the tile-level passes
 size_t align256(size_t v);
 bool gdef_fits(int64_t n_rays, int32_t n_samples) { return n_samples <= 256 && n_rays * (int64_t)n_samples <= ((int64_t)1 << 26); }
-constexpr size_t GDEF_HEAD_BYTES = 256;        // gd_ctrl: the unit queue's counters and the entry count
+constexpr size_t GDEF_HEAD_BYTES = 512;        // gd_ctrl: the unit queue's counters, the entry / unit count, the tickets, a done counter per segment launch
 // entries: one per sample + a unit per tile (the unified form pads what a tile leaves to a whole unit); flags: one word per unit
 size_t gdef_entries(int64_t n_rays, int32_t n_samples) { return (size_t)n_rays * n_samples + (size_t)((n_rays + 31) / 32) * 32; }
 size_t gdef_flag_bytes(int64_t n_rays, int32_t n_samples) { return align256((gdef_entries(n_rays, n_samples) / 32 + 64) * sizeof(unsigned)); }
@@ -3105,9 +3108,7 @@ template <int FORM> constexpr bool form_defers() { return SPLIT_DEFERS || (FORM 
 template <int FORM, bool CHAIN, bool CULL>
 void launch_form(bool deferred, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const KArgs& ka) {
     if constexpr ((FORM == FORM_F32 || FORM == FORM_F32_FOLD) && !CULL) {
-        if constexpr (!CHAIN) {
-            if (deferred && ka.gd_ent && ka.gd_flag) { hipLaunchKernelGGL((render_fused_kernel<FORM, false, false, true, true, true>), grid, block, lds, stream, ka); return; }
-        }
+        if (deferred && ka.gd_ent && ka.gd_flag) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true, true>), grid, block, lds, stream, ka); return; }
         if (deferred && ka.gd_ent) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true>), grid, block, lds, stream, ka); return; }
     }
     if constexpr (form_defers<FORM>()) {
@@ -3293,6 +3294,8 @@ int device_ready(int* cus) {
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false, false, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, false, false, true, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, false, false, true, true, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true, false, true, true, true>), lds_bytes) &&
+                   lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, true, false, true, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32, true, false, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&render_fused_kernel<FORM_F32_FOLD, true, false, true, true>), lds_bytes) &&
                    lds_ok(reinterpret_cast<const void*>(&colour_units_kernel<FORM_F32>), lds_bytes) &&
@@ -3824,6 +3827,20 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         kx.gd_rgbw = reinterpret_cast<f32x4*>(b + GDEF_HEAD_BYTES + cnt_bytes + flag_bytes + gdef_entries(n_rays, n_samples) * sizeof(uint4));
         return true;
     };
+    // unified form: the listing launch's own wavefronts evaluate the list once they have no tile left (render_fused_kernel, UNI)
+    static int f_uni = -1, f_budget = -1;
+    // (uni_budget = units a wavefront may evaluate between two tiles: measured 0 / 4 / 24 / 100 -> 9.72 / 9.75 / 9.82 / 11.8 ms on the
+    //  bench frame -- colour work between tiles buys no overlap and unbalances the tile queue; the list is evaluated when a wavefront
+    //  has no tile left, which is what fills the end of a launch whose tiles differ in cost)
+    if (f_uni < 0) { f_uni = dbg_int("GPNERF_UNIFIED", 3, 0, 7); f_budget = dbg_int("GPNERF_UNI_BUDGET", 0, 0, 4096); }
+    auto unify = [&](KArgs& kx, long waves) -> bool {
+        if (!kx.gd_ent || !gd_flags) return false;
+        if (!zero_async(gd_flags, gdef_flag_bytes(n_rays, n_samples), stream)) return false;
+        kx.gd_flag = gd_flags;
+        kx.gd_waves = (int)waves;
+        kx.uni_budget = f_budget;
+        return true;
+    };
     // the list's evaluation and the colour map of launch slots [0, n_slots) (behind the launches that listed the entries)
     auto colour_phase = [&](const KArgs& kx, long n_slots) -> bool {
         if (hipGetLastError() != hipSuccess) return false;
@@ -3869,6 +3886,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         ku.list_in = nullptr; ku.count_in = nullptr; ku.list_out = nullptr; ku.count_out = nullptr; ku.chunk_cnt = nullptr;
         ku.p_cap = (long)(slots * RAYS_PER_WAVE);
         const bool listed = gdef_setup(ku, QUEUE_BYTES);
+        if (listed && (f_uni & 2)) unify(ku, (long)n_cus * GPNERF_MAX_WAVES);
         launch_render<true, false>(sel, deferred, dim3((unsigned)n_cus), full_block, S_(stream), ku);
         if (listed && !colour_phase(ku, (long)n_rays)) return GPNERF_E_LAUNCH;
         return fixup();
@@ -3901,6 +3919,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         const bool listed = gdef_setup(ka, need_chain);
         int begins[CHAIN_MAX_SEGS + 2];
         const int n_launch = chain_schedule((int)n_samples, begins);
+        // (the unified form here -- every segment launch evaluating what is listed so far -- measured 6.95 -> 7.86 ms on configs[2]: every
+        //  16-step visit pads its last unit, six launches each wait for their lists; GPNERF_UNIFIED bit 2 in the lab library)
+        const bool unified = listed && (f_uni & 4) && n_launch <= 100 && unify(ka, (long)grid * GPNERF_MAX_WAVES);
         for (int sg = 0; sg < n_launch; ++sg) {
             ka.seg = sg;
             ka.k_begin = begins[sg]; ka.k_end = begins[sg + 1];
@@ -3914,7 +3935,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
             launch_render<true, false>(sel, deferred, dim3(grid), full_block, S_(stream), ka);
             if (!last)     // close the gaps of the sparse list, in order: the next launch's dense input
                 hipLaunchKernelGGL(compact_list_kernel, dim3((unsigned)n_chunks), dim3(256), 0, S_(stream), (const int*)sparse,
-                                   (const unsigned*)ka.chunk_cnt, (const unsigned*)ka.count_in, ka.first_items, lists[sg & 1], ka.count_out);
+                                   (const unsigned*)ka.chunk_cnt, (const unsigned*)ka.count_in, ka.first_items, lists[sg & 1], ka.count_out,
+                                   unified ? ka.gd_ctrl : (unsigned*)nullptr);
             if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         }
         if (listed && !colour_phase(ka, (long)n_rays)) return GPNERF_E_LAUNCH;
@@ -3927,19 +3949,9 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // results; 576x576x64: 18.8 -> 18.0 ms.  (A larger remainder is better left to the queue: CUs with few waves step faster.)
     if (do_remainder) ka.n_rays = (long)((tiles - rem_tiles) * RAYS_PER_WAVE);
     const bool gdef = dynamic && !qsplit && !(flags & GPNERF_FLAG_EARLY_TERM) && gdef_setup(ka, QUEUE_BYTES);
-    // Unified form (frames of two rounds or more, nothing left to a remainder launch): the wavefronts evaluate the list themselves,
-    // between tiles and while the last tiles are still being walked (render_fused_kernel, UNI)
-    static int f_uni = -1, f_budget = -1;
-    // (uni_budget = units a wavefront may evaluate between two tiles: measured 0 / 4 / 24 / 100 -> 9.72 / 9.75 / 9.82 / 11.8 ms on the
-    //  bench frame -- colour work between tiles buys no overlap and unbalances the tile queue; the list is evaluated when a wavefront
-    //  has no tile left, which is what fills the end of a frame whose tiles differ in cost)
-    if (f_uni < 0) { f_uni = dbg_int("GPNERF_UNIFIED", 1, 0, 1); f_budget = dbg_int("GPNERF_UNI_BUDGET", 0, 0, 4096); }
-    if (gdef && f_uni && !do_remainder && !cull_mask && tiles >= 2 * slots) {
-        if (!zero_async(gd_flags, gdef_flag_bytes(n_rays, n_samples), stream)) return GPNERF_E_LAUNCH;
-        ka.gd_flag = gd_flags;
-        ka.gd_waves = (int)(blocks * g.waves);
-        ka.uni_budget = f_budget;
-    }
+    // unified form for frames of two rounds or more with nothing left to a remainder launch (whose tickets would have to start
+    // where this launch's list ends)
+    if (gdef && (f_uni & 1) && !do_remainder && !cull_mask && tiles >= 2 * slots) unify(ka, (long)blocks * g.waves);
     if (cull_mask) {
         ka.cull_mask = cull_mask;
         {

@@ -557,8 +557,11 @@ def test_frame_level_deferral_is_the_wavefront_level_one_bit_for_bit(form, fm, s
                 units = (int((a["weights"] != 0).sum()) + 31) // 32
                 if sa[5] < sb[5]:
                     listed += 1
-                    # (early termination freezes a ray below term_eps: its later weights are written as zeros, listed or not)
-                    assert sa[5] == units, (size, S, n, tuple(kw), sa, units)
+                    # a packed list: exactly `units` evaluations where a second kernel walks it; where the launch's own wavefronts do
+                    # (one launch of whole tiles: the ZJU-sized shape, frames of two rounds or more) every tile pads its last unit
+                    assert units <= sa[5], (size, S, n, tuple(kw), sa, units)
+                    if kw.get("early_term"):
+                        assert sa[5] == units, (size, S, n, tuple(kw), sa, units)
                 else:           # a launch shape that does not list (a frame between one and two rounds splits its tiles' samples instead)
                     assert sa[5] == sb[5], (size, S, n, tuple(kw), sa, sb)
         if S != 128:
