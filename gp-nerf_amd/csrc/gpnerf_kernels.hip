@@ -1298,6 +1298,7 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     unsigned* gd_flag;        // unified form: gd_flag[u] = 1 once unit u's 32 entries are written (zero at launch)
     int gd_waves;             // unified form: wavefronts of the launch (every one reports to GD_DONE when it has listed its last entry)
     int uni_budget;           // unified form: units a wavefront may evaluate between two tiles
+    int gd_slot;              // unified form: which GD_DONE counter this launch's wavefronts report to (one per launch of a call)
     uint4* gd_ent;
     f32x4* gd_rgbw;
     int* gd_cnt;
@@ -2288,7 +2289,7 @@ render_fused_kernel(const KArgs ka) {
             uni_left = kq->uni_budget;
             if (!have_tile && !uni_drain) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wave_add(kq->gd_ctrl + GD_DONE + kq->seg, 1u, lane);       // (a chained call: one counter per segment launch)
+                wave_add(kq->gd_ctrl + GD_DONE + kq->gd_slot, 1u, lane);   // (one counter per launch of the call)
                 uni_drain = true;
             }
             for (;;) {
@@ -2298,7 +2299,7 @@ render_fused_kernel(const KArgs ka) {
                 typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
                 kargs_ptr kd = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(kd));
-                if (wave_load(kd->gd_ctrl + GD_DONE + kd->seg, lane) >= (unsigned)kd->gd_waves) {
+                if (wave_load(kd->gd_ctrl + GD_DONE + kd->gd_slot, lane) >= (unsigned)kd->gd_waves) {
                     if (uni_pending >= (long)wave_load(kd->gd_ctrl + GD_COUNT, lane)) return;     // (every ticket it holds lies beyond the list)
                 }
                 __builtin_amdgcn_s_sleep(32);
@@ -3074,8 +3075,9 @@ constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue c
 size_t align256(size_t v);
 bool gdef_fits(int64_t n_rays, int32_t n_samples) { return n_samples <= 256 && n_rays * (int64_t)n_samples <= ((int64_t)1 << 26); }
 constexpr size_t GDEF_HEAD_BYTES = 512;        // gd_ctrl: the unit queue's counters, the entry / unit count, the tickets, a done counter per segment launch
-// entries: one per sample + a unit per tile (the unified form pads what a tile leaves to a whole unit); flags: one word per unit
-size_t gdef_entries(int64_t n_rays, int32_t n_samples) { return (size_t)n_rays * n_samples + (size_t)((n_rays + 31) / 32) * 32; }
+// entries: one per sample + a unit per VISIT of a work unit (the unified form pads what a visit leaves to a whole unit; a 32-ray tile
+// is one visit, or up to eight where it runs as units of several samples per step); flags: one word per unit
+size_t gdef_entries(int64_t n_rays, int32_t n_samples) { return (size_t)n_rays * n_samples + ((size_t)((n_rays + 31) / 32) * 8 + 64) * 32; }
 size_t gdef_flag_bytes(int64_t n_rays, int32_t n_samples) { return align256((gdef_entries(n_rays, n_samples) / 32 + 64) * sizeof(unsigned)); }
 size_t gdef_bytes(int64_t n_rays, int32_t n_samples) {
     return GDEF_HEAD_BYTES + align256((size_t)n_rays * sizeof(int)) + gdef_flag_bytes(n_rays, n_samples) + gdef_entries(n_rays, n_samples) * sizeof(uint4) +
@@ -3924,6 +3926,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         const bool unified = listed && (f_uni & 4) && n_launch <= 100 && unify(ka, (long)grid * GPNERF_MAX_WAVES);
         for (int sg = 0; sg < n_launch; ++sg) {
             ka.seg = sg;
+            ka.gd_slot = sg;
             ka.k_begin = begins[sg]; ka.k_end = begins[sg + 1];
             ka.queue = ctrl + 8 * sg;
             ka.list_in = sg ? lists[(sg - 1) & 1] : nullptr;
@@ -3949,9 +3952,10 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // results; 576x576x64: 18.8 -> 18.0 ms.  (A larger remainder is better left to the queue: CUs with few waves step faster.)
     if (do_remainder) ka.n_rays = (long)((tiles - rem_tiles) * RAYS_PER_WAVE);
     const bool gdef = dynamic && !qsplit && !(flags & GPNERF_FLAG_EARLY_TERM) && gdef_setup(ka, QUEUE_BYTES);
-    // unified form for frames of two rounds or more with nothing left to a remainder launch (whose tickets would have to start
-    // where this launch's list ends)
-    if (gdef && (f_uni & 1) && !do_remainder && !cull_mask && tiles >= 2 * slots) unify(ka, (long)blocks * g.waves);
+    // unified form, unless a remainder launch follows (with both launches unified -- the second's tickets starting where the first's
+    // list ends -- 576 squared measured 12.67 -> 12.89 ms, 370 squared 5.70 -> 6.01):
+    // 300 / 320 / 340 / 384 squared: 4.42 / 5.04 / 5.13 / 6.15 ms with the second kernel, 4.17 / 4.51 / 5.00 / 5.62 unified
+    if (gdef && (f_uni & 1) && !do_remainder && !cull_mask) unify(ka, (long)blocks * g.waves);
     if (cull_mask) {
         ka.cull_mask = cull_mask;
         {

@@ -534,7 +534,8 @@ def test_frame_level_deferral_is_the_wavefront_level_one_bit_for_bit(form, fm, s
             assert torch.equal(torch.nan_to_num(a[k].float()), torch.nan_to_num(b[k].float())), (tag, k)
 
     listed = 0
-    for size, S, bias in ((362, 64, -0.3), (260, 64, -0.3), (370, 33, -0.3), (300, 128, 1.0)):
+    # (the last two: nearly every weight non-zero -- the list at its worst-case capacity, every visit's padded unit on top)
+    for size, S, bias in ((362, 64, -0.3), (260, 64, -0.3), (370, 33, -0.3), (300, 128, 1.0), (260, 8, 3.0), (362, 8, 3.0)):
         sc = syn.make_scene(H=size, W=size, seed=100 + size, fill="full", pose="random", aabb_half=(0.2, 0.3, 0.12), bias_std=0.1, sigma_bias=bias)
         fr = build_frame(fm, sc)
         rays_all = rays_of(sc)
