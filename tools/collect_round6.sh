@@ -28,15 +28,15 @@ grep -v amdgpu $o/defer_sweep.txt > $d/f_defer_sweep.txt
 grep -v amdgpu $o/producers_sweep.txt > $d/f_producers_sweep.txt
 cp $o/asm_producer_hazards.txt $d/i_asm_producer_hazards.txt
 cp $o/frame_level_ab.txt $d/c_frame_level_deferral_ab.txt
-{ echo '== colour work listed per launch (default): exits of the sample-loop kernel'; cat $o/wave_times_listed.txt; echo; echo '== colour passes per wavefront (GPNERF_FRAME_DEFER=0, round 5): exits of the one kernel'; cat $o/wave_times_wavefront_passes.txt; } > $d/c_wave_exit_times.txt
+{ echo '== default: colour work listed per launch, evaluated by the launch (the time a wavefront finished its LAST TILE; it then evaluates list units until the launch ends)'; cat $o/wave_times_listed.txt; echo; echo '== list + second kernel (GPNERF_UNIFIED=0): exits of the sample-loop kernel'; cat $o/wave_times_second_kernel.txt; echo; echo '== colour passes per wavefront (GPNERF_FRAME_DEFER=0, round 5): exits of the one kernel'; cat $o/wave_times_wavefront_passes.txt; } > $d/c_wave_exit_times.txt
 python tools/pmc_derive.py gpurun_out/pmc_r06_default/summary.json "512x512x64 full fill, API output set, patch order, reference-order form, bit-exact exits on (default)" \
-    "render_fused_kernel<0, false, false, true, true> + colour_units_kernel<0> + colour_accumulate_kernel (one call)" $c $d/b_pmc_summary_headline.json --traffic profiles/pmc_traffic.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
+    "render_fused_kernel<0, false, false, true, true, true> (sample loop, then the launch's own wavefronts evaluate its colour list) + colour_accumulate_kernel (one call)" $c $d/b_pmc_summary_headline.json --traffic profiles/pmc_traffic.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
 python tools/pmc_derive.py gpurun_out/pmc_r06_default/summary_dense.json "512x512x64 full fill, API output set, patch order, reference-order form, GPNERF_FLAG_NO_EXITS (every layer of every sample: roofline.dense_*)" \
-    "render_fused_kernel<0, false, false, false, false>" $c $d/b_pmc_summary_headline_dense.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
+    "render_fused_kernel<0, false, false, false, false, false>" $c $d/b_pmc_summary_headline_dense.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
 python tools/pmc_derive.py gpurun_out/pmc_r06_c3/summary.json "512x512x128 early termination (configs[2]), reference-order form, per call (six segment launches + the colour list)" \
-    "render_fused_kernel<0, true, false, true, true> x 6 + colour_units_kernel<0> + colour_accumulate_kernel" $c $d/b_pmc_summary_config3_early_term.json | grep -E "busy|hbm_bytes|l2_hit"
+    "render_fused_kernel<0, true, false, true, true, false> x 6 + colour_units_kernel<0> + colour_accumulate_kernel" $c $d/b_pmc_summary_config3_early_term.json | grep -E "busy|hbm_bytes|l2_hit"
 python tools/pmc_derive.py gpurun_out/pmc_r06_survey/summary.json "512x512x64 survey fill (73 689 rays), API output set, patch order, reference-order form" \
-    "render_fused_kernel<0, true, false, true, true> (one launch: 2 048 whole tiles + 255 tiles as eight-samples-per-step units) + colour_units_kernel<0> + colour_accumulate_kernel" $c $d/b_pmc_summary_survey_frame.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
+    "render_fused_kernel<0, true, false, true, true, true> (one launch: 2 048 whole tiles + 255 tiles as eight-samples-per-step units, then its colour list) + colour_accumulate_kernel" $c $d/b_pmc_summary_survey_frame.json | grep -E "busy|hbm_bytes|l2_hit|valu_active"
 python tools/resource_table.py $d > /dev/null 2>&1 || true
 rm -f $d/h_kernel_resources_wip.md
 ls $d

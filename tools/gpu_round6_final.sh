@@ -42,19 +42,22 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c3 -- python3 b
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_survey -- python3 bench.py --steps 10 --warmup 3 --fill survey --no-cpu-baseline --no-extras > $o/prof_bench_survey.json 2> $o/stats_survey.err
 for f in $(find $o -name "*kernel_stats.csv"); do echo "== $f"; head -4 $f | cut -c1-160; done
 rm -rf gpurun_out/pmc_r06_default gpurun_out/pmc_r06_c3 gpurun_out/pmc_r06_survey
-CALL='colour_units_kernel<0>+colour_accumulate_kernel'      # the kernels of one gpnerf_render_fused call besides the sample loop's (last name: once per call)
-PMC_KERNEL="render_fused_kernel<0, false, false, true, true>+$CALL" bash tools/pmc_passes.sh r06_default --no-extras | tail -2
-python3 tools/pmc_summary.py gpurun_out/pmc_r06_default 'render_fused_kernel<0, false, false, false, false>' summary_dense.json > /dev/null
-PMC_KERNEL="render_fused_kernel<0, true, false, true, true>+$CALL" bash tools/pmc_passes.sh r06_c3 --samples 128 --early-term --no-extras | tail -2
-PMC_KERNEL="render_fused_kernel<0, true, false, true, true>+$CALL" bash tools/pmc_passes.sh r06_survey --fill survey --no-extras | tail -2
+# the kernels of one gpnerf_render_fused call (last name: once per call).  Template arguments <form, chained, culled, deferred, listed, unified>
+PMC_KERNEL="render_fused_kernel<0, false, false, true, true, true>+colour_accumulate_kernel" bash tools/pmc_passes.sh r06_default --no-extras | tail -2
+python3 tools/pmc_summary.py gpurun_out/pmc_r06_default 'render_fused_kernel<0, false, false, false, false, false>' summary_dense.json > /dev/null
+PMC_KERNEL="render_fused_kernel<0, true, false, true, true, false>+colour_units_kernel<0>+colour_accumulate_kernel" bash tools/pmc_passes.sh r06_c3 --samples 128 --early-term --no-extras | tail -2
+PMC_KERNEL="render_fused_kernel<0, true, false, true, true, true>+colour_accumulate_kernel" bash tools/pmc_passes.sh r06_survey --fill survey --no-extras | tail -2
 find gpurun_out/pmc_r06_* -name "*.csv" -size +2M -delete
-# frame-level against wavefront-level deferral of the colour branch on ONE box (the lab library's GPNERF_FRAME_DEFER=0 is round 5's form)
+# the three ways of running the colour branch of the samples that need it, on ONE box (lab library knobs): the launch's own wavefronts
+# evaluate the launch's list once they have no tile left (default where the launch shape allows), a second kernel evaluates it
+# (GPNERF_UNIFIED=0), every wavefront evaluates its own samples in passes of 32 inside the tile loop (GPNERF_FRAME_DEFER=0, round 5)
 (
 source tools/diag_env.sh
-run() { python bench.py --steps 10 --warmup 3 $2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('$1', '$2', round(j['ms_per_step'],3), 'ms')"; }
-for a in "" "--samples 128 --early-term" "--fill survey" "--size 1024" "--size 384" "--fold"; do
-  run "listed per launch (default)" "$a"; GPNERF_FRAME_DEFER=0 run "passes per wavefront" "$a"
+run() { python bench.py --steps 10 --warmup 3 $2 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('$1 |', '$2', '|', round(j['ms_per_step'],3), 'ms')"; }
+for a in "" "--samples 128 --early-term" "--fill survey" "--size 1024" "--size 384" "--size 320" "--size 576" "--fold"; do
+  run "default" "$a"; GPNERF_UNIFIED=0 run "list + second kernel" "$a"; GPNERF_FRAME_DEFER=0 run "passes per wavefront" "$a"
 done
 ) > $o/frame_level_ab.txt 2>&1
 timeout 300 python tools/wave_times.py 512 64 2>&1 | grep -v amdgpu > $o/wave_times_listed.txt
+GPNERF_DEBUG=1 GPNERF_UNIFIED=0 timeout 300 python tools/wave_times.py 512 64 2>&1 | grep -v amdgpu > $o/wave_times_second_kernel.txt
 GPNERF_DEBUG=1 GPNERF_FRAME_DEFER=0 timeout 300 python tools/wave_times.py 512 64 2>&1 | grep -v amdgpu > $o/wave_times_wavefront_passes.txt
