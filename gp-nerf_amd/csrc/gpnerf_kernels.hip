@@ -1419,7 +1419,8 @@ DEV ChainPlan chain_plan(kargs_cptr k) {
     long rounds = n32 / slots;
     // The last whole round of a launch of two rounds or more also runs as units of tail_p samples per step: a SIMD serves its older
     // wavefront first (it walks 5 units of 8, the younger 3), and with whole 16-step units the older ones walk their last alone
-    // (tools/wave_times.py); units a quarter as long let both finish together (512x512x128 bench frame: 9.02 -> 8.82 ms; 2: 8.91, 8: 9.2)
+    // (tools/wave_times.py); shorter units let both finish together (512x512x128 bench frame, round 4: 9.02 -> 8.82 ms with 4 samples per
+    // step; 2: 8.91, 8: 9.2.  Round 6, the colour work out of these launches: 2 samples per step 6.93 -> 6.87 ms, the default since)
     if (k->tail_p > 1 && rounds >= 2) --rounds;
     c.bulk_tiles = rounds * slots;
     const long rem = n - c.bulk_tiles * RAYS_PER_WAVE;
@@ -3156,7 +3157,7 @@ const int* chain_custom(int* n) {
     *n = f_n;
     return f_len;
 }
-// The launches' sample ranges.  Default: four segments of chain_len(), then segments twice as long.  GPNERF_CHAIN_MERGE_AFTER=k (experiment knob, under
+// The launches' sample ranges.  Default: three segments of chain_len(), one twice as long, then segments three times as long.  GPNERF_CHAIN_MERGE_AFTER=k (experiment knob, under
 // GPNERF_DEBUG=1): from sample k on every segment is as long as all the samples before it ([0,16) .. [48,64), [64,128), ...).
 // Measured on the 512x512x128 bench frame, where 5 % of the rays are alive after 64 samples: 8.82 ms with equal segments,
 // 8.89 ms with the four tail launches merged into one -- the tail levels already run several samples of a ray per step
@@ -3173,10 +3174,12 @@ int chain_schedule(int S, int* begins) {
         begins[n] = k;
         if (nc > 0) cur = custom[n < nc ? n : nc - 1];
         else if (f_merge > 0 && k >= f_merge) { cur = k; }            // from here on every segment is as long as all before it
-        else if (f_merge == 0 && n >= 4) cur = 2 * len;               // default since round 5: four segments of `len`, then twice
-                                                                      // as long (512x512x128: 16,16,16,16,32,32 -- 8.22 against
-                                                                      // 8.33 ms, profiles/r04/f_c3_schedule_sweep.txt: the few
-                                                                      // rays alive past sample 64 need fewer, fuller launches)
+        else if (f_merge == 0 && n >= 3) cur = n == 3 ? 2 * len : 3 * len;   // default: three segments of `len`, one twice, then three
+                                                                      // times as long (512x512x128: 16,16,16,32,48: the few rays
+                                                                      // alive past sample 48 need fewer, fuller launches.  Round 5
+                                                                      // had 16,16,16,16,32,32; with the colour work out of the
+                                                                      // segment launches, three boxes: 6.93 -> 6.86 ms, with the
+                                                                      // two-sample tail units below 6.84)
         ++n;
         k += cur;
         if (n == CHAIN_MAX_SEGS - 1 && k < S) { begins[n++] = k; k = S; }     // (the schedule ran out of launches: one last segment to the end)
@@ -3872,7 +3875,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     if (f_chunk < 0) f_chunk = dbg_int("GPNERF_QUEUE_CHUNK", 64, 1, 4096);
     ka.chunk = f_chunk > 0 ? f_chunk : (int)((tiles + 7) / 8);        // 0: one contiguous run per XCD
     static int f_tail = -1;
-    if (f_tail < 0) f_tail = dbg_int("GPNERF_CHAIN_TAILP", 4, 1, 8);
+    if (f_tail < 0) f_tail = dbg_int("GPNERF_CHAIN_TAILP", 2, 1, 8);
     ka.tail_p = f_tail;
     // ONE launch for a frame of whole rounds + a few tiles: the segmented form's kernel over all S samples as a single segment
     // (term_eps = 0: nothing is ever frozen), whose work units are the whole rounds' 32-ray tiles at one sample per step AND the
