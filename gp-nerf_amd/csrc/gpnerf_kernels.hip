@@ -1298,12 +1298,11 @@ struct KArgs {            // the fused kernel's only argument (see render_fused_
     unsigned* gd_flag;        // unified form: gd_flag[u] = 1 once unit u's 32 entries are written (zero at launch)
     int gd_waves;             // unified form: wavefronts of the launch (every one reports to GD_DONE when it has listed its last entry)
     int uni_budget;           // unified form: units a wavefront may evaluate between two tiles
-    int gd_slot;              // unified form: which GD_DONE counter this launch's wavefronts report to (one per launch of a call)
     uint4* gd_ent;
     f32x4* gd_rgbw;
     int* gd_cnt;
 };
-constexpr int GD_QUEUE = 0, GD_COUNT = 8, GD_TICKET = 9, GD_DONE = 10;      // words of gd_ctrl's 512-byte block, zero at launch (GD_DONE + segment launch: up to 100)
+constexpr int GD_QUEUE = 0, GD_COUNT = 8, GD_TICKET = 9, GD_DONE = 10;      // words of gd_ctrl's block, zero at launch
 // (GD_COUNT counts ENTRIES in the two-launch form and 32-entry UNITS in the unified one, where GD_TICKET hands the units out)
 
 // the forms of the fused kernel
@@ -1440,10 +1439,7 @@ DEV ChainPlan chain_plan(kargs_cptr k) {
 // with ballots.  The workgroup that holds the last entry writes the list's length.
 __global__ void __launch_bounds__(256) compact_list_kernel(const int* __restrict__ sparse, const unsigned* __restrict__ chunk_cnt,
                                                            const unsigned* __restrict__ count_in, const long first_items,
-                                                           int* __restrict__ dense, unsigned* __restrict__ count_out, unsigned* gd_ctrl = nullptr) {
-    // unified form of the colour list: the launch just finished has evaluated every unit listed so far (its wavefronts leave only
-    // then) and abandoned the tickets beyond; the next launch's tickets start at the list's end
-    if (gd_ctrl && blockIdx.x == 0 && threadIdx.x == 0) gd_ctrl[GD_TICKET] = gd_ctrl[GD_COUNT];
+                                                           int* __restrict__ dense, unsigned* __restrict__ count_out) {
     const long n_items = count_in ? (long)*count_in : first_items;
     const long start = (long)blockIdx.x * LIST_CHUNK;
     if (start >= n_items) return;
@@ -2290,7 +2286,7 @@ render_fused_kernel(const KArgs ka) {
             uni_left = kq->uni_budget;
             if (!have_tile && !uni_drain) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wave_add(kq->gd_ctrl + GD_DONE + kq->gd_slot, 1u, lane);   // (one counter per launch of the call)
+                wave_add(kq->gd_ctrl + GD_DONE, 1u, lane);
                 uni_drain = true;
             }
             for (;;) {
@@ -2300,7 +2296,7 @@ render_fused_kernel(const KArgs ka) {
                 typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
                 kargs_ptr kd = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(kd));
-                if (wave_load(kd->gd_ctrl + GD_DONE + kd->gd_slot, lane) >= (unsigned)kd->gd_waves) {
+                if (wave_load(kd->gd_ctrl + GD_DONE, lane) >= (unsigned)kd->gd_waves) {
                     if (uni_pending >= (long)wave_load(kd->gd_ctrl + GD_COUNT, lane)) return;     // (every ticket it holds lies beyond the list)
                 }
                 __builtin_amdgcn_s_sleep(32);
@@ -3075,7 +3071,7 @@ constexpr size_t QUEUE_BYTES = 256;     // head of the workspace: 8 tile-queue c
 // frame whose every weight is non-zero); frames beyond 2^26 samples (1024 x 1024 x 64: 2.1 GB) keep the tile-level passes
 size_t align256(size_t v);
 bool gdef_fits(int64_t n_rays, int32_t n_samples) { return n_samples <= 256 && n_rays * (int64_t)n_samples <= ((int64_t)1 << 26); }
-constexpr size_t GDEF_HEAD_BYTES = 512;        // gd_ctrl: the unit queue's counters, the entry / unit count, the tickets, a done counter per segment launch
+constexpr size_t GDEF_HEAD_BYTES = 256;        // gd_ctrl: the unit queue's counters, the entry / unit count, the tickets, the wavefronts that are done listing
 // entries: one per sample + a unit per VISIT of a work unit (the unified form pads what a visit leaves to a whole unit; a 32-ray tile
 // is one visit, or up to eight where it runs as units of several samples per step); flags: one word per unit
 size_t gdef_entries(int64_t n_rays, int32_t n_samples) { return (size_t)n_rays * n_samples + ((size_t)((n_rays + 31) / 32) * 8 + 64) * 32; }
@@ -3837,7 +3833,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     // (uni_budget = units a wavefront may evaluate between two tiles: measured 0 / 4 / 24 / 100 -> 9.72 / 9.75 / 9.82 / 11.8 ms on the
     //  bench frame -- colour work between tiles buys no overlap and unbalances the tile queue; the list is evaluated when a wavefront
     //  has no tile left, which is what fills the end of a launch whose tiles differ in cost)
-    if (f_uni < 0) { f_uni = dbg_int("GPNERF_UNIFIED", 3, 0, 7); f_budget = dbg_int("GPNERF_UNI_BUDGET", 0, 0, 4096); }
+    if (f_uni < 0) { f_uni = dbg_int("GPNERF_UNIFIED", 3, 0, 3); f_budget = dbg_int("GPNERF_UNI_BUDGET", 0, 0, 4096); }
     auto unify = [&](KArgs& kx, long waves) -> bool {
         if (!kx.gd_ent || !gd_flags) return false;
         if (!zero_async(gd_flags, gdef_flag_bytes(n_rays, n_samples), stream)) return false;
@@ -3924,12 +3920,11 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
         const bool listed = gdef_setup(ka, need_chain);
         int begins[CHAIN_MAX_SEGS + 2];
         const int n_launch = chain_schedule((int)n_samples, begins);
-        // (the unified form here -- every segment launch evaluating what is listed so far -- measured 6.95 -> 7.86 ms on configs[2]: every
-        //  16-step visit pads its last unit, six launches each wait for their lists; GPNERF_UNIFIED bit 2 in the lab library)
-        const bool unified = listed && (f_uni & 4) && n_launch <= 100 && unify(ka, (long)grid * GPNERF_MAX_WAVES);
+        // (the unified form here -- every segment launch evaluating what is listed so far, the next launch's tickets starting at the
+        //  list's end -- measured 6.95 -> 7.86 ms on configs[2]: every 16-step visit pads its last unit and six launches each wait
+        //  for their lists.  The list is evaluated once, by colour_units_kernel behind the last launch.)
         for (int sg = 0; sg < n_launch; ++sg) {
             ka.seg = sg;
-            ka.gd_slot = sg;
             ka.k_begin = begins[sg]; ka.k_end = begins[sg + 1];
             ka.queue = ctrl + 8 * sg;
             ka.list_in = sg ? lists[(sg - 1) & 1] : nullptr;
@@ -3941,8 +3936,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
             launch_render<true, false>(sel, deferred, dim3(grid), full_block, S_(stream), ka);
             if (!last)     // close the gaps of the sparse list, in order: the next launch's dense input
                 hipLaunchKernelGGL(compact_list_kernel, dim3((unsigned)n_chunks), dim3(256), 0, S_(stream), (const int*)sparse,
-                                   (const unsigned*)ka.chunk_cnt, (const unsigned*)ka.count_in, ka.first_items, lists[sg & 1], ka.count_out,
-                                   unified ? ka.gd_ctrl : (unsigned*)nullptr);
+                                   (const unsigned*)ka.chunk_cnt, (const unsigned*)ka.count_in, ka.first_items, lists[sg & 1], ka.count_out);
             if (hipGetLastError() != hipSuccess) return GPNERF_E_LAUNCH;
         }
         if (listed && !colour_phase(ka, (long)n_rays)) return GPNERF_E_LAUNCH;

@@ -3,6 +3,13 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 o=gpurun_out/r6f; rm -rf $o; mkdir -p $o
 timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $o/gpu_tests.txt
+# the headline's PMC passes first: roofline.traffic of the bench lines below is read from profiles/pmc_traffic.json, which is derived here
+# from THIS collection's counters (tools/collect_round6.sh derives the committed copy from the same summary)
+rm -rf gpurun_out/pmc_r06_default
+PMC_KERNEL="render_fused_kernel<0, false, false, true, true, true>+colour_accumulate_kernel" bash tools/pmc_passes.sh r06_default --no-extras | tail -2
+python3 tools/pmc_summary.py gpurun_out/pmc_r06_default 'render_fused_kernel<0, false, false, false, false, false>' summary_dense.json > /dev/null
+python3 tools/pmc_derive.py gpurun_out/pmc_r06_default/summary.json "512x512x64 full fill, API output set, patch order, reference-order form, bit-exact exits on (default)" \
+    "render_fused_kernel<0, false, false, true, true, true> + colour_accumulate_kernel (one call)" "$(cat gpurun_out/HEAD_COMMIT 2>/dev/null || echo HEAD)" $o/pmc_headline_on_box.json --traffic profiles/pmc_traffic.json > /dev/null
 timeout 900 python bench.py > $o/bench_default.json 2> $o/bench_default.err
 timeout 300 python bench.py --steps 20 --warmup 3 --fold --no-cpu-baseline --no-extras > $o/bench_folded.json 2> $o/bench_folded.err
 timeout 300 python bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras > $o/bench_c3.json 2> $o/bench_c3.err
@@ -41,10 +48,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_default -- pyth
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_c3 -- python3 bench.py --steps 10 --warmup 3 --samples 128 --early-term --no-cpu-baseline --no-extras > $o/prof_bench_c3.json 2> $o/stats_c3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_survey -- python3 bench.py --steps 10 --warmup 3 --fill survey --no-cpu-baseline --no-extras > $o/prof_bench_survey.json 2> $o/stats_survey.err
 for f in $(find $o -name "*kernel_stats.csv"); do echo "== $f"; head -4 $f | cut -c1-160; done
-rm -rf gpurun_out/pmc_r06_default gpurun_out/pmc_r06_c3 gpurun_out/pmc_r06_survey
+rm -rf gpurun_out/pmc_r06_c3 gpurun_out/pmc_r06_survey
 # the kernels of one gpnerf_render_fused call (last name: once per call).  Template arguments <form, chained, culled, deferred, listed, unified>
-PMC_KERNEL="render_fused_kernel<0, false, false, true, true, true>+colour_accumulate_kernel" bash tools/pmc_passes.sh r06_default --no-extras | tail -2
-python3 tools/pmc_summary.py gpurun_out/pmc_r06_default 'render_fused_kernel<0, false, false, false, false, false>' summary_dense.json > /dev/null
 PMC_KERNEL="render_fused_kernel<0, true, false, true, true, false>+colour_units_kernel<0>+colour_accumulate_kernel" bash tools/pmc_passes.sh r06_c3 --samples 128 --early-term --no-extras | tail -2
 PMC_KERNEL="render_fused_kernel<0, true, false, true, true, true>+colour_accumulate_kernel" bash tools/pmc_passes.sh r06_survey --fill survey --no-extras | tail -2
 find gpurun_out/pmc_r06_* -name "*.csv" -size +2M -delete
