@@ -16,6 +16,26 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_WORKSPACES = {}
+
+
+def _workspace(dev, nbytes):
+    """The scratch a gpnerf_render_fused call borrows (tile queues, chained lists, the colour list: 0.5 GB for 512 x 512 x 64, 2 GB for
+    1024 x 1024 x 64).  One tensor per (device, stream), kept and grown rather than allocated per call: the call owns it only until the
+    stream reaches its end, and calls on one stream are ordered -- while a fresh torch.empty of that size per call can fall out of the
+    caching allocator's pool and cost a device allocation (milliseconds of idle device) every frame."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _WORKSPACES.pop(key, None)
+        ws = None               # (release the smaller one first)
+        while len(_WORKSPACES) >= 4:        # (streams come and go: at most four are remembered)
+            _WORKSPACES.pop(next(iter(_WORKSPACES)))
+        ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 def _require_gpu(t, what):
     if not t.is_cuda:
         raise L.GpnerfError(f"{what} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
@@ -416,7 +436,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     ws_bytes = int(lib.gpnerf_render_workspace_bytes(n_launch, S)) if load_balance else 0
     if workspace_cap is not None:       # lend less than the launch could use (it then keeps to the forms that fit: include/gpnerf_hip.h `workspace`)
         ws_bytes = min(ws_bytes, int(workspace_cap))
-    ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8) if ws_bytes else None
+    ws = _workspace(dev, ws_bytes) if ws_bytes else None
     L.check(lib.gpnerf_render_fused(C.byref(frame.c), rays.data_ptr(), n_launch, S, flags, float(term_eps),
                                     ray_order.data_ptr() if ray_order is not None else None, C.byref(o),
                                     ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(dev)), "gpnerf_render_fused")
