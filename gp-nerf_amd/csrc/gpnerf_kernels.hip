@@ -2129,22 +2129,15 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
 // Unified form (render_fused_kernel<., false, false, true, true, true>): the launch's wavefronts evaluate the list themselves,
 // between tiles and when the tile queue has nothing left for them.  `pending` = the unit this wavefront holds a ticket for (-1:
 // none).  Takes tickets UNI_BATCH at a time, evaluates the next unit if its flag is up, returns whether it did.
-constexpr unsigned UNI_BATCH = 4;       // tickets a wavefront takes at a time (the ticket counter is one address for 2 048 wavefronts)
+// One 32-entry unit of the colour list: lane i (both halves) evaluates entry i exactly as render_tile's colour pass does -- sample_point
+// from the ray's row, gather_views, mean / variance, mlp_colour: same operands, same order, same bits -- and writes (r, g, b, w) where
+// colour_accumulate_kernel finds it.  valid: this lane's entry is one (null entries pad a unit; an invalid lane computes on ray 0).
 template <int FORM>
-DEV bool consume_unit(float* lds, const int lane, long& pending, long& pending_end) {
+DEV void colour_entries(float* lds, const int lane, const bool valid, const uint4 e) {
     typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
     kargs_ptr kb = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kb));
-    if (pending >= pending_end) {
-        pending = (long)wave_add(kb->gd_ctrl + GD_TICKET, UNI_BATCH, lane);
-        pending_end = pending + UNI_BATCH;
-    }
-    if (wave_load(kb->gd_flag + pending, lane) == 0u) return false;         // (not written yet, or a ticket beyond the list so far)
-    const int n = lane & 31, half = lane >> 5;
-    const unsigned* const pe = reinterpret_cast<const unsigned*>(kb->gd_ent + (size_t)pending * 32 + n);
-    uint4 e;
-    e.x = agent_load(pe); e.y = agent_load(pe + 1); e.z = agent_load(pe + 2); e.w = 0u;
-    const bool valid = e.x != 0xffffffffu;
+    const int half = lane >> 5;
     const int slot = valid ? (int)e.x : 0, kk = (int)(e.y & 255u), rank = (int)(e.y >> 8);
     const int ray = kb->out.order ? kb->out.order[slot] : slot;
     const f32x4 r0 = *reinterpret_cast<const f32x4*>(kb->rays + (size_t)ray * 8);
@@ -2166,10 +2159,27 @@ DEV bool consume_unit(float* lds, const int lane, long& pending, long& pending_e
         f32x4 v; v[0] = cq[0]; v[1] = cq[1]; v[2] = cq[2]; v[3] = __builtin_bit_cast(float, e.z);
         ko->gd_rgbw[(size_t)slot * S + rank] = v;
     }
-    if (ko->out.step_stats && lane == 0) {
+    if (ko->out.step_stats && lane == 0) {     // (the diagnostic launch) one colour evaluation; [2] = steps minus colour evaluations
         atomicAdd(ko->out.step_stats + 5, 1u);
         atomicAdd(ko->out.step_stats + 2, 0xffffffffu);
     }
+}
+
+constexpr unsigned UNI_BATCH = 4;       // tickets a wavefront takes at a time (the ticket counter is one address for 2 048 wavefronts)
+template <int FORM>
+DEV bool consume_unit(float* lds, const int lane, long& pending, long& pending_end) {
+    typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
+    kargs_ptr kb = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kb));
+    if (pending >= pending_end) {
+        pending = (long)wave_add(kb->gd_ctrl + GD_TICKET, UNI_BATCH, lane);
+        pending_end = pending + UNI_BATCH;
+    }
+    if (wave_load(kb->gd_flag + pending, lane) == 0u) return false;         // (not written yet, or a ticket beyond the list so far)
+    const unsigned* const pe = reinterpret_cast<const unsigned*>(kb->gd_ent + (size_t)pending * 32 + (lane & 31));
+    uint4 e;
+    e.x = agent_load(pe); e.y = agent_load(pe + 1); e.z = agent_load(pe + 2); e.w = 0u;      // (written through by another CU: read past this one's caches)
+    colour_entries<FORM>(lds, lane, e.x != 0xffffffffu, e);
     ++pending;
     return true;
 }
@@ -2318,35 +2328,9 @@ DEV void colour_unit(float* lds, const int lane, const long unit, const unsigned
     typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
     kargs_ptr kb = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kb));
-    const int n = lane & 31, half = lane >> 5;
-    const size_t at = (size_t)unit * 32 + n;
+    const size_t at = (size_t)unit * 32 + (lane & 31);
     const bool valid = at < total;
-    const uint4 e = kb->gd_ent[valid ? at : (size_t)total - 1];
-    const int slot = (int)e.x, kk = (int)(e.y & 255u), rank = (int)(e.y >> 8);
-    const int ray = kb->out.order ? kb->out.order[slot] : slot;
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(kb->rays + (size_t)ray * 8);
-    const f32x4 r1 = *reinterpret_cast<const f32x4*>(kb->rays + (size_t)ray * 8 + 4);
-    const int S = kb->S;
-    const unsigned flags = kb->flags;
-    const bool neg = (flags & GPNERF_FLAG_NEG_RAY) != 0, flip = (flags & GPNERF_FLAG_FLIP_SAMPLES) != 0;
-    const float step = (S > 1) ? 1.f / (float)(S - 1) : 0.f;
-    float zq, qx_, qy_, qz_;
-    sample_point(r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], flip ? (S - 1 - kk) : kk, S, step, zq, qx_, qy_, qz_);
-    float xq[NV][18], vq[NV][3], cq[3], mvq[36];
-    gather_views<FORM>(kb->fr, qx_, qy_, qz_, neg, half, xq, vq);
-    Stamps st;
-    if constexpr (FORM == FORM_F32) { mean_var_ref(xq, mvq); mlp_colour_ref(lds, lane, xq, mvq, cq, st); }
-    else { mean_var(xq, mvq); mlp_colour(lds, lane, xq, mvq, cq, st); }
-    kargs_ptr ko = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ko));
-    if (valid && half == 0) {
-        f32x4 v; v[0] = cq[0]; v[1] = cq[1]; v[2] = cq[2]; v[3] = __builtin_bit_cast(float, e.z);
-        ko->gd_rgbw[(size_t)slot * S + rank] = v;
-    }
-    if (ko->out.step_stats && lane == 0) {     // (the diagnostic launch) one colour evaluation; [2] = steps minus colour evaluations
-        atomicAdd(ko->out.step_stats + 5, 1u);
-        atomicAdd(ko->out.step_stats + 2, 0xffffffffu);
-    }
+    colour_entries<FORM>(lds, lane, valid, kb->gd_ent[valid ? at : (size_t)total - 1]);
 }
 
 constexpr int UNIT_WAVES = 8;            // wavefronts of a colour_units_kernel workgroup (12, three per SIMD at 168 registers: the same time, A/B on one box)
