@@ -1633,9 +1633,10 @@ DEV bool render_tile(float* lds, const int lane, const long tile, const int seg,
     for (;; k += P) {
         if constexpr (GDEF) {
             // Frame-level deferral: the samples waiting for their colour branch leave the wavefront altogether -- 32 at a time (what
-            // is left at the tile's end) they are appended to the launch's entry list, and colour_units_kernel evaluates the list 32
-            // entries per wavefront step, whichever tiles they came from; colour_accumulate_kernel then adds every ray's terms in
-            // sample order.  The same arithmetic on the same operands in the same order as the passes below: the same bits.
+            // is left at the tile's end) they are appended to the launch's entry list, which is evaluated 32 entries per wavefront
+            // step, whichever tiles they came from (by this launch's own wavefronts once they have no tile left: UNI; by
+            // colour_units_kernel otherwise); colour_accumulate_kernel then adds every ray's terms in sample order.  The same arithmetic
+            // on the same operands in the same order as the passes below: the same bits.
             if (q_cnt >= 32 || (q_cnt > 0 && !(k < k_lim))) {
                 const int nb = min(q_cnt, 32);
                 const uint2 e = dq[(q_head + (n < nb ? n : 0)) & (DEFER_QUEUE - 1)];
@@ -3792,7 +3793,8 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     const bool deferred = f_defer && (ka.skip & 2) && !out->raw;
     const int sel = guard ? SEL_GUARD : (split16 ? SEL_SPLIT : (folded ? SEL_FOLD : SEL_REF));
     // Frame-level deferral (fp32 forms, persistent launches of whole tiles): the sample loop only LISTS the samples whose weight is
-    // not zero; colour_units_kernel evaluates the list and colour_accumulate_kernel adds every ray's terms in order (see there).
+    // not zero; the list is evaluated by the launch's own wavefronts (`unify`, below) or by colour_units_kernel, and
+    // colour_accumulate_kernel adds every ray's terms in order (see there).
     static int f_gdef = -1;
     if (f_gdef < 0) f_gdef = dbg_int("GPNERF_FRAME_DEFER", 1, 0, 1);
     const bool gdef_ok = f_gdef && deferred && !culling && !cull_mask && (sel == SEL_REF || sel == SEL_FOLD) && !(flags & GPNERF_FLAG_OCC_CULL) &&
