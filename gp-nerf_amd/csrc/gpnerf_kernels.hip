@@ -3092,7 +3092,19 @@ template <int FORM> constexpr bool form_defers() { return SPLIT_DEFERS || (FORM 
 template <int FORM, bool CHAIN, bool CULL>
 void launch_form(bool deferred, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const KArgs& ka) {
     if constexpr ((FORM == FORM_F32 || FORM == FORM_F32_FOLD) && !CULL) {
-        if (deferred && ka.gd_ent && ka.gd_flag) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true, true>), grid, block, lds, stream, ka); return; }
+        if (deferred && ka.gd_ent && ka.gd_flag) {
+            // the unified form's wavefronts wait for each other (every one reports before any leaves): a COOPERATIVE launch, which
+            // the runtime starts only with the whole grid resident -- a plain launch could leave workgroups behind another tenant's
+            // kernel while the resident ones wait for them
+            KArgs kc = ka;
+            void* args[] = {&kc};
+            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&render_fused_kernel<FORM, CHAIN, false, true, true, true>), grid, block, args,
+                                           (unsigned)lds, stream) != hipSuccess) {
+                (void)hipGetLastError();
+                hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true, true>), grid, block, lds, stream, ka);
+            }
+            return;
+        }
         if (deferred && ka.gd_ent) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true>), grid, block, lds, stream, ka); return; }
     }
     if constexpr (form_defers<FORM>()) {

@@ -160,7 +160,7 @@ typedef struct GpnerfOutputs {
                                   fma(0, rgb, c) = c to the colour map, so only the samples that need it are evaluated, 32 at a
                                   time: listed for the launch as a whole where the workspace has room for the list (fp32 forms
                                   on the tile queue) and evaluated by the launch's own wavefronts once they have no tile left
-                                  (frames of two rounds or more) or by a second kernel (exactly ceil(listed / 32) evaluations),
+                                  (launches on the tile queue with no remainder launch behind them) or by a second kernel (exactly ceil(listed / 32) evaluations),
                                   out of a queue per wavefront otherwise (never with `raw`, never under GPNERF_FLAG_NO_EXITS);
                               [6], [7] reserved (0).
                               All of it is bit-exact; bench.py prices its roofline on the work done:
@@ -213,8 +213,8 @@ int gpnerf_fold_volumes(const GpnerfFrame* frame, float* const* out, void* strea
  *     difference (never with GPNERF_FLAG_EARLY_TERM).  On the tile queue the fp32 forms also keep the LIST of the samples whose
  *     colour branch has to run there (32 bytes per sample of the launch: an entry and a result; launches of up to 2^26 samples)
  *     -- the sample loop then only lists them, the list is evaluated 32 entries per wavefront step, balanced whatever the rays
- *     (by the same launch's wavefronts as they run out of tiles where the frame has two rounds of them or more, by a second
- *     kernel otherwise), and a last kernel adds every ray's terms in sample order: the colour map's bits are those of the loop
+ *     (by the same launch's wavefronts as they run out of tiles -- a cooperative launch, its wavefronts wait for each other --
+ *     or by a second kernel behind the segment launches of early termination), and a last kernel adds every ray's terms in sample order: the colour map's bits are those of the loop
  *     that evaluates them in place, which is what a workspace too small for the list gets (gpnerf_render_workspace_bytes
  *     includes it).
  *     The workspace is private to the call until the stream reaches its end. */

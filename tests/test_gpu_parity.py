@@ -559,7 +559,7 @@ def test_frame_level_deferral_is_the_wavefront_level_one_bit_for_bit(form, fm, s
                 if sa[5] < sb[5]:
                     listed += 1
                     # a packed list: exactly `units` evaluations where a second kernel walks it; where the launch's own wavefronts do
-                    # (one launch of whole tiles: the ZJU-sized shape, frames of two rounds or more) every tile pads its last unit
+                    # (plain launches on the tile queue, the one-launch ZJU-sized shape) every tile pads its last unit
                     assert units <= sa[5], (size, S, n, tuple(kw), sa, units)
                     if kw.get("early_term"):
                         assert sa[5] == units, (size, S, n, tuple(kw), sa, units)
@@ -570,7 +570,7 @@ def test_frame_level_deferral_is_the_wavefront_level_one_bit_for_bit(form, fm, s
             a = fm.render_fused(fr, rays_all, S, want=want, **fkw)
             same(a, c, (size, S, "every layer of every sample"))
     # the launches did take the frame-level path: a packed list needs fewer evaluations than per-wavefront passes (frames of two
-    # rounds or more without a remainder launch evaluate the list themselves and pad what a tile leaves to a whole unit: the
+    # round without a remainder launch evaluate the list themselves and pad what a tile leaves to a whole unit: the
     # per-wavefront count, 362 x 362 here)
     assert listed >= 12, listed
 
