@@ -90,6 +90,7 @@ FLAG_FLIP_SAMPLES = 16
 FLAG_SPLIT_GUARD = 32
 FLAG_REF_ORDER = 64
 FLAG_NO_EXITS = 128
+FLAG_SHARED_DEVICE = 256
 FOLD_FIRST_LEVEL = 2
 
 # every symbol include/gpnerf_hip.h declares: (restype, argtypes)

@@ -3092,19 +3092,11 @@ template <int FORM> constexpr bool form_defers() { return SPLIT_DEFERS || (FORM 
 template <int FORM, bool CHAIN, bool CULL>
 void launch_form(bool deferred, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const KArgs& ka) {
     if constexpr ((FORM == FORM_F32 || FORM == FORM_F32_FOLD) && !CULL) {
-        if (deferred && ka.gd_ent && ka.gd_flag) {
-            // the unified form's wavefronts wait for each other (every one reports before any leaves): a COOPERATIVE launch, which
-            // the runtime starts only with the whole grid resident -- a plain launch could leave workgroups behind another tenant's
-            // kernel while the resident ones wait for them
-            KArgs kc = ka;
-            void* args[] = {&kc};
-            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&render_fused_kernel<FORM, CHAIN, false, true, true, true>), grid, block, args,
-                                           (unsigned)lds, stream) != hipSuccess) {
-                (void)hipGetLastError();
-                hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true, true>), grid, block, lds, stream, ka);
-            }
-            return;
-        }
+        // (the unified form's wavefronts wait for each other -- every one reports before any leaves -- which assumes the grid becomes
+        //  resident without depending on another tenant that waits the same way: GPNERF_FLAG_SHARED_DEVICE selects the second kernel.
+        //  As a cooperative launch, which guarantees residency, it cost 0.04 ms per call and, with the next frame's producers on a
+        //  second stream, the whole overlap of the pipelined evaluation loop: 7.0 -> 8.5 ms per frame)
+        if (deferred && ka.gd_ent && ka.gd_flag) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true, true>), grid, block, lds, stream, ka); return; }
         if (deferred && ka.gd_ent) { hipLaunchKernelGGL((render_fused_kernel<FORM, CHAIN, false, true, true>), grid, block, lds, stream, ka); return; }
     }
     if constexpr (form_defers<FORM>()) {
@@ -3833,7 +3825,7 @@ int gpnerf_render_fused(const GpnerfFrame* f, const float* rays, int64_t n_rays,
     //  has no tile left, which is what fills the end of a launch whose tiles differ in cost)
     if (f_uni < 0) { f_uni = dbg_int("GPNERF_UNIFIED", 3, 0, 3); f_budget = dbg_int("GPNERF_UNI_BUDGET", 0, 0, 4096); }
     auto unify = [&](KArgs& kx, long waves) -> bool {
-        if (!kx.gd_ent || !gd_flags) return false;
+        if (!kx.gd_ent || !gd_flags || (flags & GPNERF_FLAG_SHARED_DEVICE)) return false;
         if (!zero_async(gd_flags, gdef_flag_bytes(n_rays, n_samples), stream)) return false;
         kx.gd_flag = gd_flags;
         kx.gd_waves = (int)waves;

@@ -324,7 +324,7 @@ def patch_order_rays(mask, H, W, n, patch_w=32, patch_h=8):
 
 def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_eps=1e-5,
                  want=("weights", "z_vals", "rgb_in", "ray_mask"), ray_order=None, occ_cull=False, load_balance=True,
-                 split_f16=False, flip=None, subset=False, guard=None, fold=None, reserve_cus=0, exits=True, workspace_cap=None):
+                 split_f16=False, flip=None, subset=False, guard=None, fold=None, reserve_cus=0, exits=True, workspace_cap=None, shared_device=False):
     """gpnerf_render_fused over rays [N,8] (device).  Returns a dict of device tensors [N,...].
     neg_ray: the Projector's front test (h_z < 0).  flip: raw2outputs(neg=True); defaults to neg_ray for the dense renderer
     (BaseRender.py:86-88) and to False with occ_cull, because the progressive renderer's integral never flips
@@ -344,6 +344,7 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     form -- coarse levels folded into the sigma feature layer per frame (Frame.fold_volumes), log2(e)-scaled layers: ~8 % faster layer for layer (the same time once both defer the colour branch),
     the same 1e-5 at initialisation scale, 5-10 x further from the reference on trained-like parameters.  "keep": True without
     re-folding a Frame that is already folded.
+    shared_device=True: other processes' kernels share the device (GPNERF_FLAG_SHARED_DEVICE): no launch waits for its own workgroups.
     exits=False: every layer evaluated for every sample (GPNERF_FLAG_NO_EXITS).  By default the fp32 forms leave out what cannot
     change an output, bit for bit: the sigma feature layer of levels whose features are zero in all 32 samples of a step, and the
     colour branch of samples whose weight alpha * T is zero (the rest are listed and evaluated 32 at a time -- by a second launch
@@ -398,6 +399,8 @@ def render_fused(frame, rays, n_samples, neg_ray=False, early_term=False, term_e
     flags |= (int(reserve_cus) & 0xff) << 24
     if not exits:
         flags |= L.FLAG_NO_EXITS
+    if shared_device:
+        flags |= L.FLAG_SHARED_DEVICE
     if split_f16:
         if not frame.c.head_blob_split:
             raise L.GpnerfError("split_f16 needs the f16 hi/lo head image (build the frame from pack_head()'s tensor)")

@@ -77,6 +77,13 @@ extern "C" {
                                       (the sigma feature layer in empty space; the colour branch run only for samples whose weight
                                       alpha * T is not zero; the sample loop ended where every ray's transmittance is exactly 0:
                                       GpnerfOutputs.step_stats) -- the A/B that shows they change no bit */
+#define GPNERF_FLAG_SHARED_DEVICE 256u /* other processes' kernels share this device: no launch of this call waits for its own
+                                      workgroups.  (By default a launch on the tile queue that lists its colour work lets its own
+                                      wavefronts evaluate the list once they have no tile left, every wavefront reporting before any
+                                      leaves: fine on a device the process has to itself -- one process per GPU -- or shares with
+                                      kernels that end on their own, a deadlock hazard only against another tenant's kernel that
+                                      waits the same way while holding compute units.  With this flag the list goes to a second
+                                      kernel: the same bits, 1-10 % slower.) */
 #define GPNERF_FLAG_RESERVE_CUS(n) (((uint32_t)(n) & 0xffu) << 24)
                                    /* bits 24..31: plan the launch for n fewer compute units (rounded down to a multiple of 8: one
                                       per XCD round).  The persistent workgroups then leave n CUs idle for kernels of other
@@ -213,8 +220,8 @@ int gpnerf_fold_volumes(const GpnerfFrame* frame, float* const* out, void* strea
  *     difference (never with GPNERF_FLAG_EARLY_TERM).  On the tile queue the fp32 forms also keep the LIST of the samples whose
  *     colour branch has to run there (32 bytes per sample of the launch: an entry and a result; launches of up to 2^26 samples)
  *     -- the sample loop then only lists them, the list is evaluated 32 entries per wavefront step, balanced whatever the rays
- *     (by the same launch's wavefronts as they run out of tiles -- a cooperative launch, its wavefronts wait for each other --
- *     or by a second kernel behind the segment launches of early termination), and a last kernel adds every ray's terms in sample order: the colour map's bits are those of the loop
+ *     (by the same launch's wavefronts as they run out of tiles, or by a second kernel: behind the segment launches of early
+ *     termination, and always under GPNERF_FLAG_SHARED_DEVICE), and a last kernel adds every ray's terms in sample order: the colour map's bits are those of the loop
  *     that evaluates them in place, which is what a workspace too small for the list gets (gpnerf_render_workspace_bytes
  *     includes it).
  *     The workspace is private to the call until the stream reaches its end. */

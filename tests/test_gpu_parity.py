@@ -551,6 +551,9 @@ def test_frame_level_deferral_is_the_wavefront_level_one_bit_for_bit(form, fm, s
                 b = fm.render_fused(fr, rays, S, want=want + ("step_stats",), workspace_cap=small, **dict(fkw, **kw))
                 sa, sb = a.pop("step_stats").cpu().numpy().astype(np.int64), b.pop("step_stats").cpu().numpy().astype(np.int64)
                 same(a, b, (size, S, n, tuple(kw)))
+                if n == rays_all.shape[0]:          # GPNERF_FLAG_SHARED_DEVICE: the list always goes to the second kernel -- the same bits
+                    c = fm.render_fused(fr, rays, S, want=want, shared_device=True, **dict(fkw, **kw))
+                    same(c, b, (size, S, n, tuple(kw), "shared device"))
                 # (steps and opaque tails are the launch's; the units of several samples per step take the level-by-level exit of the
                 #  sigma feature layer only when they list: never fewer levels left out)
                 assert sa[0] == sb[0] and sa[3] == sb[3] and sa[1] >= sb[1] and sa[4] >= sb[4], (sa, sb)
