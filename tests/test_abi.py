@@ -95,6 +95,22 @@ def test_host_only_entry_points_run_without_a_gpu(pkg):
     assert t[0] == 64 and t[1] == 2 and t[2] == 0
 
 
+def test_the_workspace_covers_the_colour_list_at_its_worst(pkg):
+    """gpnerf_render_workspace_bytes (host arithmetic only): a launch that lists the samples whose colour branch has to run needs an
+    entry and a result per SAMPLE at worst (every weight non-zero: 16 + 16 bytes), a padded unit per visit of a work unit on top and
+    a flag per unit (include/gpnerf_hip.h `workspace`); launches beyond 2^26 samples or of less than a round of wavefronts do not
+    list.  It grows with the launch and is positive for every launch that can use a tile queue."""
+    lib = pkg._lib.lib()
+    ws = lambda n, s: int(lib.gpnerf_render_workspace_bytes(n, s))
+    n, s = 512 * 512, 64
+    assert ws(n, s) >= 32 * n * s + 16 * 8 * n, "room for the list at full occupancy plus eight padded units per 32-ray tile"
+    assert ws(n, s) < 40 * n * s, "... and not much more than that"
+    assert ws(1024 * 1024, 128) < 16 * 1024 * 1024 * 128, "2^27 samples: no list (the wavefronts keep their passes)"
+    assert ws(2048, 64) < 32 * 2048 * 64, "a launch of one round of workgroups at most never lists"
+    assert 0 < ws(4096, 64) <= ws(65536, 64) <= ws(n, s)
+    assert ws(0, 64) == 0
+
+
 def test_missing_library_fails_loudly(pkg, monkeypatch):
     L = pkg._lib
     monkeypatch.setattr(L, "_lib", None)
