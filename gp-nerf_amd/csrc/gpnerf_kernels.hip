@@ -2166,7 +2166,10 @@ DEV void colour_entries(float* lds, const int lane, const bool valid, const uint
     }
 }
 
-constexpr unsigned UNI_BATCH = 4;       // tickets a wavefront takes at a time (the ticket counter is one address for 2 048 wavefronts)
+constexpr unsigned UNI_BATCH = 1;       // tickets a wavefront takes at a time: one atomic on one address per unit is no burden (what was, in a first
+                                        // version: two extra device-scope loads of the counters per attempt, 9.8 -> 14.1 ms); 1 / 2 / 4 / 8 at a
+                                        // time: bench frame 9.84 / 9.86 / 9.84 / 9.90 ms, 320 x 320 4.50 / 4.53 / 4.55 / 4.65 -- a wavefront that
+                                        // holds tickets it is not working on yet only delays the launch's end
 template <int FORM>
 DEV bool consume_unit(float* lds, const int lane, long& pending, long& pending_end) {
     typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
